@@ -1,0 +1,48 @@
+"""ctypes loader for the C-ABI kernel library (include/pase_amd.h).
+
+The product path loads pase_amd/libpase_hip.so (hipcc, gfx950) and refuses to run without it:
+there is NO CPU fallback.  `use_library()` exists only so the kernel tests can point the very same
+Python wrappers at the SIMT-emulator build of the same sources (tests/hipemu) on a GPU-less box.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_SO = os.path.join(_HERE, "libpase_hip.so")
+
+_lib = None
+_device_type = "cuda"
+
+
+class PaseLibraryError(RuntimeError):
+    pass
+
+
+def use_library(path, device_type):
+    """TEST HOOK: bind the wrappers to another build of the same C ABI (the CPU emulator)."""
+    global _lib, _device_type
+    _lib = ctypes.CDLL(path) if path is not None else None
+    _device_type = device_type
+    if _lib is not None:
+        _declare(_lib)
+
+
+def device_type():
+    return _device_type
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(HIP_SO):
+            raise PaseLibraryError(
+                "pase_amd: %s is missing. Build it with `python -m pase_amd.build hip` "
+                "(or __graft_entry__.build()); there is no CPU fallback." % HIP_SO)
+        _lib = ctypes.CDLL(HIP_SO)
+        _declare(_lib)
+    return _lib
+
+
+def _declare(l):
+    from . import kernels
+    kernels.declare(l)

@@ -1,0 +1,110 @@
+"""Build helpers: compile pase_amd/csrc/*.hip for gfx950 into pase_amd/libpase_hip.so (in-tree, so
+the .so travels to the GPU box with the gpurun snapshot), and -- for the CPU kernel tests only --
+the same sources against the SIMT emulator into tests/hipemu/libpase_emu.so.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "pase_amd", "csrc")
+INCLUDE = os.path.join(ROOT, "include")
+HIP_SO = os.path.join(ROOT, "pase_amd", "libpase_hip.so")
+EMU_DIR = os.path.join(ROOT, "tests", "hipemu")
+EMU_SO = os.path.join(EMU_DIR, "libpase_emu.so")
+
+
+def _sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _digest(paths, extra=""):
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _deps():
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
+    return sorted(hdrs)
+
+
+def _up_to_date(out, digest):
+    stamp = out + ".sha256"
+    return os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == digest
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout)
+        raise RuntimeError("build failed: " + " ".join(cmd))
+    return r.stdout
+
+
+def build_hip(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
+    srcs = _sources()
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", INCLUDE, "-I", CSRC,
+             "-Wno-unused-result"]
+    digest = _digest(srcs + _deps(), " ".join(flags))
+    if not force and _up_to_date(HIP_SO, digest):
+        return HIP_SO
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    for s in srcs:
+        o = s[:-4] + ".o"
+        objs.append(o)
+        procs.append(subprocess.Popen([hipcc, "-c", s, "-o", o] + [f for f in flags if f != "-shared"],
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for pr, s in zip(procs, srcs):
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            sys.stderr.write(out)
+            raise RuntimeError("hipcc failed on " + s)
+        if verbose and out:
+            print(out)
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_SO] + objs)
+    with open(HIP_SO + ".sha256", "w") as f:
+        f.write(digest)
+    return HIP_SO
+
+
+def build_emu(force=False):
+    """g++ build of the same kernel sources against tests/hipemu (CPU kernel tests only)."""
+    srcs = _sources()
+    emu_srcs = [os.path.join(EMU_DIR, "hipemu.cpp")]
+    flags = ["-O2", "-std=c++17", "-fPIC", "-shared", "-DPASE_HIPEMU", "-I", INCLUDE, "-I", CSRC, "-I", EMU_DIR,
+             "-pthread", "-Wno-unused-result", "-fno-strict-aliasing"]
+    digest = _digest(srcs + _deps() + emu_srcs + [os.path.join(EMU_DIR, "hipemu.h")], " ".join(flags))
+    if not force and _up_to_date(EMU_SO, digest):
+        return EMU_SO
+    objs = []
+    procs = []
+    for s in srcs + emu_srcs:
+        o = os.path.join(EMU_DIR, os.path.basename(s) + ".emu.o")
+        objs.append(o)
+        cmd = ["g++", "-x", "c++", "-c", s, "-o", o] + [f for f in flags if f != "-shared"]
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for pr, s in zip(procs, srcs + emu_srcs):
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            sys.stderr.write(out)
+            raise RuntimeError("g++ (emu) failed on " + s)
+    _run(["g++", "-shared", "-fPIC", "-pthread", "-o", EMU_SO] + objs)
+    with open(EMU_SO + ".sha256", "w") as f:
+        f.write(digest)
+    return EMU_SO
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["hip"]
+    if "hip" in which:
+        print(build_hip(force="--force" in which, verbose=True))
+    if "emu" in which:
+        print(build_emu(force="--force" in which))

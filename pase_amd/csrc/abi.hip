@@ -1,0 +1,10 @@
+// abi.hip -- ABI self-description so the Python ctypes mirror can verify struct layouts at load.
+#include "hip_compat.h"
+#include "pase_amd.h"
+
+extern "C" int pase_abi_sizeof(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(PaseConvGemm);
+        default: return -1;
+    }
+}

@@ -1,0 +1,55 @@
+// hip_compat.h -- the one place that differs between the real gfx950 build (hipcc) and the
+// CPU SIMT-emulator build used by the `-m "not gpu"` kernel tests (tests/hipemu, -DPASE_HIPEMU).
+// Kernel sources include only this header.
+#pragma once
+
+#ifdef PASE_HIPEMU
+#include "hipemu.h"
+#define PASE_LAUNCH(kernel, grid, block, stream, ...) \
+    hipemu::launch(grid, block, [=]() { kernel(__VA_ARGS__); })
+__device__ __forceinline__ f32x16 pase_mfma_32x32x2(float a, float b, f32x16 c) {
+    return emu_mfma_32x32x2(a, b, c);
+}
+#else
+#include <hip/hip_runtime.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define PASE_LAUNCH(kernel, grid, block, stream, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
+// v_mfma_f32_32x32x2_f32: exact fp32 (k-ordered fmaf chain), 64 cycles/SIMD, 157 TFLOP/s chip peak.
+// Fragment layout (cdna_hip_programming.md §3): A[i=l&31][k=l>>5], B[k=l>>5][j=l&31],
+// D: col=l&31, row=(reg&3)+8*(reg>>2)+4*(l>>5).
+__device__ __forceinline__ f32x16 pase_mfma_32x32x2(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+#endif
+
+#define PASE_CHECK_LAUNCH()                      \
+    do {                                         \
+        hipError_t e__ = hipGetLastError();      \
+        if (e__ != hipSuccess) return (int)e__;  \
+    } while (0)
+
+__device__ __forceinline__ float pase_wave_sum32(float v) {
+    // sum over the 32 lanes that share (lane>>5); result valid in every lane of the half-wave
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16);
+    return v;
+}
+__device__ __forceinline__ float pase_wave_sum64(float v) {
+    v = pase_wave_sum32(v);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+__device__ __forceinline__ double pase_wave_sum64d(double v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}

@@ -1,0 +1,121 @@
+"""pase_conv_gemm vs torch CPU fp32 reference (F.conv1d / F.conv_transpose1d), on the emulator
+(CPU, `not gpu`) and on the real gfx950 library (`gpu`)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from pase_amd import kernels as K
+
+
+def _tol(dev):
+    return dict(rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,T,S", [
+    (3, 5, 11, 1, 70, 2),       # odd k stride 1: pad (5,5)
+    (4, 70, 11, 2, 64, 3),      # strided: pad (4,5); Cout > 64 -> 128x128 tile
+    (2, 6, 20, 10, 200, 2),     # block-1 shape: k=20 s=10 pad (9,10)
+    (1, 8, 251, 1, 300, 2),     # sinc shape: Cin=1, K=251 (not a multiple of 16)
+    (20, 130, 1, 1, 37, 3),     # 1x1, M spans two row tiles, N ragged
+])
+def test_conv_fwd_reflect(dev, Cin, Cout, k, stride, T, S):
+    torch.manual_seed(0)
+    x = torch.randn(S, Cin, T)
+    w = torch.randn(Cout, Cin, k) * 0.2
+    b = torch.randn(Cout)
+    sc = torch.rand(Cin) + 0.5
+    sh = torch.randn(Cin) * 0.1
+    al = torch.rand(Cin) * 0.5
+    if k > 1:
+        P = (k // 2 - 1, k // 2) if (stride > 1 or k % 2 == 0) else (k // 2, k // 2)
+    else:
+        P = (0, 0)
+    xin = x * sc[None, :, None] + sh[None, :, None]
+    xin = torch.where(xin > 0, xin, xin * al[None, :, None])
+    xp = F.pad(xin, P, mode="reflect") if k > 1 else xin
+    ref = F.conv1d(xp, w, b, stride=stride)
+    Tout = ref.shape[2]
+    y = torch.zeros(S, Cout, Tout, device=dev)
+    nt = K.stat_tiles(Cout, S, Tout)
+    stat = torch.zeros(nt, Cout, 2, device=dev)
+    K.conv_gemm(x.to(dev), w.reshape(Cout, -1).contiguous().to(dev), y, S=S, Cin=Cin, Tin=T, M=Cout,
+                K=Cin * k, taps=k, Ncols=Tout, Tout=Tout, bias=b.to(dev), in_scale=sc.to(dev),
+                in_shift=sh.to(dev), in_alpha=al.to(dev), stat_part=stat, stride=stride, padL=P[0],
+                pad_mode=K.PAD_REFLECT)
+    torch.testing.assert_close(y.cpu(), ref, **_tol(dev))
+    st = stat.cpu().double().sum(0)
+    torch.testing.assert_close(st[:, 0], ref.double().sum((0, 2)), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(st[:, 1], (ref.double() ** 2).sum((0, 2)), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,T,S", [
+    (6, 5, 30, 4, 10, 2),
+    (5, 70, 30, 10, 7, 2),
+    (4, 3, 11, 1, 20, 1),
+])
+def test_conv_transpose_as_pixel_shuffle(dev, Cin, Cout, k, stride, T, S):
+    """nn.ConvTranspose1d(k, stride, padding=(k-stride)//2) == stride-1 conv with stride*Cout rows
+    + pixel-shuffle store (modules.py:558-589 GDeconv1DBlock)."""
+    torch.manual_seed(1)
+    x = torch.randn(S, Cin, T)
+    w = torch.randn(Cin, Cout, k) * 0.2       # ConvTranspose1d weight layout (in, out, k)
+    b = torch.randn(Cout)
+    pad = max(0, (stride - k) // -2)
+    ref = F.conv_transpose1d(x, w, b, stride=stride, padding=pad)
+    Tout = ref.shape[2]
+    R = -(-k // stride)                         # taps per phase
+    # pack: Wp[(p, co), (ci, r)] = w[ci, co, p + stride*r]
+    wp = torch.zeros(stride, Cout, Cin, R)
+    for p in range(stride):
+        for r in range(R):
+            kk = p + stride * r
+            if kk < k:
+                wp[p, :, :, r] = w[:, :, kk].t()
+    wp = wp.reshape(stride * Cout, Cin * R).contiguous()
+    # output u = stride*q + p - pad ; input t = q - r  ->  q ranges over [0, T + R - 1)
+    Ncols = T + R - 1
+    y = torch.full((S, Cout, Tout), 7.0, device=dev)
+    K.conv_gemm(x.to(dev), wp.to(dev), y, S=S, Cin=Cin, Tin=T, M=stride * Cout, K=Cin * R, taps=R,
+                Ncols=Ncols, Tout=Tout, bias=b.to(dev), stride=1, tapstep=-1, padL=0,
+                pad_mode=K.PAD_ZERO, Cout_store=Cout, ps=stride, poff=-pad)
+    torch.testing.assert_close(y.cpu(), ref, **_tol(dev))
+
+
+def test_qrnn_linear_tap_major(dev):
+    """torchqrnn Linear over cat([x_t, x_{t-1}], channel) == k=2 causal conv, tap-major K order."""
+    torch.manual_seed(2)
+    S, Cin, H, T = 2, 6, 9, 33
+    x = torch.randn(S, Cin, T)
+    W = torch.randn(3 * H, 2 * Cin) * 0.3
+    b = torch.randn(3 * H)
+    xm1 = torch.cat([torch.zeros(S, Cin, 1), x[:, :, :-1]], 2)
+    src = torch.cat([x, xm1], 1)                 # (S, 2Cin, T)
+    ref = torch.einsum("ok,skt->sot", W, src) + b[None, :, None]
+    y = torch.zeros(S, 3 * H, T, device=dev)
+    K.conv_gemm(x.to(dev), W.to(dev), y, S=S, Cin=Cin, Tin=T, M=3 * H, K=2 * Cin, taps=2, Ncols=T,
+                Tout=T, bias=b.to(dev), tap_major=1, tapstep=-1, padL=0, pad_mode=K.PAD_ZERO)
+    torch.testing.assert_close(y.cpu(), ref, **_tol(dev))
+
+
+def test_mse_context_epilogue(dev):
+    """Fused MLP-head projection + ContextualizedLoss(MSELoss, r=7) (losses.py:6-37)."""
+    torch.manual_seed(3)
+    B, Cin, D, r, Fr = 3, 10, 5, 7, 21
+    h = torch.randn(B, Cin, Fr)
+    W = torch.randn(D * r, Cin) * 0.3
+    b = torch.randn(D * r)
+    label = torch.randn(B, D, Fr)
+    pred = torch.einsum("ok,bkt->bot", W, h) + b[None, :, None]
+    pad_ = F.pad(label, (r // 2, r // 2))
+    tg = torch.cat([pad_[:, :, t:t + r].contiguous().view(B, -1).unsqueeze(2) for t in range(Fr)], 2)
+    ref_loss = F.mse_loss(pred, tg)
+    y = torch.zeros(B, D * r, Fr, device=dev)
+    g = torch.zeros(B, D * r, Fr, device=dev)
+    acc = torch.zeros(1, dtype=torch.float64, device=dev)
+    n = pred.numel()
+    K.conv_gemm(h.to(dev), W.to(dev), y, S=B, Cin=Cin, Tin=Fr, M=D * r, K=Cin, taps=1, Ncols=Fr, Tout=Fr,
+                bias=b.to(dev), epilogue=K.EPI_MSE_CTX, label=label.to(dev), grad_out=g, loss_acc=acc,
+                grad_scale=2.0 / n, r_ctx=r, label_D=D)
+    torch.testing.assert_close(y.cpu(), pred, **_tol(dev))
+    torch.testing.assert_close((acc.cpu() / n).float()[0], ref_loss, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(g.cpu(), 2.0 * (pred - tg) / n, rtol=1e-4, atol=1e-7)
