@@ -26,6 +26,7 @@ extern "C" {
 
 enum { PASE_PAD_ZERO = 0, PASE_PAD_REFLECT = 1 };
 enum { PASE_EPI_STORE = 0, PASE_EPI_MSE_CTX = 1 };
+enum { PASE_LOSS_NONE = 0, PASE_LOSS_L1 = 1, PASE_LOSS_MSE = 2, PASE_LOSS_BCE_LOGITS = 3 };
 
 /* ------------------------------------------------------------------------------------------
  * pase_conv_gemm -- implicit-GEMM 1-D convolution on v_mfma_f32_32x32x2_f32.
@@ -67,7 +68,126 @@ int pase_conv_gemm(const PaseConvGemm* desc, void* stream);
 /* number of column tiles (= first dim of stat_part) the launch above will use */
 int pase_conv_gemm_stat_tiles(int M, int S, int Ncols, int tile_hint);
 
-/* sizeof() of the ABI structs (0 = PaseConvGemm), for binding self-checks */
+/* ------------------------------------------------------------------------------------------
+ * pase_wgrad_gemm -- weight (+bias) gradient contraction, split-K with fp32 atomics.
+ *
+ *   dw[m, j(ci,kk)] += sum_{s,q} g[s, g_coff+m, q] * Z~[s, z_coff+ci, q*stride + kk*tapstep - padL]
+ *   dbias[m]        += sum_{s,q} g[s, g_coff+m, q]                       (if dbias != NULL)
+ *
+ * Replaces the conv1d / conv_transpose1d / linear weight-gradient kernels autograd dispatches for
+ * `tot_loss.backward()` (WorkerScheduler/worker_scheduler.py:67).  The caller zeroes dw / dbias.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct PaseWgrad {
+    const float* g;        /* (S, g_ctot, Tg): rows [g_coff, g_coff+M), first Ncols time steps      */
+    const float* z;        /* (S, z_ctot, Tz): channels [z_coff, z_coff+Cin), on-load transform     */
+    float* dw;             /* (M, ldw) row-major, column j = ci*taps+kk (or kk*Cin+ci)              */
+    float* dbias;          /* (M) or NULL                                                         */
+    const float* in_scale; const float* in_shift; const float* in_alpha;   /* (Cin) or NULL        */
+    int S, M, Tg, g_ctot, g_coff, Ncols;
+    int Cin, Tz, z_ctot, z_coff, taps, tap_major, stride, tapstep, padL, pad_mode, ldw;
+    int splitk;            /* 0 = auto                                                            */
+} PaseWgrad;
+int pase_wgrad_gemm(const PaseWgrad* desc, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm1d (training-mode batch statistics) pieces.  Reference: nn.BatchNorm1d built by
+ * build_norm_layer (pase/models/modules.py:77-79), applied in FeBlock.forward (:1072-1074) and as
+ * norm_out (frontend.py:206-210,267-268; affine=False -> gamma = beta = NULL).
+ * pase_bn_finalize turns the per-tile (sum, sumsq) partials written by pase_conv_gemm into the
+ * on-load affine (scale = gamma*rstd, shift = beta - mean*scale), saves mean / rstd for backward
+ * and updates running_mean / running_var (momentum, unbiased variance) exactly like torch.
+ * ------------------------------------------------------------------------------------------ */
+int pase_bn_finalize(const float* stat_part, int ntiles, int C, double count, const float* gamma,
+                     const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                     float* scale, float* shift, float* mean_out, float* rstd_out, void* stream);
+
+/* out[s, o_coff+c, f] = mean_{i<d} act(bn(y[s, c, f*d+i])): WaveFe.fuse_skip's
+ * skip.view(b, f, T//d, d).mean(3) (pase/models/frontend.py:213-232), applied BEFORE the 1x1
+ * dense-skip projection (mean-pool and a bias-free 1x1 conv commute exactly). */
+int pase_bn_act_pool(const float* y, float* out, const float* scale, const float* shift, const float* alpha,
+                     int S, int C, int T, int F, int d, int o_ctot, int o_coff, void* stream);
+
+/* out = act(bn(y)) materialised (public encoder output after norm_out; API-compat activations) */
+int pase_bn_act_apply(const float* y, float* out, const float* scale, const float* shift, const float* alpha,
+                      int S, int C, int T, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Backward of  a = PReLU(BN(y))  (either stage optional).  The gradient w.r.t. `a` is assembled
+ * on the fly from (1) the data-gradient a pase_conv_gemm dgrad launch wrote in padded
+ * coordinates -- reflect padding folds mirrored edges back, the autograd of
+ * F.pad(mode='reflect') at modules.py:1071 -- and (2) the pooled dense-skip gradient
+ * (autograd of fuse_skip's mean, frontend.py:225-226).
+ *   reduce: sums[c] = { sum dz, sum dz*xhat, sum dA*z*[z<=0] }  (doubles, caller zeroes)
+ *           -> dbeta = sums[.,0], dgamma = sums[.,1], dalpha = sums[.,2]
+ *   apply : dy = scale*(dz - sums0/N - xhat*sums1/N)  (has_bn)   or   dy = dz
+ * ------------------------------------------------------------------------------------------ */
+typedef struct PaseActBwd {
+    const float* y;        /* (S, C, T) raw layer output                                          */
+    const float* dsrc;     /* (S, dsrc_ctot, Tp) padded data-gradient, or NULL                    */
+    const float* dpool;    /* (S, dpool_ctot, pool_F) pooled-branch gradient, or NULL             */
+    const float* scale; const float* shift; const float* alpha;   /* forward on-load params, NULL = identity */
+    const float* mean; const float* rstd;                         /* from pase_bn_finalize (has_bn) */
+    double* sums;          /* (C, 3)                                                              */
+    float* dy;             /* (S, C, T) output of the apply pass                                  */
+    int S, C, T;
+    int dsrc_ctot, dsrc_coff, Tp, padL, pad_mode;
+    int dpool_ctot, dpool_coff, pool_F, pool_d;
+    float pool_inv;        /* 1 / pool_d                                                          */
+    int has_bn;
+} PaseActBwd;
+int pase_act_bwd_reduce(const PaseActBwd* desc, void* stream);
+int pase_act_bwd_apply(const PaseActBwd* desc, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * QRNN (third-party salesforce/pytorch-qrnn; call sites pase/models/modules.py:48-53,
+ * frontend.py:256-259): gates (S, 3H, F) in chunk order Z | F | O.
+ *   fwd: C_t = sig(F_t)*tanh(Z_t) + (1-sig(F_t))*C_{t-1}, H_t = sig(O_t)*C_t  (C_{-1} = 0)
+ *        h_out (S, h_ctot, F) at channel offset h_coff, c_out (S, H, F) saved for backward.
+ *   bwd: d(gates) from dH.
+ * ------------------------------------------------------------------------------------------ */
+int pase_qrnn_scan_fwd(const float* gates, float* h_out, float* c_out, int S, int H, int F, int h_ctot,
+                       int h_coff, void* stream);
+int pase_qrnn_scan_bwd(const float* gates, const float* c_saved, const float* dh, float* dgates, int S, int H,
+                       int F, int dh_ctot, int dh_coff, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Single-output heads + losses.
+ *   pase_head1_fwd: y[s,t] = bias + sum_c w[c]*act(z[s,c,t]) (final Conv1d(hidden,1,1) of
+ *     DecoderMinion / MLPMinion, Minions/minions.py:431,:510) fused with L1 / MSE /
+ *     BCE-with-logits against `target` (S,1,T): loss_acc += sum(loss), dy = dloss/dy * grad_scale.
+ *   pase_head1_bwd: dz (S,C,T), sums = {dw[c], dalpha[c], -} x C then db at sums[3*C].
+ *   pase_ctx_loss : ContextualizedLoss.__call__ (pase/losses.py:33-37) on a materialised
+ *     prediction (B, M, F); r_ctx > 1 gathers the target with contextualize_r's stacking (:14-31).
+ * ------------------------------------------------------------------------------------------ */
+int pase_head1_fwd(const float* z, const float* in_scale, const float* in_shift, const float* in_alpha,
+                   const float* w, const float* bias, const float* target, float* y, float* dy, double* loss_acc,
+                   int S, int C, int T, int loss_type, float grad_scale, void* stream);
+int pase_head1_bwd(const float* z, const float* in_alpha, const float* w, const float* dy, float* dz,
+                   double* sums, int S, int C, int T, void* stream);
+int pase_ctx_loss(const float* pred, const float* label, float* dpred, double* loss_acc, int B, int M, int F,
+                  int r_ctx, int label_D, int loss_type, float grad_scale, void* stream);
+
+/* Sinc band-pass bank: SincConv_fast.forward filter synthesis (pase/models/modules.py:881-915) and
+ * its gradient w.r.t. low_hz_ / band_hz_.  n_ and window_ are the module's constant buffers. */
+int pase_sinc_filters(const float* low_hz_, const float* band_hz_, const float* n_, const float* window_,
+                      float* filt, int C, int Kw, float min_low, float min_band, float sr, void* stream);
+int pase_sinc_filters_bwd(const float* low_hz_, const float* band_hz_, const float* n_, const float* window_,
+                          const float* dfilt, float* dlow, float* dband, int C, int Kw, float min_low,
+                          float min_band, float sr, void* stream);
+
+/* dst[(p*O + o), (red*taps_p + j)] = src[red*s_red + o*s_out + (p + st*j)*s_k]  (0 beyond k),
+ * taps_p = ceil(k/st): the A operand that turns pase_conv_gemm into the data-gradient of a strided
+ * conv / the forward of nn.ConvTranspose1d (phase decomposition). */
+int pase_pack_dgrad(const float* src, float* dst, int R, int O, int k, int st, long s_red, long s_out, long s_k,
+                    void* stream);
+
+/* torch.optim.Adam (defaults; WorkerScheduler/trainer.py:91,111,134) over flat buffers; lr and step
+ * are device scalars so a captured hipGraph stays valid.  grad_mul pre-scales g (1/world_size). */
+int pase_adam_step(float* p, const float* g, float* m, float* v, long n, const float* lr, const int* step,
+                   float beta1, float beta2, float eps, float grad_mul, void* stream);
+int pase_step_tick(int* step, void* stream);
+
+/* sizeof() of the ABI structs (0 = PaseConvGemm, 1 = PaseWgrad, 2 = PaseActBwd), for binding self-checks */
 int pase_abi_sizeof(int which);
 
 #ifdef __cplusplus

@@ -5,6 +5,8 @@
 extern "C" int pase_abi_sizeof(int which) {
     switch (which) {
         case 0: return (int)sizeof(PaseConvGemm);
+        case 1: return (int)sizeof(PaseWgrad);
+        case 2: return (int)sizeof(PaseActBwd);
         default: return -1;
     }
 }

@@ -1,0 +1,272 @@
+// norm_act.hip -- the HBM-bound kernels around the contractions: BatchNorm statistics finalisation,
+// dense-skip mean-pooling, normalise(+PReLU) materialisation, and the BatchNorm+PReLU backward
+// (reduce + apply) with the reflect-pad fold and the pooled dense-skip gradient merged in.
+//
+// Reference semantics: nn.BatchNorm1d in training mode (pase/models/modules.py:79 via
+// build_norm_layer, applied in FeBlock.forward :1072-1074; frontend.py:206-210 norm_out with
+// affine=False), nn.PReLU (modules.py:111-113), fuse_skip's view(...).mean(3)
+// (pase/models/frontend.py:213-232) and F.pad(mode='reflect') (modules.py:1061-1071), whose
+// autograd backward adds the mirrored edge gradients back onto the interior.
+//
+// Roofline: every kernel here streams each tensor once with consecutive lanes on consecutive
+// addresses; they are priced against HBM bandwidth (bytes = 4 * elements touched).
+#include "hip_compat.h"
+#include "pase_amd.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ double block_sum_d(double v, double* sh) {
+    // sh: >= NT/64 doubles of LDS
+    v = pase_wave_sum64d(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) t += sh[w];
+    return t;
+}
+
+// ---- E1: finalise batch statistics -> on-load affine (scale, shift), running stats -------------
+__global__ void __launch_bounds__(NT) bn_finalize_kernel(const float* stat_part, int ntiles, int C, double count,
+                                                         const float* gamma, const float* beta, float eps,
+                                                         float momentum, float* running_mean, float* running_var,
+                                                         float* scale, float* shift, float* mean_out,
+                                                         float* rstd_out) {
+    __shared__ double sh[NT / 64];
+    const int c = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = threadIdx.x; t < ntiles; t += NT) {
+        const float* q = stat_part + ((size_t)t * C + c) * 2;
+        s1 += (double)q[0];
+        s2 += (double)q[1];
+    }
+    s1 = block_sum_d(s1, sh);
+    s2 = block_sum_d(s2, sh);
+    if (threadIdx.x == 0) {
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        const double g = gamma ? (double)gamma[c] : 1.0;
+        const double b = beta ? (double)beta[c] : 0.0;
+        scale[c] = (float)(g * rstd);
+        shift[c] = (float)(b - mean * g * rstd);
+        mean_out[c] = (float)mean;
+        rstd_out[c] = (float)rstd;
+        if (running_mean) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+            running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+        }
+    }
+}
+
+// ---- E2: dense-skip pooling  P[s, c, f] = mean_i act(bn(y[s, c, f*d + i])) ----------------------
+// G lanes cooperate on one output (G = 64 for d >= 64 so the 786 MB block-0 tensor is read coalesced)
+template <int G>
+__global__ void __launch_bounds__(NT) bn_act_pool_kernel(const float* y, float* out, const float* scale,
+                                                         const float* shift, const float* alpha, int S, int C,
+                                                         int T, int F, int d, int o_ctot, int o_coff) {
+    const long nout = (long)S * C * F;
+    const long gid = ((long)blockIdx.x * NT + threadIdx.x) / G;
+    const int gl = threadIdx.x % G;
+    const bool ok = gid < nout;
+    const long g = ok ? gid : 0;
+    const int f = (int)(g % F);
+    const long sc_ = g / F;
+    const int c = (int)(sc_ % C);
+    const int s = (int)(sc_ / C);
+    const float a = scale ? scale[c] : 1.f, b = shift ? shift[c] : 0.f;
+    const float al = alpha ? alpha[c] : 1.f;
+    const float* row = y + ((size_t)s * C + c) * (size_t)T + (size_t)f * d;
+    float acc = 0.f;
+    if (ok)
+        for (int i = gl; i < d; i += G) {
+            float v = row[i] * a + b;
+            v = v > 0.f ? v : v * al;
+            acc += v;
+        }
+    if (G > 1) {
+#pragma unroll
+        for (int m = 1; m < G; m <<= 1) acc += __shfl_xor(acc, m);
+    }
+    if (ok && gl == 0) out[((size_t)s * o_ctot + o_coff + c) * (size_t)F + f] = acc / (float)d;
+}
+
+// ---- E3: materialise  out = act(bn(y))  (public outputs: the embedding; API-compat activations) --
+__global__ void __launch_bounds__(NT) bn_act_apply_kernel(const float* y, float* out, const float* scale,
+                                                          const float* shift, const float* alpha, int C, int T,
+                                                          long total) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int c = (int)((i / T) % C);
+        float v = y[i];
+        if (scale) v = v * scale[c] + shift[c];
+        if (alpha) v = v > 0.f ? v : v * alpha[c];
+        out[i] = v;
+    }
+}
+
+// ---- gradient w.r.t. the post-activation tensor, assembled from its producers -------------------
+//   * dsrc: data-gradient written by conv_gemm in *padded* coordinates (length Tp, left pad padL);
+//           reflect padding folds the mirrored edges back (autograd of F.pad(mode='reflect')),
+//   * dpool: gradient of the mean-pooled dense-skip branch, broadcast back over its d inputs.
+__device__ __forceinline__ float grad_post_act(const PaseActBwd& p, int s, int c, int t) {
+    float v = 0.f;
+    if (p.dsrc) {
+        const float* row = p.dsrc + ((size_t)s * p.dsrc_ctot + p.dsrc_coff + c) * (size_t)p.Tp;
+        const int i = t + p.padL;
+        if (i < p.Tp) v = row[i];
+        if (p.pad_mode == PASE_PAD_REFLECT) {
+            const int padR = p.Tp - p.T - p.padL;
+            if (t >= 1 && t <= p.padL) v += row[p.padL - t];
+            if (t >= p.T - 1 - padR && t <= p.T - 2) v += row[p.padL + 2 * (p.T - 1) - t];
+        }
+    }
+    if (p.dpool) {
+        const int f = t / p.pool_d;
+        if (f < p.pool_F) v += p.dpool[((size_t)s * p.dpool_ctot + p.dpool_coff + c) * (size_t)p.pool_F + f] * p.pool_inv;
+    }
+    return v;
+}
+
+// ---- E4: reduce pass.  sums[c] = { sum dz, sum dz*xhat, sum dA*z*[z<=0] } ------------------------
+__global__ void __launch_bounds__(NT) act_bwd_reduce_kernel(PaseActBwd p, int chunks) {
+    __shared__ double sh[NT / 64];
+    const int row = blockIdx.x / chunks;      // (s, c)
+    const int ch = blockIdx.x % chunks;
+    const int s = row / p.C, c = row % p.C;
+    const float a = p.scale ? p.scale[c] : 1.f, b = p.shift ? p.shift[c] : 0.f;
+    const float al = p.alpha ? p.alpha[c] : 1.f;
+    const float mean = p.mean ? p.mean[c] : 0.f, rstd = p.rstd ? p.rstd[c] : 1.f;
+    const float* yrow = p.y + ((size_t)s * p.C + c) * (size_t)p.T;
+    const int per = (p.T + chunks - 1) / chunks;
+    const int t0 = ch * per, t1 = min(p.T, t0 + per);
+    double s_dz = 0.0, s_dzx = 0.0, s_da = 0.0;
+    for (int t = t0 + threadIdx.x; t < t1; t += NT) {
+        const float yv = yrow[t];
+        const float z = yv * a + b;
+        const float dA = grad_post_act(p, s, c, t);
+        const float dz = z > 0.f ? dA : dA * al;
+        const float xhat = (yv - mean) * rstd;
+        s_dz += (double)dz;
+        s_dzx += (double)(dz * xhat);
+        if (!(z > 0.f)) s_da += (double)(dA * z);
+    }
+    s_dz = block_sum_d(s_dz, sh);
+    s_dzx = block_sum_d(s_dzx, sh);
+    s_da = block_sum_d(s_da, sh);
+    if (threadIdx.x == 0) {
+        atomicAdd(p.sums + (size_t)c * 3 + 0, s_dz);
+        atomicAdd(p.sums + (size_t)c * 3 + 1, s_dzx);
+        atomicAdd(p.sums + (size_t)c * 3 + 2, s_da);
+    }
+}
+
+// ---- E5: apply pass.  dy = scale * (dz - mean(dz) - xhat * mean(dz*xhat))   (BN)  or  dy = dz ----
+__global__ void __launch_bounds__(NT) act_bwd_apply_kernel(PaseActBwd p, int chunks) {
+    const int row = blockIdx.x / chunks;
+    const int ch = blockIdx.x % chunks;
+    const int s = row / p.C, c = row % p.C;
+    const float a = p.scale ? p.scale[c] : 1.f, b = p.shift ? p.shift[c] : 0.f;
+    const float al = p.alpha ? p.alpha[c] : 1.f;
+    const float mean = p.mean ? p.mean[c] : 0.f, rstd = p.rstd ? p.rstd[c] : 1.f;
+    float m1 = 0.f, m2 = 0.f;
+    if (p.has_bn) {
+        const double n = (double)p.S * (double)p.T;
+        m1 = (float)(p.sums[(size_t)c * 3 + 0] / n);
+        m2 = (float)(p.sums[(size_t)c * 3 + 1] / n);
+    }
+    const float* yrow = p.y + ((size_t)s * p.C + c) * (size_t)p.T;
+    float* drow = p.dy + ((size_t)s * p.C + c) * (size_t)p.T;
+    const int per = (p.T + chunks - 1) / chunks;
+    const int t0 = ch * per, t1 = min(p.T, t0 + per);
+    for (int t = t0 + threadIdx.x; t < t1; t += NT) {
+        const float yv = yrow[t];
+        const float z = yv * a + b;
+        const float dA = grad_post_act(p, s, c, t);
+        const float dz = z > 0.f ? dA : dA * al;
+        float out = dz;
+        if (p.has_bn) {
+            const float xhat = (yv - mean) * rstd;
+            out = a * (dz - m1 - xhat * m2);
+        }
+        drow[t] = out;
+    }
+}
+
+}  // namespace
+
+extern "C" int pase_bn_finalize(const float* stat_part, int ntiles, int C, double count, const float* gamma,
+                                const float* beta, float eps, float momentum, float* running_mean,
+                                float* running_var, float* scale, float* shift, float* mean_out, float* rstd_out,
+                                void* stream) {
+    if (C <= 0) return 0;
+    PASE_LAUNCH(bn_finalize_kernel, dim3(C), dim3(NT), (hipStream_t)stream, stat_part, ntiles, C, count, gamma,
+                beta, eps, momentum, running_mean, running_var, scale, shift, mean_out, rstd_out);
+    PASE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pase_bn_act_pool(const float* y, float* out, const float* scale, const float* shift,
+                                const float* alpha, int S, int C, int T, int F, int d, int o_ctot, int o_coff,
+                                void* stream) {
+    if (F * d > T) return -2;
+    const long nout = (long)S * C * F;
+    if (nout <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (d >= 64) {
+        const long blocks = (nout * 64 + NT - 1) / NT;
+        PASE_LAUNCH((bn_act_pool_kernel<64>), dim3((unsigned)blocks), dim3(NT), st, y, out, scale, shift, alpha, S, C, T, F, d, o_ctot, o_coff);
+    } else if (d >= 16) {
+        const long blocks = (nout * 16 + NT - 1) / NT;
+        PASE_LAUNCH((bn_act_pool_kernel<16>), dim3((unsigned)blocks), dim3(NT), st, y, out, scale, shift, alpha, S, C, T, F, d, o_ctot, o_coff);
+    } else {
+        const long blocks = (nout + NT - 1) / NT;
+        PASE_LAUNCH((bn_act_pool_kernel<1>), dim3((unsigned)blocks), dim3(NT), st, y, out, scale, shift, alpha, S, C, T, F, d, o_ctot, o_coff);
+    }
+    PASE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pase_bn_act_apply(const float* y, float* out, const float* scale, const float* shift,
+                                 const float* alpha, int S, int C, int T, void* stream) {
+    const long total = (long)S * C * T;
+    if (total <= 0) return 0;
+    long blocks = (total + NT - 1) / NT;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    PASE_LAUNCH(bn_act_apply_kernel, dim3((unsigned)blocks), dim3(NT), (hipStream_t)stream, y, out, scale, shift,
+                alpha, C, T, total);
+    PASE_CHECK_LAUNCH();
+    return 0;
+}
+
+static int act_bwd_chunks(int T) {
+    int chunks = (T + 4095) / 4096;
+    return chunks < 1 ? 1 : chunks;
+}
+
+extern "C" int pase_act_bwd_reduce(const PaseActBwd* d, void* stream) {
+    const PaseActBwd p = *d;
+    if (!p.sums || !p.y) return -2;
+    const long rows = (long)p.S * p.C;
+    if (rows <= 0 || p.T <= 0) return 0;
+    const int chunks = act_bwd_chunks(p.T);
+    PASE_LAUNCH(act_bwd_reduce_kernel, dim3((unsigned)(rows * chunks)), dim3(NT), (hipStream_t)stream, p, chunks);
+    PASE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pase_act_bwd_apply(const PaseActBwd* d, void* stream) {
+    const PaseActBwd p = *d;
+    if (!p.dy || !p.y || (p.has_bn && !p.sums)) return -2;
+    const long rows = (long)p.S * p.C;
+    if (rows <= 0 || p.T <= 0) return 0;
+    const int chunks = act_bwd_chunks(p.T);
+    PASE_LAUNCH(act_bwd_apply_kernel, dim3((unsigned)(rows * chunks)), dim3(NT), (hipStream_t)stream, p, chunks);
+    PASE_CHECK_LAUNCH();
+    return 0;
+}

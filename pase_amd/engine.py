@@ -1,0 +1,403 @@
+"""Hand-scheduled forward / backward of the PASE(+) encoder and workers on the HIP kernels.
+
+This module is the MI355X-native replacement for what autograd + cuDNN/cuBLAS + torchqrnn do in
+the reference: every contraction is one `pase_conv_gemm` /
+`pase_wgrad_gemm` launch, every BatchNorm / PReLU is folded into the consumer's load, and the
+backward pass is an explicit schedule (no autograd graph).  It reads parameters from the
+reference-compatible nn.Modules in `pase_amd.frontend` / `pase_amd.minions` and accumulates
+gradients straight into their `.grad` buffers (which may be views of one flat buffer).
+
+Layout: all tensors NCT fp32; "Act" = a raw stored tensor + the per-channel affine / PReLU that the
+next consumer applies on load.
+"""
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import kernels as K
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+@dataclass
+class Act:
+    t: torch.Tensor                       # (S, ctot, T) raw values
+    C: int
+    coff: int = 0
+    scale: Optional[torch.Tensor] = None  # (C) on-load affine
+    shift: Optional[torch.Tensor] = None
+    alpha: Optional[torch.Tensor] = None  # (C) on-load PReLU slope
+
+    @property
+    def S(self):
+        return self.t.shape[0]
+
+    @property
+    def ctot(self):
+        return self.t.shape[1]
+
+    @property
+    def T(self):
+        return self.t.shape[2]
+
+
+def _new(shape, like, dtype=torch.float32):
+    return torch.empty(shape, device=like.device, dtype=dtype)
+
+
+def _zeros(shape, like, dtype=torch.float32):
+    return torch.zeros(shape, device=like.device, dtype=dtype)
+
+
+# =========================================================================================
+# primitive layers
+# =========================================================================================
+def reflect_pads(k, stride):
+    """FeBlock.forward padding rule (pase/models/modules.py:1059-1071), dilation 1."""
+    if k <= 1:
+        return 0, 0
+    if stride > 1 or k % 2 == 0:
+        return k // 2 - 1, k // 2
+    return k // 2, k // 2
+
+
+def conv_fwd(a: Act, w2d, bias, *, Cout, taps, stride=1, padL=0, padR=0, pad_mode=K.PAD_ZERO, want_stats=False,
+             tap_major=0, tapstep=1, out=None, out_coff=0, Tout=None):
+    """y[s,co,t] = b + sum w[co,(ci,kk)] * a~[s,ci,t*stride + kk*tapstep - padL]."""
+    S, Tin = a.S, a.T
+    if Tout is None:
+        Tout = (Tin + padL + padR - taps) // stride + 1
+    y = out if out is not None else _new((S, Cout, Tout), a.t)
+    stat = None
+    if want_stats:
+        stat = _new((K.stat_tiles(Cout, S, Tout), Cout, 2), a.t)
+    K.conv_gemm(a.t, w2d, y, S=S, Cin=a.C, Tin=Tin, M=Cout, K=a.C * taps, taps=taps, Ncols=Tout, Tout=Tout,
+                ldw=w2d.shape[1], bias=bias, in_scale=a.scale, in_shift=a.shift, in_alpha=a.alpha, stat_part=stat,
+                x_ctot=a.ctot, x_coff=a.coff, tap_major=tap_major, stride=stride, tapstep=tapstep, padL=padL,
+                pad_mode=pad_mode, y_ctot=y.shape[1], y_coff=out_coff, Cout_store=Cout)
+    return y, stat
+
+
+def conv_dgrad(dy, w_nat, *, R, O, k, stride, Tin, padL, padR, s_red, s_out, s_k):
+    """Data-gradient of a (strided) conv in *padded* coordinates: (S, O, Tin+padL+padR).
+    dXpad[s,o,u] = sum_{red,kk} W[red,o,kk] * dy[s,red,(u-kk)/stride]  (phase decomposition)."""
+    S, _, Tg = dy.shape
+    taps_p = -(-k // stride)
+    wp = _new((stride * O, R * taps_p), dy)
+    K.pack_dgrad(w_nat, wp, R=R, O=O, k=k, st=stride, s_red=s_red, s_out=s_out, s_k=s_k)
+    Tp = Tin + padL + padR
+    Ncols = -(-Tp // stride)
+    dx = _new((S, O, Tp), dy)
+    K.conv_gemm(dy, wp, dx, S=S, Cin=R, Tin=Tg, M=stride * O, K=R * taps_p, taps=taps_p, Ncols=Ncols, Tout=Tp,
+                stride=1, tapstep=-1, padL=0, pad_mode=K.PAD_ZERO, Cout_store=O, ps=stride, poff=0)
+    return dx
+
+
+def conv_wgrad(dy, a: Act, dw2d, dbias, *, taps, stride=1, padL=0, pad_mode=K.PAD_ZERO, tap_major=0, tapstep=1,
+               g_ctot=None, g_coff=0, M=None, Ncols=None):
+    S = a.S
+    M = dy.shape[1] if M is None else M
+    K.wgrad_gemm(dy, a.t, dw2d, S=S, M=M, Tg=dy.shape[2], Ncols=dy.shape[2] if Ncols is None else Ncols, Cin=a.C,
+                 Tz=a.T, taps=taps, ldw=dw2d.shape[1], dbias=dbias, g_ctot=dy.shape[1] if g_ctot is None else g_ctot,
+                 g_coff=g_coff, z_ctot=a.ctot, z_coff=a.coff, in_scale=a.scale, in_shift=a.shift, in_alpha=a.alpha,
+                 tap_major=tap_major, stride=stride, tapstep=tapstep, padL=padL, pad_mode=pad_mode)
+
+
+def deconv_fwd(a: Act, w_nat, bias, *, Cout, k, stride):
+    """nn.ConvTranspose1d(Cin, Cout, k, stride, padding=max(0,(stride-k)//-2)) (modules.py:567-575)."""
+    S, Tin = a.S, a.T
+    pad = max(0, (stride - k) // -2)
+    taps_p = -(-k // stride)
+    wp = _new((stride * Cout, a.C * taps_p), a.t)
+    K.pack_dgrad(w_nat, wp, R=a.C, O=Cout, k=k, st=stride, s_red=Cout * k, s_out=k, s_k=1)
+    Tout = (Tin - 1) * stride - 2 * pad + k
+    y = _new((S, Cout, Tout), a.t)
+    K.conv_gemm(a.t, wp, y, S=S, Cin=a.C, Tin=Tin, M=stride * Cout, K=a.C * taps_p, taps=taps_p,
+                Ncols=Tin + taps_p - 1, Tout=Tout, bias=bias, in_scale=a.scale, in_shift=a.shift, in_alpha=a.alpha,
+                x_ctot=a.ctot, x_coff=a.coff, stride=1, tapstep=-1, padL=0, pad_mode=K.PAD_ZERO, Cout_store=Cout,
+                ps=stride, poff=-pad)
+    return y
+
+
+def bn_train(stat, C, count, norm, like):
+    """Batch-statistics BatchNorm1d: returns (scale, shift, mean, rstd); updates running stats."""
+    scale, shift, mean, rstd = (_new((C,), like) for _ in range(4))
+    gamma = norm.weight if norm.affine else None
+    beta = norm.bias if norm.affine else None
+    mom = norm.momentum if norm.momentum is not None else 0.0
+    K.bn_finalize(stat, C, count, gamma, beta, norm.eps, mom, norm.running_mean, norm.running_var, scale, shift,
+                  mean, rstd)
+    if norm.num_batches_tracked is not None:
+        norm.num_batches_tracked.add_(1)
+    return scale, shift, mean, rstd
+
+
+def bn_eval(norm):
+    rstd = torch.rsqrt(norm.running_var + norm.eps)
+    if norm.affine:
+        scale = norm.weight.detach() * rstd
+        shift = norm.bias.detach() - norm.running_mean * scale
+    else:
+        scale = rstd
+        shift = -norm.running_mean * scale
+    return scale.contiguous(), shift.contiguous(), norm.running_mean, rstd
+
+
+def act_backward(y, *, C, T, S, has_bn, scale=None, shift=None, alpha=None, mean=None, rstd=None, dsrc=None,
+                 dsrc_ctot=None, dsrc_coff=0, Tp=None, padL=0, pad_mode=K.PAD_ZERO, dpool=None, dpool_ctot=0,
+                 dpool_coff=0, pool_F=0, pool_d=1):
+    """Backward of a = PReLU(BN(y)): returns (dy, sums) with sums (C,3) double =
+    {dbeta | sum dz, dgamma, dalpha}."""
+    sums = _zeros((C, 3), y, torch.float64)
+    dy = _new(tuple(y.shape), y)
+    kw = dict(S=S, C_=C, T=T, dsrc=dsrc, dsrc_ctot=dsrc_ctot, dsrc_coff=dsrc_coff, Tp=Tp, padL=padL,
+              pad_mode=pad_mode, dpool=dpool, dpool_ctot=dpool_ctot, dpool_coff=dpool_coff, pool_F=pool_F,
+              pool_d=pool_d, scale=scale, shift=shift, alpha=alpha, mean=mean, rstd=rstd, sums=sums, dy=dy,
+              has_bn=1 if has_bn else 0)
+    K.act_bwd_reduce(y, **kw)
+    K.act_bwd_apply(y, **kw)
+    return dy, sums
+
+
+class GradSink:
+    """Where parameter gradients go.  direct=True: accumulate straight into param.grad (the fused
+    trainer zeroes one flat buffer per step and lets the wgrad kernels add into views of it);
+    direct=False: collect fresh buffers (returned to autograd by the API-compat Functions)."""
+
+    def __init__(self, direct=True):
+        self.direct = direct
+        self.store = {}
+
+    def buf(self, p):
+        if self.direct and p.requires_grad:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            return p.grad
+        b = self.store.get(p)
+        if b is None:
+            b = torch.zeros_like(p)
+            self.store[p] = b
+        return b
+
+    def add(self, p, value):
+        self.buf(p).add_(value.reshape(p.shape))
+
+    def get(self, p):
+        return self.store.get(p)
+
+
+# =========================================================================================
+# encoder (WaveFe)
+# =========================================================================================
+class EncoderCtx:
+    pass
+
+
+def encoder_forward(fe, x, training, need_ctx=True):
+    """WaveFe.forward on a (S,1,T) tensor (pase/models/frontend.py:234-279 minus the dict plumbing).
+    Returns (emb (S,emb_dim,F), ctx)."""
+    assert x.dim() == 3 and x.shape[1] == fe.num_inputs, x.shape
+    x = x.contiguous()
+    S = x.shape[0]
+    ctx = EncoderCtx()
+    ctx.x = x
+    ctx.blocks = []
+    cur = Act(x, C=x.shape[1])
+    for n, blk in enumerate(fe.blocks):
+        rec = {}
+        k, st = blk.kwidth, blk.stride
+        if blk.sincnet:
+            conv = blk.conv
+            kk = conv.kernel_size
+            filt = _new((conv.out_channels, kk), x)
+            conv.n_ = conv.n_.to(x.device)
+            conv.window_ = conv.window_.to(x.device)
+            K.sinc_filters(conv.low_hz_, conv.band_hz_, conv.n_, conv.window_, filt, C_=conv.out_channels, Kw=kk,
+                           min_low=float(conv.min_low_hz), min_band=float(conv.min_band_hz),
+                           sr=float(conv.sample_rate))
+            if st > 1:
+                pL, pR = kk // 2 - 1, kk // 2
+            else:
+                pL, pR = kk // 2, kk // 2
+            w2d, bias, taps = filt, None, kk
+            rec["filt"] = filt
+        else:
+            pL, pR = reflect_pads(k, st)
+            w2d, bias, taps = blk.conv.weight.view(blk.fmaps, -1), blk.conv.bias, k
+        has_bn = blk.norm is not None
+        y, stat = conv_fwd(cur, w2d, bias, Cout=blk.fmaps, taps=taps, stride=st, padL=pL, padR=pR,
+                           pad_mode=K.PAD_REFLECT, want_stats=has_bn and training)
+        if has_bn:
+            if training:
+                scale, shift, mean, rstd = bn_train(stat, blk.fmaps, S * y.shape[2], blk.norm, x)
+            else:
+                scale, shift, mean, rstd = bn_eval(blk.norm)
+        else:
+            scale = shift = mean = rstd = None
+        rec.update(inp=cur, y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, padL=pL, padR=pR, taps=taps,
+                   has_bn=has_bn)
+        ctx.blocks.append(rec)
+        cur = Act(y, C=blk.fmaps, scale=scale, shift=shift, alpha=blk.act.weight)
+    F_ = cur.T
+    ctx.F = F_
+
+    # ---- QRNN stack (frontend.py:256-259; third-party torchqrnn) -------------------------------
+    ctx.rnn = []
+    skips = fe.denseskips_on
+    emb = fe.W.out_channels
+    if skips:
+        ccat = fe.W.in_channels + sum(b.fmaps for b in fe.blocks[:-1])
+        acat = _new((S, ccat, F_), x)
+    rnn_in = cur
+    if fe.rnn_pool:
+        layers = fe.rnn.layers
+        for li, layer in enumerate(layers):
+            H = layer.hidden_size
+            gates, _ = conv_fwd(rnn_in, layer.linear.weight, layer.linear.bias, Cout=3 * H, taps=2, tap_major=1,
+                                tapstep=-1, padL=0, padR=0, pad_mode=K.PAD_ZERO, Tout=F_)
+            last = li == len(layers) - 1
+            if last and skips:
+                h_t, h_ctot = acat, ccat
+            else:
+                h_t, h_ctot = _new((S, H, F_), x), H
+            c = _new((S, H, F_), x)
+            K.qrnn_scan_fwd(gates, h_t, c, S=S, H=H, F=F_, h_ctot=h_ctot, h_coff=0)
+            ctx.rnn.append(dict(inp=rnn_in, gates=gates, c=c, H=H))
+            rnn_in = Act(h_t, C=H)
+    elif skips:
+        # no RNN but dense skips: materialise act(bn(y_last)) into the concat buffer (pool with d=1)
+        K.bn_act_pool(cur.t, acat, cur.scale, cur.shift, cur.alpha, S=S, C_=cur.C, T=F_, F=F_, d=1, o_ctot=ccat,
+                      o_coff=0)
+        rnn_in = Act(acat, C=cur.C)
+
+    # ---- dense skips: mean-pool each block's activation to the frame rate, then ONE 1x1 GEMM over the
+    # concatenated channels (pool-then-project == project-then-pool for a bias-free 1x1 conv) -------
+    if skips:
+        off = fe.W.in_channels
+        ctx.skip_off = []
+        for n, blk in enumerate(fe.blocks[:-1]):
+            rec = ctx.blocks[n]
+            Tn = rec["y"].shape[2]
+            d = Tn // F_
+            K.bn_act_pool(rec["y"], acat, rec["scale"], rec["shift"], blk.act.weight, S=S, C_=blk.fmaps, T=Tn,
+                          F=F_, d=d, o_ctot=ccat, o_coff=off)
+            ctx.skip_off.append((off, d))
+            off += blk.fmaps
+        wcat = torch.cat([fe.W.weight.view(emb, -1)] + [p.weight.view(emb, -1) for p in fe.denseskips], dim=1)
+        ain = Act(acat, C=ccat)
+    else:
+        wcat = fe.W.weight.view(emb, -1)
+        ain = rnn_in
+    norm_out = fe.norm_out_mod
+    yemb, stat = conv_fwd(ain, wcat, fe.W.bias, Cout=emb, taps=1, want_stats=(norm_out is not None and training),
+                          Tout=F_)
+    if norm_out is not None:
+        if training:
+            scale, shift, mean, rstd = bn_train(stat, emb, S * F_, norm_out, x)
+        else:
+            scale, shift, mean, rstd = bn_eval(norm_out)
+        out = _new((S, emb, F_), x)
+        K.bn_act_apply(yemb, out, scale, shift, None, S=S, C_=emb, T=F_)
+        ctx.out_bn = (scale, shift, mean, rstd)
+    else:
+        out = yemb
+        ctx.out_bn = None
+    ctx.ain, ctx.wcat, ctx.yemb = ain, wcat, yemb
+    return out, ctx
+
+
+def encoder_backward(fe, ctx, demb, sink):
+    """Accumulates d(loss)/d(param) into `sink` given demb = d(loss)/d(emb)."""
+    demb = demb.contiguous()
+    x = ctx.x
+    S, F_ = x.shape[0], ctx.F
+    emb = fe.W.out_channels
+    # ---- norm_out (BatchNorm1d affine=False) -----------------------------------------------------
+    if ctx.out_bn is not None:
+        scale, shift, mean, rstd = ctx.out_bn
+        dyemb, _ = act_backward(ctx.yemb, C=emb, T=F_, S=S, has_bn=True, scale=scale, shift=shift, mean=mean,
+                                rstd=rstd, dsrc=demb)
+    else:
+        dyemb = demb
+    # ---- W + dense-skip projections: one wgrad + one dgrad over the concatenated channels --------
+    ain = ctx.ain
+    ccat = ain.C
+    dwcat = _zeros((emb, ccat), x)
+    conv_wgrad(dyemb, ain, dwcat, sink.buf(fe.W.bias), taps=1)
+    cw = fe.W.in_channels
+    sink.add(fe.W.weight, dwcat[:, :cw].contiguous())
+    if fe.denseskips_on:
+        off = cw
+        for p in fe.denseskips:
+            c = p.weight.shape[1]
+            sink.add(p.weight, dwcat[:, off:off + c].contiguous())
+            off += c
+    dacat = conv_dgrad(dyemb, ctx.wcat, R=emb, O=ccat, k=1, stride=1, Tin=F_, padL=0, padR=0, s_red=ccat, s_out=1,
+                       s_k=1)  # (S, ccat, F)
+    # gradient w.r.t. the last block's activation
+    dsrc, dsrc_ctot, dsrc_coff = dacat, ccat, 0
+    # ---- QRNN stack --------------------------------------------------------------------------------
+    for li in reversed(range(len(ctx.rnn))):
+        r = ctx.rnn[li]
+        layer = fe.rnn.layers[li]
+        H = r["H"]
+        dgates = _new((S, 3 * H, F_), x)
+        K.qrnn_scan_bwd(r["gates"], r["c"], dsrc, dgates, S=S, H=H, F=F_, dh_ctot=dsrc_ctot, dh_coff=dsrc_coff)
+        inp = r["inp"]
+        conv_wgrad(dgates, inp, sink.buf(layer.linear.weight), sink.buf(layer.linear.bias), taps=2, tap_major=1,
+                   tapstep=-1, padL=0, pad_mode=K.PAD_ZERO)
+        cin = inp.C
+        # dX[s,ci,u] = sum_{o,r} Wq[o, r*cin+ci] * dG[s,o,u+r]
+        wp = _new((cin, 3 * H * 2), x)
+        K.pack_dgrad(layer.linear.weight, wp, R=3 * H, O=cin, k=2, st=1, s_red=2 * cin, s_out=1, s_k=cin)
+        dxl = _new((S, cin, F_), x)
+        K.conv_gemm(dgates, wp, dxl, S=S, Cin=3 * H, Tin=F_, M=cin, K=3 * H * 2, taps=2, Ncols=F_, Tout=F_,
+                    stride=1, tapstep=1, padL=0, pad_mode=K.PAD_ZERO)
+        dsrc, dsrc_ctot, dsrc_coff = dxl, cin, 0
+    # ---- conv blocks, last to first -----------------------------------------------------------------
+    dsrc_Tp, dsrc_padL, dsrc_mode = F_, 0, K.PAD_ZERO
+    nb = len(fe.blocks)
+    for n in reversed(range(nb)):
+        blk = fe.blocks[n]
+        rec = ctx.blocks[n]
+        y = rec["y"]
+        C, Tn = blk.fmaps, y.shape[2]
+        kw = {}
+        if fe.denseskips_on and n < nb - 1:
+            off, d = ctx.skip_off[n]
+            kw = dict(dpool=dacat, dpool_ctot=ccat, dpool_coff=off, pool_F=F_, pool_d=d)
+        dy, sums = act_backward(y, C=C, T=Tn, S=S, has_bn=rec["has_bn"], scale=rec["scale"], shift=rec["shift"],
+                                alpha=blk.act.weight, mean=rec["mean"], rstd=rec["rstd"], dsrc=dsrc,
+                                dsrc_ctot=dsrc_ctot, dsrc_coff=dsrc_coff, Tp=dsrc_Tp, padL=dsrc_padL,
+                                pad_mode=dsrc_mode, **kw)
+        sums_f = sums.float()
+        if rec["has_bn"] and blk.norm.affine:
+            sink.add(blk.norm.bias, sums_f[:, 0].contiguous())
+            sink.add(blk.norm.weight, sums_f[:, 1].contiguous())
+        sink.add(blk.act.weight, sums_f[:, 2].contiguous())
+        inp = rec["inp"]
+        taps = rec["taps"]
+        if blk.sincnet:
+            conv = blk.conv
+            dfilt = _zeros((C, taps), x)
+            conv_wgrad(dy, inp, dfilt, None, taps=taps, stride=blk.stride, padL=rec["padL"], pad_mode=K.PAD_REFLECT)
+            dlow, dband = _new((C,), x), _new((C,), x)
+            K.sinc_filters_bwd(conv.low_hz_, conv.band_hz_, conv.n_, conv.window_, dfilt, dlow, dband, C_=C, Kw=taps,
+                               min_low=float(conv.min_low_hz), min_band=float(conv.min_band_hz),
+                               sr=float(conv.sample_rate))
+            sink.add(conv.low_hz_, dlow)
+            sink.add(conv.band_hz_, dband)
+        else:
+            dbias = sink.buf(blk.conv.bias) if rec["has_bn"] else None
+            conv_wgrad(dy, inp, sink.buf(blk.conv.weight).view(C, -1), dbias, taps=taps, stride=blk.stride,
+                       padL=rec["padL"], pad_mode=K.PAD_REFLECT)
+            if not rec["has_bn"]:
+                sink.add(blk.conv.bias, sums_f[:, 0].contiguous())
+        if n > 0:
+            cin = inp.C
+            dsrc = conv_dgrad(dy, blk.conv.weight, R=C, O=cin, k=taps, stride=blk.stride, Tin=inp.T,
+                              padL=rec["padL"], padR=rec["padR"], s_red=cin * taps, s_out=taps, s_k=1)
+            dsrc_ctot, dsrc_coff = cin, 0
+            dsrc_Tp, dsrc_padL, dsrc_mode = dsrc.shape[2], rec["padL"], K.PAD_REFLECT

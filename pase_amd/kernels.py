@@ -45,6 +45,7 @@ def declare(l):
         fn = getattr(l, name)
         fn.argtypes = args
         fn.restype = C.c_int
+    abi_check(l)
 
 
 # name -> argtypes for the flat (non-struct) entry points; filled in below
@@ -104,3 +105,179 @@ def conv_gemm(x, w, y, *, S, Cin, Tin, M, K, taps, Ncols, Tout, ldw=None, bias=N
     d.epilogue, d.r_ctx, d.label_D = epilogue, r_ctx, label_D
     d.tile_hint = tile_hint
     _check(_lib.lib().pase_conv_gemm(C.byref(d), _stream()), "pase_conv_gemm")
+
+
+# ======================================================================================
+# wgrad
+# ======================================================================================
+class PaseWgrad(C.Structure):
+    _fields_ = [
+        ("g", _fp), ("z", _fp), ("dw", _fp), ("dbias", _fp),
+        ("in_scale", _fp), ("in_shift", _fp), ("in_alpha", _fp),
+        ("S", C.c_int), ("M", C.c_int), ("Tg", C.c_int), ("g_ctot", C.c_int), ("g_coff", C.c_int),
+        ("Ncols", C.c_int),
+        ("Cin", C.c_int), ("Tz", C.c_int), ("z_ctot", C.c_int), ("z_coff", C.c_int), ("taps", C.c_int),
+        ("tap_major", C.c_int), ("stride", C.c_int), ("tapstep", C.c_int), ("padL", C.c_int),
+        ("pad_mode", C.c_int), ("ldw", C.c_int), ("splitk", C.c_int),
+    ]
+
+
+class PaseActBwd(C.Structure):
+    _fields_ = [
+        ("y", _fp), ("dsrc", _fp), ("dpool", _fp),
+        ("scale", _fp), ("shift", _fp), ("alpha", _fp), ("mean", _fp), ("rstd", _fp),
+        ("sums", _fp), ("dy", _fp),
+        ("S", C.c_int), ("C", C.c_int), ("T", C.c_int),
+        ("dsrc_ctot", C.c_int), ("dsrc_coff", C.c_int), ("Tp", C.c_int), ("padL", C.c_int),
+        ("pad_mode", C.c_int),
+        ("dpool_ctot", C.c_int), ("dpool_coff", C.c_int), ("pool_F", C.c_int), ("pool_d", C.c_int),
+        ("pool_inv", C.c_float), ("has_bn", C.c_int),
+    ]
+
+
+_i, _f, _d, _l = C.c_int, C.c_float, C.c_double, C.c_long
+_SIMPLE.update({
+    "pase_wgrad_gemm": [C.POINTER(PaseWgrad), _fp],
+    "pase_bn_finalize": [_fp, _i, _i, _d, _fp, _fp, _f, _f, _fp, _fp, _fp, _fp, _fp, _fp, _fp],
+    "pase_bn_act_pool": [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp],
+    "pase_bn_act_apply": [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp],
+    "pase_act_bwd_reduce": [C.POINTER(PaseActBwd), _fp],
+    "pase_act_bwd_apply": [C.POINTER(PaseActBwd), _fp],
+    "pase_qrnn_scan_fwd": [_fp, _fp, _fp, _i, _i, _i, _i, _i, _fp],
+    "pase_qrnn_scan_bwd": [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp],
+    "pase_head1_fwd": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _f, _fp],
+    "pase_head1_bwd": [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp],
+    "pase_ctx_loss": [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, _fp],
+    "pase_sinc_filters": [_fp, _fp, _fp, _fp, _fp, _i, _i, _f, _f, _f, _fp],
+    "pase_sinc_filters_bwd": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _f, _f, _f, _fp],
+    "pase_pack_dgrad": [_fp, _fp, _i, _i, _i, _i, _l, _l, _l, _fp],
+    "pase_adam_step": [_fp, _fp, _fp, _fp, _l, _fp, _fp, _f, _f, _f, _f, _fp],
+    "pase_step_tick": [_fp, _fp],
+})
+
+LOSS_NONE, LOSS_L1, LOSS_MSE, LOSS_BCE = 0, 1, 2, 3
+
+
+def abi_check(l):
+    if l.pase_abi_sizeof(1) != C.sizeof(PaseWgrad):
+        raise _lib.PaseLibraryError("ABI mismatch: PaseWgrad")
+    if l.pase_abi_sizeof(2) != C.sizeof(PaseActBwd):
+        raise _lib.PaseLibraryError("ABI mismatch: PaseActBwd")
+
+
+def wgrad_gemm(g, z, dw, *, S, M, Tg, Ncols, Cin, Tz, taps, ldw=None, dbias=None, g_ctot=None, g_coff=0,
+               z_ctot=None, z_coff=0, in_scale=None, in_shift=None, in_alpha=None, tap_major=0, stride=1,
+               tapstep=1, padL=0, pad_mode=PAD_ZERO, splitk=0):
+    d = PaseWgrad()
+    d.g, d.z, d.dw, d.dbias = _ptr(g), _ptr(z), _ptr(dw), _ptr(dbias)
+    d.in_scale, d.in_shift, d.in_alpha = _ptr(in_scale), _ptr(in_shift), _ptr(in_alpha)
+    d.S, d.M, d.Tg, d.Ncols = S, M, Tg, Ncols
+    d.g_ctot = M if g_ctot is None else g_ctot
+    d.g_coff = g_coff
+    d.Cin, d.Tz = Cin, Tz
+    d.z_ctot = Cin if z_ctot is None else z_ctot
+    d.z_coff = z_coff
+    d.taps, d.tap_major, d.stride, d.tapstep, d.padL, d.pad_mode = taps, tap_major, stride, tapstep, padL, pad_mode
+    d.ldw = Cin * taps if ldw is None else ldw
+    d.splitk = splitk
+    _check(_lib.lib().pase_wgrad_gemm(C.byref(d), _stream()), "pase_wgrad_gemm")
+
+
+def bn_finalize(stat_part, C_, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift,
+                mean_out, rstd_out):
+    _check(_lib.lib().pase_bn_finalize(_ptr(stat_part), stat_part.shape[0], C_, float(count), _ptr(gamma),
+                                       _ptr(beta), eps, momentum, _ptr(running_mean), _ptr(running_var),
+                                       _ptr(scale), _ptr(shift), _ptr(mean_out), _ptr(rstd_out), _stream()),
+           "pase_bn_finalize")
+
+
+def bn_act_pool(y, out, scale, shift, alpha, *, S, C_, T, F, d, o_ctot, o_coff):
+    _check(_lib.lib().pase_bn_act_pool(_ptr(y), _ptr(out), _ptr(scale), _ptr(shift), _ptr(alpha), S, C_, T, F, d,
+                                       o_ctot, o_coff, _stream()), "pase_bn_act_pool")
+
+
+def bn_act_apply(y, out, scale, shift, alpha, *, S, C_, T):
+    _check(_lib.lib().pase_bn_act_apply(_ptr(y), _ptr(out), _ptr(scale), _ptr(shift), _ptr(alpha), S, C_, T,
+                                        _stream()), "pase_bn_act_apply")
+
+
+def _act_bwd_desc(y, *, S, C_, T, dsrc=None, dsrc_ctot=None, dsrc_coff=0, Tp=None, padL=0, pad_mode=PAD_ZERO,
+                  dpool=None, dpool_ctot=0, dpool_coff=0, pool_F=0, pool_d=1, scale=None, shift=None, alpha=None,
+                  mean=None, rstd=None, sums=None, dy=None, has_bn=0):
+    d = PaseActBwd()
+    d.y, d.dsrc, d.dpool = _ptr(y), _ptr(dsrc), _ptr(dpool)
+    d.scale, d.shift, d.alpha, d.mean, d.rstd = _ptr(scale), _ptr(shift), _ptr(alpha), _ptr(mean), _ptr(rstd)
+    d.sums = _ptr(sums, torch.float64)
+    d.dy = _ptr(dy)
+    d.S, d.C, d.T = S, C_, T
+    d.dsrc_ctot = C_ if dsrc_ctot is None else dsrc_ctot
+    d.dsrc_coff = dsrc_coff
+    d.Tp = T if Tp is None else Tp
+    d.padL, d.pad_mode = padL, pad_mode
+    d.dpool_ctot, d.dpool_coff, d.pool_F, d.pool_d = dpool_ctot, dpool_coff, pool_F, max(1, pool_d)
+    d.pool_inv = 1.0 / max(1, pool_d)
+    d.has_bn = has_bn
+    return d
+
+
+def act_bwd_reduce(y, **kw):
+    d = _act_bwd_desc(y, **kw)
+    _check(_lib.lib().pase_act_bwd_reduce(C.byref(d), _stream()), "pase_act_bwd_reduce")
+
+
+def act_bwd_apply(y, **kw):
+    d = _act_bwd_desc(y, **kw)
+    _check(_lib.lib().pase_act_bwd_apply(C.byref(d), _stream()), "pase_act_bwd_apply")
+
+
+def qrnn_scan_fwd(gates, h_out, c_out, *, S, H, F, h_ctot, h_coff):
+    _check(_lib.lib().pase_qrnn_scan_fwd(_ptr(gates), _ptr(h_out), _ptr(c_out), S, H, F, h_ctot, h_coff, _stream()),
+           "pase_qrnn_scan_fwd")
+
+
+def qrnn_scan_bwd(gates, c_saved, dh, dgates, *, S, H, F, dh_ctot, dh_coff):
+    _check(_lib.lib().pase_qrnn_scan_bwd(_ptr(gates), _ptr(c_saved), _ptr(dh), _ptr(dgates), S, H, F, dh_ctot,
+                                         dh_coff, _stream()), "pase_qrnn_scan_bwd")
+
+
+def head1_fwd(z, w, bias, *, S, C_, T, in_scale=None, in_shift=None, in_alpha=None, target=None, y=None, dy=None,
+              loss_acc=None, loss_type=LOSS_NONE, grad_scale=0.0):
+    _check(_lib.lib().pase_head1_fwd(_ptr(z), _ptr(in_scale), _ptr(in_shift), _ptr(in_alpha), _ptr(w), _ptr(bias),
+                                     _ptr(target), _ptr(y), _ptr(dy), _ptr(loss_acc, torch.float64), S, C_, T,
+                                     loss_type, grad_scale, _stream()), "pase_head1_fwd")
+
+
+def head1_bwd(z, in_alpha, w, dy, dz, sums, *, S, C_, T):
+    _check(_lib.lib().pase_head1_bwd(_ptr(z), _ptr(in_alpha), _ptr(w), _ptr(dy), _ptr(dz),
+                                     _ptr(sums, torch.float64), S, C_, T, _stream()), "pase_head1_bwd")
+
+
+def ctx_loss(pred, label, dpred, loss_acc, *, B, M, F, r_ctx, label_D, loss_type, grad_scale):
+    _check(_lib.lib().pase_ctx_loss(_ptr(pred), _ptr(label), _ptr(dpred), _ptr(loss_acc, torch.float64), B, M, F,
+                                    r_ctx, label_D, loss_type, grad_scale, _stream()), "pase_ctx_loss")
+
+
+def sinc_filters(low, band, n_, window_, filt, *, C_, Kw, min_low, min_band, sr):
+    _check(_lib.lib().pase_sinc_filters(_ptr(low), _ptr(band), _ptr(n_), _ptr(window_), _ptr(filt), C_, Kw,
+                                        min_low, min_band, sr, _stream()), "pase_sinc_filters")
+
+
+def sinc_filters_bwd(low, band, n_, window_, dfilt, dlow, dband, *, C_, Kw, min_low, min_band, sr):
+    _check(_lib.lib().pase_sinc_filters_bwd(_ptr(low), _ptr(band), _ptr(n_), _ptr(window_), _ptr(dfilt),
+                                            _ptr(dlow), _ptr(dband), C_, Kw, min_low, min_band, sr, _stream()),
+           "pase_sinc_filters_bwd")
+
+
+def pack_dgrad(src, dst, *, R, O, k, st, s_red, s_out, s_k):
+    _check(_lib.lib().pase_pack_dgrad(_ptr(src), _ptr(dst), R, O, k, st, s_red, s_out, s_k, _stream()),
+           "pase_pack_dgrad")
+
+
+def adam_step(p, g, m, v, lr, step, *, beta1=0.9, beta2=0.999, eps=1e-8, grad_mul=1.0):
+    _check(_lib.lib().pase_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(lr),
+                                     _ptr(step, torch.int32), beta1, beta2, eps, grad_mul, _stream()),
+           "pase_adam_step")
+
+
+def step_tick(step):
+    _check(_lib.lib().pase_step_tick(_ptr(step, torch.int32), _stream()), "pase_step_tick")

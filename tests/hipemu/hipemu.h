@@ -177,3 +177,6 @@ inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 inline float __expf(float x) { return expf(x); }
 inline float __fdividef(float a, float b) { return a / b; }
 inline double rsqrt(double x) { return 1.0 / sqrt(x); }
+#include <algorithm>
+using std::min;
+using std::max;
