@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""bench.py -- PASE+ self-supervised training step on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = forward (SincNet + conv stack + QRNN + dense skips) + 12 worker heads + losses +
+backward + gradient all-reduce (N>1) + 13 Adam updates, on a synthetic batch already resident in
+HBM: cfg/frontend/PASE+.cfg + cfg/workers/workers+.cfg, bs32 per GPU, 32 000-sample chunks
+(BASELINE.json configs[2]); regression targets are N(0,1) tensors ("targets-given" mode of
+SURVEY.md section 8d).  Prints ONE JSON line from rank 0.
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_UTT_TRAIN = 122.0      # SURVEY.md 8(d) / BASELINE.md section 3: canonical algorithmic FLOPs
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def load_cfgs():
+    with open(os.path.join(ROOT, "cfg", "frontend", "PASE+.cfg")) as f:
+        fe = json.load(f)
+    from pase_amd.utils import strip_transforms, worker_parser
+    wk = strip_transforms(worker_parser(os.path.join(ROOT, "cfg", "workers", "workers+.cfg")))
+    with open(os.path.join(ROOT, "cfg", "workers", "workers+.cfg")) as f:
+        raw = json.load(f)
+    return fe, wk, raw
+
+
+def synthetic_batch(seed, B, T, raw, device):
+    g = torch.Generator(device=device).manual_seed(seed)
+    batch = {k: (0.1 * torch.randn(B, 1, T, generator=g, device=device)).clamp_(-1, 1)
+             for k in ("chunk", "chunk_ctxt", "chunk_rand", "cchunk")}
+    for w in raw["regr"]:
+        if w["name"] not in batch:
+            batch[w["name"]] = torch.randn(B, w["num_outputs"], T // 160, generator=g, device=device)
+    return batch
+
+
+def cpu_baseline(raw, fe_cfg, seconds_budget=25.0):
+    """The CPU oracle (port of the reference step: oracle/pase_oracle.py) timed on the host cores on a
+    bounded sample: full-width PASE+ / workers+ model, B=2 utterances x 32 000 samples, fwd + losses
+    + backward + Adam, as many steps as fit the budget (>= 1 after one warm-up)."""
+    from oracle import pase_oracle as O
+    from pase_amd.pase import pase
+    from pase_amd.utils import strip_transforms, worker_parser
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(2)
+    with contextlib.redirect_stdout(io.StringIO()):
+        wk = strip_transforms(worker_parser(os.path.join(ROOT, "cfg", "workers", "workers+.cfg")))
+        model = pase(frontend_cfg=dict(fe_cfg), minions_cfg=wk, cls_lst=["mi", "cmi"],
+                     regr_lst=[w["name"] for w in raw["regr"]])
+    P = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    names = [n for n, _ in model.named_parameters()]
+    for n in names:
+        P[n].requires_grad_(True)
+    opt = torch.optim.Adam([P[n] for n in names], lr=5e-4)
+    B, T = 2, 32000
+    batch = synthetic_batch(99, B, T, raw, torch.device("cpu"))
+
+    def step():
+        opt.zero_grad()
+        so = {}
+        h, chunk, preds, labels = O.pase_forward(P, fe_cfg, raw, batch, True, so)
+        O.pase_losses(raw, preds, labels)["total"].backward()
+        opt.step()
+
+    step()
+    t0 = time.time()
+    n = 0
+    while True:
+        step()
+        n += 1
+        if time.time() - t0 > seconds_budget or n >= 20:
+            break
+    dt = (time.time() - t0) / n
+    return {"value": round(B / dt, 4), "unit": "utterances/s", "cores": cores, "kind": "port",
+            "sample": "oracle/pase_oracle.py (torch-CPU restatement of the reference step) full-width PASE+ + "
+                      "workers+, B=%d x %d samples, %d timed steps after 1 warm-up, %d threads" % (B, T, n, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--chunk", type=int, default=32000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py ...")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from pase_amd import _lib
+    _lib.lib()   # fail loudly if the HIP library is missing
+    from pase_amd.trainer import trainer
+
+    fe_cfg, wk_cfg, raw = load_cfgs()
+    torch.manual_seed(2)             # train.py:376 default seed
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr = trainer(frontend_cfg=dict(fe_cfg), minions_cfg=wk_cfg,
+                     cfg=dict(fe_lr=1e-3, min_lr=5e-4, epoch=1, bpe=max(1, args.steps + args.warmup)),
+                     lr_mode="poly", device=dev)
+    B, T = args.batch, args.chunk
+    batch = synthetic_batch(1234 + rank, B, T, raw, dev)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        losses = tr.train_step(batch)
+    sync()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.time()
+    ev0.record()
+    for _ in range(args.steps):
+        losses = tr.train_step(batch)
+    ev1.record()
+    sync()
+    dt = time.time() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    utt_s = B * world * args.steps / dt
+    total_loss = float(losses["total"])
+
+    if rank == 0:
+        achieved = GFLOP_PER_UTT_TRAIN * utt_s / world / 1e3     # TFLOP/s per GPU (algorithmic)
+        out = {
+            "metric": "utterances/sec (PASE+ bs32 32k-sample chunks; encoder-frames/sec = 600 x)",
+            "value": round(utt_s, 3), "unit": "utterances/s",
+            "encoder_frames_per_s": round(utt_s * 3 * (T // 160), 1),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "PASE+.cfg + workers+.cfg self-supervised train step (BASELINE.json configs[2])",
+                       "batch_per_gpu": B, "global_batch": B * world, "chunk_samples": T,
+                       "targets": "given (N(0,1) tensors resident in HBM)", "parallelism": "dp%d" % world,
+                       "final_total_loss": round(total_loss, 5)},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "note": "whole-step algorithmic fp32 FLOPs (122.0 GFLOP/utterance, SURVEY 8d) / step time, "
+                                 "per GPU; per-kernel numbers in profiles/"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(raw, fe_cfg)
+            except Exception as e:  # the baseline leg must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "unit": "utterances/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

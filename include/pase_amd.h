@@ -83,6 +83,8 @@ typedef struct PaseWgrad {
     float* dw;             /* (M, ldw) row-major, column j = ci*taps+kk (or kk*Cin+ci)              */
     float* dbias;          /* (M) or NULL                                                         */
     const float* in_scale; const float* in_shift; const float* in_alpha;   /* (Cin) or NULL        */
+    const float* g_alpha;  /* (M) PReLU slope applied to g on load (ConvTranspose1d wgrad: g is the
+                              layer's raw input), or NULL                                         */
     int S, M, Tg, g_ctot, g_coff, Ncols;
     int Cin, Tz, z_ctot, z_coff, taps, tap_major, stride, tapstep, padL, pad_mode, ldw;
     int splitk;            /* 0 = auto                                                            */
@@ -155,7 +157,7 @@ int pase_qrnn_scan_bwd(const float* gates, const float* c_saved, const float* dh
  *   pase_head1_fwd: y[s,t] = bias + sum_c w[c]*act(z[s,c,t]) (final Conv1d(hidden,1,1) of
  *     DecoderMinion / MLPMinion, Minions/minions.py:431,:510) fused with L1 / MSE /
  *     BCE-with-logits against `target` (S,1,T): loss_acc += sum(loss), dy = dloss/dy * grad_scale.
- *   pase_head1_bwd: dz (S,C,T), sums = {dw[c], dalpha[c], -} x C then db at sums[3*C].
+ *   pase_head1_bwd: dz (S,C,T), sums = {dw[c], dalpha[c], sum_st dz[.,c,.]} x C then db at sums[3*C].
  *   pase_ctx_loss : ContextualizedLoss.__call__ (pase/losses.py:33-37) on a materialised
  *     prediction (B, M, F); r_ctx > 1 gathers the target with contextualize_r's stacking (:14-31).
  * ------------------------------------------------------------------------------------------ */

@@ -1,0 +1,158 @@
+"""Generate the golden vectors under tests/golden/ by running the LIVE reference
+(/root/reference, imported through oracle/ref_shim.py) on seeded inputs.
+
+Run in the build container only (the reference tree does not exist on the GPU box):
+    python oracle/make_golden.py
+The .npz files are small and committed; tests compare both the oracle restatement
+(oracle/pase_oracle.py) and the HIP implementation against them.
+
+Weights are NOT stored: the reference builds its modules under torch.manual_seed(seed) and the
+mirrors in pase_amd/ create the same nn.Conv1d / nn.Linear / ... in the same order, so the same seed
+reproduces the same initial weights (checked by tests/test_oracle_pins.py against the checksums
+stored here).
+"""
+import contextlib
+import io
+import json
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_shim  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+REF = ref_shim.REFERENCE_ROOT
+
+
+def seed_all(s):
+    random.seed(s)
+    np.random.seed(s)
+    torch.manual_seed(s)
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def param_checksums(sd):
+    names = list(sd.keys())
+    sums = np.array([float(sd[k].double().sum()) for k in names])
+    sq = np.array([float((sd[k].double() ** 2).sum()) for k in names])
+    return names, sums, sq
+
+
+def gen_sinc():
+    from pase.models.modules import SincConv_fast
+    m = SincConv_fast(1, 64, 251, padding="SAME")
+    x = torch.zeros(1, 1, 400)
+    m(x)
+    np.savez(os.path.join(GOLD, "sinc_init.npz"), low_hz_=m.low_hz_.detach().numpy(),
+             band_hz_=m.band_hz_.detach().numpy(), filters=m.filters.detach().numpy(),
+             window_=m.window_.numpy(), n_=m.n_.numpy())
+    # perturbed parameters (negative values, clamping at sr/2) + gradient of a seeded functional
+    seed_all(5)
+    with torch.no_grad():
+        m.low_hz_.mul_(torch.empty_like(m.low_hz_).uniform_(-1.2, 1.2))
+        m.band_hz_.mul_(torch.empty_like(m.band_hz_).uniform_(-30.0, 30.0))
+    x = torch.randn(2, 1, 700) * 0.5
+    y = m(x)
+    g = torch.randn_like(y)
+    (y * g).sum().backward()
+    np.savez(os.path.join(GOLD, "sinc_perturbed.npz"), low_hz_=m.low_hz_.detach().numpy(),
+             band_hz_=m.band_hz_.detach().numpy(), filters=m.filters.detach().numpy(), x=x.numpy(),
+             y=y.detach().numpy(), g=g.numpy(), dlow=m.low_hz_.grad.numpy(), dband=m.band_hz_.grad.numpy())
+
+
+def gen_wavefe(tag, cfg_file, seed, S, T):
+    from pase.models.frontend import wf_builder
+    seed_all(seed)
+    m = quiet(wf_builder, os.path.join(REF, "cfg", "frontend", cfg_file))
+    names, sums, sq = param_checksums(m.state_dict())
+    seed_all(seed + 1)
+    x = torch.randn(S, 1, T) * 0.1
+    m.train()
+    y_tr = m(x)
+    g = torch.randn_like(y_tr)
+    (y_tr * g).sum().backward()
+    gnames = [n for n, p in m.named_parameters()]
+    gsum = np.array([float(p.grad.double().sum()) for n, p in m.named_parameters()])
+    gsq = np.array([float((p.grad.double() ** 2).sum()) for n, p in m.named_parameters()])
+    rm = {k: v.clone() for k, v in m.state_dict().items() if "running" in k}
+    m.eval()
+    with torch.no_grad():
+        y_ev = m(x)
+        y_avg = m(x, mode="avg_norm")
+    np.savez(os.path.join(GOLD, "wavefe_%s.npz" % tag), seed=seed, S=S, T=T, param_names=np.array(names),
+             param_sum=sums, param_sq=sq, x=x.numpy(), y_train=y_tr.detach().numpy(), g=g.numpy(),
+             grad_names=np.array(gnames), grad_sum=gsum, grad_sq=gsq, y_eval=y_ev.numpy(), y_avg_norm=y_avg.numpy(),
+             running_names=np.array(list(rm.keys())), running_sum=np.array([float(v.double().sum()) for v in rm.values()]))
+
+
+def synthetic_batch(seed, B, T, workers_cfg):
+    """chunk/chunk_ctxt/chunk_rand/cchunk ~ 0.1 N(0,1) clamp +-1; targets ~ N(0,1)."""
+    g = torch.Generator().manual_seed(seed)
+    batch = {k: (0.1 * torch.randn(B, 1, T, generator=g)).clamp_(-1, 1)
+             for k in ("chunk", "chunk_ctxt", "chunk_rand", "cchunk")}
+    for w in workers_cfg["regr"]:
+        if w["name"] not in batch:
+            batch[w["name"]] = torch.randn(B, w["num_outputs"], T // 160, generator=g)
+    return batch
+
+
+def gen_pase_step(seed, B, T):
+    """One reference training step (trainer.py:229-232 -> worker_scheduler._base_scheduler) of
+    PASE+.cfg + workers+.cfg on a seeded synthetic batch: losses, gradient norms, post-Adam norms."""
+    from pase.models.pase import pase
+    from pase.utils import worker_parser
+    from pase.models.WorkerScheduler.worker_scheduler import backprop_scheduler
+    import torch.optim as optim
+    with open(os.path.join(REF, "cfg", "frontend", "PASE+.cfg")) as f:
+        fe_cfg = json.load(f)
+    minions_cfg = quiet(worker_parser, os.path.join(REF, "cfg", "workers", "workers+.cfg"))
+    for _t, lst in minions_cfg.items():
+        for c in lst:
+            c.pop("transform", None)          # train.py:64
+    with open(os.path.join(REF, "cfg", "workers", "workers+.cfg")) as f:
+        raw_cfg = json.load(f)
+    seed_all(seed)
+    model = quiet(pase, frontend_cfg=fe_cfg, minions_cfg=minions_cfg,
+                  cls_lst=[w["name"] for w in raw_cfg["cls"]], regr_lst=[w["name"] for w in raw_cfg["regr"]])
+    names, sums, sq = param_checksums(model.state_dict())
+    batch = synthetic_batch(seed + 1, B, T, raw_cfg)
+    fe_opt = optim.Adam(model.frontend.parameters(), lr=1e-3)
+    cls_opt = {w.name: optim.Adam(w.parameters(), lr=5e-4) for w in model.classification_workers}
+    regr_opt = {w.name: optim.Adam(w.parameters(), lr=5e-4) for w in model.regression_workers}
+    sched = backprop_scheduler(model, mode="base")
+    model.train()
+    h, chunk, preds, labels = model.forward(batch, 1, "cpu")
+    losses, _ = sched(preds, labels, cls_opt, regr_opt, fe_opt, device="cpu")
+    gnames = [n for n, p in model.named_parameters()]
+    gsq = np.array([float((p.grad.double() ** 2).sum()) for n, p in model.named_parameters()])
+    gsum = np.array([float(p.grad.double().sum()) for n, p in model.named_parameters()])
+    post_sq = np.array([float((p.detach().double() ** 2).sum()) for n, p in model.named_parameters()])
+    post_sum = np.array([float(p.detach().double().sum()) for n, p in model.named_parameters()])
+    np.savez(os.path.join(GOLD, "pase_plus_step.npz"), seed=seed, B=B, T=T, param_names=np.array(names),
+             param_sum=sums, param_sq=sq, loss_names=np.array(list(losses.keys())),
+             loss_values=np.array([float(v) for v in losses.values()]), chunk_emb=chunk.detach().numpy(),
+             grad_names=np.array(gnames), grad_sq=gsq, grad_sum=gsum, post_sq=post_sq, post_sum=post_sum,
+             pred_mi=preds["mi"].detach().numpy(), pred_cmi=preds["cmi"].detach().numpy(),
+             pred_cchunk_head=preds["cchunk"].detach().numpy()[:, :, :400],
+             pred_mfcc=preds["mfcc"].detach().numpy())
+
+
+if __name__ == "__main__":
+    ref_shim.install()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(os.cpu_count())
+    gen_sinc()
+    gen_wavefe("pase_plus", "PASE+.cfg", seed=2, S=3, T=8000)
+    gen_wavefe("pase", "PASE.cfg", seed=3, S=3, T=8000)
+    gen_pase_step(seed=2, B=2, T=8000)
+    for f in sorted(os.listdir(GOLD)):
+        print(f, os.path.getsize(os.path.join(GOLD, f)))

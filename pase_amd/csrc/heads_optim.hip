@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(NT) head1_fwd_kernel(const float* z, const flo
 }
 
 // backward of the head: dz[s,c,t] = w[c]*dy[s,t]*prelu'(z);  dw[c] = sum dy*act(z);  db = sum dy;
-// dalpha[c] = sum w[c]*dy*z*[z<=0].  One block per (c, chunk of s*t): reductions stay per channel.
+// dalpha[c] = sum w[c]*dy*z*[z<=0]; sums = (C,3) {dw, dalpha, sum dz} followed by db at [3C].  One block per (c, chunk of s*t): reductions stay per channel.
 __global__ void __launch_bounds__(NT) head1_bwd_kernel(const float* z, const float* in_alpha, const float* w,
                                                        const float* dy, float* dz, double* sums, int S, int C, int T,
                                                        int chunks) {
@@ -96,9 +96,17 @@ __global__ void __launch_bounds__(NT) head1_bwd_kernel(const float* z, const flo
     s_w = block_sum_d(s_w, sh);
     s_a = block_sum_d(s_a, sh);
     s_b = block_sum_d(s_b, sh);
+    // also sum dz per channel (= gradient of the hidden layer's conv bias)
+    double s_z = 0.0;
+    for (long i = i0 + threadIdx.x; i < i1; i += NT) {
+        const int s = (int)(i / T), t = (int)(i % T);
+        s_z += (double)dz[((size_t)s * C + c) * (size_t)T + t];
+    }
+    s_z = block_sum_d(s_z, sh);
     if (threadIdx.x == 0) {
         atomicAdd(sums + (size_t)c * 3 + 0, s_w);
         atomicAdd(sums + (size_t)c * 3 + 1, s_a);
+        atomicAdd(sums + (size_t)c * 3 + 2, s_z);
         if (c == 0) atomicAdd(sums + (size_t)C * 3, s_b);
     }
 }

@@ -83,7 +83,9 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_gemm_kernel(PaseWgrad p, int n
 #pragma unroll
         for (int i = 0; i < A_PER_T; ++i) {
             const int m = m0 + r0 + i * RSTEP;
-            areg[i] = (nok && m < p.M) ? grow[(size_t)m * p.Tg] : 0.f;
+            float gv = (nok && m < p.M) ? grow[(size_t)m * p.Tg] : 0.f;
+            if (p.g_alpha) gv = gv > 0.f ? gv : gv * p.g_alpha[m < p.M ? m : 0];
+            areg[i] = gv;
         }
         const float* zrow = p.z + ((size_t)s * p.z_ctot + p.z_coff) * (size_t)p.Tz;
         const int ubase = q * p.stride - p.padL;

@@ -96,13 +96,14 @@ def conv_dgrad(dy, w_nat, *, R, O, k, stride, Tin, padL, padR, s_red, s_out, s_k
 
 
 def conv_wgrad(dy, a: Act, dw2d, dbias, *, taps, stride=1, padL=0, pad_mode=K.PAD_ZERO, tap_major=0, tapstep=1,
-               g_ctot=None, g_coff=0, M=None, Ncols=None):
+               g_ctot=None, g_coff=0, M=None, Ncols=None, g_alpha=None):
     S = a.S
     M = dy.shape[1] if M is None else M
     K.wgrad_gemm(dy, a.t, dw2d, S=S, M=M, Tg=dy.shape[2], Ncols=dy.shape[2] if Ncols is None else Ncols, Cin=a.C,
                  Tz=a.T, taps=taps, ldw=dw2d.shape[1], dbias=dbias, g_ctot=dy.shape[1] if g_ctot is None else g_ctot,
                  g_coff=g_coff, z_ctot=a.ctot, z_coff=a.coff, in_scale=a.scale, in_shift=a.shift, in_alpha=a.alpha,
-                 tap_major=tap_major, stride=stride, tapstep=tapstep, padL=padL, pad_mode=pad_mode)
+                 tap_major=tap_major, stride=stride, tapstep=tapstep, padL=padL, pad_mode=pad_mode,
+                 g_alpha=g_alpha)
 
 
 def deconv_fwd(a: Act, w_nat, bias, *, Cout, k, stride):
@@ -401,3 +402,167 @@ def encoder_backward(fe, ctx, demb, sink):
                               padL=rec["padL"], padR=rec["padR"], s_red=cin * taps, s_out=taps, s_k=1)
             dsrc_ctot, dsrc_coff = cin, 0
             dsrc_Tp, dsrc_padL, dsrc_mode = dsrc.shape[2], rec["padL"], K.PAD_REFLECT
+
+
+# =========================================================================================
+# workers (Minions): sequential [GDeconv1DBlock | MLPBlock]* -> output conv, with fused losses
+# =========================================================================================
+@dataclass
+class GradSrc:
+    """A data-gradient tensor in (possibly padded) coordinates, as act_backward consumes it."""
+    t: torch.Tensor
+    ctot: int
+    coff: int = 0
+    Tp: int = 0
+    padL: int = 0
+    pad_mode: int = K.PAD_ZERO
+
+    def dense(self, C, T):
+        """(S, C, T) contiguous tensor view/copy (zero-pad mode only)."""
+        assert self.pad_mode == K.PAD_ZERO
+        return self.t[:, self.coff:self.coff + C, self.padL:self.padL + T]
+
+
+LOSS_TYPES = {"L1Loss": K.LOSS_L1, "MSELoss": K.LOSS_MSE, "BCEWithLogitsLoss": K.LOSS_BCE}
+
+
+class WorkerCtx:
+    pass
+
+
+def worker_forward(layers, out_conv, a: Act, *, loss=None, want_pred=True):
+    """Forward of a Minion.  layers: list of GDeconv1DBlock / MLPBlock containers; out_conv: the final
+    nn.Conv1d(hidden, num_outputs*r, 1).  loss: None or dict(name=<nn loss name>, r=<int|None>,
+    target=<tensor>, weight=<float>) -> fused loss + d(loss*weight)/d(pred).
+    Returns ctx with .pred (if materialised), .loss_acc (sum of per-element losses, float64[1]),
+    .numel, .dpred."""
+    ctx = WorkerCtx()
+    ctx.recs = []
+    cur = a
+    for blk in layers:
+        if hasattr(blk, "deconv"):
+            dc = blk.deconv
+            z = deconv_fwd(cur, dc.weight, dc.bias, Cout=dc.out_channels, k=blk.kwidth, stride=blk.stride)
+            ctx.recs.append(("deconv", blk, cur, z))
+            cur = Act(z, C=dc.out_channels, alpha=blk.act.weight)
+        else:
+            k = blk.context
+            z, _ = conv_fwd(cur, blk.W.weight.view(blk.fmaps, -1), blk.W.bias, Cout=blk.fmaps, taps=k, padL=k // 2,
+                            padR=k // 2, pad_mode=K.PAD_ZERO)
+            ctx.recs.append(("conv", blk, cur, z))
+            cur = Act(z, C=blk.fmaps, alpha=blk.act.weight)
+    ctx.last = cur
+    nout = out_conv.out_channels
+    B, T = cur.S, cur.T
+    ctx.numel = B * nout * T
+    ctx.pred = None
+    ctx.dpred = None
+    ctx.loss_acc = None
+    w2d = out_conv.weight.view(nout, -1)
+    if out_conv.kernel_size[0] != 1:
+        raise NotImplementedError("pase_amd worker: output conv with context > 1")
+    if loss is not None:
+        ltype = LOSS_TYPES[loss["name"]]
+        r = loss.get("r")
+        gscale = float(loss.get("weight", 1.0)) / ctx.numel
+        ctx.loss_acc = _zeros((1,), cur.t, torch.float64)
+        ctx.dpred = _new((B, nout, T), cur.t)
+    if nout == 1 and cur.scale is None and cur.coff == 0 and cur.ctot == cur.C:
+        # single-output head: streaming kernel with the loss fused
+        if want_pred:
+            ctx.pred = _new((B, 1, T), cur.t)
+        if loss is not None:
+            if r not in (None, 1):
+                raise NotImplementedError("pase_amd worker: r-context loss on a 1-output head")
+            K.head1_fwd(cur.t, w2d.view(-1), out_conv.bias, S=B, C_=cur.C, T=T, in_alpha=cur.alpha,
+                        target=loss["target"].contiguous(), y=ctx.pred, dy=ctx.dpred, loss_acc=ctx.loss_acc,
+                        loss_type=ltype, grad_scale=gscale)
+        else:
+            K.head1_fwd(cur.t, w2d.view(-1), out_conv.bias, S=B, C_=cur.C, T=T, in_alpha=cur.alpha, y=ctx.pred)
+        ctx.head1 = True
+        return ctx
+    ctx.head1 = False
+    if loss is not None and ltype == K.LOSS_MSE and r not in (None, 1):
+        # projection GEMM with the r-context MSE fused in the epilogue (prediction never stored
+        # unless asked for)
+        if want_pred:
+            ctx.pred = _new((B, nout, T), cur.t)
+        tgt = loss["target"].contiguous()
+        K.conv_gemm(cur.t, w2d, ctx.pred, S=B, Cin=cur.C, Tin=T, M=nout, K=cur.C, taps=1, Ncols=T, Tout=T,
+                    bias=out_conv.bias, in_scale=cur.scale, in_shift=cur.shift, in_alpha=cur.alpha,
+                    x_ctot=cur.ctot, x_coff=cur.coff, epilogue=K.EPI_MSE_CTX, label=tgt, grad_out=ctx.dpred,
+                    loss_acc=ctx.loss_acc, grad_scale=2.0 * gscale, r_ctx=r, label_D=tgt.shape[1])
+        return ctx
+    pred, _ = conv_fwd(cur, w2d, out_conv.bias, Cout=nout, taps=1, Tout=T)
+    ctx.pred = pred
+    if loss is not None:
+        tgt = loss["target"].contiguous()
+        rr = r if r not in (None, 1) else 0
+        K.ctx_loss(pred, tgt, ctx.dpred, ctx.loss_acc, B=B, M=nout, F=T, r_ctx=rr, label_D=tgt.shape[1],
+                   loss_type=ltype, grad_scale=gscale)
+    return ctx
+
+
+def worker_backward(layers, out_conv, ctx, dpred, sink, need_dinput=True):
+    """Backward of a Minion from dpred = d(loss)/d(pred).  Returns GradSrc for the worker input."""
+    cur = ctx.last
+    B, T = cur.S, cur.T
+    nout = out_conv.out_channels
+    x = cur.t
+    if ctx.head1:
+        C = cur.C
+        sums = _zeros((C * 3 + 1,), x, torch.float64)
+        dz = _new((B, C, T), x)
+        K.head1_bwd(cur.t, cur.alpha, out_conv.weight.view(-1), dpred.contiguous(), dz, sums, S=B, C_=C, T=T)
+        sf = sums.float()
+        s3 = sf[:C * 3].view(C, 3)
+        sink.add(out_conv.weight, s3[:, 0].contiguous())
+        sink.add(out_conv.bias, sf[C * 3:])
+        dalpha, dzsum = s3[:, 1].contiguous(), s3[:, 2].contiguous()
+        have_dz = True
+    else:
+        dpred = dpred.contiguous()
+        conv_wgrad(dpred, cur, sink.buf(out_conv.weight).view(nout, -1), sink.buf(out_conv.bias), taps=1)
+        dsrc = GradSrc(conv_dgrad(dpred, out_conv.weight, R=nout, O=cur.C, k=1, stride=1, Tin=T, padL=0, padR=0,
+                                  s_red=cur.C, s_out=1, s_k=1), ctot=cur.C, Tp=T)
+        have_dz = False
+    for kind, blk, inp, z in reversed(ctx.recs):
+        C, Tz = z.shape[1], z.shape[2]
+        if not have_dz:
+            dz, sums = act_backward(z, C=C, T=Tz, S=B, has_bn=False, alpha=blk.act.weight, dsrc=dsrc.t,
+                                    dsrc_ctot=dsrc.ctot, dsrc_coff=dsrc.coff, Tp=dsrc.Tp, padL=dsrc.padL,
+                                    pad_mode=dsrc.pad_mode)
+            sf = sums.float()
+            dzsum, dalpha = sf[:, 0].contiguous(), sf[:, 2].contiguous()
+        have_dz = False
+        sink.add(blk.act.weight, dalpha)
+        if kind == "deconv":
+            dc = blk.deconv
+            k, st = blk.kwidth, blk.stride
+            pad = max(0, (st - k) // -2)
+            cin = inp.C
+            sink.add(dc.bias, dzsum)
+            # dW[ci, co, kk] = sum_{s,t} act(in)[s,ci,t] * dz[s,co,t*st + kk - pad]
+            if inp.scale is not None:
+                raise NotImplementedError("deconv wgrad with an affine on-load input")
+            K.wgrad_gemm(inp.t, dz, sink.buf(dc.weight).view(cin, -1), S=B, M=cin, Tg=inp.T, Ncols=inp.T, Cin=C,
+                         Tz=Tz, taps=k, ldw=C * k, g_ctot=inp.ctot, g_coff=inp.coff, stride=st, tapstep=1, padL=pad,
+                         pad_mode=K.PAD_ZERO, g_alpha=inp.alpha)
+            last = blk is layers[0]
+            if need_dinput or not last:
+                din, _ = conv_fwd(Act(dz, C=C), dc.weight.view(cin, -1), None, Cout=cin, taps=k, stride=st, padL=pad,
+                                  padR=pad, pad_mode=K.PAD_ZERO, Tout=inp.T)
+                dsrc = GradSrc(din, ctot=cin, Tp=inp.T)
+        else:
+            k = blk.context
+            cin = inp.C
+            sink.add(blk.W.bias, dzsum)
+            conv_wgrad(dz, inp, sink.buf(blk.W.weight).view(C, -1), None, taps=k, padL=k // 2, pad_mode=K.PAD_ZERO)
+            last = blk is layers[0]
+            if need_dinput or not last:
+                din = conv_dgrad(dz, blk.W.weight, R=C, O=cin, k=k, stride=1, Tin=inp.T, padL=k // 2, padR=k // 2,
+                                 s_red=cin * k, s_out=k, s_k=1)
+                dsrc = GradSrc(din, ctot=cin, Tp=din.shape[2], padL=k // 2)
+    if len(ctx.recs) == 0 and ctx.head1:
+        raise NotImplementedError("1-output worker without hidden layers")
+    return dsrc if need_dinput else None

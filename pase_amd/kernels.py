@@ -113,7 +113,7 @@ def conv_gemm(x, w, y, *, S, Cin, Tin, M, K, taps, Ncols, Tout, ldw=None, bias=N
 class PaseWgrad(C.Structure):
     _fields_ = [
         ("g", _fp), ("z", _fp), ("dw", _fp), ("dbias", _fp),
-        ("in_scale", _fp), ("in_shift", _fp), ("in_alpha", _fp),
+        ("in_scale", _fp), ("in_shift", _fp), ("in_alpha", _fp), ("g_alpha", _fp),
         ("S", C.c_int), ("M", C.c_int), ("Tg", C.c_int), ("g_ctot", C.c_int), ("g_coff", C.c_int),
         ("Ncols", C.c_int),
         ("Cin", C.c_int), ("Tz", C.c_int), ("z_ctot", C.c_int), ("z_coff", C.c_int), ("taps", C.c_int),
@@ -167,8 +167,9 @@ def abi_check(l):
 
 def wgrad_gemm(g, z, dw, *, S, M, Tg, Ncols, Cin, Tz, taps, ldw=None, dbias=None, g_ctot=None, g_coff=0,
                z_ctot=None, z_coff=0, in_scale=None, in_shift=None, in_alpha=None, tap_major=0, stride=1,
-               tapstep=1, padL=0, pad_mode=PAD_ZERO, splitk=0):
+               tapstep=1, padL=0, pad_mode=PAD_ZERO, splitk=0, g_alpha=None):
     d = PaseWgrad()
+    d.g_alpha = _ptr(g_alpha)
     d.g, d.z, d.dw, d.dbias = _ptr(g), _ptr(z), _ptr(dw), _ptr(dbias)
     d.in_scale, d.in_shift, d.in_alpha = _ptr(in_scale), _ptr(in_shift), _ptr(in_alpha)
     d.S, d.M, d.Tg, d.Ncols = S, M, Tg, Ncols

@@ -1,0 +1,152 @@
+"""Mirror of pase/models/pase.py:241-356 (class `pase`): encoder + regression / contrastive
+workers, `forward(batch_dict, alpha, device) -> (h, chunk, preds, labels)`; plus the fused
+forward+loss+backward schedule used by the trainer (`loss_and_grads`).
+"""
+import torch
+import torch.nn as nn
+
+from . import engine
+from .engine import Act
+from .frontend import wf_builder
+from .minions import cls_worker_maker, make_samples, minion_maker
+from .modules import Model
+
+
+class pase(Model):
+    def __init__(self, frontend=None, frontend_cfg=None, minions_cfg=None, cls_lst=["mi", "cmi", "spc"],
+                 regr_lst=["chunk", "lps", "mfcc", "prosody"], pretrained_ckpt=None, name="adversarial"):
+        super().__init__(name=name)
+        if minions_cfg is None or len(minions_cfg) < 1:
+            raise ValueError("Please specify a stack of minions config with at least 1 minion. "
+                             "GIMME SOMETHING TO DO.")
+        print("pase config ==>", frontend_cfg)
+        self.frontend = wf_builder(frontend_cfg)
+        self.cls_lst = cls_lst
+        self.reg_lst = regr_lst
+        ninp = self.frontend.emb_dim
+        self.regression_workers = nn.ModuleList()
+        self.classification_workers = nn.ModuleList()
+        self.regularizer_workers = []
+        self.fwd_cchunk = False
+        if "concat" in frontend_cfg.keys():
+            raise NotImplementedError("pase_amd pase: 'concat' frontend cfgs")
+        print("==>concat features from {} levels".format(1))
+        print("==>input size for workers: {}".format(ninp))
+        for type, cfg_lst in minions_cfg.items():
+            for cfg in cfg_lst:
+                if type == "cls":
+                    cfg["num_inputs"] = ninp
+                    self.classification_workers.append(cls_worker_maker(cfg, ninp))
+                elif type == "regr":
+                    cfg["num_inputs"] = ninp
+                    self.regression_workers.append(minion_maker(cfg))
+                elif type == "regu":
+                    raise NotImplementedError("pase_amd pase: regularizer workers")
+        if pretrained_ckpt is not None:
+            self.load_pretrained(pretrained_ckpt, load_last=True)
+
+    # ------------------------------------------------------------------------------------------
+    # API-compatible forward (predictions materialised, autograd-capable)
+    # ------------------------------------------------------------------------------------------
+    def forward(self, x, alpha=1, device=None):
+        x_ = dict((k, v) for k, v in x.items())
+        if not self.fwd_cchunk:
+            x_.pop("cchunk", None)
+        h = self.frontend(x_, device)
+        if len(h) > 1:
+            assert len(h) == 2, len(h)
+            h, chunk = h
+        preds, labels = {}, {}
+        for worker in self.regression_workers:
+            preds[worker.name] = worker(chunk, alpha)
+            labels[worker.name] = x[worker.name].to(device).detach()
+        for worker in self.classification_workers:
+            y, label = worker(h, alpha, device=device)
+            preds[worker.name] = y
+            labels[worker.name] = label
+        return h, chunk, preds, labels
+
+    # ------------------------------------------------------------------------------------------
+    # fused training schedule: forward + all losses + backward in one hand-scheduled pass
+    # (what trainer.train_ -> model.forward -> backprop_scheduler._base_scheduler do through
+    # autograd in the reference: trainer.py:229-232, worker_scheduler.py:43-75)
+    # ------------------------------------------------------------------------------------------
+    def loss_and_grads(self, batch, sink=None, device=None, before_encoder_backward=None):
+        """Returns {worker: loss_weight*loss, 'total': sum} (0-dim float64 device tensors) and
+        accumulates every parameter gradient into `sink` (default: param.grad)."""
+        if sink is None:
+            sink = engine.GradSink(direct=True)
+        fe = self.frontend
+        keys = [k for k in ("chunk", "chunk_ctxt", "chunk_rand") if k in batch]
+        if len(keys) != 3:
+            raise ValueError("pase_amd: the fused step needs chunk / chunk_ctxt / chunk_rand")
+        x = torch.cat([batch[k] for k in keys], dim=0)
+        if device is not None:
+            x = x.to(device)
+        emb, ectx = engine.encoder_forward(fe, x, training=fe.training)
+        B = batch["chunk"].shape[0]
+        E, F_ = emb.shape[1], emb.shape[2]
+        demb = torch.zeros_like(emb)
+        losses = {}
+        total = torch.zeros((), dtype=torch.float64, device=emb.device)
+        chunk = emb[:B]
+        for worker in self.regression_workers:
+            loss = worker.loss
+            tgt = batch[worker.name]
+            if device is not None:
+                tgt = tgt.to(device)
+            wctx = engine.worker_forward(list(worker.blocks), worker.W, Act(chunk, C=E),
+                                         loss=dict(name=loss.loss_name, r=loss.r, target=tgt,
+                                                   weight=worker.loss_weight), want_pred=False)
+            dsrc = engine.worker_backward(list(worker.blocks), worker.W, wctx, wctx.dpred, sink)
+            demb[:B] += dsrc.dense(E, F_)
+            l = wctx.loss_acc[0] * (worker.loss_weight / wctx.numel)
+            losses[worker.name] = l
+            total = total + l
+            del wctx, dsrc
+        h = (emb[:B], emb[B:2 * B], emb[2 * B:3 * B])
+        for worker in self.classification_workers:
+            mn = worker.minion
+            loss = worker.loss
+            x_pos, x_neg = make_samples(h, worker.augment)
+            xin = torch.cat((x_pos, x_neg), dim=0)
+            nb = xin.shape[0]
+            if worker.time_mean:
+                xm = torch.empty(nb, 2 * E, 1, device=emb.device)
+                engine.K.bn_act_pool(xin, xm, None, None, None, S=nb, C_=2 * E, T=F_, F=1, d=F_, o_ctot=2 * E,
+                                     o_coff=0)
+                win = xm
+            else:
+                win = xin
+            Tw = win.shape[2]
+            label = torch.cat((torch.ones(nb // 2, 1, Tw, device=emb.device),
+                               torch.zeros(nb // 2, 1, Tw, device=emb.device)), dim=0)
+            wctx = engine.worker_forward(list(mn.blocks), mn.W, Act(win, C=2 * E),
+                                         loss=dict(name=loss.loss_name, r=loss.r, target=label,
+                                                   weight=worker.loss_weight), want_pred=False)
+            dsrc = engine.worker_backward(list(mn.blocks), mn.W, wctx, wctx.dpred, sink)
+            dx = dsrc.dense(2 * E, Tw)
+            if worker.time_mean:
+                dx = (dx / F_).expand(nb, 2 * E, F_)
+            # scatter back through make_samples (cls_minions.py:29-43)
+            half = nb // 2
+            pos, neg = dx[:half], dx[half:]
+            if worker.augment:
+                q = half // 2
+                # pos = [h0|h1 ; h1|h0], neg = [h0|h2 ; h1|h2]
+                demb[:B] += pos[:q, :E] + pos[q:, E:] + neg[:q, :E]
+                demb[B:2 * B] += pos[:q, E:] + pos[q:, :E] + neg[q:, :E]
+                demb[2 * B:] += neg[:q, E:] + neg[q:, E:]
+            else:
+                demb[:B] += pos[:, :E] + neg[:, :E]
+                demb[B:2 * B] += pos[:, E:]
+                demb[2 * B:] += neg[:, E:]
+            l = wctx.loss_acc[0] * (worker.loss_weight / wctx.numel)
+            losses[worker.name] = l
+            total = total + l
+            del wctx, dsrc
+        if before_encoder_backward is not None:
+            before_encoder_backward()   # all worker-head gradients are final here (DDP overlap point)
+        engine.encoder_backward(fe, ectx, demb, sink)
+        losses["total"] = total
+        return losses

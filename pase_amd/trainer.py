@@ -1,0 +1,302 @@
+"""Mirror of pase/models/WorkerScheduler/{trainer,worker_scheduler,lr_scheduler}.py for the
+`--backprop_mode base` path (README.md:129): one Adam + one LR_Scheduler + one Saver per module
+(frontend + each worker: trainer.py:86-143), `_base_scheduler` = sum of weighted losses -> one
+backward -> every optimizer steps (worker_scheduler.py:43-75).
+
+MI355X-native differences (SURVEY.md section 8e -- the reference has NO multi-GPU path):
+  * the step is the hand-scheduled `pase.loss_and_grads` (no autograd graph);
+  * each logical optimizer owns ONE flat fp32 parameter / gradient / moment buffer, so its update is
+    a single `pase_adam_step` launch and the data-parallel exchange is a handful of large RCCL
+    all-reduces over the flat gradient buffers (one process per GPU; xGMI is point-to-point, so few
+    large messages beat many small ones); worker-head gradients are complete before the encoder
+    backward starts, so their all-reduce is issued on a side stream and overlaps it;
+  * BatchNorm uses per-rank batch statistics (there is no SyncBN in the reference to match).
+"""
+import math
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import engine
+from . import kernels as K
+from .modules import Saver
+from .pase import pase
+
+
+class LR_Scheduler(object):
+    """lr_scheduler.py:16-60: 'poly' lr*(1-T/N)^0.9, 'cos', 'step'; sets optimizer.param_groups[0]['lr']."""
+
+    def __init__(self, mode, optim_name, base_lr, num_epochs, iters_per_epoch=0, lr_step=30, warmup_epochs=0):
+        self.mode = mode
+        self.name = optim_name
+        self.lr = base_lr
+        if mode == "step":
+            assert lr_step
+        self.lr_step = lr_step
+        self.iters_per_epoch = iters_per_epoch
+        self.N = num_epochs * iters_per_epoch
+        self.epoch = -1
+        self.warmup_iters = warmup_epochs * iters_per_epoch
+
+    def __call__(self, optimizer, i, epoch, loss):
+        T = epoch * self.iters_per_epoch + i
+        if self.mode == "cos":
+            lr = 0.5 * self.lr * (1 + math.cos(1.0 * T / self.N * math.pi))
+        elif self.mode == "poly":
+            lr = self.lr * pow((1 - 1.0 * T / self.N), 0.9)
+        elif self.mode == "step":
+            lr = self.lr * (0.1 ** (epoch // self.lr_step))
+        else:
+            raise NotImplementedError(self.mode)
+        if self.warmup_iters > 0 and T < self.warmup_iters:
+            lr = lr * 1.0 * T / self.warmup_iters
+        self.epoch = epoch
+        assert lr >= 0
+        optimizer.param_groups[0]["lr"] = lr
+        for g in optimizer.param_groups[1:]:
+            g["lr"] = lr * 10
+        return lr
+
+
+class FusedAdam(object):
+    """torch.optim.Adam (defaults) over one flat buffer.  Parameters are re-pointed to views of
+    `flat_p` and their .grad to views of `flat_g`; state_dict() uses torch.optim.Adam's layout so
+    reference-style `weights_*.ckpt` files stay interchangeable."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.params = [p for p in params]
+        if len(self.params) == 0:
+            raise ValueError("FusedAdam: no parameters")
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        self.flat_p = torch.empty(n, device=dev)
+        self.flat_g = torch.zeros(n, device=dev)
+        self.exp_avg = torch.zeros(n, device=dev)
+        self.exp_avg_sq = torch.zeros(n, device=dev)
+        off = 0
+        self.offsets = []
+        for p in self.params:
+            k = p.numel()
+            self.flat_p[off:off + k].copy_(p.detach().reshape(-1))
+            p.data = self.flat_p[off:off + k].view(p.shape)
+            p.grad = self.flat_g[off:off + k].view(p.shape)
+            self.offsets.append((off, k))
+            off += k
+        self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.lr_t = torch.full((1,), float(lr), device=dev)
+        self._lr_host = float(lr)
+        self.betas = betas
+        self.eps = eps
+        self.param_groups = [dict(params=self.params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False)]
+
+    def zero_grad(self, set_to_none=False):
+        self.flat_g.zero_()
+
+    def step(self, grad_mul=1.0):
+        lr = float(self.param_groups[0]["lr"])
+        if lr != self._lr_host:
+            self.lr_t.fill_(lr)
+            self._lr_host = lr
+        K.step_tick(self.step_t)
+        K.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.lr_t, self.step_t,
+                    beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, grad_mul=grad_mul)
+
+    def state_dict(self):
+        step = int(self.step_t.item())
+        state = {}
+        for i, (off, k) in enumerate(self.offsets):
+            shp = self.params[i].shape
+            state[i] = {"step": torch.tensor(float(step)),
+                        "exp_avg": self.exp_avg[off:off + k].view(shp).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[off:off + k].view(shp).clone()}
+        g = dict(self.param_groups[0])
+        g["params"] = list(range(len(self.params)))
+        return {"state": state, "param_groups": [g]}
+
+    def load_state_dict(self, sd):
+        for i, (off, k) in enumerate(self.offsets):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            self.exp_avg[off:off + k].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+            self.step_t.fill_(int(float(st["step"])))
+        if sd.get("param_groups"):
+            self.param_groups[0]["lr"] = sd["param_groups"][0].get("lr", self.param_groups[0]["lr"])
+
+
+class trainer(object):
+    """trainer.py:26-198 (constructor) + one fused training step.  `cfg` carries the train.py
+    options the reference reads: epoch, batch_size, save_path, log_freq, bpe, va_bpe, fe_opt,
+    fe_lr, min_opt, min_lr, lrdec_step, max_ckpts (train.py:338-451)."""
+
+    def __init__(self, frontend=None, frontend_cfg=None, att_cfg=None, minions_cfg=None, cfg=None, cls_lst=[],
+                 regr_lst=[], pretrained_ckpt=None, tensorboard=None, backprop_mode="base", lr_mode="step",
+                 name="Pase_base", device=None):
+        if att_cfg:
+            raise NotImplementedError("pase_amd trainer: pase_attention")
+        if backprop_mode != "base":
+            raise NotImplementedError("pase_amd trainer: backprop_mode %r (PASE+ recipe uses 'base')" % backprop_mode)
+        if len(cls_lst) == 0 and "cls" in minions_cfg:
+            cls_lst = [w["name"] for w in minions_cfg["cls"]]
+        if len(regr_lst) == 0 and "regr" in minions_cfg:
+            regr_lst = [w["name"] for w in minions_cfg["regr"]]
+        self.model = pase(frontend=frontend, frontend_cfg=frontend_cfg, minions_cfg=minions_cfg, cls_lst=cls_lst,
+                          regr_lst=regr_lst, pretrained_ckpt=pretrained_ckpt, name=name)
+        if device is not None:
+            self.model.to(device)
+        cfg = dict(cfg or {})
+        self.cfg = cfg
+        self.epoch = cfg.get("epoch", 1)
+        self.bsize = cfg.get("batch_size", 32)
+        self.save_path = cfg.get("save_path", "ckpt")
+        self.log_freq = cfg.get("log_freq", 100)
+        self.bpe = cfg.get("bpe", 1)
+        self.va_bpe = cfg.get("va_bpe", 1)
+        fe_opt, min_opt = cfg.get("fe_opt", "Adam"), cfg.get("min_opt", "Adam")
+        if fe_opt.lower() != "adam" or min_opt.lower() != "adam":
+            raise NotImplementedError("pase_amd trainer: only Adam (train.py:390-391 defaults)")
+        fe_lr, min_lr = cfg.get("fe_lr", 0.001), cfg.get("min_lr", 0.0005)
+        lrdec = cfg.get("lrdec_step", 30)
+        max_ckpts = cfg.get("max_ckpts", 5)
+        self.savers = []
+        self.frontend_optim = FusedAdam(self.model.frontend.parameters(), lr=fe_lr)
+        self.fe_scheduler = LR_Scheduler(lr_mode, lr_step=lrdec, optim_name="frontend", base_lr=fe_lr,
+                                         num_epochs=self.epoch, iters_per_epoch=self.bpe)
+        self.savers.append(Saver(self.model.frontend, self.save_path, max_ckpts=max_ckpts,
+                                 optimizer=self.frontend_optim, prefix="PASE-"))
+        self.cls_optim, self.cls_scheduler = {}, {}
+        for worker in self.model.classification_workers:
+            self.cls_optim[worker.name] = FusedAdam(worker.parameters(), lr=min_lr)
+            self.cls_scheduler[worker.name] = LR_Scheduler(lr_mode, lr_step=lrdec, optim_name=worker.name,
+                                                           base_lr=min_lr, num_epochs=self.epoch,
+                                                           iters_per_epoch=self.bpe)
+            self.savers.append(Saver(worker, self.save_path, max_ckpts=max_ckpts,
+                                     optimizer=self.cls_optim[worker.name], prefix="M-{}-".format(worker.name)))
+        self.regr_optim, self.regr_scheduler = {}, {}
+        for worker in self.model.regression_workers:
+            self.regr_optim[worker.name] = FusedAdam(worker.parameters(), lr=min_lr)
+            self.regr_scheduler[worker.name] = LR_Scheduler(lr_mode, lr_step=lrdec, optim_name=worker.name,
+                                                            base_lr=min_lr, num_epochs=self.epoch,
+                                                            iters_per_epoch=self.bpe)
+            self.savers.append(Saver(worker, self.save_path, max_ckpts=max_ckpts,
+                                     optimizer=self.regr_optim[worker.name], prefix="M-{}-".format(worker.name)))
+        self.epoch_beg = 0
+        self.alphaSG = 1
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self._side = None
+        if self.world > 1:
+            self.broadcast_parameters()
+
+    # --------------------------------------------------------------------------------------
+    def optimizers(self):
+        return list(self.cls_optim.values()) + list(self.regr_optim.values()) + [self.frontend_optim]
+
+    def worker_optimizers(self):
+        return list(self.cls_optim.values()) + list(self.regr_optim.values())
+
+    def broadcast_parameters(self):
+        """Rank 0's initial weights (and BN running stats) to every rank."""
+        for opt in self.optimizers():
+            dist.broadcast(opt.flat_p, src=0)
+        for b in self.model.buffers():
+            dist.broadcast(b, src=0)
+
+    def _allreduce(self, opts):
+        for opt in opts:
+            dist.all_reduce(opt.flat_g, op=dist.ReduceOp.SUM)
+
+    def train_step(self, batch, device=None):
+        """_base_scheduler (worker_scheduler.py:43-75): zero grads, total = sum w*loss, backward,
+        every optimizer steps.  Returns the loss dict (device scalars; no host sync)."""
+        self.model.train()
+        for opt in self.optimizers():
+            opt.zero_grad()
+        sink = engine.GradSink(direct=True)
+        if self.world > 1:
+            losses = self._step_ddp(batch, sink, device)
+        else:
+            losses = self.model.loss_and_grads(batch, sink, device)
+            for opt in self.optimizers():
+                opt.step()
+        return losses
+
+    def _step_ddp(self, batch, sink, device):
+        """Data-parallel step: per-rank batch, sum-all-reduce of the flat gradient buffers over
+        RCCL/xGMI (mean via grad_mul = 1/world in the Adam kernel).  The worker-head buffers
+        (87 MB of the 119 MB) are final before the encoder backward starts: their all-reduce runs
+        on a side stream underneath it."""
+        use_side = torch.cuda.is_available() and next(self.model.parameters()).is_cuda
+        model = self.model
+        if use_side:
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            hook = self._make_overlap_hook()
+            losses = model.loss_and_grads(batch, sink, device, before_encoder_backward=hook)
+            self._allreduce([self.frontend_optim])
+            torch.cuda.current_stream().wait_stream(self._side)
+        else:
+            losses = model.loss_and_grads(batch, sink, device)
+            self._allreduce(self.optimizers())
+        inv = 1.0 / self.world
+        for opt in self.optimizers():
+            opt.step(grad_mul=inv)
+        return losses
+
+    def _make_overlap_hook(self):
+        def hook():
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                self._allreduce(self.worker_optimizers())
+        return hook
+
+    def adjust_lr(self, bidx, epoch, losses=None):
+        """trainer.py:245-254 (called every log_freq iterations in the reference)."""
+        lrs = {"frontend": self.fe_scheduler(self.frontend_optim, bidx, epoch, 0.0)}
+        for name, sch in self.cls_scheduler.items():
+            lrs[name] = sch(self.cls_optim[name], bidx, epoch, 0.0)
+        for name, sch in self.regr_scheduler.items():
+            lrs[name] = sch(self.regr_optim[name], bidx, epoch, 0.0)
+        return lrs
+
+    def save_epoch(self, e, step):
+        """trainer.py:263-272: FE_e{e}.ckpt (bare frontend state_dict, what load_pretrained
+        consumes) + one rotating Saver checkpoint per module."""
+        os.makedirs(self.save_path, exist_ok=True)
+        torch.save(self.model.frontend.state_dict(), os.path.join(self.save_path, "FE_e{}.ckpt".format(e)))
+        for saver in self.savers:
+            saver.save(saver.prefix[:-1], step)
+
+    def resume_training(self, device=None):
+        """trainer.py:339-363: every Saver's latest checkpoint, equal steps, epoch_beg = step // bpe."""
+        steps = []
+        for saver in self.savers:
+            cur = saver.read_latest_checkpoint()
+            if cur is None:
+                return False
+            steps.append(saver.load_ckpt_step(cur))
+            saver.load_weights()
+        if len(set(steps)) != 1:
+            raise ValueError("checkpoints at different steps: %r" % steps)
+        self.epoch_beg = steps[0] // self.bpe
+        return True
+
+    def train_(self, dataloader, valid_dataloader=None, device=None):
+        """Epoch loop of trainer.py:200-278 without the tqdm / tensorboard / aux-supervisor side
+        channels (out of scope)."""
+        for e in range(self.epoch_beg, self.epoch):
+            iterator = iter(dataloader)
+            for bidx in range(1, self.bpe + 1):
+                try:
+                    batch = next(iterator)
+                except StopIteration:
+                    iterator = iter(dataloader)
+                    batch = next(iterator)
+                losses = self.train_step(batch, device)
+                if bidx % self.log_freq == 0 or bidx >= self.bpe:
+                    lrs = self.adjust_lr(bidx, e, losses)
+                    print("epoch {} batch {}/{}: ".format(e, bidx, self.bpe) +
+                          " ".join("{}={:.4f}".format(k, float(v)) for k, v in losses.items()) +
+                          " lr_fe={:.6f}".format(lrs["frontend"]))
+            self.save_epoch(e, e * self.bpe + bidx)

@@ -1,0 +1,141 @@
+"""Pin the CPU oracle (oracle/pase_oracle.py) against (a) the golden vectors generated from the LIVE
+reference by oracle/make_golden.py and (b), when /root/reference is present, the live reference
+itself on fresh random cases.  Also pins the weight-initialisation parity of the pase_amd mirrors
+(same seed -> same initial weights as the reference).  CPU only (`not gpu`)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pase_oracle as O
+from util import GOLD, assert_close, is_noise_grad, load_cfg, oracle_params, quiet, seed_all, synthetic_batch, with_losses
+
+
+def _npz(name):
+    return np.load(os.path.join(GOLD, name), allow_pickle=False)
+
+
+def test_sinc_known_answers():
+    """SURVEY.md section 8c known-answer pins of the deterministic SincConv_fast initialisation."""
+    low, band = O.sinc_init()
+    assert_close(low[:3, 0], torch.tensor([30.0, 58.68235, 88.49165]), rtol=1e-6, atol=1e-4)
+    assert_close(band[:3, 0], torch.tensor([28.68235, 29.80930, 30.98054]), rtol=1e-6, atol=1e-4)
+    assert abs(float(low[-1]) - 7574.873) < 1e-2 and abs(float(band[-1]) - 325.127) < 1e-2
+    f = O.sinc_filters(low, band)
+    assert f.shape == (64, 1, 251)
+    assert torch.equal(f, torch.flip(f, dims=[2]))
+    assert float(f[0, 0, 125]) == 1.0
+    assert abs(float(f[0, 0, 124]) - 0.99871814) < 1e-6
+    assert abs(float(f[63, 0, 0]) - 0.0018330044) < 1e-7
+    assert abs(float(f.sum()) - 6.6129384) < 1e-3
+
+
+def test_sinc_golden():
+    g = _npz("sinc_init.npz")
+    low, band = O.sinc_init()
+    assert_close(low, g["low_hz_"], rtol=0, atol=0)
+    assert_close(band, g["band_hz_"], rtol=0, atol=0)
+    assert_close(O.sinc_filters(low, band), g["filters"], rtol=1e-6, atol=1e-7)
+    w, n_ = O.sinc_constants()
+    assert_close(w, g["window_"], rtol=0, atol=0)
+    assert_close(n_, g["n_"], rtol=0, atol=0)
+    p = _npz("sinc_perturbed.npz")
+    low = torch.tensor(p["low_hz_"], requires_grad=True)
+    band = torch.tensor(p["band_hz_"], requires_grad=True)
+    f = O.sinc_filters(low, band)
+    assert_close(f, p["filters"], rtol=1e-6, atol=1e-7)
+    y = torch.nn.functional.conv1d(torch.nn.functional.pad(torch.tensor(p["x"]), (125, 125), mode="reflect"), f)
+    assert_close(y, p["y"], rtol=1e-5, atol=1e-5)
+    (y * torch.tensor(p["g"])).sum().backward()
+    assert_close(low.grad, p["dlow"], rtol=1e-4, atol=1e-6)
+    assert_close(band.grad, p["dband"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag,cfgfile", [("pase_plus", "frontend/PASE+.cfg"), ("pase", "frontend/PASE.cfg")])
+def test_encoder_golden(tag, cfgfile):
+    """oracle WaveFe forward/backward == live reference on the seeded golden case; the pase_amd
+    mirror initialises to the same weights under the same seed."""
+    from pase_amd.frontend import wf_builder
+    g = _npz("wavefe_%s.npz" % tag)
+    cfg = load_cfg(cfgfile)
+    seed_all(int(g["seed"]))
+    fe = quiet(wf_builder, dict(cfg))
+    sd = fe.state_dict()
+    assert list(sd.keys()) == [str(s) for s in g["param_names"]]
+    assert_close(torch.tensor([float(v.double().sum()) for v in sd.values()]), g["param_sum"], rtol=1e-7, atol=1e-6)
+    assert_close(torch.tensor([float((v.double() ** 2).sum()) for v in sd.values()]), g["param_sq"], rtol=1e-7,
+                 atol=1e-6)
+    P = oracle_params(fe)
+    x = torch.tensor(g["x"])
+    so = {}
+    y = O.encoder_forward(P, cfg, x, True, so)
+    assert_close(y, g["y_train"], rtol=1e-4, atol=1e-4, what="train fwd")
+    (y * torch.tensor(g["g"])).sum().backward()
+    names = [str(s) for s in g["grad_names"]]
+    keep = [i for i, n in enumerate(names) if not is_noise_grad(n)]
+    gsq = torch.tensor([float((P[names[i]].grad.double() ** 2).sum()) for i in keep])
+    assert_close(gsq.sqrt(), np.sqrt(g["grad_sq"][keep]), rtol=2e-3, atol=1e-5, what="grad norms")
+    for k, v in so.items():
+        P[k] = v
+    with torch.no_grad():
+        ye = O.encoder_forward(P, cfg, x, False)
+    assert_close(ye, g["y_eval"], rtol=1e-4, atol=1e-4, what="eval fwd")
+    assert_close(O.select_output(ye, "avg_norm"), g["y_avg_norm"], rtol=1e-4, atol=1e-4)
+
+
+def test_pase_step_golden():
+    """oracle full PASE+ step (12 workers, losses, grads, Adam) == live reference trainer step."""
+    from pase_amd.pase import pase
+    g = _npz("pase_plus_step.npz")
+    fe_cfg = load_cfg("frontend/PASE+.cfg")
+    raw = load_cfg("workers/workers+.cfg")
+    seed_all(int(g["seed"]))
+    model = quiet(pase, frontend_cfg=dict(fe_cfg), minions_cfg=with_losses(load_cfg("workers/workers+.cfg")),
+                  cls_lst=["mi", "cmi"], regr_lst=[w["name"] for w in raw["regr"]])
+    sd = model.state_dict()
+    assert list(sd.keys()) == [str(s) for s in g["param_names"]]
+    assert_close(torch.tensor([float((v.double() ** 2).sum()) for v in sd.values()]), g["param_sq"], rtol=1e-7,
+                 atol=1e-6, what="init parity")
+    P = oracle_params(model)
+    B, T = int(g["B"]), int(g["T"])
+    batch = synthetic_batch(int(g["seed"]) + 1, B, T, raw["regr"])
+    h, chunk, preds, labels = O.pase_forward(P, fe_cfg, raw, batch, True)
+    assert_close(chunk, g["chunk_emb"], rtol=1e-4, atol=1e-4, what="chunk embedding")
+    assert_close(preds["mi"], g["pred_mi"], rtol=1e-4, atol=1e-4)
+    assert_close(preds["cmi"], g["pred_cmi"], rtol=1e-4, atol=1e-4)
+    assert_close(preds["mfcc"], g["pred_mfcc"], rtol=1e-4, atol=1e-4)
+    assert_close(preds["cchunk"][:, :, :400], g["pred_cchunk_head"], rtol=1e-4, atol=1e-4)
+    losses = O.pase_losses(raw, preds, labels)
+    gl = dict(zip([str(s) for s in g["loss_names"]], g["loss_values"]))
+    for k, v in gl.items():
+        assert abs(float(losses[k]) - v) <= 1e-4 * max(1.0, abs(v)), (k, float(losses[k]), v)
+    losses["total"].backward()
+    names = [str(s) for s in g["grad_names"]]
+    keep = [i for i, n in enumerate(names) if not is_noise_grad(n)]
+    gsq = torch.tensor([float((P[names[i]].grad.double() ** 2).sum()) for i in keep])
+    assert_close(gsq.sqrt(), np.sqrt(g["grad_sq"][keep]), rtol=5e-3, atol=1e-6, what="grad norms")
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="live reference tree not present")
+def test_oracle_vs_live_reference_random_cfg():
+    from oracle import ref_shim
+    ref_shim.install()
+    from pase.models.frontend import wf_builder as ref_builder
+    cfg = dict(kwidths=[51, 20, 11, 11, 11, 11, 11, 11], strides=[1, 10, 2, 1, 2, 1, 2, 2],
+               fmaps=[8, 8, 12, 12, 16, 16, 20, 20], emb_dim=24, rnn_dim=20, denseskips=True, norm_out=True,
+               rnn_pool=True, rnn_layers=2)
+    seed_all(11)
+    ref = quiet(ref_builder, dict(cfg))
+    P = oracle_params(ref)
+    x = torch.randn(4, 1, 3200) * 0.2
+    ref.train()
+    yr = ref(x)
+    yo = O.encoder_forward(P, cfg, x, True)
+    assert_close(yo, yr, rtol=1e-5, atol=1e-5)
+    gsel = torch.randn_like(yr)
+    (yr * gsel).sum().backward()
+    (yo * gsel).sum().backward()
+    for n, p in ref.named_parameters():
+        if not is_noise_grad(n):
+            assert_close(P[n].grad, p.grad, rtol=1e-3, atol=1e-4, what=n)

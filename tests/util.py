@@ -1,0 +1,113 @@
+"""Shared helpers for the parity tests."""
+import contextlib
+import io
+import json
+import os
+import random
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+CFG = os.path.join(ROOT, "cfg")
+
+MINI_FE = dict(kwidths=[31, 20, 11, 11, 11, 11, 11, 11], strides=[1, 10, 2, 1, 2, 1, 2, 2],
+               fmaps=[4, 4, 6, 6, 8, 8, 10, 10], emb_dim=12, rnn_dim=10, denseskips=True, norm_out=True,
+               rnn_pool=True, rnn_layers=1)
+MINI_FE_PLAIN = dict(kwidths=[31, 20, 11, 11, 11, 11, 11, 11], strides=[1, 10, 2, 1, 2, 1, 2, 2],
+                     fmaps=[4, 4, 6, 6, 8, 8, 10, 10], emb_dim=7, norm_out=True)   # PASE.cfg-shaped
+
+
+def mini_workers():
+    return {"regr": [
+        {"num_outputs": 1, "dropout": 0, "dropout_time": 0.0, "hidden_layers": 1, "name": "cchunk", "type": "decoder",
+         "hidden_size": 6, "fmaps": [10, 8, 6], "strides": [4, 4, 10], "kwidths": [30, 30, 30], "loss": "L1Loss"},
+        {"num_outputs": 5, "dropout": 0, "hidden_size": 9, "hidden_layers": 1, "name": "lps", "context": 1, "r": 7,
+         "loss": "MSELoss", "skip": False},
+        {"num_outputs": 3, "dropout": 0, "hidden_size": 7, "hidden_layers": 1, "name": "prosody", "context": 1,
+         "r": 7, "loss": "MSELoss", "skip": False, "loss_weight": 0.5}],
+        "cls": [
+        {"num_outputs": 1, "dropout": 0, "hidden_size": 8, "hidden_layers": 1, "name": "mi",
+         "loss": "BCEWithLogitsLoss", "skip": False},
+        {"num_outputs": 1, "dropout": 0, "hidden_size": 8, "hidden_layers": 1, "name": "cmi", "augment": True,
+         "loss": "BCEWithLogitsLoss", "skip": False}]}
+
+
+def seed_all(s):
+    random.seed(s)
+    np.random.seed(s)
+    torch.manual_seed(s)
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def with_losses(cfg):
+    from pase_amd.losses import ContextualizedLoss
+    for _t, lst in cfg.items():
+        for c in lst:
+            c["loss"] = ContextualizedLoss(getattr(nn, c["loss"])(), c.get("r"))
+            c.pop("transform", None)
+    return cfg
+
+
+def randomize_affine(module, seed=123):
+    """give BN affine / PReLU slopes non-trivial values so every term of the backward is exercised"""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            if n.endswith("norm.weight"):
+                p.copy_(torch.empty(p.shape).uniform_(0.5, 1.5, generator=g))
+            elif n.endswith("norm.bias"):
+                p.copy_(torch.empty(p.shape).normal_(0, 0.2, generator=g))
+            elif n.endswith("act.weight"):
+                p.copy_(torch.empty(p.shape).uniform_(0.05, 0.4, generator=g))
+
+
+def oracle_params(module):
+    """state_dict -> dict of leaf tensors (float params require grad) for the oracle"""
+    P = {k: v.detach().cpu().clone() for k, v in module.state_dict().items()}
+    for n, _ in module.named_parameters():
+        P[n].requires_grad_(True)
+    return P
+
+
+def synthetic_batch(seed, B, T, regr_cfg):
+    """same generator as oracle/make_golden.py:synthetic_batch"""
+    g = torch.Generator().manual_seed(seed)
+    batch = {k: (0.1 * torch.randn(B, 1, T, generator=g)).clamp_(-1, 1)
+             for k in ("chunk", "chunk_ctxt", "chunk_rand", "cchunk")}
+    for w in regr_cfg:
+        if w["name"] not in batch:
+            batch[w["name"]] = torch.randn(B, w["num_outputs"], T // 160, generator=g)
+    return batch
+
+
+def load_cfg(rel):
+    with open(os.path.join(CFG, rel)) as f:
+        return json.load(f)
+
+
+def assert_close(a, b, rtol=1e-4, atol=1e-4, what=""):
+    a = a.detach().cpu().double() if torch.is_tensor(a) else torch.as_tensor(a).double()
+    b = b.detach().cpu().double() if torch.is_tensor(b) else torch.as_tensor(b).double()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    if not bool((err <= tol).all()):
+        i = int((err - tol).argmax())
+        raise AssertionError("%s: max |err| %.3e (ref scale %.3e) at flat index %d: got %.6e want %.6e" % (
+            what, float(err.max()), float(b.abs().max()), i, float(a.reshape(-1)[i]), float(b.reshape(-1)[i])))
+
+
+def is_noise_grad(name):
+    """Biases that feed straight into a BatchNorm have an analytically ZERO gradient (the BN mean
+    subtraction cancels them); what any implementation computes there is fp32 round-off, so they
+    are excluded from gradient / post-Adam comparisons (Adam turns that noise into +-lr steps in
+    the reference too)."""
+    import re
+    n = name.replace("frontend.", "")
+    return bool(re.fullmatch(r"blocks\.\d+\.conv\.bias", n)) or n == "W.bias"
