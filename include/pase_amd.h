@@ -62,11 +62,16 @@ typedef struct PaseConvGemm {
     int y_ctot, y_coff, Cout_store, ps, poff, Tout;
     int epilogue, r_ctx, label_D;
     int tile_hint;         /* 0 = auto, 64 = 64x256 block tile, 128 = 128x128                     */
+    int splitk;            /* 1: none; >1: split the reduction, partial tiles atomically added into a
+                              caller-zeroed y (EPI_STORE without stat_part only); 0: library decides --
+                              query pase_conv_gemm_splitk() and zero y when it returns > 1        */
 } PaseConvGemm;
 
 int pase_conv_gemm(const PaseConvGemm* desc, void* stream);
-/* number of column tiles (= first dim of stat_part) the launch above will use */
-int pase_conv_gemm_stat_tiles(int M, int S, int Ncols, int tile_hint);
+/* number of column tiles (= first dim of stat_part) the launch described by desc will use */
+int pase_conv_gemm_stat_tiles(const PaseConvGemm* desc);
+/* the split-K factor the launch will actually use (after clamping) */
+int pase_conv_gemm_splitk(const PaseConvGemm* desc);
 
 /* ------------------------------------------------------------------------------------------
  * pase_wgrad_gemm -- weight (+bias) gradient contraction, split-K with fp32 atomics.

@@ -13,120 +13,189 @@
 //   * optional per-output-channel partial sums (sum, sum of squares) for the following BatchNorm
 //     (training-mode batch statistics, modules.py:79 / frontend.py:208), deterministic (no atomics),
 //   * optional fused r-context MSE epilogue (pase/losses.py:6-37 ContextualizedLoss): the
-//     (B, D*r, F) prediction/target pair of a regression worker is never materialised.
+//     (B, D*r, F) prediction/target pair of a regression worker is never materialised,
+//   * optional split-K (few output tiles, long reduction: the data-gradients of the wide heads).
 //
-// gfx950 mapping: 256 threads = 4 waves; block tile BM x BN x 16; each wave owns a 64x64 sub-tile as
-// 2x2 v_mfma_f32_32x32x2_f32 tiles (exact fp32, 64 accumulator VGPRs).  A/B K-tiles are gathered
-// global -> registers -> LDS (double-buffered, one barrier per K-tile); fp32 MFMA needs only one
-// operand dword per lane per 64-cycle instruction, so the im2col gather + ds_read_b32 fragment reads
-// stay far below the LDS / L1 limits and the kernel is bound by the MFMA pipe.
+// gfx950 mapping.  256 threads = 4 waves; block tile BM x BN; each wave owns a 64x64 sub-tile as 2x2
+// v_mfma_f32_32x32x2_f32 tiles (exact fp32, 64 accumulator VGPRs).  The input is NOT expanded to an
+// im2col tile: per stage the block stages, with fully coalesced row loads, the raw sliding-window
+// SPANS of CB input channels (length (BN-1)*stride + TB, affine+PReLU and padding applied once per
+// element) plus the matching [BM x CB*TB] weight slab into LDS (double-buffered, register
+// prefetch, one barrier per stage).  An MFMA B fragment is then a strided ds_read_b32 straight out
+// of the span: column j, tap kk -> Xs[cl][j*stride + kk]; each lane walks its (channel row, tap)
+// offset incrementally, so neither integer division nor a table lookup sits in the MFMA loop.
+// Loads are issued as raw prefetches one stage ahead and only touched (affine / PReLU, ds_write)
+// after the MFMA loop of the current stage, so HBM/L2 latency hides under the matrix pipe.
 // Two shapes: <128,128> (waves 2x2) and <64,256> (waves 1x4) for the 64-row layers.
 #include "hip_compat.h"
 #include "pase_amd.h"
 
 namespace {
 
-constexpr int BK = 16;
 constexpr int NTHREADS = 256;
+constexpr int KGMAX = 48;     // flat k (channels x taps) per stage
+constexpr int XSMAX = 3072;   // staged span floats per stage
+constexpr int XPT = XSMAX / NTHREADS;
+
+struct ConvPlan {
+    int CB, TB, SPAN, n_gc, n_gt, flat, tiles_per_seq, splitk;
+    unsigned span_magic;      // ceil(2^32 / SPAN)
+    unsigned ncols_magic;     // ceil(2^32 / Ncols)  (flat mode)
+};
 
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
     // bijective XCD-aware remap (cdna_hip_programming.md T1): blocks that run on one XCD (bid % 8)
-    // get a contiguous range of tile ids, so row-tiles sharing a B panel hit the same L2.
+    // get a contiguous range of tile ids, so row-tiles sharing an input span hit the same L2.
     const int q = nwg / 8, r = nwg % 8;
     const int xcd = bid % 8, idx = bid / 8;
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + idx;
 }
 
+__device__ __forceinline__ unsigned div_magic(unsigned e, unsigned magic) {
+    // e / d with magic = ceil(2^32 / d); magic == 0 encodes d == 1 (2^32 does not fit)
+    return magic ? (unsigned)(((unsigned long long)e * magic) >> 32) : e;
+}
+
 template <int BM, int BN>
-__global__ void __launch_bounds__(NTHREADS) conv_gemm_kernel(PaseConvGemm p) {
-    constexpr int WAVES_M = BM / 64;
+__global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, ConvPlan pl) {
     constexpr int WAVES_N = BN / 64;
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves");
-    constexpr int A_PER_T = BM * BK / NTHREADS;  // 8 or 4
-    constexpr int B_PER_T = BN * BK / NTHREADS;  // 8 or 16
-    constexpr int B_KSTEP = NTHREADS / BN;       // 2 or 1
-    constexpr int LDA = BM + 1;                  // +1: conflict-free transposed ds_write
-    __shared__ float As[2][BK][LDA];
-    __shared__ float Bs[2][BK][BN];
+    static_assert((BM / 64) * WAVES_N == 4, "4 waves");
+    constexpr int A_ROWS = BM / 8;   // rows per thread per k slot
+    constexpr int LDA = BM + 1;
+    __shared__ float As[2][KGMAX][LDA];
+    __shared__ float Xs[2][XSMAX];
+    __shared__ int kinfo[2][2];   // per stage: {flat k count, taps in this sub-range}
     __shared__ float red[WAVES_N][BM][2];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = pase_uniform(tid >> 6);   // provably wave-uniform: tile-shape branches stay scalar
     const int wm = wave / WAVES_N;
     const int wn = wave % WAVES_N;
+    const int fr = lane & 31;
+    const int fk = lane >> 5;
 
+    // ---- tile decode -----------------------------------------------------------------------
     const int ntot = p.S * p.Ncols;
     const int n_row_tiles = (p.M + BM - 1) / BM;
-    const int n_col_tiles = (ntot + BN - 1) / BN;
-    const int tile = xcd_swizzle(blockIdx.x, n_row_tiles * n_col_tiles);
+    const int n_col_tiles = pl.flat ? (ntot + BN - 1) / BN : p.S * pl.tiles_per_seq;
+    const int ntiles = n_row_tiles * n_col_tiles;
+    const int split = blockIdx.x / ntiles;
+    const int tile = xcd_swizzle(blockIdx.x % ntiles, ntiles);
     const int mt = tile % n_row_tiles;
     const int nt = tile / n_row_tiles;
     const int m0 = mt * BM;
-    const int n0 = nt * BN;
+    int ts, q0, ncols_valid;        // tile's sequence, first column, number of valid columns
+    if (pl.flat) {
+        ts = 0;
+        q0 = nt * BN;               // flattened column index n0
+        ncols_valid = min(BN, ntot - q0);
+    } else {
+        ts = nt / pl.tiles_per_seq;
+        q0 = (nt - ts * pl.tiles_per_seq) * BN;
+        ncols_valid = min(BN, p.Ncols - q0);
+    }
 
-    // ---- per-thread loader state -------------------------------------------------------------
-    // B (im2col gather): fixed column j, k-rows kr0 + i*B_KSTEP
-    const int bj = tid % BN;
-    const int bkr0 = tid / BN;
-    const int bn_ = n0 + bj;
-    const bool bcol_ok = bn_ < ntot;
-    const int bs = bcol_ok ? bn_ / p.Ncols : 0;
-    const int bq = bcol_ok ? bn_ % p.Ncols : 0;
-    const int ubase = bq * p.stride - p.padL;
-    const float* xcol = p.x + ((size_t)bs * p.x_ctot + p.x_coff) * (size_t)p.Tin;
-    // A: k-col = tid % BK, rows tid / BK + i * (NTHREADS / BK)
-    const int akc = tid % BK;
-    const int ar0 = tid / BK;
+    // ---- stage enumeration: g = gc * n_gt + gt ; this split's range -------------------------
+    const int G = pl.n_gc * pl.n_gt;
+    const int g_per = (G + pl.splitk - 1) / pl.splitk;
+    const int g_begin = split * g_per;
+    const int g_end = min(G, g_begin + g_per);
+    if (g_begin >= g_end) return;   // uniform for the whole block, before any barrier
 
-    float areg[A_PER_T], breg[B_PER_T];
+    float areg[2][A_ROWS];
+    float xreg[XPT];
+    int kg_next = 0, tbe_next = 0, ci0_next = 0;
+    unsigned xmask = 0u;
 
-    auto load_tile = [&](int k0) {
-        // ---- A tile: W[m][k], K contiguous
-        {
-            const int kf = k0 + akc;
-            const bool kok = kf < p.K;
+    auto load_stage = [&](int g) {
+        const int gc = g / pl.n_gt, gt = g - gc * pl.n_gt;
+        const int ci0 = gc * pl.CB, kk0 = gt * pl.TB;
+        const int TBe = min(pl.TB, p.taps - kk0);
+        const int CBe = min(pl.CB, p.Cin - ci0);
+        const int KGe = CBe * TBe;
+        kg_next = KGe;
+        tbe_next = TBe;
+        // ---- A slab: rows (tid>>5) + 8*i, flat-k slots (tid&31) and (tid&31)+32; K-contiguous rows
 #pragma unroll
-            for (int i = 0; i < A_PER_T; ++i) {
-                const int m = m0 + ar0 + i * (NTHREADS / BK);
-                areg[i] = (kok && m < p.M) ? p.w[(size_t)m * p.ldw + kf] : 0.f;
+        for (int h = 0; h < 2; ++h) {
+            const int kl = (tid & 31) + 32 * h;
+            const bool kok = kl < KGe;
+            int ka = 0;
+            if (kok) {
+                const int cl = kl / TBe, kkl = kl - cl * TBe;
+                ka = p.tap_major ? (kk0 + kkl) * p.Cin + ci0 + cl : (ci0 + cl) * p.taps + kk0 + kkl;
+            }
+#pragma unroll
+            for (int i = 0; i < A_ROWS; ++i) {
+                const int m = m0 + (tid >> 5) + 8 * i;
+                areg[h][i] = (kok && m < p.M) ? p.w[(size_t)m * p.ldw + ka] : 0.f;
             }
         }
-        // ---- B tile: gather with padding + on-load transform
-        {
-            int kf = k0 + bkr0;
-            int ci, kk;
-            if (p.tap_major) { kk = kf / p.Cin; ci = kf - kk * p.Cin; }
-            else             { ci = kf / p.taps; kk = kf - ci * p.taps; }
+        // ---- X spans: CBe rows of SPAN floats, consecutive threads on consecutive samples.
+        // Only the raw loads are issued here (they stay in flight under the MFMAs of the current
+        // stage); the on-load affine / PReLU is applied in store_stage, after the MFMA loop.
+        const int total = CBe * pl.SPAN;
+        const int span_lo = pl.flat ? 0 : q0 * p.stride - p.padL + (p.tapstep > 0 ? kk0 : -(kk0 + TBe - 1));
+        ci0_next = ci0;
+        xmask = 0u;
 #pragma unroll
-            for (int i = 0; i < B_PER_T; ++i) {
-                float v = 0.f;
-                if (bcol_ok && kf < p.K) {
-                    int u = ubase + kk * p.tapstep;
+        for (int t = 0; t < XPT; ++t) {
+            const int e = tid + NTHREADS * t;
+            float v = 0.f;
+            if (e < total) {
+                const int cl = (int)div_magic((unsigned)e, pl.span_magic);
+                const int i = e - cl * pl.SPAN;
+                const int ci = ci0 + cl;
+                int s = ts, u;
+                bool ok;
+                if (pl.flat) {
+                    const unsigned n = (unsigned)(q0 + i);
+                    s = (int)div_magic(n, pl.ncols_magic);   // may overshoot by one for huge n*Ncols
+                    u = (int)n - s * p.Ncols;
+                    if (u < 0) { --s; u += p.Ncols; }
+                    ok = (int)n < ntot;
+                } else {
+                    u = span_lo + i;
                     if (p.pad_mode == PASE_PAD_REFLECT) {
                         if (u < 0) u = -u;
                         if (u >= p.Tin) u = 2 * (p.Tin - 1) - u;
                     }
-                    if (u >= 0 && u < p.Tin) {
-                        v = xcol[(size_t)ci * p.Tin + u];
-                        if (p.in_scale) v = v * p.in_scale[ci] + p.in_shift[ci];
-                        if (p.in_alpha) v = v > 0.f ? v : v * p.in_alpha[ci];
-                    }
+                    ok = u >= 0 && u < p.Tin;
                 }
-                breg[i] = v;
-                // advance (ci,kk) by B_KSTEP flat k positions
-                kf += B_KSTEP;
-                if (p.tap_major) { ci += B_KSTEP; while (ci >= p.Cin) { ci -= p.Cin; ++kk; } }
-                else             { kk += B_KSTEP; while (kk >= p.taps) { kk -= p.taps; ++ci; } }
+                if (ok) {
+                    v = p.x[((size_t)s * p.x_ctot + p.x_coff + ci) * (size_t)p.Tin + u];
+                    xmask |= 1u << t;
+                }
             }
+            xreg[t] = v;
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_stage = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < A_PER_T; ++i) As[buf][akc][ar0 + i * (NTHREADS / BK)] = areg[i];
+        for (int h = 0; h < 2; ++h) {
+            const int kl = (tid & 31) + 32 * h;
+            if (kl < KGMAX) {
 #pragma unroll
-        for (int i = 0; i < B_PER_T; ++i) Bs[buf][bkr0 + i * B_KSTEP][bj] = breg[i];
+                for (int i = 0; i < A_ROWS; ++i) As[buf][kl][(tid >> 5) + 8 * i] = areg[h][i];
+            }
+        }
+        if (p.in_scale || p.in_alpha) {
+#pragma unroll
+            for (int t = 0; t < XPT; ++t) {
+                if (xmask & (1u << t)) {
+                    const int ci = ci0_next + (int)div_magic((unsigned)(tid + NTHREADS * t), pl.span_magic);
+                    float v = xreg[t];
+                    if (p.in_scale) v = v * p.in_scale[ci] + p.in_shift[ci];
+                    if (p.in_alpha) v = v > 0.f ? v : v * p.in_alpha[ci];
+                    xreg[t] = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < XPT; ++t) Xs[buf][tid + NTHREADS * t] = xreg[t];
+        if (tid == 0) { kinfo[buf][0] = kg_next; kinfo[buf][1] = tbe_next; }
     };
 
     f32x16 acc[2][2];
@@ -137,28 +206,50 @@ __global__ void __launch_bounds__(NTHREADS) conv_gemm_kernel(PaseConvGemm p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int nk = (p.K + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
+    // wave-uniform "this 32-wide block has work" flags (ragged tiles: T_out = 200, M = 273, ...)
+    const bool row_ok0 = m0 + wm * 64 < p.M, row_ok1 = m0 + wm * 64 + 32 < p.M;
+    const bool col_ok0 = wn * 64 < ncols_valid, col_ok1 = wn * 64 + 32 < ncols_valid;
+    const bool full_tile = row_ok0 && row_ok1 && col_ok0 && col_ok1;
+    const int xc0 = (wn * 64 + fr) * (pl.flat ? 1 : p.stride);
+    const int xc1 = (wn * 64 + 32 + fr) * (pl.flat ? 1 : p.stride);
+
+    load_stage(g_begin);
+    store_stage(0);
     __syncthreads();
-    const int fr = lane & 31;   // fragment row/col within a 32-wide MFMA tile
-    const int fk = lane >> 5;   // k within the K=2 step
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile((kt + 1) * BK);   // global loads in flight under the MFMAs
-#pragma unroll
-        for (int ks = 0; ks < BK / 2; ++ks) {
-            const int kb = ks * 2 + fk;
-            const float a0 = As[cur][kb][wm * 64 + fr];
-            const float a1 = As[cur][kb][wm * 64 + 32 + fr];
-            const float b0 = Bs[cur][kb][wn * 64 + fr];
-            const float b1 = Bs[cur][kb][wn * 64 + 32 + fr];
+    for (int g = g_begin; g < g_end; ++g) {
+        const int cur = (g - g_begin) & 1;
+        if (g + 1 < g_end) load_stage(g + 1);   // global loads in flight under the MFMAs
+        const int kg = kinfo[cur][0];
+        const int tbe = kinfo[cur][1];
+        const int nks = (kg + 1) >> 1;
+        // this lane's flat k = 2*ks + fk -> (channel row cl, tap kkl) -> span offset, kept incrementally
+        int kkl = fk, xo = (p.tapstep > 0) ? fk : tbe - 1 - fk;
+        if (kkl >= tbe) { kkl -= tbe; xo += (p.tapstep > 0) ? pl.SPAN - tbe : pl.SPAN + tbe; }
+        const int wrap_add = (p.tapstep > 0) ? pl.SPAN - tbe : pl.SPAN + tbe;
+        const int step2 = (p.tapstep > 0) ? 2 : -2;
+        const float* as_ = &As[cur][fk][wm * 64 + fr];
+        const float* xs_ = &Xs[cur][0];
+        // All four MFMAs are issued unconditionally: rows / columns beyond the tile edge multiply
+        // zero-filled A rows or finite staged data and are discarded in the epilogue.  (Branching
+        // around individual MFMAs costs far more than the wasted issue slots: it splits the loop
+        // into basic blocks and serialises every ds_read behind the previous step's MFMAs.)
+#pragma unroll 2
+        for (int ks = 0; ks < nks; ++ks) {
+            // the padded k of an odd stage reads slot 0 (initialised); its A column is zero
+            const int off = (ks * 2 + fk < kg) ? xo : 0;
+            const float a0 = as_[ks * 2 * LDA];
+            const float a1 = as_[ks * 2 * LDA + 32];
+            const float b0 = xs_[off + xc0];
+            const float b1 = xs_[off + xc1];
             acc[0][0] = pase_mfma_32x32x2(a0, b0, acc[0][0]);
             acc[0][1] = pase_mfma_32x32x2(a0, b1, acc[0][1]);
             acc[1][0] = pase_mfma_32x32x2(a1, b0, acc[1][0]);
             acc[1][1] = pase_mfma_32x32x2(a1, b1, acc[1][1]);
+            kkl += 2; xo += step2;
+            if (kkl >= tbe) { kkl -= tbe; xo += wrap_add; }
+            if (kkl >= tbe) { kkl -= tbe; xo += wrap_add; }   // tbe == 1: two channel rows per step
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
+        if (g + 1 < g_end) store_stage(cur ^ 1);
         __syncthreads();
     }
 
@@ -169,10 +260,16 @@ __global__ void __launch_bounds__(NTHREADS) conv_gemm_kernel(PaseConvGemm p) {
     bool cok[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        const int n = n0 + wn * 64 + b * 32 + fr;
-        cok[b] = n < ntot;
-        cs[b] = cok[b] ? n / p.Ncols : 0;
-        cq[b] = cok[b] ? n % p.Ncols : 0;
+        const int j = wn * 64 + b * 32 + fr;
+        cok[b] = j < ncols_valid;
+        if (pl.flat) {
+            const int n = q0 + j;
+            cs[b] = cok[b] ? n / p.Ncols : 0;
+            cq[b] = cok[b] ? n % p.Ncols : 0;
+        } else {
+            cs[b] = ts;
+            cq[b] = q0 + j;
+        }
     }
 
     if (p.epilogue == PASE_EPI_STORE) {
@@ -185,7 +282,7 @@ __global__ void __launch_bounds__(NTHREADS) conv_gemm_kernel(PaseConvGemm p) {
                 const bool mok = m < p.M;
                 const int ph = mok ? m / p.Cout_store : 0;
                 const int co = mok ? m - ph * p.Cout_store : 0;
-                const float bv = (mok && p.bias) ? p.bias[co] : 0.f;
+                const float bv = (mok && p.bias && split == 0) ? p.bias[co] : 0.f;
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
@@ -193,7 +290,9 @@ __global__ void __launch_bounds__(NTHREADS) conv_gemm_kernel(PaseConvGemm p) {
                     const int pos = cq[b] * p.ps + ph + p.poff;
                     const bool ok = mok && cok[b] && pos >= 0 && pos < p.Tout;
                     if (ok) {
-                        p.y[((size_t)cs[b] * p.y_ctot + p.y_coff + co) * (size_t)p.Tout + pos] = v;
+                        float* dst = p.y + ((size_t)cs[b] * p.y_ctot + p.y_coff + co) * (size_t)p.Tout + pos;
+                        if (pl.splitk > 1) atomicAdd(dst, v);
+                        else *dst = v;
                         s1 += v;
                         s2 += v * v;
                     }
@@ -259,29 +358,87 @@ __global__ void __launch_bounds__(NTHREADS) conv_gemm_kernel(PaseConvGemm p) {
     }
 }
 
+struct HostPlan {
+    ConvPlan pl;
+    int BN, narrow;
+    long blocks;
+    int n_col_tiles;
+};
+
+HostPlan make_plan(const PaseConvGemm& p) {
+    HostPlan h;
+    h.narrow = (p.tile_hint == 64) || (p.tile_hint == 0 && p.M <= 64);
+    const int BM = h.narrow ? 64 : 128;
+    h.BN = h.narrow ? 256 : 128;
+    ConvPlan& pl = h.pl;
+    pl.flat = (p.taps == 1 && p.stride == 1 && p.padL == 0 && p.tapstep == 1) ? 1 : 0;
+    if (pl.flat) {
+        pl.TB = 1;
+        pl.SPAN = h.BN;
+        pl.CB = XSMAX / h.BN;
+        if (pl.CB > KGMAX) pl.CB = KGMAX;
+    } else {
+        pl.TB = p.taps <= KGMAX ? p.taps : 32;
+        pl.SPAN = (h.BN - 1) * p.stride + pl.TB;
+        pl.CB = KGMAX / pl.TB;
+        if (pl.CB * pl.SPAN > XSMAX) pl.CB = XSMAX / pl.SPAN;
+    }
+    if (pl.CB > p.Cin) pl.CB = p.Cin;
+    if (pl.CB < 1) pl.CB = 0;   // span does not fit: rejected by the caller
+    pl.n_gc = pl.CB ? (p.Cin + pl.CB - 1) / pl.CB : 0;
+    pl.n_gt = (p.taps + pl.TB - 1) / pl.TB;
+    pl.tiles_per_seq = (p.Ncols + h.BN - 1) / h.BN;
+    pl.span_magic = (unsigned)((0x100000000ULL + pl.SPAN - 1) / (unsigned long long)pl.SPAN);
+    pl.ncols_magic = (unsigned)((0x100000000ULL + p.Ncols - 1) / (unsigned long long)p.Ncols);
+    const long ntot = (long)p.S * p.Ncols;
+    h.n_col_tiles = pl.flat ? (int)((ntot + h.BN - 1) / h.BN) : p.S * pl.tiles_per_seq;
+    const long tiles = (long)((p.M + BM - 1) / BM) * h.n_col_tiles;
+    int splitk = 1;
+    const int G = pl.n_gc * pl.n_gt;
+    if (p.splitk > 1) splitk = p.splitk;
+    else if (p.splitk == 0 && !p.stat_part && p.epilogue == PASE_EPI_STORE && tiles < 192) {
+        // auto: few output tiles and a long reduction (head / deconv data-gradients) -> fill the chip
+        splitk = (int)((384 + tiles - 1) / tiles);
+        if (splitk > G / 6) splitk = G / 6;
+        if (splitk < 1) splitk = 1;
+    }
+    if (splitk > G) splitk = G > 0 ? G : 1;
+    if (splitk > 1) {   // every split must own at least one stage
+        const int g_per = (G + splitk - 1) / splitk;
+        splitk = (G + g_per - 1) / g_per;
+    }
+    pl.splitk = splitk;
+    h.blocks = tiles * splitk;
+    return h;
+}
+
 }  // namespace
 
 extern "C" int pase_conv_gemm(const PaseConvGemm* d, void* stream) {
     const PaseConvGemm p = *d;
     if (p.M <= 0 || p.K <= 0 || p.S <= 0 || p.Ncols <= 0) return 0;
+    if (p.K != p.Cin * p.taps) return -4;
     if (p.epilogue == PASE_EPI_MSE_CTX && (!p.label || !p.loss_acc || p.r_ctx < 1)) return -2;
     if (p.pad_mode == PASE_PAD_REFLECT && (p.padL >= p.Tin)) return -3;
-    const long ntot = (long)p.S * p.Ncols;
+    if (p.tapstep != 1 && p.tapstep != -1) return -5;
+    const HostPlan h = make_plan(p);
+    if (h.pl.CB < 1) return -6;
+    if (h.pl.splitk > 1 && (p.stat_part || p.epilogue != PASE_EPI_STORE)) return -7;
+    if ((long)p.S * p.Ncols >= 0x7fffffffL) return -8;
     hipStream_t st = (hipStream_t)stream;
-    const bool narrow = (p.tile_hint == 64) || (p.tile_hint == 0 && p.M <= 64);
-    if (narrow) {
-        const long tiles = ((p.M + 63) / 64) * ((ntot + 255) / 256);
-        PASE_LAUNCH((conv_gemm_kernel<64, 256>), dim3((unsigned)tiles), dim3(NTHREADS), st, p);
+    if (h.narrow) {
+        PASE_LAUNCH((conv_gemm_kernel<64, 256>), dim3((unsigned)h.blocks), dim3(NTHREADS), st, p, h.pl);
     } else {
-        const long tiles = ((p.M + 127) / 128) * ((ntot + 127) / 128);
-        PASE_LAUNCH((conv_gemm_kernel<128, 128>), dim3((unsigned)tiles), dim3(NTHREADS), st, p);
+        PASE_LAUNCH((conv_gemm_kernel<128, 128>), dim3((unsigned)h.blocks), dim3(NTHREADS), st, p, h.pl);
     }
     PASE_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int pase_conv_gemm_stat_tiles(int M, int S, int Ncols, int tile_hint) {
-    const long ntot = (long)S * Ncols;
-    const bool narrow = (tile_hint == 64) || (tile_hint == 0 && M <= 64);
-    return (int)(narrow ? (ntot + 255) / 256 : (ntot + 127) / 128);
+extern "C" int pase_conv_gemm_stat_tiles(const PaseConvGemm* d) {
+    return make_plan(*d).n_col_tiles;
+}
+
+extern "C" int pase_conv_gemm_splitk(const PaseConvGemm* d) {
+    return make_plan(*d).pl.splitk;
 }

@@ -10,6 +10,7 @@
 __device__ __forceinline__ f32x16 pase_mfma_32x32x2(float a, float b, f32x16 c) {
     return emu_mfma_32x32x2(a, b, c);
 }
+__device__ __forceinline__ int pase_uniform(int v) { return v; }
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -22,6 +23,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x16 pase_mfma_32x32x2(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+// value known to be identical across the wave (e.g. threadIdx.x / 64): make it an SGPR so branches
+// on it are scalar (cdna_hip_programming.md T20: threadIdx-derived values are divergent to hipcc)
+__device__ __forceinline__ int pase_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #endif
 
 #define PASE_CHECK_LAUNCH()                      \

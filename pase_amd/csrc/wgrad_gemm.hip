@@ -8,113 +8,180 @@
 // (pase/models/modules.py:1047-1051, :543, :571-575; frontend.py:182,195; Minions/minions.py:510),
 // driven by `tot_loss.backward()` in WorkerScheduler/worker_scheduler.py:67.
 // For nn.Conv1d G is dY and Z the layer input; for nn.ConvTranspose1d the roles swap (G = layer
-// input at the low rate, Z = dY at the high rate) and the result lands directly in the
-// (in, out, k) weight layout.
+// input at the low rate, with its PReLU applied on load via g_alpha; Z = dY at the high rate) and the
+// result lands directly in the (in, out, k) weight layout.
 //
 // GEMM view: M x Nw x Kred with Kred = S*Ncols (19 200 ... 3 072 000): the reduction is the long
 // axis, so the grid is (row tiles x col tiles x split-K) and partial tiles are combined with fp32
-// global atomics into a caller-zeroed dW.  Same 4-wave / 2x2x(32x32x2) register tiling and
-// double-buffered LDS as conv_gemm.hip; both operands are K-contiguous in HBM so the loaders put
-// consecutive lanes along K.
+// global atomics into a caller-zeroed dW.
+//
+// gfx950 mapping: 4 waves, 2x2 32x32x2 MFMA tiles per wave (as conv_gemm.hip).  Per stage the block
+// takes a chunk of 32 consecutive time steps of one sequence and stages, with coalesced row loads,
+// (a) the [BM x 32] slab of G and (b) the raw sliding-window SPANS (31*stride + taps samples) of the
+// few input channels that the tile's (ci,kk) columns touch -- not an im2col tile.  Each lane's two
+// B columns map to fixed LDS offsets (channel row + tap), so the MFMA loop is
+// `Zs[off_j + kq*stride]`: no index arithmetic, no per-element gathers.
 #include "hip_compat.h"
 #include "pase_amd.h"
 
 namespace {
 
-constexpr int BK = 16;
 constexpr int NTHREADS = 256;
+constexpr int BKQ = 32;                 // reduction positions per stage
+constexpr int ZS_DATA = 4864;           // staged span floats per stage
+constexpr int ZS_ONES = 320;            // region of 1.0f (bias column / padding columns)
+constexpr int ZS_TOTAL = ZS_DATA + ZS_ONES;
+constexpr int ZPT = ZS_DATA / NTHREADS; // 19
+
+struct WgradPlan {
+    int flat, SPANW, chunks_per_seq, n_chunks, kt_per_split, n_row_tiles, n_col_tiles;
+    unsigned span_magic, ncols_magic;
+};
+
+__device__ __forceinline__ unsigned div_magic(unsigned e, unsigned magic) {
+    // e / d with magic = ceil(2^32 / d); magic == 0 encodes d == 1 (2^32 does not fit)
+    return magic ? (unsigned)(((unsigned long long)e * magic) >> 32) : e;
+}
 
 template <int BM, int BN>
-__global__ void __launch_bounds__(NTHREADS) wgrad_gemm_kernel(PaseWgrad p, int n_row_tiles, int n_col_tiles,
-                                                              int kt_per_split) {
+__global__ void __launch_bounds__(NTHREADS) wgrad_gemm_kernel(PaseWgrad p, WgradPlan pl) {
     constexpr int WAVES_N = BN / 64;
-    constexpr int A_PER_T = BM * BK / NTHREADS;
-    constexpr int B_PER_T = BN * BK / NTHREADS;
-    constexpr int RSTEP = NTHREADS / BK;  // 16 rows / cols per pass
-    __shared__ float As[2][BK][BM + 1];
-    __shared__ float Bs[2][BK][BN + 1];
+    constexpr int A_ROWS = BM / 8;
+    __shared__ float As[2][BKQ][BM + 1];
+    __shared__ float Zs[2][ZS_TOTAL];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = pase_uniform(tid >> 6);
     const int wm = wave / WAVES_N;
     const int wn = wave % WAVES_N;
+    const int fr = lane & 31;
+    const int fk = lane >> 5;
 
-    const int tiles = n_row_tiles * n_col_tiles;
+    const int tiles = pl.n_row_tiles * pl.n_col_tiles;
     const int tile = blockIdx.x % tiles;
     const int split = blockIdx.x / tiles;
-    const int mt = tile % n_row_tiles;
-    const int ct = tile / n_row_tiles;
+    const int mt = tile % pl.n_row_tiles;
+    const int ct = tile / pl.n_row_tiles;
     const int m0 = mt * BM;
     const int j0 = ct * BN;
 
     const int Kw = p.Cin * p.taps;
     const int Nw = Kw + (p.dbias ? 1 : 0);
-    const long kred = (long)p.S * p.Ncols;
-    const int nk_total = (int)((kred + BK - 1) / BK);
-    const int kt_begin = split * kt_per_split;
-    const int kt_end = min(nk_total, kt_begin + kt_per_split);
-    if (kt_begin >= kt_end) return;   // whole block exits together (no barrier reached yet)
+    const int c_begin = split * pl.kt_per_split;
+    const int c_end = min(pl.n_chunks, c_begin + pl.kt_per_split);
+    if (c_begin >= c_end) return;   // whole block exits together (no barrier reached yet)
 
-    // loader coordinates: consecutive lanes along the reduction axis n = (s, q)
-    const int kc = tid % BK;
-    const int r0 = tid / BK;
-    // per-thread fixed B columns -> (ci, kk)
-    int bci[B_PER_T], bkk[B_PER_T];
+    // channels touched by this tile's columns, and this lane's two fixed B offsets
+    const int c_lo = j0 / p.taps;
+    const int j_last = min(j0 + BN, Kw) - 1;
+    const int NC = j_last >= j0 ? j_last / p.taps - c_lo + 1 : 0;
+    int boff[2];
 #pragma unroll
-    for (int i = 0; i < B_PER_T; ++i) {
-        const int j = j0 + r0 + i * RSTEP;
+    for (int b = 0; b < 2; ++b) {
+        const int j = j0 + wn * 64 + b * 32 + fr;
         if (j < Kw) {
-            if (p.tap_major) { bkk[i] = j / p.Cin; bci[i] = j - bkk[i] * p.Cin; }
-            else             { bci[i] = j / p.taps; bkk[i] = j - bci[i] * p.taps; }
+            const int ci = j / p.taps, kk = j - ci * p.taps;
+            boff[b] = (ci - c_lo) * pl.SPANW + (p.tapstep > 0 ? kk : p.taps - 1 - kk);
         } else {
-            bci[i] = (j == Kw && p.dbias) ? -1 : -2;   // -1: ones column (bias), -2: out of range
-            bkk[i] = 0;
+            boff[b] = ZS_DATA;      // ones (bias column when j == Kw, discarded otherwise)
         }
     }
+    const int zstep = pl.flat ? 1 : p.stride;
+    for (int i = tid; i < ZS_ONES; i += NTHREADS) { Zs[0][ZS_DATA + i] = 1.f; Zs[1][ZS_DATA + i] = 1.f; }
 
-    float areg[A_PER_T], breg[B_PER_T];
-    auto load_tile = [&](int kt) {
-        const long n = (long)kt * BK + kc;
-        const bool nok = n < kred;
-        const int s = nok ? (int)(n / p.Ncols) : 0;
-        const int q = nok ? (int)(n - (long)s * p.Ncols) : 0;
-        const float* grow = p.g + ((size_t)s * p.g_ctot + p.g_coff) * (size_t)p.Tg + q;
-#pragma unroll
-        for (int i = 0; i < A_PER_T; ++i) {
-            const int m = m0 + r0 + i * RSTEP;
-            float gv = (nok && m < p.M) ? grow[(size_t)m * p.Tg] : 0.f;
-            if (p.g_alpha) gv = gv > 0.f ? gv : gv * p.g_alpha[m < p.M ? m : 0];
-            areg[i] = gv;
-        }
-        const float* zrow = p.z + ((size_t)s * p.z_ctot + p.z_coff) * (size_t)p.Tz;
-        const int ubase = q * p.stride - p.padL;
-#pragma unroll
-        for (int i = 0; i < B_PER_T; ++i) {
-            float v = 0.f;
-            const int ci = bci[i];
-            if (nok && ci >= 0) {
-                int u = ubase + bkk[i] * p.tapstep;
-                if (p.pad_mode == PASE_PAD_REFLECT) {
-                    if (u < 0) u = -u;
-                    if (u >= p.Tz) u = 2 * (p.Tz - 1) - u;
-                }
-                if (u >= 0 && u < p.Tz) {
-                    v = zrow[(size_t)ci * p.Tz + u];
-                    if (p.in_scale) v = v * p.in_scale[ci] + p.in_shift[ci];
-                    if (p.in_alpha) v = v > 0.f ? v : v * p.in_alpha[ci];
-                }
-            } else if (nok && ci == -1) {
-                v = 1.f;
+    float areg[A_ROWS];
+    float zreg[ZPT];
+    unsigned zmask = 0u;
+    const int ntot = p.S * p.Ncols;
+
+    auto load_stage = [&](int c) {
+        int s, q0;
+        if (pl.flat) { s = 0; q0 = c * BKQ; }
+        else { s = c / pl.chunks_per_seq; q0 = (c - s * pl.chunks_per_seq) * BKQ; }
+        // ---- G slab: lanes along time (128 B runs), rows (tid>>5) + 8*i
+        {
+            const int kq = tid & 31;
+            int sg = s, qg = q0 + kq;
+            bool ok;
+            if (pl.flat) {
+                const unsigned n = (unsigned)qg;
+                ok = (int)n < ntot;
+                sg = (int)div_magic(n, pl.ncols_magic);
+                qg = (int)n - sg * p.Ncols;
+                if (qg < 0) { --sg; qg += p.Ncols; }
+            } else {
+                ok = qg < p.Ncols;
             }
-            breg[i] = v;
+            const float* grow = p.g + ((size_t)sg * p.g_ctot + p.g_coff) * (size_t)p.Tg + qg;
+#pragma unroll
+            for (int i = 0; i < A_ROWS; ++i) {
+                const int m = m0 + (tid >> 5) + 8 * i;
+                areg[i] = (ok && m < p.M) ? grow[(size_t)m * p.Tg] : 0.f;   // raw prefetch
+            }
+        }
+        // ---- Z spans: NC rows of SPANW floats
+        const int total = NC * pl.SPANW;
+        zmask = 0u;
+        const int u0 = pl.flat ? 0 : q0 * p.stride - p.padL + (p.tapstep > 0 ? 0 : -(p.taps - 1));
+#pragma unroll
+        for (int t = 0; t < ZPT; ++t) {
+            const int e = tid + NTHREADS * t;
+            float v = 0.f;
+            if (e < total) {
+                const int cl = (int)div_magic((unsigned)e, pl.span_magic);
+                const int i = e - cl * pl.SPANW;
+                const int ci = c_lo + cl;
+                int sz = s, u;
+                bool ok;
+                if (pl.flat) {
+                    const unsigned n = (unsigned)(q0 + i);
+                    ok = (int)n < ntot;
+                    sz = (int)div_magic(n, pl.ncols_magic);
+                    u = (int)n - sz * p.Ncols;
+                    if (u < 0) { --sz; u += p.Ncols; }
+                } else {
+                    u = u0 + i;
+                    if (p.pad_mode == PASE_PAD_REFLECT) {
+                        if (u < 0) u = -u;
+                        if (u >= p.Tz) u = 2 * (p.Tz - 1) - u;
+                    }
+                    ok = u >= 0 && u < p.Tz;
+                }
+                if (ok) {
+                    v = p.z[((size_t)sz * p.z_ctot + p.z_coff + ci) * (size_t)p.Tz + u];   // raw prefetch
+                    zmask |= 1u << t;
+                }
+            }
+            zreg[t] = v;
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_stage = [&](int buf) {
+        // on-load transforms are applied here, after the MFMA loop the prefetch was hidden under
+        if (p.g_alpha) {
 #pragma unroll
-        for (int i = 0; i < A_PER_T; ++i) As[buf][kc][r0 + i * RSTEP] = areg[i];
+            for (int i = 0; i < A_ROWS; ++i) {
+                const int m = m0 + (tid >> 5) + 8 * i;
+                const float gv = areg[i];
+                if (m < p.M) areg[i] = gv > 0.f ? gv : gv * p.g_alpha[m];
+            }
+        }
+        if (p.in_scale || p.in_alpha) {
 #pragma unroll
-        for (int i = 0; i < B_PER_T; ++i) Bs[buf][kc][r0 + i * RSTEP] = breg[i];
+            for (int t = 0; t < ZPT; ++t) {
+                if (zmask & (1u << t)) {
+                    const int ci = c_lo + (int)div_magic((unsigned)(tid + NTHREADS * t), pl.span_magic);
+                    float v = zreg[t];
+                    if (p.in_scale) v = v * p.in_scale[ci] + p.in_shift[ci];
+                    if (p.in_alpha) v = v > 0.f ? v : v * p.in_alpha[ci];
+                    zreg[t] = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < A_ROWS; ++i) As[buf][tid & 31][(tid >> 5) + 8 * i] = areg[i];
+#pragma unroll
+        for (int t = 0; t < ZPT; ++t) Zs[buf][tid + NTHREADS * t] = zreg[t];
     };
 
     f32x16 acc[2][2];
@@ -125,27 +192,29 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_gemm_kernel(PaseWgrad p, int n
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    load_tile(kt_begin);
-    store_tile(0);
+    const bool row_ok0 = m0 + wm * 64 < p.M, row_ok1 = m0 + wm * 64 + 32 < p.M;
+    const bool col_ok0 = j0 + wn * 64 < Nw, col_ok1 = j0 + wn * 64 + 32 < Nw;
+    const bool full_tile = row_ok0 && row_ok1 && col_ok0 && col_ok1;
+
+    load_stage(c_begin);
+    store_stage(0);
     __syncthreads();
-    const int fr = lane & 31;
-    const int fk = lane >> 5;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int cur = (kt - kt_begin) & 1;
-        if (kt + 1 < kt_end) load_tile(kt + 1);
-#pragma unroll
-        for (int ks = 0; ks < BK / 2; ++ks) {
-            const int kb = ks * 2 + fk;
-            const float a0 = As[cur][kb][wm * 64 + fr];
-            const float a1 = As[cur][kb][wm * 64 + 32 + fr];
-            const float b0 = Bs[cur][kb][wn * 64 + fr];
-            const float b1 = Bs[cur][kb][wn * 64 + 32 + fr];
+    for (int c = c_begin; c < c_end; ++c) {
+        const int cur = (c - c_begin) & 1;
+        if (c + 1 < c_end) load_stage(c + 1);
+#pragma unroll 4
+        for (int ks = 0; ks < BKQ / 2; ++ks) {   // unconditional MFMAs (see conv_gemm.hip)
+            const int kq = ks * 2 + fk;
+            const float a0 = As[cur][kq][wm * 64 + fr];
+            const float a1 = As[cur][kq][wm * 64 + 32 + fr];
+            const float b0 = Zs[cur][boff[0] + kq * zstep];
+            const float b1 = Zs[cur][boff[1] + kq * zstep];
             acc[0][0] = pase_mfma_32x32x2(a0, b0, acc[0][0]);
             acc[0][1] = pase_mfma_32x32x2(a0, b1, acc[0][1]);
             acc[1][0] = pase_mfma_32x32x2(a1, b0, acc[1][0]);
             acc[1][1] = pase_mfma_32x32x2(a1, b1, acc[1][1]);
         }
-        if (kt + 1 < kt_end) store_tile(cur ^ 1);
+        if (c + 1 < c_end) store_stage(cur ^ 1);
         __syncthreads();
     }
 
@@ -172,27 +241,47 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_gemm_kernel(PaseWgrad p, int n
 extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
     const PaseWgrad p = *d;
     if (p.M <= 0 || p.Cin <= 0 || p.S <= 0 || p.Ncols <= 0) return 0;
+    if (p.tap_major) return -4;          // express tap-major weights as per-tap launches (ldw + offset)
+    if (p.tapstep != 1 && p.tapstep != -1) return -5;
+    if (p.pad_mode == PASE_PAD_REFLECT && p.padL >= p.Tz) return -3;
+    if ((long)p.S * p.Ncols >= 0x7fffffffL) return -8;
     hipStream_t st = (hipStream_t)stream;
     const int Nw = p.Cin * p.taps + (p.dbias ? 1 : 0);
-    const long kred = (long)p.S * p.Ncols;
-    const int nk = (int)((kred + BK - 1) / BK);
-    const bool narrow = p.M <= 64;
+    bool narrow = p.M <= 64;
+    WgradPlan pl;
+    pl.flat = (p.taps == 1 && p.stride == 1 && p.padL == 0 && p.tapstep == 1) ? 1 : 0;
+    pl.SPANW = pl.flat ? BKQ : (BKQ - 1) * p.stride + p.taps;
+    auto fits = [&](int bn) {
+        long max_nc = (bn - 1) / p.taps + 2;     // channels a tile of bn (ci,kk) columns can touch
+        if (max_nc > p.Cin) max_nc = p.Cin;
+        return max_nc * pl.SPANW <= ZS_DATA;
+    };
+    if (narrow && !fits(256)) narrow = false;
+    if (!narrow && !fits(128)) return -6;
     const int BMv = narrow ? 64 : 128, BNv = narrow ? 256 : 128;
-    const int nrt = (p.M + BMv - 1) / BMv, nct = (Nw + BNv - 1) / BNv;
-    const int tiles = nrt * nct;
+    if ((BKQ - 1) * (pl.flat ? 1 : p.stride) + 1 > ZS_ONES) return -6;
+    pl.n_row_tiles = (p.M + BMv - 1) / BMv;
+    pl.n_col_tiles = (Nw + BNv - 1) / BNv;
+    const long kred = (long)p.S * p.Ncols;
+    pl.chunks_per_seq = (p.Ncols + BKQ - 1) / BKQ;
+    pl.n_chunks = pl.flat ? (int)((kred + BKQ - 1) / BKQ) : p.S * pl.chunks_per_seq;
+    pl.span_magic = (unsigned)((0x100000000ULL + pl.SPANW - 1) / (unsigned long long)pl.SPANW);
+    pl.ncols_magic = (unsigned)((0x100000000ULL + p.Ncols - 1) / (unsigned long long)p.Ncols);
+    const int tiles = pl.n_row_tiles * pl.n_col_tiles;
     int splitk = p.splitk;
     if (splitk <= 0) {
-        splitk = (1536 + tiles - 1) / tiles;            // ~6 workgroups per CU in flight
-        const int max_split = (nk + 7) / 8;             // at least 8 K-tiles (2 k MFMAs/wave) per split
+        splitk = (1024 + tiles - 1) / tiles;              // ~2 resident waves of workgroups (2 WG/CU)
+        const int max_split = (pl.n_chunks + 3) / 4;      // at least 4 stages (256 MFMAs/wave) per split
         if (splitk > max_split) splitk = max_split;
         if (splitk < 1) splitk = 1;
     }
-    const int kt_per_split = (nk + splitk - 1) / splitk;
-    splitk = (nk + kt_per_split - 1) / kt_per_split;
+    if (splitk > pl.n_chunks) splitk = pl.n_chunks;
+    pl.kt_per_split = (pl.n_chunks + splitk - 1) / splitk;
+    splitk = (pl.n_chunks + pl.kt_per_split - 1) / pl.kt_per_split;
     if (narrow)
-        PASE_LAUNCH((wgrad_gemm_kernel<64, 256>), dim3((unsigned)(tiles * splitk)), dim3(NTHREADS), st, p, nrt, nct, kt_per_split);
+        PASE_LAUNCH((wgrad_gemm_kernel<64, 256>), dim3((unsigned)(tiles * splitk)), dim3(NTHREADS), st, p, pl);
     else
-        PASE_LAUNCH((wgrad_gemm_kernel<128, 128>), dim3((unsigned)(tiles * splitk)), dim3(NTHREADS), st, p, nrt, nct, kt_per_split);
+        PASE_LAUNCH((wgrad_gemm_kernel<128, 128>), dim3((unsigned)(tiles * splitk)), dim3(NTHREADS), st, p, pl);
     PASE_CHECK_LAUNCH();
     return 0;
 }

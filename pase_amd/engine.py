@@ -72,7 +72,8 @@ def conv_fwd(a: Act, w2d, bias, *, Cout, taps, stride=1, padL=0, padR=0, pad_mod
     y = out if out is not None else _new((S, Cout, Tout), a.t)
     stat = None
     if want_stats:
-        stat = _new((K.stat_tiles(Cout, S, Tout), Cout, 2), a.t)
+        stat = _new((K.stat_tiles(M=Cout, S=S, Ncols=Tout, Cin=a.C, taps=taps, stride=stride, padL=padL,
+                                  tapstep=tapstep), Cout, 2), a.t)
     K.conv_gemm(a.t, w2d, y, S=S, Cin=a.C, Tin=Tin, M=Cout, K=a.C * taps, taps=taps, Ncols=Tout, Tout=Tout,
                 ldw=w2d.shape[1], bias=bias, in_scale=a.scale, in_shift=a.shift, in_alpha=a.alpha, stat_part=stat,
                 x_ctot=a.ctot, x_coff=a.coff, tap_major=tap_major, stride=stride, tapstep=tapstep, padL=padL,
@@ -96,14 +97,14 @@ def conv_dgrad(dy, w_nat, *, R, O, k, stride, Tin, padL, padR, s_red, s_out, s_k
 
 
 def conv_wgrad(dy, a: Act, dw2d, dbias, *, taps, stride=1, padL=0, pad_mode=K.PAD_ZERO, tap_major=0, tapstep=1,
-               g_ctot=None, g_coff=0, M=None, Ncols=None, g_alpha=None):
+               g_ctot=None, g_coff=0, M=None, Ncols=None, g_alpha=None, dw_col_off=0):
     S = a.S
     M = dy.shape[1] if M is None else M
     K.wgrad_gemm(dy, a.t, dw2d, S=S, M=M, Tg=dy.shape[2], Ncols=dy.shape[2] if Ncols is None else Ncols, Cin=a.C,
                  Tz=a.T, taps=taps, ldw=dw2d.shape[1], dbias=dbias, g_ctot=dy.shape[1] if g_ctot is None else g_ctot,
                  g_coff=g_coff, z_ctot=a.ctot, z_coff=a.coff, in_scale=a.scale, in_shift=a.shift, in_alpha=a.alpha,
                  tap_major=tap_major, stride=stride, tapstep=tapstep, padL=padL, pad_mode=pad_mode,
-                 g_alpha=g_alpha)
+                 g_alpha=g_alpha, dw_col_off=dw_col_off)
 
 
 def deconv_fwd(a: Act, w_nat, bias, *, Cout, k, stride):
@@ -347,9 +348,11 @@ def encoder_backward(fe, ctx, demb, sink):
         dgates = _new((S, 3 * H, F_), x)
         K.qrnn_scan_bwd(r["gates"], r["c"], dsrc, dgates, S=S, H=H, F=F_, dh_ctot=dsrc_ctot, dh_coff=dsrc_coff)
         inp = r["inp"]
-        conv_wgrad(dgates, inp, sink.buf(layer.linear.weight), sink.buf(layer.linear.bias), taps=2, tap_major=1,
-                   tapstep=-1, padL=0, pad_mode=K.PAD_ZERO)
         cin = inp.C
+        # Linear over [x_t ; x_{t-1}] (tap-major columns): one wgrad per tap into the two column halves
+        dwq = sink.buf(layer.linear.weight)
+        conv_wgrad(dgates, inp, dwq, sink.buf(layer.linear.bias), taps=1, padL=0, pad_mode=K.PAD_ZERO)
+        conv_wgrad(dgates, inp, dwq, None, taps=1, padL=1, pad_mode=K.PAD_ZERO, dw_col_off=cin)
         # dX[s,ci,u] = sum_{o,r} Wq[o, r*cin+ci] * dG[s,o,u+r]
         wp = _new((cin, 3 * H * 2), x)
         K.pack_dgrad(layer.linear.weight, wp, R=3 * H, O=cin, k=2, st=1, s_red=2 * cin, s_out=1, s_k=cin)

@@ -28,15 +28,17 @@ class PaseConvGemm(C.Structure):
         ("y_ctot", C.c_int), ("y_coff", C.c_int), ("Cout_store", C.c_int), ("ps", C.c_int),
         ("poff", C.c_int), ("Tout", C.c_int),
         ("epilogue", C.c_int), ("r_ctx", C.c_int), ("label_D", C.c_int),
-        ("tile_hint", C.c_int),
+        ("tile_hint", C.c_int), ("splitk", C.c_int),
     ]
 
 
 def declare(l):
     l.pase_conv_gemm.argtypes = [C.POINTER(PaseConvGemm), C.c_void_p]
     l.pase_conv_gemm.restype = C.c_int
-    l.pase_conv_gemm_stat_tiles.argtypes = [C.c_int] * 4
+    l.pase_conv_gemm_stat_tiles.argtypes = [C.POINTER(PaseConvGemm)]
     l.pase_conv_gemm_stat_tiles.restype = C.c_int
+    l.pase_conv_gemm_splitk.argtypes = [C.POINTER(PaseConvGemm)]
+    l.pase_conv_gemm_splitk.restype = C.c_int
     l.pase_abi_sizeof.argtypes = [C.c_int]
     l.pase_abi_sizeof.restype = C.c_int
     if l.pase_abi_sizeof(0) != C.sizeof(PaseConvGemm):
@@ -77,16 +79,12 @@ def _check(rc, name):
         raise RuntimeError("%s failed with code %d" % (name, rc))
 
 
-def stat_tiles(M, S, Ncols, tile_hint=0):
-    return _lib.lib().pase_conv_gemm_stat_tiles(M, S, Ncols, tile_hint)
-
-
-def conv_gemm(x, w, y, *, S, Cin, Tin, M, K, taps, Ncols, Tout, ldw=None, bias=None,
-              in_scale=None, in_shift=None, in_alpha=None, stat_part=None,
-              x_ctot=None, x_coff=0, tap_major=0, stride=1, tapstep=1, padL=0, pad_mode=PAD_ZERO,
-              y_ctot=None, y_coff=0, Cout_store=None, ps=1, poff=0,
-              epilogue=EPI_STORE, label=None, grad_out=None, loss_acc=None, grad_scale=0.0,
-              r_ctx=0, label_D=0, tile_hint=0):
+def _conv_desc(x, w, y, *, S, Cin, Tin, M, K, taps, Ncols, Tout, ldw=None, bias=None,
+               in_scale=None, in_shift=None, in_alpha=None, stat_part=None,
+               x_ctot=None, x_coff=0, tap_major=0, stride=1, tapstep=1, padL=0, pad_mode=PAD_ZERO,
+               y_ctot=None, y_coff=0, Cout_store=None, ps=1, poff=0,
+               epilogue=EPI_STORE, label=None, grad_out=None, loss_acc=None, grad_scale=0.0,
+               r_ctx=0, label_D=0, tile_hint=0, splitk=0):
     d = PaseConvGemm()
     d.x, d.w, d.y, d.bias = _ptr(x), _ptr(w), _ptr(y), _ptr(bias)
     d.in_scale, d.in_shift, d.in_alpha = _ptr(in_scale), _ptr(in_shift), _ptr(in_alpha)
@@ -104,6 +102,26 @@ def conv_gemm(x, w, y, *, S, Cin, Tin, M, K, taps, Ncols, Tout, ldw=None, bias=N
     d.y_coff, d.Cout_store, d.ps, d.poff, d.Tout = y_coff, cs, ps, poff, Tout
     d.epilogue, d.r_ctx, d.label_D = epilogue, r_ctx, label_D
     d.tile_hint = tile_hint
+    d.splitk = splitk
+    return d
+
+
+def stat_tiles(*, M, S, Ncols, Cin, taps, stride=1, padL=0, tapstep=1, tile_hint=0):
+    """first dim of the stat_part buffer a conv_gemm launch with these dims writes"""
+    d = PaseConvGemm()
+    d.M, d.S, d.Ncols, d.Cin, d.taps, d.stride, d.padL, d.tapstep, d.tile_hint = (M, S, Ncols, Cin, taps, stride,
+                                                                                  padL, tapstep, tile_hint)
+    d.K = Cin * taps
+    d.splitk = 1
+    return _lib.lib().pase_conv_gemm_stat_tiles(C.byref(d))
+
+
+def conv_gemm(x, w, y, **kw):
+    """see include/pase_amd.h PaseConvGemm.  With splitk > 1 the output is zero-filled here first."""
+    d = _conv_desc(x, w, y, **kw)
+    if d.splitk != 1:
+        if _lib.lib().pase_conv_gemm_splitk(C.byref(d)) > 1:
+            y.zero_()
     _check(_lib.lib().pase_conv_gemm(C.byref(d), _stream()), "pase_conv_gemm")
 
 
@@ -167,10 +185,10 @@ def abi_check(l):
 
 def wgrad_gemm(g, z, dw, *, S, M, Tg, Ncols, Cin, Tz, taps, ldw=None, dbias=None, g_ctot=None, g_coff=0,
                z_ctot=None, z_coff=0, in_scale=None, in_shift=None, in_alpha=None, tap_major=0, stride=1,
-               tapstep=1, padL=0, pad_mode=PAD_ZERO, splitk=0, g_alpha=None):
+               tapstep=1, padL=0, pad_mode=PAD_ZERO, splitk=0, g_alpha=None, dw_col_off=0):
     d = PaseWgrad()
     d.g_alpha = _ptr(g_alpha)
-    d.g, d.z, d.dw, d.dbias = _ptr(g), _ptr(z), _ptr(dw), _ptr(dbias)
+    d.g, d.z, d.dw, d.dbias = _ptr(g), _ptr(z), _ptr(dw) + 4 * dw_col_off, _ptr(dbias)
     d.in_scale, d.in_shift, d.in_alpha = _ptr(in_scale), _ptr(in_shift), _ptr(in_alpha)
     d.S, d.M, d.Tg, d.Ncols = S, M, Tg, Ncols
     d.g_ctot = M if g_ctot is None else g_ctot

@@ -36,7 +36,7 @@ def test_conv_fwd_reflect(dev, Cin, Cout, k, stride, T, S):
     ref = F.conv1d(xp, w, b, stride=stride)
     Tout = ref.shape[2]
     y = torch.zeros(S, Cout, Tout, device=dev)
-    nt = K.stat_tiles(Cout, S, Tout)
+    nt = K.stat_tiles(M=Cout, S=S, Ncols=Tout, Cin=Cin, taps=k, stride=stride, padL=P[0])
     stat = torch.zeros(nt, Cout, 2, device=dev)
     K.conv_gemm(x.to(dev), w.reshape(Cout, -1).contiguous().to(dev), y, S=S, Cin=Cin, Tin=T, M=Cout,
                 K=Cin * k, taps=k, Ncols=Tout, Tout=Tout, bias=b.to(dev), in_scale=sc.to(dev),
@@ -119,3 +119,33 @@ def test_mse_context_epilogue(dev):
     torch.testing.assert_close(y.cpu(), pred, **_tol(dev))
     torch.testing.assert_close((acc.cpu() / n).float()[0], ref_loss, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(g.cpu(), 2.0 * (pred - tg) / n, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("splitk", [1, 3])
+def test_long_reduction_splitk_and_ragged_flat(dev, splitk):
+    """1x1 data-gradient shape of the wide heads: few output tiles, long K (split-K with atomics);
+    columns flattened across sequences with a ragged tail (T=37 x S=5)."""
+    torch.manual_seed(4)
+    S, Cin, Cout, T = 5, 300, 70, 37
+    x = torch.randn(S, Cin, T)
+    w = torch.randn(Cout, Cin) * 0.1
+    ref = torch.einsum("ok,skt->sot", w, x)
+    y = torch.full((S, Cout, T), 3.0, device=dev)
+    K.conv_gemm(x.to(dev), w.to(dev), y, S=S, Cin=Cin, Tin=T, M=Cout, K=Cin, taps=1, Ncols=T, Tout=T, splitk=splitk)
+    torch.testing.assert_close(y.cpu(), ref, rtol=1e-4, atol=1e-4)
+
+
+def test_channel_slices_and_large_taps(dev):
+    """reads a channel slice of a wider buffer, writes a channel slice of a wider buffer, taps > 48
+    (tap sub-ranges), zero padding."""
+    torch.manual_seed(5)
+    S, Cin, Cout, T, k = 2, 3, 9, 150, 61
+    xw = torch.randn(S, Cin + 4, T)
+    w = torch.randn(Cout, Cin, k) * 0.2
+    ref = F.conv1d(xw[:, 2:2 + Cin], w, padding=k // 2)
+    yw = torch.zeros(S, Cout + 5, T, device=dev)
+    K.conv_gemm(xw.to(dev), w.reshape(Cout, -1).contiguous().to(dev), yw, S=S, Cin=Cin, Tin=T, M=Cout, K=Cin * k,
+                taps=k, Ncols=T, Tout=T, x_ctot=Cin + 4, x_coff=2, y_ctot=Cout + 5, y_coff=1, padL=k // 2,
+                pad_mode=K.PAD_ZERO)
+    torch.testing.assert_close(yw.cpu()[:, 1:1 + Cout], ref, rtol=2e-5, atol=2e-5)
+    assert float(yw.cpu()[:, 0].abs().max()) == 0.0
