@@ -1,0 +1,94 @@
+"""Data-parallel step, world_size 2 over gloo on CPU (kernels on the SIMT emulator): the N>1 path of
+trainer.train_step -- per-rank batch, sum-all-reduce of the flat gradient buffers, 1/N folded into
+the Adam kernel -- equals a single process that averages the two per-rank gradients itself.
+BatchNorm statistics are per rank, so the reference value is built from two
+independent per-batch backward passes, exactly what each rank computes."""
+import os
+import sys
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from util import MINI_FE, is_noise_grad, mini_workers, quiet, seed_all, with_losses
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _batch(seed, B=2, T=1600):
+    g = torch.Generator().manual_seed(seed)
+    b = {k: torch.randn(B, 1, T, generator=g) * 0.3 for k in ("chunk", "chunk_ctxt", "chunk_rand", "cchunk")}
+    b["lps"] = torch.randn(B, 5, T // 160, generator=g)
+    b["prosody"] = torch.randn(B, 3, T // 160, generator=g)
+    return b
+
+
+def _make_trainer():
+    from pase_amd.trainer import trainer
+    seed_all(0)
+    return quiet(trainer, frontend_cfg=dict(MINI_FE), minions_cfg=with_losses(mini_workers()),
+                 cfg=dict(fe_lr=1e-3, min_lr=5e-4, epoch=1, bpe=4), lr_mode="poly")
+
+
+def _worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HIPEMU_THREADS"] = "2"
+    from pase_amd import _lib, build
+    _lib.use_library(build.build_emu(), "cpu")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if rank == 1:
+        torch.manual_seed(999)      # different initial weights on purpose: broadcast must fix it
+    tr = _make_trainer() if rank == 0 else None
+    if rank == 1:
+        from pase_amd.trainer import trainer
+        tr = quiet(trainer, frontend_cfg=dict(MINI_FE), minions_cfg=with_losses(mini_workers()),
+                   cfg=dict(fe_lr=1e-3, min_lr=5e-4, epoch=1, bpe=4), lr_mode="poly")
+    assert tr.world == 2
+    losses = tr.train_step(_batch(100 + rank))
+    sd = {n: p.detach().clone() for n, p in tr.model.named_parameters()}
+    torch.save({"params": sd, "total": float(losses["total"])}, os.path.join(outdir, "rank%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_matches_manual_average():
+    from pase_amd import _lib, build
+    from pase_amd import engine
+    so = build.build_emu()
+    port = 29500 + (os.getpid() % 2000)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(2, port, d), nprocs=2, join=True)
+        r0 = torch.load(os.path.join(d, "rank0.pt"))
+        r1 = torch.load(os.path.join(d, "rank1.pt"))
+    for n in r0["params"]:
+        assert torch.equal(r0["params"][n], r1["params"][n]), "ranks diverged on " + n
+    # single-process reference: two per-batch gradient passes from the same initial weights
+    _lib.use_library(so, "cpu")
+    try:
+        tr = _make_trainer()
+        init = {k: v.clone() for k, v in tr.model.state_dict().items()}
+        grads = []
+        for r in range(2):
+            with torch.no_grad():
+                for k, v in tr.model.state_dict().items():
+                    v.copy_(init[k])
+            for opt in tr.optimizers():
+                opt.zero_grad()
+            tr.model.train()
+            tr.model.loss_and_grads(_batch(100 + r), engine.GradSink(direct=True))
+            grads.append([opt.flat_g.clone() for opt in tr.optimizers()])
+        with torch.no_grad():
+            for k, v in tr.model.state_dict().items():
+                v.copy_(init[k])
+        for i, opt in enumerate(tr.optimizers()):
+            opt.flat_g.copy_(grads[0][i] + grads[1][i])
+            opt.step(grad_mul=0.5)
+        for n, p in tr.model.named_parameters():
+            if not is_noise_grad(n):     # analytically-zero gradients: Adam amplifies atomic-order round-off
+                torch.testing.assert_close(p.detach(), r0["params"][n], rtol=0, atol=5e-6, msg=n)
+    finally:
+        _lib.use_library(None, "cuda")

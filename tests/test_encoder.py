@@ -1,0 +1,114 @@
+"""WaveFe on the HIP kernels vs the CPU oracle: forward, every parameter gradient, BatchNorm running
+statistics, eval mode, dict input / output modes.  dev='emu' runs the same kernel sources on the CPU
+SIMT emulator (mini widths); dev='gpu' additionally checks the full-width PASE / PASE+ configs against
+the golden vectors generated from the live reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pase_oracle as O
+from util import (GOLD, MINI_FE, MINI_FE_PLAIN, assert_close, is_noise_grad, load_cfg, oracle_params, quiet,
+                  randomize_affine, seed_all)
+
+
+def _build(cfg, dev, seed=0):
+    from pase_amd.frontend import wf_builder
+    seed_all(seed)
+    fe = quiet(wf_builder, dict(cfg))
+    randomize_affine(fe)
+    return fe.to(dev)
+
+
+@pytest.mark.parametrize("cfg", [MINI_FE, MINI_FE_PLAIN, dict(MINI_FE, rnn_layers=2)], ids=["plus", "plain", "2xqrnn"])
+def test_mini_train_forward_backward(dev, cfg):
+    fe = _build(cfg, dev)
+    P = oracle_params(fe)
+    x = torch.randn(6, 1, 1600) * 0.3
+    fe.train()
+    y = fe(x.to(dev))
+    so = {}
+    yo = O.encoder_forward(P, cfg, x, True, so)
+    assert y.shape == yo.shape
+    assert_close(y, yo, rtol=1e-4, atol=1e-4, what="forward")
+    g = torch.randn_like(yo)
+    (yo * g).sum().backward()
+    (y * g.to(dev)).sum().backward()
+    for n, p in fe.named_parameters():
+        if is_noise_grad(n):
+            continue
+        ref = P[n].grad
+        assert_close(p.grad, ref, rtol=1e-3, atol=1e-4 * max(1.0, float(ref.abs().max())), what=n)
+    sd = fe.state_dict()
+    for k, v in so.items():
+        assert_close(sd[k], v, rtol=1e-5, atol=1e-6, what=k)
+    assert int(sd["blocks.1.norm.num_batches_tracked"]) == 1
+
+
+def test_mini_eval_modes_and_dict_input(dev):
+    cfg = MINI_FE
+    fe = _build(cfg, dev, seed=3)
+    with torch.no_grad():      # non-trivial running stats
+        for n, b in fe.named_buffers():
+            if n.endswith("running_mean"):
+                b.normal_(0, 0.1)
+            if n.endswith("running_var"):
+                b.uniform_(0.5, 1.5)
+    P = oracle_params(fe)
+    fe.eval()
+    x = torch.randn(2, 1, 1760) * 0.3       # not a multiple of the 160 hop after the strides
+    with torch.no_grad():
+        yo = O.encoder_forward(P, cfg, x, False)
+        for mode in (None, "avg_norm", "avg_concat", "avg_norm_concat"):
+            y = fe(x.to(dev), mode=mode)
+            assert_close(y, O.select_output(yo, mode), rtol=1e-4, atol=1e-4, what=str(mode))
+        batch = {k: torch.randn(2, 1, 1600) * 0.3 for k in ("chunk", "chunk_ctxt", "chunk_rand")}
+        h, chunk = fe({k: v.to(dev) for k, v in batch.items()}, device=dev)
+        ho, co = O.encoder_forward_batch(P, cfg, batch, False)
+        assert len(h) == 3
+        for a, b in zip(h, ho):
+            assert_close(a, b, rtol=1e-4, atol=1e-4)
+        assert_close(chunk, co, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("tag,cfgfile", [("pase_plus", "frontend/PASE+.cfg"), ("pase", "frontend/PASE.cfg")])
+def test_full_width_golden(dev, tag, cfgfile):
+    """Full-width PASE / PASE+ encoder vs vectors produced by the live reference (fp32 |err| <= 1e-4
+    on the normalised embedding: BASELINE.json north_star tolerance)."""
+    if dev.type == "cpu":
+        pytest.skip("full-width configs are GPU-only (emulator covers the mini configs)")
+    from pase_amd.frontend import wf_builder
+    g = np.load(os.path.join(GOLD, "wavefe_%s.npz" % tag))
+    cfg = load_cfg(cfgfile)
+    seed_all(int(g["seed"]))
+    fe = quiet(wf_builder, dict(cfg)).to(dev)
+    x = torch.tensor(g["x"]).to(dev)
+    fe.train()
+    y = fe(x)
+    assert tuple(y.shape) == g["y_train"].shape
+    assert_close(y, g["y_train"], rtol=0, atol=1e-4, what="train forward")
+    (y * torch.tensor(g["g"]).to(dev)).sum().backward()
+    names = [str(s) for s in g["grad_names"]]
+    params = dict(fe.named_parameters())
+    keep = [i for i, n in enumerate(names) if not is_noise_grad(n)]
+    gsq = torch.tensor([float((params[names[i]].grad.double() ** 2).sum()) for i in keep])
+    assert_close(gsq.sqrt(), np.sqrt(g["grad_sq"][keep]), rtol=2e-3, atol=1e-5, what="grad norms")
+    fe.eval()
+    with torch.no_grad():
+        assert_close(fe(x), g["y_eval"], rtol=0, atol=1e-4, what="eval forward")
+        assert_close(fe(x, mode="avg_norm"), g["y_avg_norm"], rtol=0, atol=1e-4)
+
+
+def test_readme_shapes(dev):
+    """BASELINE.json configs[0] / README.md:31-39: (1,1,100000) -> (1,256,625) for PASE+.cfg and
+    (1,100,625) for PASE.cfg (SURVEY.md headline fact 6)."""
+    if dev.type == "cpu":
+        pytest.skip("full-width configs are GPU-only")
+    from pase_amd.frontend import wf_builder
+    for cfgfile, emb in (("frontend/PASE+.cfg", 256), ("frontend/PASE.cfg", 100)):
+        fe = quiet(wf_builder, load_cfg(cfgfile)).to(dev).eval()
+        with torch.no_grad():
+            y = fe(torch.randn(1, 1, 100000, device=dev))
+        assert tuple(y.shape) == (1, emb, 625)
+        assert bool(torch.isfinite(y).all())

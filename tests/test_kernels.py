@@ -1,0 +1,239 @@
+"""Unit parity tests of the non-GEMM kernels and the wgrad contraction against torch fp32 / autograd."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from pase_amd import kernels as K
+from util import GOLD, assert_close
+
+
+def test_wgrad_conv_reflect_stride(dev):
+    torch.manual_seed(0)
+    S, Cin, Cout, k, st, T = 3, 5, 70, 11, 2, 80
+    x = torch.randn(S, Cin, T, requires_grad=False)
+    sc, sh, al = torch.rand(Cin) + 0.5, torch.randn(Cin) * 0.1, torch.rand(Cin) * 0.5
+    w = torch.randn(Cout, Cin, k, requires_grad=True)
+    b = torch.zeros(Cout, requires_grad=True)
+    xin = x * sc[None, :, None] + sh[None, :, None]
+    xin = torch.where(xin > 0, xin, xin * al[None, :, None])
+    y = F.conv1d(F.pad(xin, (4, 5), mode="reflect"), w, b, stride=st)
+    g = torch.randn_like(y)
+    (y * g).sum().backward()
+    dw = torch.zeros(Cout, Cin * k, device=dev)
+    db = torch.zeros(Cout, device=dev)
+    K.wgrad_gemm(g.to(dev), x.to(dev), dw, S=S, M=Cout, Tg=y.shape[2], Ncols=y.shape[2], Cin=Cin, Tz=T, taps=k,
+                 dbias=db, in_scale=sc.to(dev), in_shift=sh.to(dev), in_alpha=al.to(dev), stride=st, padL=4,
+                 pad_mode=K.PAD_REFLECT)
+    assert_close(dw.view(Cout, Cin, k), w.grad, rtol=1e-4, atol=1e-3, what="dW")
+    assert_close(db, b.grad, rtol=1e-4, atol=1e-3, what="db")
+
+
+def test_wgrad_flat_1x1_and_narrow(dev):
+    torch.manual_seed(1)
+    for (S, Cin, Cout, T) in [(5, 40, 9, 37), (4, 20, 150, 50)]:
+        x = torch.randn(S, Cin, T)
+        g = torch.randn(S, Cout, T)
+        ref = torch.einsum("sot,sct->oc", g, x)
+        dw = torch.zeros(Cout, Cin, device=dev)
+        db = torch.zeros(Cout, device=dev)
+        K.wgrad_gemm(g.to(dev), x.to(dev), dw, S=S, M=Cout, Tg=T, Ncols=T, Cin=Cin, Tz=T, taps=1, dbias=db)
+        assert_close(dw, ref, rtol=1e-4, atol=1e-3)
+        assert_close(db, g.sum((0, 2)), rtol=1e-4, atol=1e-3)
+
+
+def test_wgrad_conv_transpose_roles_swapped(dev):
+    """nn.ConvTranspose1d weight gradient: G = PReLU(layer input) at the low rate, Z = dY."""
+    torch.manual_seed(2)
+    S, Cin, Cout, k, st, T = 2, 70, 6, 30, 4, 12
+    z_in = torch.randn(S, Cin, T)
+    al = torch.rand(Cin) * 0.5
+    w = torch.randn(Cin, Cout, k, requires_grad=True)
+    a = torch.where(z_in > 0, z_in, z_in * al[None, :, None])
+    pad = (k - st) // 2
+    y = F.conv_transpose1d(a, w, None, stride=st, padding=pad)
+    g = torch.randn_like(y)
+    (y * g).sum().backward()
+    dw = torch.zeros(Cin, Cout * k, device=dev)
+    K.wgrad_gemm(z_in.to(dev), g.to(dev), dw, S=S, M=Cin, Tg=T, Ncols=T, Cin=Cout, Tz=y.shape[2], taps=k,
+                 stride=st, padL=pad, pad_mode=K.PAD_ZERO, g_alpha=al.to(dev))
+    assert_close(dw.view(Cin, Cout, k), w.grad, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("F_", [7, 200, 625])
+def test_qrnn_scan_fwd_bwd(dev, F_):
+    """ForgetMult recurrence incl. the multi-chunk carry (F > 256) vs a sequential torch loop."""
+    torch.manual_seed(3)
+    S, H = 2, 5
+    gates = torch.randn(S, 3 * H, F_, requires_grad=True)
+    Z, Fg, O = gates.chunk(3, 1)
+    Z, Fg, O = torch.tanh(Z), torch.sigmoid(Fg), torch.sigmoid(O)
+    cs, c = [], None
+    for t in range(F_):
+        ct = Fg[:, :, t] * Z[:, :, t]
+        if c is not None:
+            ct = ct + (1 - Fg[:, :, t]) * c
+        cs.append(ct)
+        c = ct
+    C = torch.stack(cs, 2)
+    Hh = O * C
+    dh = torch.randn_like(Hh)
+    (Hh * dh).sum().backward()
+    hbuf = torch.zeros(S, H + 3, F_, device=dev)       # write into a channel slice of a wider buffer
+    cbuf = torch.zeros(S, H, F_, device=dev)
+    gd = gates.detach().to(dev)
+    K.qrnn_scan_fwd(gd, hbuf, cbuf, S=S, H=H, F=F_, h_ctot=H + 3, h_coff=2)
+    assert_close(hbuf[:, 2:2 + H], Hh, rtol=1e-5, atol=1e-5)
+    assert_close(cbuf, C, rtol=1e-5, atol=1e-5)
+    dg = torch.zeros(S, 3 * H, F_, device=dev)
+    dhw = torch.zeros(S, H + 1, F_)
+    dhw[:, 1:] = dh
+    K.qrnn_scan_bwd(gd, cbuf, dhw.to(dev), dg, S=S, H=H, F=F_, dh_ctot=H + 1, dh_coff=1)
+    assert_close(dg, gates.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_sinc_filters_and_gradient(dev):
+    from oracle import pase_oracle as O
+    p = np.load(os.path.join(GOLD, "sinc_perturbed.npz"))
+    low, band = torch.tensor(p["low_hz_"]), torch.tensor(p["band_hz_"])
+    win, n_ = O.sinc_constants()
+    filt = torch.zeros(64, 251, device=dev)
+    args = dict(C_=64, Kw=251, min_low=50.0, min_band=50.0, sr=16000.0)
+    K.sinc_filters(low.to(dev), band.to(dev), n_.contiguous().to(dev), win.contiguous().to(dev), filt, **args)
+    assert_close(filt, p["filters"][:, 0], rtol=1e-5, atol=2e-6, what="filters vs live reference")
+    # gradient: dF from the reference conv, chained by the HIP kernel
+    lo = torch.tensor(p["low_hz_"], requires_grad=True)
+    ba = torch.tensor(p["band_hz_"], requires_grad=True)
+    f = O.sinc_filters(lo, ba)
+    f.retain_grad()
+    y = F.conv1d(F.pad(torch.tensor(p["x"]), (125, 125), mode="reflect"), f)
+    (y * torch.tensor(p["g"])).sum().backward()
+    dlow, dband = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    K.sinc_filters_bwd(low.to(dev), band.to(dev), n_.contiguous().to(dev), win.contiguous().to(dev),
+                       f.grad[:, 0].contiguous().to(dev), dlow, dband, **args)
+    assert_close(dlow, p["dlow"][:, 0], rtol=1e-3, atol=1e-6 * float(np.abs(p["dlow"]).max()) + 1e-7)
+    assert_close(dband, p["dband"][:, 0], rtol=1e-3, atol=1e-6 * float(np.abs(p["dband"]).max()) + 1e-7)
+
+
+def test_adam_matches_torch(dev):
+    torch.manual_seed(4)
+    p0 = torch.randn(1000)
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pt], lr=3e-3)
+    p = p0.clone().to(dev)
+    m, v = torch.zeros(1000, device=dev), torch.zeros(1000, device=dev)
+    lr = torch.tensor([3e-3], device=dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    for i in range(5):
+        g = torch.randn(1000)
+        pt.grad = g.clone()
+        opt.step()
+        K.step_tick(step)
+        K.adam_step(p, (2.0 * g).to(dev), m, v, lr, step, grad_mul=0.5)
+    assert int(step.item()) == 5
+    assert_close(p, pt.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_bn_finalize_running_stats(dev):
+    torch.manual_seed(5)
+    C, S, T = 6, 4, 50
+    y = torch.randn(S, C, T) * 2 + 1
+    bn = torch.nn.BatchNorm1d(C)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_()
+    ref = bn(y)
+    # emulate the conv epilogue partials: 3 column tiles
+    parts = torch.stack([torch.stack([y[:, :, a:b].sum((0, 2)), (y[:, :, a:b] ** 2).sum((0, 2))], 1)
+                         for a, b in ((0, 20), (20, 35), (35, 50))]).contiguous()
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    sc, sh, mean, rstd = (torch.zeros(C, device=dev) for _ in range(4))
+    K.bn_finalize(parts.to(dev), C, S * T, bn.weight.detach().to(dev), bn.bias.detach().to(dev), 1e-5, 0.1, rm, rv,
+                  sc, sh, mean, rstd)
+    out = torch.zeros(S, C, T, device=dev)
+    K.bn_act_apply(y.to(dev), out, sc, sh, None, S=S, C_=C, T=T)
+    assert_close(out, ref, rtol=1e-5, atol=1e-5)
+    assert_close(rm, bn.running_mean, rtol=1e-5, atol=1e-6)
+    assert_close(rv, bn.running_var, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("d", [1, 4, 16, 160])
+def test_bn_act_pool(dev, d):
+    torch.manual_seed(6)
+    S, C, F_ = 2, 3, 5
+    y = torch.randn(S, C, F_ * d + (1 if d > 1 else 0))
+    sc, sh, al = torch.rand(C) + 0.5, torch.randn(C), torch.rand(C)
+    a = y * sc[None, :, None] + sh[None, :, None]
+    a = torch.where(a > 0, a, a * al[None, :, None])
+    ref = a[:, :, :F_ * d].reshape(S, C, F_, d).mean(3)
+    out = torch.zeros(S, C + 2, F_, device=dev)
+    K.bn_act_pool(y.to(dev), out, sc.to(dev), sh.to(dev), al.to(dev), S=S, C_=C, T=y.shape[2], F=F_, d=d,
+                  o_ctot=C + 2, o_coff=1)
+    assert_close(out[:, 1:1 + C], ref, rtol=1e-5, atol=1e-5)
+
+
+def test_act_backward_reflect_fold_and_pool_branch(dev):
+    """d/dy of sum(g1 * conv-input-padded(a)) + sum(g2 * meanpool(a)), a = PReLU(BN_train(y))."""
+    torch.manual_seed(7)
+    S, C, T, pL, pR, d = 3, 4, 24, 4, 5, 4
+    y = torch.randn(S, C, T, requires_grad=True)
+    gamma = (torch.rand(C) + 0.5).requires_grad_(True)
+    beta = torch.randn(C, requires_grad=True)
+    al = (torch.rand(C) * 0.5).requires_grad_(True)
+    z = F.batch_norm(y, None, None, gamma, beta, True, 0.1, 1e-5)
+    a = F.prelu(z, al)
+    g1 = torch.randn(S, C, T + pL + pR)
+    g2 = torch.randn(S, C, T // d)
+    loss = (F.pad(a, (pL, pR), mode="reflect") * g1).sum() + (a.view(S, C, T // d, d).mean(3) * g2).sum()
+    loss.backward()
+    mean = y.detach().mean((0, 2))
+    var = y.detach().var((0, 2), unbiased=False)
+    rstd = torch.rsqrt(var + 1e-5)
+    scale = gamma.detach() * rstd
+    shift = beta.detach() - mean * scale
+    sums = torch.zeros(C, 3, dtype=torch.float64, device=dev)
+    dy = torch.zeros(S, C, T, device=dev)
+    kw = dict(S=S, C_=C, T=T, dsrc=g1.to(dev), Tp=T + pL + pR, padL=pL, pad_mode=K.PAD_REFLECT, dpool=g2.to(dev),
+              dpool_ctot=C, dpool_coff=0, pool_F=T // d, pool_d=d, scale=scale.to(dev), shift=shift.to(dev),
+              alpha=al.detach().to(dev), mean=mean.to(dev), rstd=rstd.to(dev), sums=sums, dy=dy, has_bn=1)
+    K.act_bwd_reduce(y.detach().to(dev), **kw)
+    K.act_bwd_apply(y.detach().to(dev), **kw)
+    assert_close(dy, y.grad, rtol=1e-4, atol=1e-5, what="dy")
+    assert_close(sums[:, 0], beta.grad, rtol=1e-4, atol=1e-5, what="dbeta")
+    assert_close(sums[:, 1], gamma.grad, rtol=1e-4, atol=1e-5, what="dgamma")
+    assert_close(sums[:, 2], al.grad, rtol=1e-4, atol=1e-5, what="dalpha")
+
+
+@pytest.mark.parametrize("loss_name,lt", [("L1Loss", K.LOSS_L1), ("BCEWithLogitsLoss", K.LOSS_BCE)])
+def test_head1_forward_backward(dev, loss_name, lt):
+    torch.manual_seed(8)
+    S, C, T = 3, 6, 40
+    z = torch.randn(S, C, T, requires_grad=True)
+    al = (torch.rand(C) * 0.5).requires_grad_(True)
+    w = torch.randn(1, C, 1, requires_grad=True)
+    b = torch.randn(1, requires_grad=True)
+    y = F.conv1d(F.prelu(z, al), w, b)
+    tgt = torch.rand(S, 1, T) if lt == K.LOSS_BCE else torch.randn(S, 1, T)
+    loss = getattr(torch.nn, loss_name)()(y, tgt)
+    loss.backward()
+    yk = torch.zeros(S, 1, T, device=dev)
+    dyk = torch.zeros(S, 1, T, device=dev)
+    acc = torch.zeros(1, dtype=torch.float64, device=dev)
+    n = S * T
+    K.head1_fwd(z.detach().to(dev), w.detach().view(-1).to(dev), b.detach().to(dev), S=S, C_=C, T=T,
+                in_alpha=al.detach().to(dev), target=tgt.to(dev), y=yk, dy=dyk, loss_acc=acc, loss_type=lt,
+                grad_scale=1.0 / n)
+    assert_close(yk, y, rtol=1e-5, atol=1e-5)
+    assert abs(float(acc) / n - float(loss)) < 1e-5
+    dz = torch.zeros(S, C, T, device=dev)
+    sums = torch.zeros(C * 3 + 1, dtype=torch.float64, device=dev)
+    K.head1_bwd(z.detach().to(dev), al.detach().to(dev), w.detach().view(-1).to(dev), dyk, dz, sums, S=S, C_=C, T=T)
+    assert_close(dz, z.grad, rtol=1e-4, atol=1e-6)
+    s3 = sums[:C * 3].view(C, 3)
+    assert_close(s3[:, 0], w.grad.view(-1), rtol=1e-4, atol=1e-6)
+    assert_close(s3[:, 1], al.grad, rtol=1e-4, atol=1e-6)
+    assert_close(s3[:, 2], z.grad.sum((0, 2)), rtol=1e-4, atol=1e-6)
+    assert_close(sums[C * 3:], b.grad, rtol=1e-4, atol=1e-6)

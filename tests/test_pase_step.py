@@ -1,0 +1,147 @@
+"""The full self-supervised step (encoder + workers + losses + backward + Adam) on the HIP kernels
+vs the CPU oracle / the live-reference golden step."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pase_oracle as O
+from util import (GOLD, MINI_FE, assert_close, is_noise_grad, load_cfg, mini_workers, oracle_params, quiet,
+                  randomize_affine, seed_all, synthetic_batch, with_losses)
+
+
+def _mini_model(dev, seed=0):
+    from pase_amd.pase import pase
+    seed_all(seed)
+    m = quiet(pase, frontend_cfg=dict(MINI_FE), minions_cfg=with_losses(mini_workers()), cls_lst=["mi", "cmi"],
+              regr_lst=["cchunk", "lps", "prosody"])
+    randomize_affine(m)
+    return m.to(dev)
+
+
+def _mini_batch(seed=1, B=2, T=1600):
+    g = torch.Generator().manual_seed(seed)
+    batch = {k: torch.randn(B, 1, T, generator=g) * 0.3 for k in ("chunk", "chunk_ctxt", "chunk_rand", "cchunk")}
+    batch["lps"] = torch.randn(B, 5, T // 160, generator=g)
+    batch["prosody"] = torch.randn(B, 3, T // 160, generator=g)
+    return batch
+
+
+def _check_grads(model, P, rtol=1e-3):
+    for n, p in model.named_parameters():
+        if is_noise_grad(n):
+            continue
+        ref = P[n].grad
+        assert_close(p.grad, ref, rtol=rtol, atol=1e-4 * max(1e-2, float(ref.abs().max())), what=n)
+
+
+def test_fused_step_losses_and_grads(dev):
+    m = _mini_model(dev)
+    P = oracle_params(m)
+    batch = _mini_batch()
+    raw = mini_workers()
+    h, chunk, preds, labels = O.pase_forward(P, MINI_FE, raw, batch, True)
+    lo = O.pase_losses(raw, preds, labels)
+    lo["total"].backward()
+    m.train()
+    lf = m.loss_and_grads({k: v.to(dev) for k, v in batch.items()})
+    for k, v in lo.items():
+        assert abs(float(lf[k]) - float(v)) <= 1e-4 * max(1.0, abs(float(v))), (k, float(lf[k]), float(v))
+    _check_grads(m, P)
+
+
+def test_api_compat_forward_and_autograd(dev):
+    """pase.forward(batch) -> (h, chunk, preds, labels) + worker.loss(...) + .backward(): the
+    reference's own calling convention (trainer.py:229, worker_scheduler.py:43-75)."""
+    m = _mini_model(dev, seed=4)
+    P = oracle_params(m)
+    batch = _mini_batch(seed=5)
+    raw = mini_workers()
+    h, chunk, preds, labels = O.pase_forward(P, MINI_FE, raw, batch, True)
+    O.pase_losses(raw, preds, labels)["total"].backward()
+    m.train()
+    h2, chunk2, preds2, labels2 = m({k: v.to(dev) for k, v in batch.items()}, device=dev)
+    assert set(preds2) == set(preds)
+    tot = 0
+    for w in list(m.classification_workers) + list(m.regression_workers):
+        assert_close(preds2[w.name], preds[w.name], rtol=1e-4, atol=1e-4, what="pred " + w.name)
+        assert_close(labels2[w.name], labels[w.name], rtol=0, atol=0, what="label " + w.name)
+        tot = tot + w.loss_weight * w.loss(preds2[w.name], labels2[w.name])
+    tot.backward()
+    _check_grads(m, P)
+
+
+def test_trainer_three_adam_steps(dev):
+    """loss curve + parameters after 3 fused steps track the oracle + torch.optim.Adam."""
+    from pase_amd.trainer import trainer
+    seed_all(0)
+    tr = quiet(trainer, frontend_cfg=dict(MINI_FE), minions_cfg=with_losses(mini_workers()),
+               cfg=dict(fe_lr=1e-3, min_lr=5e-4, epoch=2, bpe=10), lr_mode="poly", device=dev)
+    m = tr.model
+    P = oracle_params(m)
+    names = [n for n, _ in m.named_parameters()]
+    opts = [torch.optim.Adam([P[n]], lr=1e-3 if n.startswith("frontend.") else 5e-4) for n in names]
+    raw = mini_workers()
+    for step in range(3):
+        batch = _mini_batch(seed=10 + step)
+        for o in opts:
+            o.zero_grad()
+        so = {}
+        h, chunk, preds, labels = O.pase_forward(P, MINI_FE, raw, batch, True, so)
+        lo = O.pase_losses(raw, preds, labels)
+        lo["total"].backward()
+        for o in opts:
+            o.step()
+        with torch.no_grad():
+            for k, v in so.items():
+                P["frontend." + k].copy_(v)
+        lf = tr.train_step({k: v.to(dev) for k, v in batch.items()})
+        assert abs(float(lf["total"]) - float(lo["total"])) <= 2e-4 * abs(float(lo["total"])), step
+    for n, p in m.named_parameters():
+        if not is_noise_grad(n):
+            assert_close(p, P[n], rtol=0, atol=3e-4, what=n)
+    sd = tr.frontend_optim.state_dict()
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+    lrs = tr.adjust_lr(5, 0)
+    assert abs(lrs["frontend"] - 1e-3 * (1 - 5 / 20) ** 0.9) < 1e-12
+
+
+def test_full_width_golden_step(dev):
+    """PASE+.cfg + workers+.cfg (12 workers) one step vs the live reference's trainer step."""
+    if dev.type == "cpu":
+        pytest.skip("full-width step is GPU-only")
+    from pase_amd.trainer import trainer
+    g = np.load(os.path.join(GOLD, "pase_plus_step.npz"))
+    raw = load_cfg("workers/workers+.cfg")
+    seed_all(int(g["seed"]))
+    tr = quiet(trainer, frontend_cfg=load_cfg("frontend/PASE+.cfg"),
+               minions_cfg=with_losses(load_cfg("workers/workers+.cfg")),
+               cfg=dict(fe_lr=1e-3, min_lr=5e-4, epoch=1, bpe=10), lr_mode="poly", device=dev)
+    batch = synthetic_batch(int(g["seed"]) + 1, int(g["B"]), int(g["T"]), raw["regr"])
+    batch = {k: v.to(dev) for k, v in batch.items()}
+    m = tr.model
+    # API-compat forward first (train mode, same batch) for the prediction tensors
+    m.train()
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    h, chunk, preds, labels = m(batch, device=dev)
+    assert_close(chunk, g["chunk_emb"], rtol=0, atol=1e-4, what="chunk embedding")
+    assert_close(preds["mi"], g["pred_mi"], rtol=1e-4, atol=1e-4)
+    assert_close(preds["cmi"], g["pred_cmi"], rtol=1e-4, atol=1e-4)
+    assert_close(preds["mfcc"], g["pred_mfcc"], rtol=1e-4, atol=1e-4)
+    assert_close(preds["cchunk"][:, :, :400], g["pred_cchunk_head"], rtol=1e-4, atol=1e-4)
+    del h, chunk, preds, labels
+    with torch.no_grad():      # undo the running-stat update of the extra forward
+        for k, v in m.state_dict().items():
+            v.copy_(sd0[k])
+    losses = tr.train_step(batch)
+    gl = dict(zip([str(s) for s in g["loss_names"]], g["loss_values"]))
+    for k, v in gl.items():
+        assert abs(float(losses[k]) - v) <= 1e-4 * max(1.0, abs(v)), (k, float(losses[k]), v)
+    names = [str(s) for s in g["grad_names"]]
+    params = dict(m.named_parameters())
+    keep = [i for i, n in enumerate(names) if not is_noise_grad(n)]
+    gsq = torch.tensor([float((params[names[i]].grad.double() ** 2).sum()) for i in keep])
+    assert_close(gsq.sqrt(), np.sqrt(g["grad_sq"][keep]), rtol=5e-3, atol=1e-6, what="grad norms")
+    psq = torch.tensor([float((params[names[i]].detach().double() ** 2).sum()) for i in keep])
+    assert_close(psq.sqrt(), np.sqrt(g["post_sq"][keep]), rtol=1e-4, atol=1e-5, what="post-Adam parameter norms")
