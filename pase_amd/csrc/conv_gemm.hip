@@ -38,10 +38,17 @@ constexpr int XSMAX = 3072;   // staged span floats per stage
 constexpr int XPT = XSMAX / NTHREADS;
 
 struct ConvPlan {
-    int CB, TB, SPAN, n_gc, n_gt, flat, tiles_per_seq, splitk;
+    int CB, TB, SPAN, n_gc, n_gt, mode, tiles_per_seq, splitk, avec;
     unsigned span_magic;      // ceil(2^32 / SPAN)
-    unsigned ncols_magic;     // ceil(2^32 / Ncols)  (flat mode)
+    unsigned ncols_magic;     // ceil(2^32 / Ncols)
 };
+// column-tile modes
+//   MODE_FLAT  : 1x1, stride 1, no padding: columns are the flattened (s, q) index, a row of the
+//                staged slab is just BN consecutive columns (may cross any number of sequences)
+//   MODE_SEG   : general taps/stride/padding with Ncols >= BN: columns are the flattened (s, q)
+//                index; a tile touches at most two sequences, each staged as its own span
+//   MODE_PERSEQ: Ncols < BN: one (ragged) tile row per sequence
+enum { MODE_FLAT = 0, MODE_SEG = 1, MODE_PERSEQ = 2 };
 
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
     // bijective XCD-aware remap (cdna_hip_programming.md T1): blocks that run on one XCD (bid % 8)
@@ -61,7 +68,8 @@ template <int BM, int BN>
 __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, ConvPlan pl) {
     constexpr int WAVES_N = BN / 64;
     static_assert((BM / 64) * WAVES_N == 4, "4 waves");
-    constexpr int A_ROWS = BM / 8;   // rows per thread per k slot
+    constexpr int A_ROWS = BM / 8;   // rows per thread per k slot (scalar path)
+    constexpr int A_VROWS = BM / 16; // rows per thread (float4 path)
     constexpr int LDA = BM + 1;
     __shared__ float As[2][KGMAX][LDA];
     __shared__ float Xs[2][XSMAX];
@@ -79,23 +87,31 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
     // ---- tile decode -----------------------------------------------------------------------
     const int ntot = p.S * p.Ncols;
     const int n_row_tiles = (p.M + BM - 1) / BM;
-    const int n_col_tiles = pl.flat ? (ntot + BN - 1) / BN : p.S * pl.tiles_per_seq;
+    const int n_col_tiles = (pl.mode == MODE_PERSEQ) ? p.S * pl.tiles_per_seq : (ntot + BN - 1) / BN;
     const int ntiles = n_row_tiles * n_col_tiles;
     const int split = blockIdx.x / ntiles;
     const int tile = xcd_swizzle(blockIdx.x % ntiles, ntiles);
     const int mt = tile % n_row_tiles;
     const int nt = tile / n_row_tiles;
     const int m0 = mt * BM;
-    int ts, q0, ncols_valid;        // tile's sequence, first column, number of valid columns
-    if (pl.flat) {
-        ts = 0;
-        q0 = nt * BN;               // flattened column index n0
-        ncols_valid = min(BN, ntot - q0);
+    // segment A = first sequence touched (s0, columns qA .. qA+lenA-1), segment B = the next one
+    int s0, qA, lenA, lenB, n0 = 0;
+    if (pl.mode == MODE_PERSEQ) {
+        s0 = nt / pl.tiles_per_seq;
+        qA = (nt - s0 * pl.tiles_per_seq) * BN;
+        lenA = min(BN, p.Ncols - qA);
+        lenB = 0;
     } else {
-        ts = nt / pl.tiles_per_seq;
-        q0 = (nt - ts * pl.tiles_per_seq) * BN;
-        ncols_valid = min(BN, p.Ncols - q0);
+        n0 = nt * BN;
+        s0 = n0 / p.Ncols;
+        qA = n0 - s0 * p.Ncols;
+        lenA = min(BN, p.Ncols - qA);
+        lenB = min(BN - lenA, ntot - n0 - lenA);
+        if (lenB < 0) lenB = 0;
     }
+    const int ncols_valid = (pl.mode == MODE_FLAT) ? min(BN, ntot - n0) : lenA + lenB;
+    const int xstep = (pl.mode == MODE_FLAT) ? 1 : p.stride;
+    const int SA = (lenA - 1) * xstep + pl.TB;       // LDS row offset of segment B
 
     // ---- stage enumeration: g = gc * n_gt + gt ; this split's range -------------------------
     const int G = pl.n_gc * pl.n_gt;
@@ -104,12 +120,48 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
     const int g_end = min(G, g_begin + g_per);
     if (g_begin >= g_end) return;   // uniform for the whole block, before any barrier
 
-    float areg[2][A_ROWS];
+    float areg[2 * A_ROWS];
     float xreg[XPT];
+    int xoff[XPT];                 // element offset of slot t relative to channel ci0 of sequence 0
+    unsigned xmask = 0u;           // slot t holds a real sample (else zero padding / out of range)
     int kg_next = 0, tbe_next = 0, ci0_next = 0;
-    unsigned xmask = 0u;
 
-    auto load_stage = [&](int g) {
+    // slot t of this thread = element e = tid + 256 t of the [CB][SPAN] slab -> (cl, i) -> (s, u)
+    auto slot_setup = [&](int kk0, int TBe) __attribute__((always_inline)) {
+        xmask = 0u;
+        const int koffs = (p.tapstep > 0) ? kk0 : -(kk0 + TBe - 1);
+#pragma unroll
+        for (int t = 0; t < XPT; ++t) {
+            const int e = tid + NTHREADS * t;
+            const int cl = (int)div_magic((unsigned)e, pl.span_magic);
+            const int i = e - cl * pl.SPAN;
+            int s, u;
+            bool ok;
+            if (pl.mode == MODE_FLAT) {
+                const unsigned n = (unsigned)(n0 + i);
+                s = (int)div_magic(n, pl.ncols_magic);   // may overshoot by one for huge n*Ncols
+                u = (int)n - s * p.Ncols;
+                if (u < 0) { --s; u += p.Ncols; }
+                ok = (int)n < ntot;
+            } else {
+                const bool segB = i >= SA;
+                s = segB ? s0 + 1 : s0;
+                u = (segB ? i - SA : qA * p.stride + i) - p.padL + koffs;
+                ok = segB ? lenB > 0 : true;
+                if (p.pad_mode == PASE_PAD_REFLECT) {
+                    if (u < 0) u = -u;
+                    if (u >= p.Tin) u = 2 * (p.Tin - 1) - u;
+                }
+                ok = ok && u >= 0 && u < p.Tin;
+            }
+            xoff[t] = ok ? (s * p.x_ctot + cl) * p.Tin + u : 0;
+            if (ok) xmask |= 1u << t;
+        }
+    };
+    const bool slots_invariant = pl.n_gt == 1;
+    if (slots_invariant) slot_setup(0, p.taps);
+
+    auto load_stage = [&](int g) __attribute__((always_inline)) {
         const int gc = g / pl.n_gt, gt = g - gc * pl.n_gt;
         const int ci0 = gc * pl.CB, kk0 = gt * pl.TB;
         const int TBe = min(pl.TB, p.taps - kk0);
@@ -117,75 +169,79 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
         const int KGe = CBe * TBe;
         kg_next = KGe;
         tbe_next = TBe;
-        // ---- A slab: rows (tid>>5) + 8*i, flat-k slots (tid&31) and (tid&31)+32; K-contiguous rows
+        ci0_next = ci0;
+        // ---- A slab [BM x KGe], rows K-contiguous in HBM.  Raw prefetch only.
+        if (pl.avec) {
+            // float4 along K: lane group of 16 covers up to 64 k of one row
+            const int k4 = (tid & 15) * 4;
+            const float* wrow = p.w + (size_t)(m0 + (tid >> 4)) * p.ldw + (size_t)ci0 * p.taps + kk0 + k4;
+            const bool kok = k4 < KGe;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int kl = (tid & 31) + 32 * h;
-            const bool kok = kl < KGe;
-            int ka = 0;
-            if (kok) {
-                const int cl = kl / TBe, kkl = kl - cl * TBe;
-                ka = p.tap_major ? (kk0 + kkl) * p.Cin + ci0 + cl : (ci0 + cl) * p.taps + kk0 + kkl;
+            for (int i = 0; i < A_VROWS; ++i) {
+                const int m = m0 + (tid >> 4) + 16 * i;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kok && m < p.M) v = *reinterpret_cast<const float4*>(wrow + (size_t)16 * i * p.ldw);
+                areg[4 * i + 0] = v.x; areg[4 * i + 1] = v.y; areg[4 * i + 2] = v.z; areg[4 * i + 3] = v.w;
             }
+        } else {
 #pragma unroll
-            for (int i = 0; i < A_ROWS; ++i) {
-                const int m = m0 + (tid >> 5) + 8 * i;
-                areg[h][i] = (kok && m < p.M) ? p.w[(size_t)m * p.ldw + ka] : 0.f;
+            for (int h = 0; h < 2; ++h) {
+                const int kl = (tid & 31) + 32 * h;
+                const bool kok = kl < KGe;
+                int ka = 0;
+                if (kok) {
+                    const int cl = kl / TBe, kkl = kl - cl * TBe;
+                    ka = p.tap_major ? (kk0 + kkl) * p.Cin + ci0 + cl : (ci0 + cl) * p.taps + kk0 + kkl;
+                }
+#pragma unroll
+                for (int i = 0; i < A_ROWS; ++i) {
+                    const int m = m0 + (tid >> 5) + 8 * i;
+                    areg[h * A_ROWS + i] = (kok && m < p.M) ? p.w[(size_t)m * p.ldw + ka] : 0.f;
+                }
             }
         }
-        // ---- X spans: CBe rows of SPAN floats, consecutive threads on consecutive samples.
-        // Only the raw loads are issued here (they stay in flight under the MFMAs of the current
-        // stage); the on-load affine / PReLU is applied in store_stage, after the MFMA loop.
+        // ---- X spans: CBe rows of SPAN floats, consecutive threads on consecutive samples.  Only the
+        // raw loads are issued here (they stay in flight under the MFMAs of the current stage); the
+        // on-load affine / PReLU is applied in store_stage, after the MFMA loop.
+        if (!slots_invariant) slot_setup(kk0, TBe);
         const int total = CBe * pl.SPAN;
-        const int span_lo = pl.flat ? 0 : q0 * p.stride - p.padL + (p.tapstep > 0 ? kk0 : -(kk0 + TBe - 1));
-        ci0_next = ci0;
-        xmask = 0u;
+        const float* xb = p.x + (size_t)(p.x_coff + ci0) * p.Tin;
 #pragma unroll
         for (int t = 0; t < XPT; ++t) {
-            const int e = tid + NTHREADS * t;
-            float v = 0.f;
-            if (e < total) {
-                const int cl = (int)div_magic((unsigned)e, pl.span_magic);
-                const int i = e - cl * pl.SPAN;
-                const int ci = ci0 + cl;
-                int s = ts, u;
-                bool ok;
-                if (pl.flat) {
-                    const unsigned n = (unsigned)(q0 + i);
-                    s = (int)div_magic(n, pl.ncols_magic);   // may overshoot by one for huge n*Ncols
-                    u = (int)n - s * p.Ncols;
-                    if (u < 0) { --s; u += p.Ncols; }
-                    ok = (int)n < ntot;
-                } else {
-                    u = span_lo + i;
-                    if (p.pad_mode == PASE_PAD_REFLECT) {
-                        if (u < 0) u = -u;
-                        if (u >= p.Tin) u = 2 * (p.Tin - 1) - u;
-                    }
-                    ok = u >= 0 && u < p.Tin;
-                }
-                if (ok) {
-                    v = p.x[((size_t)s * p.x_ctot + p.x_coff + ci) * (size_t)p.Tin + u];
-                    xmask |= 1u << t;
-                }
-            }
-            xreg[t] = v;
+            const bool ok = ((xmask >> t) & 1u) && (tid + NTHREADS * t) < total;
+            xreg[t] = ok ? xb[xoff[t]] : 0.f;
         }
     };
-    auto store_stage = [&](int buf) {
+    auto store_stage = [&](int buf) __attribute__((always_inline)) {
+        if (pl.avec) {
+            const int k4 = (tid & 15) * 4;
+            if (k4 < KGMAX) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int kl = (tid & 31) + 32 * h;
-            if (kl < KGMAX) {
+                for (int i = 0; i < A_VROWS; ++i) {
+                    const int r = (tid >> 4) + 16 * i;
+                    As[buf][k4 + 0][r] = areg[4 * i + 0];
+                    As[buf][k4 + 1][r] = areg[4 * i + 1];
+                    As[buf][k4 + 2][r] = areg[4 * i + 2];
+                    As[buf][k4 + 3][r] = areg[4 * i + 3];
+                }
+            }
+        } else {
 #pragma unroll
-                for (int i = 0; i < A_ROWS; ++i) As[buf][kl][(tid >> 5) + 8 * i] = areg[h][i];
+            for (int h = 0; h < 2; ++h) {
+                const int kl = (tid & 31) + 32 * h;
+                if (kl < KGMAX) {
+#pragma unroll
+                    for (int i = 0; i < A_ROWS; ++i) As[buf][kl][(tid >> 5) + 8 * i] = areg[h * A_ROWS + i];
+                }
             }
         }
         if (p.in_scale || p.in_alpha) {
+            const int total = kg_next / tbe_next * pl.SPAN;
 #pragma unroll
             for (int t = 0; t < XPT; ++t) {
-                if (xmask & (1u << t)) {
-                    const int ci = ci0_next + (int)div_magic((unsigned)(tid + NTHREADS * t), pl.span_magic);
+                const int e = tid + NTHREADS * t;
+                if (((xmask >> t) & 1u) && e < total) {
+                    const int ci = ci0_next + (int)div_magic((unsigned)e, pl.span_magic);
                     float v = xreg[t];
                     if (p.in_scale) v = v * p.in_scale[ci] + p.in_shift[ci];
                     if (p.in_alpha) v = v > 0.f ? v : v * p.in_alpha[ci];
@@ -210,8 +266,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
     const bool row_ok0 = m0 + wm * 64 < p.M, row_ok1 = m0 + wm * 64 + 32 < p.M;
     const bool col_ok0 = wn * 64 < ncols_valid, col_ok1 = wn * 64 + 32 < ncols_valid;
     const bool full_tile = row_ok0 && row_ok1 && col_ok0 && col_ok1;
-    const int xc0 = (wn * 64 + fr) * (pl.flat ? 1 : p.stride);
-    const int xc1 = (wn * 64 + 32 + fr) * (pl.flat ? 1 : p.stride);
+    // LDS offset of this lane's two columns within a slab row (segment B starts at SA)
+    const int j0c = wn * 64 + fr, j1c = wn * 64 + 32 + fr;
+    const int xc0 = (pl.mode != MODE_FLAT && j0c >= lenA) ? SA + (j0c - lenA) * xstep : j0c * xstep;
+    const int xc1 = (pl.mode != MODE_FLAT && j1c >= lenA) ? SA + (j1c - lenA) * xstep : j1c * xstep;
 
     load_stage(g_begin);
     store_stage(0);
@@ -262,13 +320,13 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
     for (int b = 0; b < 2; ++b) {
         const int j = wn * 64 + b * 32 + fr;
         cok[b] = j < ncols_valid;
-        if (pl.flat) {
-            const int n = q0 + j;
+        if (pl.mode == MODE_FLAT) {
+            const int n = n0 + j;
             cs[b] = cok[b] ? n / p.Ncols : 0;
             cq[b] = cok[b] ? n % p.Ncols : 0;
         } else {
-            cs[b] = ts;
-            cq[b] = q0 + j;
+            cs[b] = j < lenA ? s0 : s0 + 1;
+            cq[b] = j < lenA ? qA + j : j - lenA;
         }
     }
 
@@ -371,15 +429,17 @@ HostPlan make_plan(const PaseConvGemm& p) {
     const int BM = h.narrow ? 64 : 128;
     h.BN = h.narrow ? 256 : 128;
     ConvPlan& pl = h.pl;
-    pl.flat = (p.taps == 1 && p.stride == 1 && p.padL == 0 && p.tapstep == 1) ? 1 : 0;
-    if (pl.flat) {
+    const bool flat = (p.taps == 1 && p.stride == 1 && p.padL == 0 && p.tapstep == 1);
+    pl.mode = flat ? MODE_FLAT : (p.Ncols >= h.BN ? MODE_SEG : MODE_PERSEQ);
+    if (flat) {
         pl.TB = 1;
         pl.SPAN = h.BN;
         pl.CB = XSMAX / h.BN;
         if (pl.CB > KGMAX) pl.CB = KGMAX;
     } else {
         pl.TB = p.taps <= KGMAX ? p.taps : 32;
-        pl.SPAN = (h.BN - 1) * p.stride + pl.TB;
+        // a tile may touch two sequences: each segment carries its own halo of TB samples
+        pl.SPAN = (h.BN - 1) * p.stride + (pl.mode == MODE_SEG ? 2 : 1) * pl.TB;
         pl.CB = KGMAX / pl.TB;
         if (pl.CB * pl.SPAN > XSMAX) pl.CB = XSMAX / pl.SPAN;
     }
@@ -390,8 +450,12 @@ HostPlan make_plan(const PaseConvGemm& p) {
     pl.tiles_per_seq = (p.Ncols + h.BN - 1) / h.BN;
     pl.span_magic = (unsigned)((0x100000000ULL + pl.SPAN - 1) / (unsigned long long)pl.SPAN);
     pl.ncols_magic = (unsigned)((0x100000000ULL + p.Ncols - 1) / (unsigned long long)p.Ncols);
+    // float4 weight loads: rows 16-B aligned, whole channels per stage, natural (ci, kk) K order
+    pl.avec = (!p.tap_major && pl.n_gt == 1 && (p.ldw % 4) == 0 && ((pl.CB * pl.TB) % 4) == 0 &&
+               (((unsigned long long)(size_t)p.w) % 16) == 0 && pl.CB * pl.TB <= 64 && pl.CB > 0 &&
+               (p.Cin % pl.CB) == 0) ? 1 : 0;
     const long ntot = (long)p.S * p.Ncols;
-    h.n_col_tiles = pl.flat ? (int)((ntot + h.BN - 1) / h.BN) : p.S * pl.tiles_per_seq;
+    h.n_col_tiles = (pl.mode == MODE_PERSEQ) ? p.S * pl.tiles_per_seq : (int)((ntot + h.BN - 1) / h.BN);
     const long tiles = (long)((p.M + BM - 1) / BM) * h.n_col_tiles;
     int splitk = 1;
     const int G = pl.n_gc * pl.n_gt;
@@ -425,6 +489,7 @@ extern "C" int pase_conv_gemm(const PaseConvGemm* d, void* stream) {
     if (h.pl.CB < 1) return -6;
     if (h.pl.splitk > 1 && (p.stat_part || p.epilogue != PASE_EPI_STORE)) return -7;
     if ((long)p.S * p.Ncols >= 0x7fffffffL) return -8;
+    if ((long)p.S * p.x_ctot * (long)p.Tin >= 0x7fffffffL) return -8;   // int element offsets in the loader
     hipStream_t st = (hipStream_t)stream;
     if (h.narrow) {
         PASE_LAUNCH((conv_gemm_kernel<64, 256>), dim3((unsigned)h.blocks), dim3(NTHREADS), st, p, h.pl);

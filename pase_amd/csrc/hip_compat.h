@@ -11,6 +11,7 @@ __device__ __forceinline__ f32x16 pase_mfma_32x32x2(float a, float b, f32x16 c) 
     return emu_mfma_32x32x2(a, b, c);
 }
 __device__ __forceinline__ int pase_uniform(int v) { return v; }
+#define PASE_LAUNDER(x) ((void)0)
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -26,6 +27,8 @@ __device__ __forceinline__ f32x16 pase_mfma_32x32x2(float a, float b, f32x16 c) 
 // value known to be identical across the wave (e.g. threadIdx.x / 64): make it an SGPR so branches
 // on it are scalar (cdna_hip_programming.md T20: threadIdx-derived values are divergent to hipcc)
 __device__ __forceinline__ int pase_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// make the compiler forget what it knows about x (blocks loop-invariant hoisting of values derived from it)
+#define PASE_LAUNDER(x) asm volatile("" : "+v"(x))
 #endif
 
 #define PASE_CHECK_LAUNCH()                      \

@@ -28,13 +28,14 @@ namespace {
 
 constexpr int NTHREADS = 256;
 constexpr int BKQ = 32;                 // reduction positions per stage
-constexpr int ZS_DATA = 4864;           // staged span floats per stage
 constexpr int ZS_ONES = 320;            // region of 1.0f (bias column / padding columns)
-constexpr int ZS_TOTAL = ZS_DATA + ZS_ONES;
-constexpr int ZPT = ZS_DATA / NTHREADS; // 19
+// staged span floats per stage = ZPT * 256; two instantiations: ZPT = 9 (2304 floats: every k > 1 layer
+// of PASE+; fits 2 waves/SIMD) and ZPT = 19 (4864 floats: 1x1 layers with 128 input channels per tile,
+// the stride-10 block-1 layer; 1 wave/SIMD)
+constexpr int ZPT_SMALL = 9, ZPT_LARGE = 19;
 
 struct WgradPlan {
-    int flat, SPANW, chunks_per_seq, n_chunks, kt_per_split, n_row_tiles, n_col_tiles;
+    int gvec, flat, SPANW, chunks_per_seq, n_chunks, kt_per_split, n_row_tiles, n_col_tiles;
     unsigned span_magic, ncols_magic;
 };
 
@@ -43,8 +44,10 @@ __device__ __forceinline__ unsigned div_magic(unsigned e, unsigned magic) {
     return magic ? (unsigned)(((unsigned long long)e * magic) >> 32) : e;
 }
 
-template <int BM, int BN>
-__global__ void __launch_bounds__(NTHREADS) wgrad_gemm_kernel(PaseWgrad p, WgradPlan pl) {
+template <int BM, int BN, int ZPT>
+__global__ void __launch_bounds__(NTHREADS, (ZPT <= ZPT_SMALL ? 2 : 1)) wgrad_gemm_kernel(PaseWgrad p, WgradPlan pl) {
+    constexpr int ZS_DATA = ZPT * NTHREADS;
+    constexpr int ZS_TOTAL = ZS_DATA + ZS_ONES;
     constexpr int WAVES_N = BN / 64;
     constexpr int A_ROWS = BM / 8;
     __shared__ float As[2][BKQ][BM + 1];
@@ -88,30 +91,57 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_gemm_kernel(PaseWgrad p, Wgrad
         }
     }
     const int zstep = pl.flat ? 1 : p.stride;
+    bool gvec_next = false;
     for (int i = tid; i < ZS_ONES; i += NTHREADS) { Zs[0][ZS_DATA + i] = 1.f; Zs[1][ZS_DATA + i] = 1.f; }
 
     float areg[A_ROWS];
     float zreg[ZPT];
     unsigned zmask = 0u;
     const int ntot = p.S * p.Ncols;
+    const int total = NC * pl.SPANW;
+    const int zrow_skip = p.Tz - pl.SPANW;   // slot e -> element offset e + cl * (Tz - SPANW) from the span start
+    int lic = 0;   // laundered zero, refreshed every stage: keeps the per-slot index math INSIDE the
+                   // stage (hoisted out of the loop it would pin ~40 VGPRs for the whole kernel)
+    auto zrel = [&](int t) __attribute__((always_inline)) {
+        const int e = tid + NTHREADS * t + lic;
+        return e + (int)div_magic((unsigned)e, pl.span_magic) * zrow_skip;
+    };
 
-    auto load_stage = [&](int c) {
+    auto load_stage = [&](int c) __attribute__((always_inline)) {
         int s, q0;
-        if (pl.flat) { s = 0; q0 = c * BKQ; }
-        else { s = c / pl.chunks_per_seq; q0 = (c - s * pl.chunks_per_seq) * BKQ; }
-        // ---- G slab: lanes along time (128 B runs), rows (tid>>5) + 8*i
-        {
+        if (pl.flat) {
+            const int nc = c * BKQ;
+            s = nc / p.Ncols;
+            q0 = nc - s * p.Ncols;
+        } else {
+            s = c / pl.chunks_per_seq;
+            q0 = (c - s * pl.chunks_per_seq) * BKQ;
+        }
+        PASE_LAUNDER(lic);
+        // a flat chunk that crosses a sequence boundary takes the per-element path
+        const bool straddle = pl.flat && (q0 + BKQ > p.Ncols);
+        // ---- G slab [BM x 32]: lanes along time.  Raw prefetch only.
+        if (pl.gvec && !straddle) {
+            const int k4 = (tid & 7) * 4;
+            const bool ok = q0 + k4 < p.Ncols;       // Ncols % 4 == 0: a float4 is all-valid or all-out
+            const float* grow = p.g + ((size_t)s * p.g_ctot + p.g_coff) * (size_t)p.Tg + q0 + k4;
+#pragma unroll
+            for (int i = 0; i < A_ROWS / 4; ++i) {
+                const int m = m0 + (tid >> 3) + 32 * i;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok && m < p.M) v = *reinterpret_cast<const float4*>(grow + (size_t)m * p.Tg);
+                areg[4 * i + 0] = v.x; areg[4 * i + 1] = v.y; areg[4 * i + 2] = v.z; areg[4 * i + 3] = v.w;
+            }
+        } else {
             const int kq = tid & 31;
             int sg = s, qg = q0 + kq;
-            bool ok;
+            bool ok = qg < p.Ncols;
             if (pl.flat) {
-                const unsigned n = (unsigned)qg;
-                ok = (int)n < ntot;
-                sg = (int)div_magic(n, pl.ncols_magic);
-                qg = (int)n - sg * p.Ncols;
+                const int n = c * BKQ + kq;
+                ok = n < ntot;
+                sg = (int)div_magic((unsigned)n, pl.ncols_magic);
+                qg = n - sg * p.Ncols;
                 if (qg < 0) { --sg; qg += p.Ncols; }
-            } else {
-                ok = qg < p.Ncols;
             }
             const float* grow = p.g + ((size_t)sg * p.g_ctot + p.g_coff) * (size_t)p.Tg + qg;
 #pragma unroll
@@ -120,50 +150,77 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_gemm_kernel(PaseWgrad p, Wgrad
                 areg[i] = (ok && m < p.M) ? grow[(size_t)m * p.Tg] : 0.f;   // raw prefetch
             }
         }
-        // ---- Z spans: NC rows of SPANW floats
-        const int total = NC * pl.SPANW;
+        // ---- Z spans: NC rows of SPANW floats.  Two paths only: (fast) the whole span is real
+        // data of one sequence -> slot address = span start + e + cl*(Tz - SPANW); (slow) chunk at a
+        // sequence edge / crossing sequences -> per-slot padding + sequence logic.
         zmask = 0u;
-        const int u0 = pl.flat ? 0 : q0 * p.stride - p.padL + (p.tapstep > 0 ? 0 : -(p.taps - 1));
+        const int u0 = pl.flat ? q0 : q0 * p.stride - p.padL + (p.tapstep > 0 ? 0 : -(p.taps - 1));
+        const bool fast = pl.flat ? (!straddle && (long)c * BKQ + BKQ <= ntot) : (u0 >= 0 && u0 + pl.SPANW <= p.Tz);
+        if (fast) {
+            const float* zb = p.z + ((size_t)s * p.z_ctot + p.z_coff + c_lo) * (size_t)p.Tz + u0;
 #pragma unroll
-        for (int t = 0; t < ZPT; ++t) {
-            const int e = tid + NTHREADS * t;
-            float v = 0.f;
-            if (e < total) {
-                const int cl = (int)div_magic((unsigned)e, pl.span_magic);
-                const int i = e - cl * pl.SPANW;
-                const int ci = c_lo + cl;
-                int sz = s, u;
-                bool ok;
-                if (pl.flat) {
-                    const unsigned n = (unsigned)(q0 + i);
-                    ok = (int)n < ntot;
-                    sz = (int)div_magic(n, pl.ncols_magic);
-                    u = (int)n - sz * p.Ncols;
-                    if (u < 0) { --sz; u += p.Ncols; }
-                } else {
-                    u = u0 + i;
-                    if (p.pad_mode == PASE_PAD_REFLECT) {
-                        if (u < 0) u = -u;
-                        if (u >= p.Tz) u = 2 * (p.Tz - 1) - u;
+            for (int t = 0; t < ZPT; ++t) {
+                const bool ok = (tid + NTHREADS * t) < total;
+                zreg[t] = ok ? zb[zrel(t)] : 0.f;
+                if (ok) zmask |= 1u << t;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < ZPT; ++t) {
+                const int e = tid + NTHREADS * t + lic;
+                float v = 0.f;
+                if (e < total) {
+                    const int cl = (int)div_magic((unsigned)e, pl.span_magic);
+                    const int i = e - cl * pl.SPANW;
+                    int sz = s, u;
+                    bool ok;
+                    if (pl.flat) {
+                        const int n = c * BKQ + i;
+                        sz = (int)div_magic((unsigned)n, pl.ncols_magic);
+                        u = n - sz * p.Ncols;
+                        if (u < 0) { --sz; u += p.Ncols; }
+                        ok = n < ntot;
+                    } else {
+                        u = u0 + i;
+                        if (p.pad_mode == PASE_PAD_REFLECT) {
+                            if (u < 0) u = -u;
+                            if (u >= p.Tz) u = 2 * (p.Tz - 1) - u;
+                        }
+                        ok = u >= 0 && u < p.Tz;
                     }
-                    ok = u >= 0 && u < p.Tz;
+                    if (ok) {
+                        v = p.z[((size_t)sz * p.z_ctot + p.z_coff + c_lo + cl) * (size_t)p.Tz + u];
+                        zmask |= 1u << t;
+                    }
                 }
-                if (ok) {
-                    v = p.z[((size_t)sz * p.z_ctot + p.z_coff + ci) * (size_t)p.Tz + u];   // raw prefetch
-                    zmask |= 1u << t;
+                zreg[t] = v;
+            }
+        }
+        gvec_next = pl.gvec && !straddle;
+    };
+    auto store_stage = [&](int buf) __attribute__((always_inline)) {
+        // on-load transforms are applied here, after the MFMA loop the prefetch was hidden under
+        if (gvec_next) {
+            const int k4 = (tid & 7) * 4;
+#pragma unroll
+            for (int i = 0; i < A_ROWS / 4; ++i) {
+                const int r = (tid >> 3) + 32 * i;
+                float al = 1.f;
+                if (p.g_alpha && m0 + r < p.M) al = p.g_alpha[m0 + r];
+#pragma unroll
+                for (int cidx = 0; cidx < 4; ++cidx) {
+                    float gv = areg[4 * i + cidx];
+                    if (p.g_alpha) gv = gv > 0.f ? gv : gv * al;
+                    As[buf][k4 + cidx][r] = gv;
                 }
             }
-            zreg[t] = v;
-        }
-    };
-    auto store_stage = [&](int buf) {
-        // on-load transforms are applied here, after the MFMA loop the prefetch was hidden under
-        if (p.g_alpha) {
+        } else {
 #pragma unroll
             for (int i = 0; i < A_ROWS; ++i) {
-                const int m = m0 + (tid >> 5) + 8 * i;
-                const float gv = areg[i];
-                if (m < p.M) areg[i] = gv > 0.f ? gv : gv * p.g_alpha[m];
+                const int r = (tid >> 5) + 8 * i;
+                float gv = areg[i];
+                if (p.g_alpha && m0 + r < p.M) gv = gv > 0.f ? gv : gv * p.g_alpha[m0 + r];
+                As[buf][tid & 31][r] = gv;
             }
         }
         if (p.in_scale || p.in_alpha) {
@@ -178,8 +235,6 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_gemm_kernel(PaseWgrad p, Wgrad
                 }
             }
         }
-#pragma unroll
-        for (int i = 0; i < A_ROWS; ++i) As[buf][tid & 31][(tid >> 5) + 8 * i] = areg[i];
 #pragma unroll
         for (int t = 0; t < ZPT; ++t) Zs[buf][tid + NTHREADS * t] = zreg[t];
     };
@@ -202,7 +257,7 @@ __global__ void __launch_bounds__(NTHREADS) wgrad_gemm_kernel(PaseWgrad p, Wgrad
     for (int c = c_begin; c < c_end; ++c) {
         const int cur = (c - c_begin) & 1;
         if (c + 1 < c_end) load_stage(c + 1);
-#pragma unroll 4
+#pragma unroll 2
         for (int ks = 0; ks < BKQ / 2; ++ks) {   // unconditional MFMAs (see conv_gemm.hip)
             const int kq = ks * 2 + fk;
             const float a0 = As[cur][kq][wm * 64 + fr];
@@ -251,13 +306,14 @@ extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
     WgradPlan pl;
     pl.flat = (p.taps == 1 && p.stride == 1 && p.padL == 0 && p.tapstep == 1) ? 1 : 0;
     pl.SPANW = pl.flat ? BKQ : (BKQ - 1) * p.stride + p.taps;
-    auto fits = [&](int bn) {
+    auto need = [&](int bn) {
         long max_nc = (bn - 1) / p.taps + 2;     // channels a tile of bn (ci,kk) columns can touch
         if (max_nc > p.Cin) max_nc = p.Cin;
-        return max_nc * pl.SPANW <= ZS_DATA;
+        return max_nc * pl.SPANW;
     };
-    if (narrow && !fits(256)) narrow = false;
-    if (!narrow && !fits(128)) return -6;
+    if (narrow && need(256) > ZPT_LARGE * NTHREADS) narrow = false;
+    if (!narrow && need(128) > ZPT_LARGE * NTHREADS) return -6;
+    const bool small = need(narrow ? 256 : 128) <= ZPT_SMALL * NTHREADS;
     const int BMv = narrow ? 64 : 128, BNv = narrow ? 256 : 128;
     if ((BKQ - 1) * (pl.flat ? 1 : p.stride) + 1 > ZS_ONES) return -6;
     pl.n_row_tiles = (p.M + BMv - 1) / BMv;
@@ -267,6 +323,7 @@ extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
     pl.n_chunks = pl.flat ? (int)((kred + BKQ - 1) / BKQ) : p.S * pl.chunks_per_seq;
     pl.span_magic = (unsigned)((0x100000000ULL + pl.SPANW - 1) / (unsigned long long)pl.SPANW);
     pl.ncols_magic = (unsigned)((0x100000000ULL + p.Ncols - 1) / (unsigned long long)p.Ncols);
+    pl.gvec = ((p.Tg % 4) == 0 && (p.Ncols % 4) == 0 && (((unsigned long long)(size_t)p.g) % 16) == 0) ? 1 : 0;
     const int tiles = pl.n_row_tiles * pl.n_col_tiles;
     int splitk = p.splitk;
     if (splitk <= 0) {
@@ -278,10 +335,11 @@ extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
     if (splitk > pl.n_chunks) splitk = pl.n_chunks;
     pl.kt_per_split = (pl.n_chunks + splitk - 1) / splitk;
     splitk = (pl.n_chunks + pl.kt_per_split - 1) / pl.kt_per_split;
-    if (narrow)
-        PASE_LAUNCH((wgrad_gemm_kernel<64, 256>), dim3((unsigned)(tiles * splitk)), dim3(NTHREADS), st, p, pl);
-    else
-        PASE_LAUNCH((wgrad_gemm_kernel<128, 128>), dim3((unsigned)(tiles * splitk)), dim3(NTHREADS), st, p, pl);
+    const dim3 grid((unsigned)(tiles * splitk)), block(NTHREADS);
+    if (narrow && small)       PASE_LAUNCH((wgrad_gemm_kernel<64, 256, ZPT_SMALL>), grid, block, st, p, pl);
+    else if (narrow)           PASE_LAUNCH((wgrad_gemm_kernel<64, 256, ZPT_LARGE>), grid, block, st, p, pl);
+    else if (small)            PASE_LAUNCH((wgrad_gemm_kernel<128, 128, ZPT_SMALL>), grid, block, st, p, pl);
+    else                       PASE_LAUNCH((wgrad_gemm_kernel<128, 128, ZPT_LARGE>), grid, block, st, p, pl);
     PASE_CHECK_LAUNCH();
     return 0;
 }

@@ -17,6 +17,9 @@ def _tol(dev):
     (2, 6, 20, 10, 200, 2),     # block-1 shape: k=20 s=10 pad (9,10)
     (1, 8, 251, 1, 300, 2),     # sinc shape: Cin=1, K=251 (not a multiple of 16)
     (20, 130, 1, 1, 37, 3),     # 1x1, M spans two row tiles, N ragged
+    (8, 70, 11, 1, 200, 3),     # column tiles straddle sequences (two spans per tile), float4 weight loads
+    (8, 70, 11, 2, 410, 3),     # same, strided, T_out = 205
+    (4, 8, 20, 10, 3000, 2),    # narrow 64x256 tile straddling sequences, stride 10
 ])
 def test_conv_fwd_reflect(dev, Cin, Cout, k, stride, T, S):
     torch.manual_seed(0)
