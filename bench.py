@@ -149,8 +149,35 @@ def main():
     utt_s = B * world * args.steps / dt
     total_loss = float(losses["total"])
 
+    # ---- dominant-kernel roofline, measured live: two extra steps with every MFMA-kernel launch
+    # bracketed by HIP events on the launch stream (outside the timed region above)
+    from pase_amd import kernels as K
+    K.GEMM_TIMER = K.GemmTimer()
+    extra = 2
+    for _ in range(extra):
+        tr.train_step(batch)
+    fams = K.GEMM_TIMER.summary()
+    K.GEMM_TIMER = None
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "summary_r01.json")) as f:
+            prof = json.load(f)
+        for row in prof.get("hbm_traffic_per_step", []):
+            if row["kernel"].startswith("conv_gemm_kernel<128, 128>"):
+                # PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs), GB per launch,
+                # FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B)
+                calls = [k["calls"] for k in prof["step_kernel_time"]["families"]
+                         if k["kernel"].startswith("conv_gemm_kernel<128, 128>")][0]
+                traffic = round((row["fetch_MB_x2"] + row["write_MB"]) / 1e3 / calls, 4)
+    except Exception:
+        traffic = None
+
     if rank == 0:
         achieved = GFLOP_PER_UTT_TRAIN * utt_s / world / 1e3     # TFLOP/s per GPU (algorithmic)
+        cg = fams.get("conv_gemm", dict(launches=1, flops=0.0, ms=1.0))
+        wg = fams.get("wgrad_gemm", dict(launches=1, flops=0.0, ms=1.0))
+        cg_tf = cg["flops"] / cg["ms"] / 1e9
+        wg_tf = wg["flops"] / wg["ms"] / 1e9
         out = {
             "metric": "utterances/sec (PASE+ bs32 32k-sample chunks; encoder-frames/sec = 600 x)",
             "value": round(utt_s, 3), "unit": "utterances/s",
@@ -161,10 +188,24 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "chunk_samples": T,
                        "targets": "given (N(0,1) tensors resident in HBM)", "parallelism": "dp%d" % world,
                        "final_total_loss": round(total_loss, 5)},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                         "note": "whole-step algorithmic fp32 FLOPs (122.0 GFLOP/utterance, SURVEY 8d) / step time, "
-                                 "per GPU; per-kernel numbers in profiles/"},
+            "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (all launches of one step)",
+                         "achieved": round(cg_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(cg_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "GB per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/summary_r01.json)",
+                         "launches_per_step": cg["launches"] // extra,
+                         "avg_launch_ms": round(cg["ms"] / cg["launches"], 4),
+                         "algorithmic_gflop_per_launch": round(cg["flops"] / cg["launches"] / 1e9, 2),
+                         "note": "sum of the launches' executed contraction FLOPs (2*S*Ncols*M*K from each "
+                                 "descriptor) / sum of HIP-event durations on the launch stream"},
+            "roofline_wgrad": {"bound": "mfma", "kernel": "wgrad_gemm_kernel", "achieved": round(wg_tf, 2),
+                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(wg_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                               "launches_per_step": wg["launches"] // extra,
+                               "avg_launch_ms": round(wg["ms"] / wg["launches"], 4)},
+            "roofline_step": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                              "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                              "note": "canonical algorithmic FLOPs (122.0 GFLOP per utterance, SURVEY 8d: minimal "
+                                      "algorithm, dense skips pooled first) x utterances/s per GPU"},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -280,32 +280,53 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
         const int kg = kinfo[cur][0];
         const int tbe = kinfo[cur][1];
         const int nks = (kg + 1) >> 1;
-        // this lane's flat k = 2*ks + fk -> (channel row cl, tap kkl) -> span offset, kept incrementally
-        int kkl = fk, xo = (p.tapstep > 0) ? fk : tbe - 1 - fk;
-        if (kkl >= tbe) { kkl -= tbe; xo += (p.tapstep > 0) ? pl.SPAN - tbe : pl.SPAN + tbe; }
-        const int wrap_add = (p.tapstep > 0) ? pl.SPAN - tbe : pl.SPAN + tbe;
-        const int step2 = (p.tapstep > 0) ? 2 : -2;
+        // K order inside a stage: channel rows are taken two at a time ("super-row" = 2*tbe flat k, so
+        // an MFMA step never straddles super-rows even for odd tap counts).  Step j of a super-row
+        // gives this lane flat position f = 2j + fk -> row f >= tbe, tap f - row*tbe.  All of it is
+        // scalar loop state plus 3-4 VALU; operands for step ks+1 are fetched from LDS BEFORE the
+        // MFMAs of step ks are issued (register double buffer), so the ds_read latency hides under
+        // the 256 matrix-pipe cycles of the current step.
+        const int row_hi = (p.tapstep > 0) ? pl.SPAN - tbe : pl.SPAN + 2 * tbe - 1;   // f >= tbe
+        const int row_lo = (p.tapstep > 0) ? 0 : tbe - 1;                            // f <  tbe
         const float* as_ = &As[cur][fk][wm * 64 + fr];
         const float* xs_ = &Xs[cur][0];
-        // All four MFMAs are issued unconditionally: rows / columns beyond the tile edge multiply
-        // zero-filled A rows or finite staged data and are discarded in the epilogue.  (Branching
-        // around individual MFMAs costs far more than the wasted issue slots: it splits the loop
-        // into basic blocks and serialises every ds_read behind the previous step's MFMAs.)
-#pragma unroll 2
-        for (int ks = 0; ks < nks; ++ks) {
-            // the padded k of an odd stage reads slot 0 (initialised); its A column is zero
-            const int off = (ks * 2 + fk < kg) ? xo : 0;
-            const float a0 = as_[ks * 2 * LDA];
-            const float a1 = as_[ks * 2 * LDA + 32];
-            const float b0 = xs_[off + xc0];
-            const float b1 = xs_[off + xc1];
-            acc[0][0] = pase_mfma_32x32x2(a0, b0, acc[0][0]);
-            acc[0][1] = pase_mfma_32x32x2(a0, b1, acc[0][1]);
-            acc[1][0] = pase_mfma_32x32x2(a1, b0, acc[1][0]);
-            acc[1][1] = pase_mfma_32x32x2(a1, b1, acc[1][1]);
-            kkl += 2; xo += step2;
-            if (kkl >= tbe) { kkl -= tbe; xo += wrap_add; }
-            if (kkl >= tbe) { kkl -= tbe; xo += wrap_add; }   // tbe == 1: two channel rows per step
+        int j = 0, srbase = 0;
+        auto fetch = [&](int ks, float& a0, float& a1, float& b0, float& b1) __attribute__((always_inline)) {
+            const int f = 2 * j + fk;
+            int off = (f >= tbe) ? row_hi : row_lo;
+            off = (p.tapstep > 0) ? off + f : off - f;
+            off += srbase;
+            if (ks * 2 + fk >= kg) off = 0;      // padded k of an odd stage: A column is zero, read an initialised slot
+            const int ka = min(ks * 2, KGMAX - 2) * LDA;   // (the one fetch past the end stays in bounds)
+            a0 = as_[ka];
+            a1 = as_[ka + 32];
+            b0 = xs_[off + xc0];
+            b1 = xs_[off + xc1];
+            if (++j == tbe) { j = 0; srbase += 2 * pl.SPAN; }
+        };
+        // ping-pong operand registers (P/Q), two k-steps per iteration: no register copies, so the
+        // wait before a step's MFMAs covers only that step's own ds_reads
+        float pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1;
+        fetch(0, pa0, pa1, pb0, pb1);
+        const int nks2 = (nks + 1) & ~1;     // an odd step count is padded with a zero-weight step (A rows
+                                             // beyond kg are zero-filled) so the loop body is branch-free
+        for (int ks = 0; ks < nks2; ks += 2) {
+            fetch(ks + 1, qa0, qa1, qb0, qb1);
+            PASE_SCHED_BARRIER();   // keep the next step's ds_reads ABOVE this step's MFMAs
+            // All MFMAs are issued unconditionally: rows / columns beyond the tile edge multiply
+            // zero-filled A rows or finite staged data and are discarded in the epilogue.
+            acc[0][0] = pase_mfma_32x32x2(pa0, pb0, acc[0][0]);
+            acc[0][1] = pase_mfma_32x32x2(pa0, pb1, acc[0][1]);
+            acc[1][0] = pase_mfma_32x32x2(pa1, pb0, acc[1][0]);
+            acc[1][1] = pase_mfma_32x32x2(pa1, pb1, acc[1][1]);
+            PASE_SCHED_BARRIER();
+            fetch(ks + 2, pa0, pa1, pb0, pb1);
+            PASE_SCHED_BARRIER();
+            acc[0][0] = pase_mfma_32x32x2(qa0, qb0, acc[0][0]);
+            acc[0][1] = pase_mfma_32x32x2(qa0, qb1, acc[0][1]);
+            acc[1][0] = pase_mfma_32x32x2(qa1, qb0, acc[1][0]);
+            acc[1][1] = pase_mfma_32x32x2(qa1, qb1, acc[1][1]);
+            PASE_SCHED_BARRIER();
         }
         if (g + 1 < g_end) store_stage(cur ^ 1);
         __syncthreads();

@@ -12,6 +12,7 @@ __device__ __forceinline__ f32x16 pase_mfma_32x32x2(float a, float b, f32x16 c) 
 }
 __device__ __forceinline__ int pase_uniform(int v) { return v; }
 #define PASE_LAUNDER(x) ((void)0)
+#define PASE_SCHED_BARRIER() ((void)0)
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -29,6 +30,8 @@ __device__ __forceinline__ f32x16 pase_mfma_32x32x2(float a, float b, f32x16 c) 
 __device__ __forceinline__ int pase_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // make the compiler forget what it knows about x (blocks loop-invariant hoisting of values derived from it)
 #define PASE_LAUNDER(x) asm volatile("" : "+v"(x))
+// pin the instruction order across this point (software-pipelined ds_read -> MFMA loops)
+#define PASE_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #endif
 
 #define PASE_CHECK_LAUNCH()                      \

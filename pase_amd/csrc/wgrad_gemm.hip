@@ -257,17 +257,38 @@ __global__ void __launch_bounds__(NTHREADS, (ZPT <= ZPT_SMALL ? 2 : 1)) wgrad_ge
     for (int c = c_begin; c < c_end; ++c) {
         const int cur = (c - c_begin) & 1;
         if (c + 1 < c_end) load_stage(c + 1);
+        // software-pipelined operand fetch (ping-pong registers, schedule pinned): the ds_reads of step
+        // ks+1 are in flight under the four MFMAs of step ks.  MFMAs are unconditional (see conv_gemm.hip).
+        {
+            const float* as_ = &As[cur][fk][wm * 64 + fr];
+            const float* z0_ = &Zs[cur][boff[0] + fk * zstep];
+            const float* z1_ = &Zs[cur][boff[1] + fk * zstep];
+            auto fetch = [&](int ks, float& a0, float& a1, float& b0, float& b1) __attribute__((always_inline)) {
+                const int kc = min(ks, BKQ / 2 - 1);      // the one fetch past the end stays in bounds
+                a0 = as_[kc * 2 * (BM + 1)];
+                a1 = as_[kc * 2 * (BM + 1) + 32];
+                b0 = z0_[kc * 2 * zstep];
+                b1 = z1_[kc * 2 * zstep];
+            };
+            float pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1;
+            fetch(0, pa0, pa1, pb0, pb1);
 #pragma unroll 2
-        for (int ks = 0; ks < BKQ / 2; ++ks) {   // unconditional MFMAs (see conv_gemm.hip)
-            const int kq = ks * 2 + fk;
-            const float a0 = As[cur][kq][wm * 64 + fr];
-            const float a1 = As[cur][kq][wm * 64 + 32 + fr];
-            const float b0 = Zs[cur][boff[0] + kq * zstep];
-            const float b1 = Zs[cur][boff[1] + kq * zstep];
-            acc[0][0] = pase_mfma_32x32x2(a0, b0, acc[0][0]);
-            acc[0][1] = pase_mfma_32x32x2(a0, b1, acc[0][1]);
-            acc[1][0] = pase_mfma_32x32x2(a1, b0, acc[1][0]);
-            acc[1][1] = pase_mfma_32x32x2(a1, b1, acc[1][1]);
+            for (int ks = 0; ks < BKQ / 2; ks += 2) {
+                fetch(ks + 1, qa0, qa1, qb0, qb1);
+                PASE_SCHED_BARRIER();
+                acc[0][0] = pase_mfma_32x32x2(pa0, pb0, acc[0][0]);
+                acc[0][1] = pase_mfma_32x32x2(pa0, pb1, acc[0][1]);
+                acc[1][0] = pase_mfma_32x32x2(pa1, pb0, acc[1][0]);
+                acc[1][1] = pase_mfma_32x32x2(pa1, pb1, acc[1][1]);
+                PASE_SCHED_BARRIER();
+                fetch(ks + 2, pa0, pa1, pb0, pb1);
+                PASE_SCHED_BARRIER();
+                acc[0][0] = pase_mfma_32x32x2(qa0, qb0, acc[0][0]);
+                acc[0][1] = pase_mfma_32x32x2(qa0, qb1, acc[0][1]);
+                acc[1][0] = pase_mfma_32x32x2(qa1, qb0, acc[1][0]);
+                acc[1][1] = pase_mfma_32x32x2(qa1, qb1, acc[1][1]);
+                PASE_SCHED_BARRIER();
+            }
         }
         if (c + 1 < c_end) store_stage(cur ^ 1);
         __syncthreads();

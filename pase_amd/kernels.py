@@ -116,13 +116,47 @@ def stat_tiles(*, M, S, Ncols, Cin, taps, stride=1, padL=0, tapstep=1, tile_hint
     return _lib.lib().pase_conv_gemm_stat_tiles(C.byref(d))
 
 
+class GemmTimer(object):
+    """Measurement hook (bench.py): brackets every MFMA-kernel launch with HIP events recorded on the
+    stream the kernel is launched on, together with the launch's algorithmic FLOPs."""
+
+    def __init__(self):
+        self.records = []
+
+    def start(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def stop(self, family, flops, ev0):
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record(torch.cuda.current_stream())
+        self.records.append((family, flops, ev0, ev1))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        fam = {}
+        for family, flops, e0, e1 in self.records:
+            f = fam.setdefault(family, dict(launches=0, flops=0.0, ms=0.0))
+            f["launches"] += 1
+            f["flops"] += flops
+            f["ms"] += e0.elapsed_time(e1)
+        return fam
+
+
+GEMM_TIMER = None
+
+
 def conv_gemm(x, w, y, **kw):
     """see include/pase_amd.h PaseConvGemm.  With splitk > 1 the output is zero-filled here first."""
     d = _conv_desc(x, w, y, **kw)
     if d.splitk != 1:
         if _lib.lib().pase_conv_gemm_splitk(C.byref(d)) > 1:
             y.zero_()
+    ev0 = GEMM_TIMER.start() if GEMM_TIMER is not None else None
     _check(_lib.lib().pase_conv_gemm(C.byref(d), _stream()), "pase_conv_gemm")
+    if ev0 is not None:
+        GEMM_TIMER.stop("conv_gemm", 2.0 * d.S * d.Ncols * d.M * d.K, ev0)
 
 
 # ======================================================================================
@@ -199,7 +233,10 @@ def wgrad_gemm(g, z, dw, *, S, M, Tg, Ncols, Cin, Tz, taps, ldw=None, dbias=None
     d.taps, d.tap_major, d.stride, d.tapstep, d.padL, d.pad_mode = taps, tap_major, stride, tapstep, padL, pad_mode
     d.ldw = Cin * taps if ldw is None else ldw
     d.splitk = splitk
+    ev0 = GEMM_TIMER.start() if GEMM_TIMER is not None else None
     _check(_lib.lib().pase_wgrad_gemm(C.byref(d), _stream()), "pase_wgrad_gemm")
+    if ev0 is not None:
+        GEMM_TIMER.stop("wgrad_gemm", 2.0 * S * Ncols * M * (Cin * taps + (1 if dbias is not None else 0)), ev0)
 
 
 def bn_finalize(stat_part, C_, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift,
