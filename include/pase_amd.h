@@ -129,14 +129,14 @@ int pase_bn_act_apply(const float* y, float* out, const float* scale, const floa
  *   apply : dy = scale*(dz - sums0/N - xhat*sums1/N)  (has_bn)   or   dy = dz
  * ------------------------------------------------------------------------------------------ */
 typedef struct PaseActBwd {
-    const float* y;        /* (S, C, T) raw layer output                                          */
+    const float* y;        /* (S, y_ctot, T) raw layer output; channels [y_coff, y_coff+C)          */
     const float* dsrc;     /* (S, dsrc_ctot, Tp) padded data-gradient, or NULL                    */
     const float* dpool;    /* (S, dpool_ctot, pool_F) pooled-branch gradient, or NULL             */
     const float* scale; const float* shift; const float* alpha;   /* forward on-load params, NULL = identity */
     const float* mean; const float* rstd;                         /* from pase_bn_finalize (has_bn) */
     double* sums;          /* (C, 3)                                                              */
-    float* dy;             /* (S, C, T) output of the apply pass                                  */
-    int S, C, T;
+    float* dy;             /* (S, y_ctot, T) output of the apply pass, same channel slice as y    */
+    int S, C, T, y_ctot, y_coff;
     int dsrc_ctot, dsrc_coff, Tp, padL, pad_mode;
     int dpool_ctot, dpool_coff, pool_F, pool_d;
     float pool_inv;        /* 1 / pool_d                                                          */

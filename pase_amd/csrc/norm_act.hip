@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(NT) act_bwd_reduce_kernel(PaseActBwd p, int ch
     const float a = p.scale ? p.scale[c] : 1.f, b = p.shift ? p.shift[c] : 0.f;
     const float al = p.alpha ? p.alpha[c] : 1.f;
     const float mean = p.mean ? p.mean[c] : 0.f, rstd = p.rstd ? p.rstd[c] : 1.f;
-    const float* yrow = p.y + ((size_t)s * p.C + c) * (size_t)p.T;
+    const float* yrow = p.y + ((size_t)s * p.y_ctot + p.y_coff + c) * (size_t)p.T;
     const int per = (p.T + chunks - 1) / chunks;
     const int t0 = ch * per, t1 = min(p.T, t0 + per);
     double s_dz = 0.0, s_dzx = 0.0, s_da = 0.0;
@@ -180,8 +180,8 @@ __global__ void __launch_bounds__(NT) act_bwd_apply_kernel(PaseActBwd p, int chu
         m1 = (float)(p.sums[(size_t)c * 3 + 0] / n);
         m2 = (float)(p.sums[(size_t)c * 3 + 1] / n);
     }
-    const float* yrow = p.y + ((size_t)s * p.C + c) * (size_t)p.T;
-    float* drow = p.dy + ((size_t)s * p.C + c) * (size_t)p.T;
+    const float* yrow = p.y + ((size_t)s * p.y_ctot + p.y_coff + c) * (size_t)p.T;
+    float* drow = p.dy + ((size_t)s * p.y_ctot + p.y_coff + c) * (size_t)p.T;
     const int per = (p.T + chunks - 1) / chunks;
     const int t0 = ch * per, t1 = min(p.T, t0 + per);
     for (int t = t0 + threadIdx.x; t < t1; t += NT) {

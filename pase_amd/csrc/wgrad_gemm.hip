@@ -35,6 +35,7 @@ constexpr int ZS_ONES = 320;            // region of 1.0f (bias column / padding
 constexpr int ZPT_SMALL = 9, ZPT_LARGE = 19;
 
 struct WgradPlan {
+    int bias_rowsum;   // dbias from row sums of the G slab in column-tile 0 (no extra all-ones column tile)
     int gvec, flat, SPANW, chunks_per_seq, n_chunks, kt_per_split, n_row_tiles, n_col_tiles;
     unsigned span_magic, ncols_magic;
 };
@@ -70,7 +71,7 @@ __global__ void __launch_bounds__(NTHREADS, (ZPT <= ZPT_SMALL ? 2 : 1)) wgrad_ge
     const int j0 = ct * BN;
 
     const int Kw = p.Cin * p.taps;
-    const int Nw = Kw + (p.dbias ? 1 : 0);
+    const int Nw = Kw + ((p.dbias && !pl.bias_rowsum) ? 1 : 0);
     const int c_begin = split * pl.kt_per_split;
     const int c_end = min(pl.n_chunks, c_begin + pl.kt_per_split);
     if (c_begin >= c_end) return;   // whole block exits together (no barrier reached yet)
@@ -198,12 +199,17 @@ __global__ void __launch_bounds__(NTHREADS, (ZPT <= ZPT_SMALL ? 2 : 1)) wgrad_ge
         }
         gvec_next = pl.gvec && !straddle;
     };
-    auto store_stage = [&](int buf) __attribute__((always_inline)) {
-        // on-load transforms are applied here, after the MFMA loop the prefetch was hidden under
+    // The staging stores are split into NP pieces so they can be issued BETWEEN the MFMAs of the
+    // current stage (a wave that has just issued four 64-cycle MFMAs has ~200 idle issue cycles):
+    // piece q handles element e of an N-element list when e*NP/N == q.  part < 0 stores everything.
+    constexpr int NP = 6;
+    auto store_piece = [&](int buf, int part) __attribute__((always_inline)) {
+        // on-load transforms (g_alpha on G, affine/PReLU on Z) are applied here
         if (gvec_next) {
             const int k4 = (tid & 7) * 4;
 #pragma unroll
             for (int i = 0; i < A_ROWS / 4; ++i) {
+                if (part >= 0 && (i * NP) / (A_ROWS / 4) != part) continue;
                 const int r = (tid >> 3) + 32 * i;
                 float al = 1.f;
                 if (p.g_alpha && m0 + r < p.M) al = p.g_alpha[m0 + r];
@@ -217,26 +223,24 @@ __global__ void __launch_bounds__(NTHREADS, (ZPT <= ZPT_SMALL ? 2 : 1)) wgrad_ge
         } else {
 #pragma unroll
             for (int i = 0; i < A_ROWS; ++i) {
+                if (part >= 0 && (i * NP) / A_ROWS != part) continue;
                 const int r = (tid >> 5) + 8 * i;
                 float gv = areg[i];
                 if (p.g_alpha && m0 + r < p.M) gv = gv > 0.f ? gv : gv * p.g_alpha[m0 + r];
                 As[buf][tid & 31][r] = gv;
             }
         }
-        if (p.in_scale || p.in_alpha) {
 #pragma unroll
-            for (int t = 0; t < ZPT; ++t) {
-                if (zmask & (1u << t)) {
-                    const int ci = c_lo + (int)div_magic((unsigned)(tid + NTHREADS * t), pl.span_magic);
-                    float v = zreg[t];
-                    if (p.in_scale) v = v * p.in_scale[ci] + p.in_shift[ci];
-                    if (p.in_alpha) v = v > 0.f ? v : v * p.in_alpha[ci];
-                    zreg[t] = v;
-                }
+        for (int t = 0; t < ZPT; ++t) {
+            if (part >= 0 && (t * NP) / ZPT != part) continue;
+            float v = zreg[t];
+            if ((p.in_scale || p.in_alpha) && (zmask & (1u << t))) {
+                const int ci = c_lo + (int)div_magic((unsigned)(tid + NTHREADS * t), pl.span_magic);
+                if (p.in_scale) v = v * p.in_scale[ci] + p.in_shift[ci];
+                if (p.in_alpha) v = v > 0.f ? v : v * p.in_alpha[ci];
             }
+            Zs[buf][tid + NTHREADS * t] = v;
         }
-#pragma unroll
-        for (int t = 0; t < ZPT; ++t) Zs[buf][tid + NTHREADS * t] = zreg[t];
     };
 
     f32x16 acc[2][2];
@@ -250,9 +254,11 @@ __global__ void __launch_bounds__(NTHREADS, (ZPT <= ZPT_SMALL ? 2 : 1)) wgrad_ge
     const bool row_ok0 = m0 + wm * 64 < p.M, row_ok1 = m0 + wm * 64 + 32 < p.M;
     const bool col_ok0 = j0 + wn * 64 < Nw, col_ok1 = j0 + wn * 64 + 32 < Nw;
     const bool full_tile = row_ok0 && row_ok1 && col_ok0 && col_ok1;
+    const bool do_rowsum = pl.bias_rowsum && p.dbias && ct == 0;
+    float rowsum = 0.f;
 
     load_stage(c_begin);
-    store_stage(0);
+    store_piece(0, -1);
     __syncthreads();
     for (int c = c_begin; c < c_end; ++c) {
         const int cur = (c - c_begin) & 1;
@@ -272,8 +278,10 @@ __global__ void __launch_bounds__(NTHREADS, (ZPT <= ZPT_SMALL ? 2 : 1)) wgrad_ge
             };
             float pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1;
             fetch(0, pa0, pa1, pb0, pb1);
-#pragma unroll 2
-            for (int ks = 0; ks < BKQ / 2; ks += 2) {
+            const bool has_next = c + 1 < c_end;
+#pragma unroll
+            for (int it = 0; it < BKQ / 4; ++it) {       // 8 iterations x 2 k-steps, fully unrolled
+                const int ks = it * 2;
                 fetch(ks + 1, qa0, qa1, qb0, qb1);
                 PASE_SCHED_BARRIER();
                 acc[0][0] = pase_mfma_32x32x2(pa0, pb0, acc[0][0]);
@@ -288,11 +296,21 @@ __global__ void __launch_bounds__(NTHREADS, (ZPT <= ZPT_SMALL ? 2 : 1)) wgrad_ge
                 acc[1][0] = pase_mfma_32x32x2(qa1, qb0, acc[1][0]);
                 acc[1][1] = pase_mfma_32x32x2(qa1, qb1, acc[1][1]);
                 PASE_SCHED_BARRIER();
+                // next stage's staging stores ride in the issue slots behind these MFMAs (the
+                // prefetch was issued >= 4 k-steps = 1000+ cycles ago)
+                if (it >= BKQ / 4 - NP && has_next) {
+                    store_piece(cur ^ 1, it - (BKQ / 4 - NP));
+                    PASE_SCHED_BARRIER();
+                }
             }
         }
-        if (c + 1 < c_end) store_stage(cur ^ 1);
+        if (do_rowsum && tid < BM) {
+#pragma unroll 8
+            for (int kq = 0; kq < BKQ; ++kq) rowsum += As[cur][kq][tid];
+        }
         __syncthreads();
     }
+    if (do_rowsum && tid < BM && m0 + tid < p.M) atomicAdd(p.dbias + m0 + tid, rowsum);
 
     const int rbase = 4 * (lane >> 5);
 #pragma unroll
@@ -322,7 +340,6 @@ extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
     if (p.pad_mode == PASE_PAD_REFLECT && p.padL >= p.Tz) return -3;
     if ((long)p.S * p.Ncols >= 0x7fffffffL) return -8;
     hipStream_t st = (hipStream_t)stream;
-    const int Nw = p.Cin * p.taps + (p.dbias ? 1 : 0);
     bool narrow = p.M <= 64;
     WgradPlan pl;
     pl.flat = (p.taps == 1 && p.stride == 1 && p.padL == 0 && p.tapstep == 1) ? 1 : 0;
@@ -337,6 +354,8 @@ extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
     const bool small = need(narrow ? 256 : 128) <= ZPT_SMALL * NTHREADS;
     const int BMv = narrow ? 64 : 128, BNv = narrow ? 256 : 128;
     if ((BKQ - 1) * (pl.flat ? 1 : p.stride) + 1 > ZS_ONES) return -6;
+    pl.bias_rowsum = (p.dbias && ((p.Cin * p.taps) % BNv) == 0) ? 1 : 0;
+    const int Nw = p.Cin * p.taps + ((p.dbias && !pl.bias_rowsum) ? 1 : 0);
     pl.n_row_tiles = (p.M + BMv - 1) / BMv;
     pl.n_col_tiles = (Nw + BNv - 1) / BNv;
     const long kred = (long)p.S * p.Ncols;

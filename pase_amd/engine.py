@@ -149,12 +149,12 @@ def bn_eval(norm):
 
 def act_backward(y, *, C, T, S, has_bn, scale=None, shift=None, alpha=None, mean=None, rstd=None, dsrc=None,
                  dsrc_ctot=None, dsrc_coff=0, Tp=None, padL=0, pad_mode=K.PAD_ZERO, dpool=None, dpool_ctot=0,
-                 dpool_coff=0, pool_F=0, pool_d=1):
+                 dpool_coff=0, pool_F=0, pool_d=1, y_ctot=None, y_coff=0, dy_out=None):
     """Backward of a = PReLU(BN(y)): returns (dy, sums) with sums (C,3) double =
     {dbeta | sum dz, dgamma, dalpha}."""
     sums = _zeros((C, 3), y, torch.float64)
-    dy = _new(tuple(y.shape), y)
-    kw = dict(S=S, C_=C, T=T, dsrc=dsrc, dsrc_ctot=dsrc_ctot, dsrc_coff=dsrc_coff, Tp=Tp, padL=padL,
+    dy = dy_out if dy_out is not None else _new(tuple(y.shape), y)
+    kw = dict(S=S, C_=C, T=T, y_ctot=y_ctot, y_coff=y_coff, dsrc=dsrc, dsrc_ctot=dsrc_ctot, dsrc_coff=dsrc_coff, Tp=Tp, padL=padL,
               pad_mode=pad_mode, dpool=dpool, dpool_ctot=dpool_ctot, dpool_coff=dpool_coff, pool_F=pool_F,
               pool_d=pool_d, scale=scale, shift=shift, alpha=alpha, mean=mean, rstd=rstd, sums=sums, dy=dy,
               has_bn=1 if has_bn else 0)
@@ -569,3 +569,59 @@ def worker_backward(layers, out_conv, ctx, dpred, sink, need_dinput=True):
     if len(ctx.recs) == 0 and ctx.head1:
         raise NotImplementedError("1-output worker without hidden layers")
     return dsrc if need_dinput else None
+
+
+def mlp_group_step(workers, a: Act, targets, sink):
+    """Forward + loss + backward of several one-hidden-layer MLP regression workers that read the
+    SAME input (the chunk embedding): their first layers run as ONE stacked GEMM (9 x (256->256) ->
+    one 2304-row launch instead of nine 100-workgroup launches), their input gradient as ONE dgrad,
+    their first-layer weight gradients as ONE wgrad.  Heads (hidden -> num_outputs*r, fused r-context
+    MSE) stay per worker.  Returns ({name: (loss_acc, numel)}, d(input) as a dense (B, Cin, F) tensor).
+    Reference: MLPMinion.forward (Minions/minions.py:512-528) x N + ContextualizedLoss."""
+    B, F_, cin = a.S, a.T, a.C
+    x = a.t
+    hs = [w.blocks[0].fmaps for w in workers]
+    offs = [sum(hs[:i]) for i in range(len(hs))]
+    htot = sum(hs)
+    w1cat = torch.cat([w.blocks[0].W.weight.view(h, -1) for w, h in zip(workers, hs)], dim=0)
+    b1cat = torch.cat([w.blocks[0].W.bias for w in workers], dim=0)
+    z_all, _ = conv_fwd(a, w1cat, b1cat, Cout=htot, taps=1, Tout=F_)
+    dz_all = _new((B, htot, F_), x)
+    out = {}
+    for w, h, off in zip(workers, hs, offs):
+        blk, oc = w.blocks[0], w.W
+        nout = oc.out_channels
+        loss = w.loss
+        cur = Act(z_all, C=h, coff=off, alpha=blk.act.weight)
+        numel = B * nout * F_
+        gscale = float(w.loss_weight) / numel
+        acc = _zeros((1,), x, torch.float64)
+        dpred = _new((B, nout, F_), x)
+        tgt = targets[w.name].contiguous()
+        w2d = oc.weight.view(nout, -1)
+        r = loss.r
+        if loss.loss_name == "MSELoss" and r not in (None, 1):
+            K.conv_gemm(z_all, w2d, None, S=B, Cin=h, Tin=F_, M=nout, K=h, taps=1, Ncols=F_, Tout=F_, bias=oc.bias,
+                        in_alpha=cur.alpha, x_ctot=htot, x_coff=off, epilogue=K.EPI_MSE_CTX, label=tgt,
+                        grad_out=dpred, loss_acc=acc, grad_scale=2.0 * gscale, r_ctx=r, label_D=tgt.shape[1])
+        else:
+            pred, _ = conv_fwd(cur, w2d, oc.bias, Cout=nout, taps=1, Tout=F_)
+            K.ctx_loss(pred, tgt, dpred, acc, B=B, M=nout, F=F_, r_ctx=(r if r not in (None, 1) else 0),
+                       label_D=tgt.shape[1], loss_type=LOSS_TYPES[loss.loss_name], grad_scale=gscale)
+        out[w.name] = (acc, numel)
+        # head backward
+        conv_wgrad(dpred, cur, sink.buf(oc.weight).view(nout, -1), sink.buf(oc.bias), taps=1)
+        dA = conv_dgrad(dpred, oc.weight, R=nout, O=h, k=1, stride=1, Tin=F_, padL=0, padR=0, s_red=h, s_out=1, s_k=1)
+        _, sums = act_backward(z_all, C=h, T=F_, S=B, has_bn=False, alpha=blk.act.weight, dsrc=dA, dsrc_ctot=h, Tp=F_,
+                               y_ctot=htot, y_coff=off, dy_out=dz_all)
+        sf = sums.float()
+        sink.add(blk.act.weight, sf[:, 2].contiguous())
+        sink.add(blk.W.bias, sf[:, 0].contiguous())
+        del dpred, dA
+    # stacked first layer: one wgrad, one dgrad
+    dw1 = _zeros((htot, cin), x)
+    conv_wgrad(dz_all, a, dw1, None, taps=1)
+    for w, h, off in zip(workers, hs, offs):
+        sink.add(w.blocks[0].W.weight, dw1[off:off + h])
+    dx = conv_dgrad(dz_all, w1cat, R=htot, O=cin, k=1, stride=1, Tin=F_, padL=0, padR=0, s_red=cin, s_out=1, s_k=1)
+    return out, dx

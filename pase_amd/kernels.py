@@ -179,7 +179,7 @@ class PaseActBwd(C.Structure):
         ("y", _fp), ("dsrc", _fp), ("dpool", _fp),
         ("scale", _fp), ("shift", _fp), ("alpha", _fp), ("mean", _fp), ("rstd", _fp),
         ("sums", _fp), ("dy", _fp),
-        ("S", C.c_int), ("C", C.c_int), ("T", C.c_int),
+        ("S", C.c_int), ("C", C.c_int), ("T", C.c_int), ("y_ctot", C.c_int), ("y_coff", C.c_int),
         ("dsrc_ctot", C.c_int), ("dsrc_coff", C.c_int), ("Tp", C.c_int), ("padL", C.c_int),
         ("pad_mode", C.c_int),
         ("dpool_ctot", C.c_int), ("dpool_coff", C.c_int), ("pool_F", C.c_int), ("pool_d", C.c_int),
@@ -259,13 +259,15 @@ def bn_act_apply(y, out, scale, shift, alpha, *, S, C_, T):
 
 def _act_bwd_desc(y, *, S, C_, T, dsrc=None, dsrc_ctot=None, dsrc_coff=0, Tp=None, padL=0, pad_mode=PAD_ZERO,
                   dpool=None, dpool_ctot=0, dpool_coff=0, pool_F=0, pool_d=1, scale=None, shift=None, alpha=None,
-                  mean=None, rstd=None, sums=None, dy=None, has_bn=0):
+                  mean=None, rstd=None, sums=None, dy=None, has_bn=0, y_ctot=None, y_coff=0):
     d = PaseActBwd()
     d.y, d.dsrc, d.dpool = _ptr(y), _ptr(dsrc), _ptr(dpool)
     d.scale, d.shift, d.alpha, d.mean, d.rstd = _ptr(scale), _ptr(shift), _ptr(alpha), _ptr(mean), _ptr(rstd)
     d.sums = _ptr(sums, torch.float64)
     d.dy = _ptr(dy)
     d.S, d.C, d.T = S, C_, T
+    d.y_ctot = C_ if y_ctot is None else y_ctot
+    d.y_coff = y_coff
     d.dsrc_ctot = C_ if dsrc_ctot is None else dsrc_ctot
     d.dsrc_coff = dsrc_coff
     d.Tp = T if Tp is None else Tp

@@ -90,7 +90,25 @@ class pase(Model):
         losses = {}
         total = torch.zeros((), dtype=torch.float64, device=emb.device)
         chunk = emb[:B]
+        # one-hidden-layer MLP workers share their input: run their first layers stacked
+        from .minions import MLPMinion
+        group = [w for w in self.regression_workers
+                 if isinstance(w, MLPMinion) and len(w.blocks) == 1 and w.blocks[0].context == 1
+                 and w.W.kernel_size[0] == 1 and w.W.out_channels > 1]
+        if len(group) > 1:
+            tg = {w.name: (batch[w.name].to(device) if device is not None else batch[w.name]) for w in group}
+            res, dx = engine.mlp_group_step(group, Act(chunk, C=E), tg, sink)
+            demb[:B] += dx
+            for w in group:
+                acc, numel = res[w.name]
+                l = acc[0] * (w.loss_weight / numel)
+                losses[w.name] = l
+                total = total + l
+        else:
+            group = []
         for worker in self.regression_workers:
+            if any(worker is g for g in group):
+                continue
             loss = worker.loss
             tgt = batch[worker.name]
             if device is not None:
