@@ -286,23 +286,32 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
         // scalar loop state plus 3-4 VALU; operands for step ks+1 are fetched from LDS BEFORE the
         // MFMAs of step ks are issued (register double buffer), so the ds_read latency hides under
         // the 256 matrix-pipe cycles of the current step.
-        const int row_hi = (p.tapstep > 0) ? pl.SPAN - tbe : pl.SPAN + 2 * tbe - 1;   // f >= tbe
-        const int row_lo = (p.tapstep > 0) ? 0 : tbe - 1;                            // f <  tbe
+        // K order inside a stage: channel rows are taken two at a time ("super-row" = 2*tbe flat k,
+        // tbe MFMA steps, so a step never straddles super-rows even for odd tap counts).  This lane's
+        // flat position in step j is f = 2j + fk.  Its span offset advances by +-2 per step, plus one
+        // extra jump D when f crosses from the first to the second row (step j == jc, a per-lane
+        // constant) and the same D at the end of the super-row: ~7 VALU per step, no division, no table.
+        const int ts = p.tapstep;
+        int xo = (fk >= tbe) ? ((ts > 0) ? pl.SPAN - tbe : pl.SPAN + 2 * tbe - 1) : ((ts > 0) ? 0 : tbe - 1);
+        xo = (ts > 0) ? xo + fk : xo - fk;
+        const bool one_tap = tbe == 1;                       // rows of one tap: plain 2*SPAN stride
+        const int xstepk = one_tap ? 2 * pl.SPAN : 2 * ts;
+        const int D = one_tap ? 0 : ((ts > 0) ? pl.SPAN - tbe : pl.SPAN + tbe);
+        const int jc = one_tap ? -1 : (tbe - fk + 1) / 2 - 1;
+        const int xo_lim = XSMAX - 1 - max(xc0, xc1);        // a padded / look-ahead step must stay inside Xs
         const float* as_ = &As[cur][fk][wm * 64 + fr];
         const float* xs_ = &Xs[cur][0];
-        int j = 0, srbase = 0;
+        int j = 0;
         auto fetch = [&](int ks, float& a0, float& a1, float& b0, float& b1) __attribute__((always_inline)) {
-            const int f = 2 * j + fk;
-            int off = (f >= tbe) ? row_hi : row_lo;
-            off = (p.tapstep > 0) ? off + f : off - f;
-            off += srbase;
-            if (ks * 2 + fk >= kg) off = 0;      // padded k of an odd stage: A column is zero, read an initialised slot
             const int ka = min(ks * 2, KGMAX - 2) * LDA;   // (the one fetch past the end stays in bounds)
+            const int xoc = min(xo, xo_lim);
             a0 = as_[ka];
             a1 = as_[ka + 32];
-            b0 = xs_[off + xc0];
-            b1 = xs_[off + xc1];
-            if (++j == tbe) { j = 0; srbase += 2 * pl.SPAN; }
+            b0 = xs_[xoc + xc0];
+            b1 = xs_[xoc + xc1];
+            const int endj = (j == tbe - 1) ? D : 0;       // uniform
+            xo += xstepk + ((j == jc) ? D : 0) + endj;
+            j = (j == tbe - 1) ? 0 : j + 1;
         };
         // ping-pong operand registers (P/Q), two k-steps per iteration: no register copies, so the
         // wait before a step's MFMAs covers only that step's own ds_reads
@@ -310,24 +319,33 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
         fetch(0, pa0, pa1, pb0, pb1);
         const int nks2 = (nks + 1) & ~1;     // an odd step count is padded with a zero-weight step (A rows
                                              // beyond kg are zero-filled) so the loop body is branch-free
+        // Interleave: the index arithmetic + ds_reads of the NEXT step are spread between the four MFMAs
+        // of the current step (a wave that has issued a 64-cycle MFMA cannot issue the next one for
+        // ~60 cycles anyway), instead of sitting in a serial block behind them.
+#define PASE_STEP_SCHED()                                             \
+        PASE_SGB(0x008, 1); PASE_SGB(0x002, 3); PASE_SGB(0x100, 1);   \
+        PASE_SGB(0x008, 1); PASE_SGB(0x002, 3); PASE_SGB(0x100, 1);   \
+        PASE_SGB(0x008, 1); PASE_SGB(0x002, 3); PASE_SGB(0x100, 1);   \
+        PASE_SGB(0x008, 1); PASE_SGB(0x002, 3);
         for (int ks = 0; ks < nks2; ks += 2) {
             fetch(ks + 1, qa0, qa1, qb0, qb1);
-            PASE_SCHED_BARRIER();   // keep the next step's ds_reads ABOVE this step's MFMAs
             // All MFMAs are issued unconditionally: rows / columns beyond the tile edge multiply
             // zero-filled A rows or finite staged data and are discarded in the epilogue.
             acc[0][0] = pase_mfma_32x32x2(pa0, pb0, acc[0][0]);
             acc[0][1] = pase_mfma_32x32x2(pa0, pb1, acc[0][1]);
             acc[1][0] = pase_mfma_32x32x2(pa1, pb0, acc[1][0]);
             acc[1][1] = pase_mfma_32x32x2(pa1, pb1, acc[1][1]);
+            PASE_STEP_SCHED();
             PASE_SCHED_BARRIER();
             fetch(ks + 2, pa0, pa1, pb0, pb1);
-            PASE_SCHED_BARRIER();
             acc[0][0] = pase_mfma_32x32x2(qa0, qb0, acc[0][0]);
             acc[0][1] = pase_mfma_32x32x2(qa0, qb1, acc[0][1]);
             acc[1][0] = pase_mfma_32x32x2(qa1, qb0, acc[1][0]);
             acc[1][1] = pase_mfma_32x32x2(qa1, qb1, acc[1][1]);
+            PASE_STEP_SCHED();
             PASE_SCHED_BARRIER();
         }
+#undef PASE_STEP_SCHED
         if (g + 1 < g_end) store_stage(cur ^ 1);
         __syncthreads();
     }

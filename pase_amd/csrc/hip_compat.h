@@ -13,6 +13,7 @@ __device__ __forceinline__ f32x16 pase_mfma_32x32x2(float a, float b, f32x16 c) 
 __device__ __forceinline__ int pase_uniform(int v) { return v; }
 #define PASE_LAUNDER(x) ((void)0)
 #define PASE_SCHED_BARRIER() ((void)0)
+#define PASE_SGB(mask, n) ((void)0)
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -32,6 +33,8 @@ __device__ __forceinline__ int pase_uniform(int v) { return __builtin_amdgcn_rea
 #define PASE_LAUNDER(x) asm volatile("" : "+v"(x))
 // pin the instruction order across this point (software-pipelined ds_read -> MFMA loops)
 #define PASE_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// ask the scheduler for `n` instructions of class `mask` next (0x8 MFMA, 0x2 VALU, 0x4 SALU, 0x100 DS read)
+#define PASE_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 #endif
 
 #define PASE_CHECK_LAUNCH()                      \

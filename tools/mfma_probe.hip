@@ -79,7 +79,7 @@ int main() {
     float *g, *out;
     hipMalloc(&g, 64u << 20); hipMemset(g, 0, 64u << 20);
     hipMalloc(&out, 16u << 20);
-    for (int blocks : {512, 2048}) {
+    for (int blocks : {256, 512, 2048}) {
         run<0>("P0 regs only      ", g, out, blocks);
         run<1>("P1 +LDS reads     ", g, out, blocks);
         run<2>("P2 +restage+barrier", g, out, blocks);
