@@ -105,20 +105,20 @@ def synthetic_batch(seed, B, T, workers_cfg):
     return batch
 
 
-def gen_pase_step(seed, B, T):
-    """One reference training step (trainer.py:229-232 -> worker_scheduler._base_scheduler) of
-    PASE+.cfg + workers+.cfg on a seeded synthetic batch: losses, gradient norms, post-Adam norms."""
+def gen_pase_step(seed, B, T, fe_name="PASE+.cfg", wk_name="workers+.cfg", out="pase_plus_step.npz"):
+    """One reference training step (trainer.py:229-232 -> worker_scheduler._base_scheduler) of a
+    frontend cfg + workers cfg on a seeded synthetic batch: losses, gradient norms, post-Adam norms."""
     from pase.models.pase import pase
     from pase.utils import worker_parser
     from pase.models.WorkerScheduler.worker_scheduler import backprop_scheduler
     import torch.optim as optim
-    with open(os.path.join(REF, "cfg", "frontend", "PASE+.cfg")) as f:
+    with open(os.path.join(REF, "cfg", "frontend", fe_name)) as f:
         fe_cfg = json.load(f)
-    minions_cfg = quiet(worker_parser, os.path.join(REF, "cfg", "workers", "workers+.cfg"))
+    minions_cfg = quiet(worker_parser, os.path.join(REF, "cfg", "workers", wk_name))
     for _t, lst in minions_cfg.items():
         for c in lst:
             c.pop("transform", None)          # train.py:64
-    with open(os.path.join(REF, "cfg", "workers", "workers+.cfg")) as f:
+    with open(os.path.join(REF, "cfg", "workers", wk_name)) as f:
         raw_cfg = json.load(f)
     seed_all(seed)
     model = quiet(pase, frontend_cfg=fe_cfg, minions_cfg=minions_cfg,
@@ -130,6 +130,7 @@ def gen_pase_step(seed, B, T):
     regr_opt = {w.name: optim.Adam(w.parameters(), lr=5e-4) for w in model.regression_workers}
     sched = backprop_scheduler(model, mode="base")
     model.train()
+    random.seed(seed + 2)          # the SPC worker draws its frames from Python's `random`
     h, chunk, preds, labels = model.forward(batch, 1, "cpu")
     losses, _ = sched(preds, labels, cls_opt, regr_opt, fe_opt, device="cpu")
     gnames = [n for n, p in model.named_parameters()]
@@ -137,13 +138,17 @@ def gen_pase_step(seed, B, T):
     gsum = np.array([float(p.grad.double().sum()) for n, p in model.named_parameters()])
     post_sq = np.array([float((p.detach().double() ** 2).sum()) for n, p in model.named_parameters()])
     post_sum = np.array([float(p.detach().double().sum()) for n, p in model.named_parameters()])
-    np.savez(os.path.join(GOLD, "pase_plus_step.npz"), seed=seed, B=B, T=T, param_names=np.array(names),
+    extra = {}
+    if "mfcc" in preds:
+        extra["pred_mfcc"] = preds["mfcc"].detach().numpy()
+    if "spc" in preds:
+        extra["pred_spc"] = preds["spc"].detach().numpy()
+    np.savez(os.path.join(GOLD, out), seed=seed, B=B, T=T, param_names=np.array(names),
              param_sum=sums, param_sq=sq, loss_names=np.array(list(losses.keys())),
              loss_values=np.array([float(v) for v in losses.values()]), chunk_emb=chunk.detach().numpy(),
              grad_names=np.array(gnames), grad_sq=gsq, grad_sum=gsum, post_sq=post_sq, post_sum=post_sum,
              pred_mi=preds["mi"].detach().numpy(), pred_cmi=preds["cmi"].detach().numpy(),
-             pred_cchunk_head=preds["cchunk"].detach().numpy()[:, :, :400],
-             pred_mfcc=preds["mfcc"].detach().numpy())
+             pred_cchunk_head=preds["cchunk"].detach().numpy()[:, :, :400], **extra)
 
 
 if __name__ == "__main__":
@@ -154,5 +159,6 @@ if __name__ == "__main__":
     gen_wavefe("pase_plus", "PASE+.cfg", seed=2, S=3, T=8000)
     gen_wavefe("pase", "PASE.cfg", seed=3, S=3, T=8000)
     gen_pase_step(seed=2, B=2, T=8000)
+    gen_pase_step(seed=4, B=2, T=8000, fe_name="PASE.cfg", wk_name="workers.cfg", out="pase_step_cfg2.npz")
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)))

@@ -247,6 +247,23 @@ def make_samples(h, augment):
     return pos, neg
 
 
+def spc_samples(x, ctxt_frames=5, seq_pad=16):
+    """SPCMinion.forward sampling + gathering (Minions/minions.py:606-640): three `random.choice`
+    draws (anchor t, future start, past end), returns the (2B, (N+1)*C, 1) MLP input."""
+    import random
+    N, M = ctxt_frames, seq_pad + ctxt_frames
+    T, bsz = x.size(2), x.size(0)
+    t = random.choice(list(range(M + 1, T - M)))
+    future_t = random.choice(list(range(t + seq_pad, T - N)))
+    past_t = random.choice(list(range(N, t - seq_pad)))
+    future = x[:, :, future_t:future_t + N].contiguous().view(bsz, -1)
+    past = x[:, :, past_t - N:past_t].contiguous().view(bsz, -1)
+    current = x[:, :, t].contiguous()
+    pos = torch.cat((current, future), 1)
+    neg = torch.cat((current, past), 1)
+    return torch.cat((pos, neg), 0).unsqueeze(2)
+
+
 def make_labels(y):
     """cls_minions.py:47-51."""
     bsz, slen = y.size(0) // 2, y.size(2)
@@ -269,12 +286,15 @@ def pase_forward(P, fe_cfg, workers_cfg, batch, training=True, stats_out=None):
         labels[w["name"]] = batch[w["name"]]
     for i, w in enumerate(workers_cfg.get("cls", [])):
         pre = "classification_workers.%d.minion." % i
-        pos, neg = make_samples(h, w.get("augment", False))
-        x = torch.cat((pos, neg), 0)
-        if w["name"] == "cmi":
-            x = x.mean(2, keepdim=True)
-        elif w["name"] != "mi":
-            raise NotImplementedError(w["name"])
+        if w["name"] == "spc":
+            x = spc_samples(chunk, w.get("ctxt_frames", 5), w.get("seq_pad", 16))
+        else:
+            pos, neg = make_samples(h, w.get("augment", False))
+            x = torch.cat((pos, neg), 0)
+            if w["name"] == "cmi":
+                x = x.mean(2, keepdim=True)
+            elif w["name"] != "mi":
+                raise NotImplementedError(w["name"])
         y = mlp_minion(P, pre, x, w.get("hidden_layers", 2))
         preds[w["name"]] = y
         labels[w["name"]] = make_labels(y)

@@ -4,6 +4,7 @@ minion_maker (:11-35), cls_worker_maker (cls_minions.py:10-27).  Parameter conta
 reference's state_dict; arithmetic on the HIP kernels via pase_amd.engine.
 """
 import json
+import random
 
 import torch
 import torch.nn as nn
@@ -117,6 +118,45 @@ class DecoderMinion(_MinionBase):
         return y
 
 
+class SPCMinion(MLPMinion):
+    """Sequence-predicting-coding worker (Minions/minions.py:575-649): one random anchor frame t per
+    batch (Python `random.choice`, same RNG stream as the reference), the next `ctxt_frames` frames
+    at a random future offset (positive) / a random past window (negative), flattened to
+    (2B, (ctxt_frames+1)*emb, 1) and pushed through the MLP."""
+
+    def __init__(self, num_inputs, num_outputs, dropout, hidden_size=256, hidden_layers=2, ctxt_frames=5,
+                 seq_pad=16, skip=True, loss=None, loss_weight=1., keys=None, name="SPCMinion"):
+        super().__init__(num_inputs=(ctxt_frames + 1) * num_inputs, num_outputs=num_outputs, dropout=dropout,
+                         hidden_size=hidden_size, hidden_layers=hidden_layers, skip=skip, loss=loss,
+                         loss_weight=loss_weight, keys=keys, name=name)
+        self.ctxt_frames = ctxt_frames
+        self.seq_pad = seq_pad
+
+    def sample(self, T):
+        """(t, future_t, past_t): minions.py:614-628, three random.choice draws in this order."""
+        N, M = self.ctxt_frames, self.seq_pad + self.ctxt_frames
+        t = random.choice(list(range(M + 1, T - M)))
+        future_t = random.choice(list(range(t + self.seq_pad, T - N)))
+        past_t = random.choice(list(range(N, t - self.seq_pad)))
+        return t, future_t, past_t
+
+    def gather(self, x, t, future_t, past_t):
+        bsz, N = x.size(0), self.ctxt_frames
+        future = x[:, :, future_t:future_t + N].contiguous().view(bsz, -1)
+        past = x[:, :, past_t - N:past_t].contiguous().view(bsz, -1)
+        current = x[:, :, t].contiguous()
+        pos = torch.cat((current, future), dim=1)
+        neg = torch.cat((current, past), dim=1)
+        return torch.cat((pos, neg), dim=0).unsqueeze(2)
+
+    def forward(self, x, alpha=1, device=None):
+        x_full = self.gather(x, *self.sample(x.size(2)))
+        y = self._run(x_full)
+        if self.skip:
+            raise NotImplementedError("pase_amd SPCMinion: skip=True")
+        return y
+
+
 def minion_maker(cfg):
     """minions.py:11-35 (mlp / decoder; the wavernn / spc / gap / gru / regularizer types are not
     reachable from cfg/workers/workers+.cfg)."""
@@ -131,6 +171,8 @@ def minion_maker(cfg):
         return MLPMinion(**cfg)
     if mtype == "decoder":
         return DecoderMinion(**cfg)
+    if mtype == "spc":
+        return SPCMinion(**cfg)
     raise NotImplementedError("pase_amd minion_maker: minion type {}".format(mtype))
 
 
@@ -179,6 +221,21 @@ class GIM(LIM):
         self.time_mean = True
 
 
+class SPC(Model):
+    """cls_minions.py:101-115: SPCMinion + make_labels."""
+
+    def __init__(self, cfg, emb_dim):
+        super().__init__(name=cfg["name"])
+        cfg["num_inputs"] = emb_dim
+        self.minion = minion_maker(cfg)
+        self.loss = self.minion.loss
+        self.loss_weight = self.minion.loss_weight
+
+    def forward(self, x, alpha=1, device=None):
+        y = self.minion(x, alpha)
+        return y, make_labels(y).to(device)
+
+
 def cls_worker_maker(cfg, emb_dim):
     """cls_minions.py:10-27 (spc / gap are workers.cfg-only / unshipped; not in the PASE+ path)."""
     print("=" * 50)
@@ -188,6 +245,8 @@ def cls_worker_maker(cfg, emb_dim):
         return LIM(cfg, emb_dim)
     if cfg["name"] == "cmi":
         return GIM(cfg, emb_dim)
-    if cfg["name"] in ("spc", "gap"):
-        raise NotImplementedError("pase_amd: the %s worker is outside the PASE+ (workers+.cfg) path" % cfg["name"])
+    if cfg["name"] == "spc":
+        return SPC(cfg, emb_dim)
+    if cfg["name"] == "gap":
+        raise NotImplementedError("pase_amd: the gap worker has no shipped cfg and is not built")
     return minion_maker(cfg)

@@ -61,7 +61,10 @@ class pase(Model):
             preds[worker.name] = worker(chunk, alpha)
             labels[worker.name] = x[worker.name].to(device).detach()
         for worker in self.classification_workers:
-            y, label = worker(h, alpha, device=device)
+            if worker.name == "spc":
+                y, label = worker(chunk, alpha, device=device)
+            else:
+                y, label = worker(h, alpha, device=device)
             preds[worker.name] = y
             labels[worker.name] = label
         return h, chunk, preds, labels
@@ -126,6 +129,29 @@ class pase(Model):
         for worker in self.classification_workers:
             mn = worker.minion
             loss = worker.loss
+            if worker.name == "spc":
+                # SPC reads the chunk embedding only (pase.py:346-347); frames are gathered / the
+                # gradient scattered back with index plumbing, the MLP runs on the kernels
+                t, ft, pt = mn.sample(F_)
+                N = mn.ctxt_frames
+                xin = mn.gather(chunk, t, ft, pt).contiguous()
+                nb = xin.shape[0]
+                label = torch.cat((torch.ones(nb // 2, 1, 1, device=emb.device),
+                                   torch.zeros(nb // 2, 1, 1, device=emb.device)), dim=0)
+                wctx = engine.worker_forward(list(mn.blocks), mn.W, Act(xin, C=xin.shape[1]),
+                                             loss=dict(name=loss.loss_name, r=loss.r, target=label,
+                                                       weight=worker.loss_weight), want_pred=False)
+                dsrc = engine.worker_backward(list(mn.blocks), mn.W, wctx, wctx.dpred, sink)
+                dx = dsrc.dense(xin.shape[1], 1)[:, :, 0]
+                pos, neg = dx[:B], dx[B:]
+                demb[:B, :, t] += pos[:, :E] + neg[:, :E]
+                demb[:B, :, ft:ft + N] += pos[:, E:].reshape(B, E, N)
+                demb[:B, :, pt - N:pt] += neg[:, E:].reshape(B, E, N)
+                l = wctx.loss_acc[0] * (worker.loss_weight / wctx.numel)
+                losses[worker.name] = l
+                total = total + l
+                del wctx, dsrc
+                continue
             x_pos, x_neg = make_samples(h, worker.augment)
             xin = torch.cat((x_pos, x_neg), dim=0)
             nb = xin.shape[0]

@@ -84,15 +84,19 @@ def test_encoder_golden(tag, cfgfile):
     assert_close(O.select_output(ye, "avg_norm"), g["y_avg_norm"], rtol=1e-4, atol=1e-4)
 
 
-def test_pase_step_golden():
-    """oracle full PASE+ step (12 workers, losses, grads, Adam) == live reference trainer step."""
+@pytest.mark.parametrize("gold,fe,wk", [("pase_plus_step.npz", "frontend/PASE+.cfg", "workers/workers+.cfg"),
+                                        ("pase_step_cfg2.npz", "frontend/PASE.cfg", "workers/workers.cfg")])
+def test_pase_step_golden(gold, fe, wk):
+    """oracle full step (all workers, losses, grads) == live reference trainer step, for PASE+.cfg +
+    workers+.cfg (BASELINE configs[2]) and PASE.cfg + workers.cfg incl. the SPC worker (configs[1])."""
+    import random
     from pase_amd.pase import pase
-    g = _npz("pase_plus_step.npz")
-    fe_cfg = load_cfg("frontend/PASE+.cfg")
-    raw = load_cfg("workers/workers+.cfg")
+    g = _npz(gold)
+    fe_cfg = load_cfg(fe)
+    raw = load_cfg(wk)
     seed_all(int(g["seed"]))
-    model = quiet(pase, frontend_cfg=dict(fe_cfg), minions_cfg=with_losses(load_cfg("workers/workers+.cfg")),
-                  cls_lst=["mi", "cmi"], regr_lst=[w["name"] for w in raw["regr"]])
+    model = quiet(pase, frontend_cfg=dict(fe_cfg), minions_cfg=with_losses(load_cfg(wk)),
+                  cls_lst=[w["name"] for w in raw["cls"]], regr_lst=[w["name"] for w in raw["regr"]])
     sd = model.state_dict()
     assert list(sd.keys()) == [str(s) for s in g["param_names"]]
     assert_close(torch.tensor([float((v.double() ** 2).sum()) for v in sd.values()]), g["param_sq"], rtol=1e-7,
@@ -100,11 +104,14 @@ def test_pase_step_golden():
     P = oracle_params(model)
     B, T = int(g["B"]), int(g["T"])
     batch = synthetic_batch(int(g["seed"]) + 1, B, T, raw["regr"])
+    random.seed(int(g["seed"]) + 2)
     h, chunk, preds, labels = O.pase_forward(P, fe_cfg, raw, batch, True)
     assert_close(chunk, g["chunk_emb"], rtol=1e-4, atol=1e-4, what="chunk embedding")
     assert_close(preds["mi"], g["pred_mi"], rtol=1e-4, atol=1e-4)
     assert_close(preds["cmi"], g["pred_cmi"], rtol=1e-4, atol=1e-4)
     assert_close(preds["mfcc"], g["pred_mfcc"], rtol=1e-4, atol=1e-4)
+    if "pred_spc" in g.files:
+        assert_close(preds["spc"], g["pred_spc"], rtol=1e-4, atol=1e-4)
     assert_close(preds["cchunk"][:, :, :400], g["pred_cchunk_head"], rtol=1e-4, atol=1e-4)
     losses = O.pase_losses(raw, preds, labels)
     gl = dict(zip([str(s) for s in g["loss_names"]], g["loss_values"]))

@@ -107,16 +107,19 @@ def test_trainer_three_adam_steps(dev):
     assert abs(lrs["frontend"] - 1e-3 * (1 - 5 / 20) ** 0.9) < 1e-12
 
 
-def test_full_width_golden_step(dev):
-    """PASE+.cfg + workers+.cfg (12 workers) one step vs the live reference's trainer step."""
+@pytest.mark.parametrize("gold,fe,wk", [("pase_plus_step.npz", "frontend/PASE+.cfg", "workers/workers+.cfg"),
+                                        ("pase_step_cfg2.npz", "frontend/PASE.cfg", "workers/workers.cfg")])
+def test_full_width_golden_step(dev, gold, fe, wk):
+    """Full-width one step vs the live reference's trainer step: PASE+.cfg + workers+.cfg (12 workers)
+    and PASE.cfg + workers.cfg (decoder, r-less regressors, SPC / LIM / GIM)."""
     if dev.type == "cpu":
         pytest.skip("full-width step is GPU-only")
+    import random
     from pase_amd.trainer import trainer
-    g = np.load(os.path.join(GOLD, "pase_plus_step.npz"))
-    raw = load_cfg("workers/workers+.cfg")
+    g = np.load(os.path.join(GOLD, gold))
+    raw = load_cfg(wk)
     seed_all(int(g["seed"]))
-    tr = quiet(trainer, frontend_cfg=load_cfg("frontend/PASE+.cfg"),
-               minions_cfg=with_losses(load_cfg("workers/workers+.cfg")),
+    tr = quiet(trainer, frontend_cfg=load_cfg(fe), minions_cfg=with_losses(load_cfg(wk)),
                cfg=dict(fe_lr=1e-3, min_lr=5e-4, epoch=1, bpe=10), lr_mode="poly", device=dev)
     batch = synthetic_batch(int(g["seed"]) + 1, int(g["B"]), int(g["T"]), raw["regr"])
     batch = {k: v.to(dev) for k, v in batch.items()}
@@ -124,16 +127,20 @@ def test_full_width_golden_step(dev):
     # API-compat forward first (train mode, same batch) for the prediction tensors
     m.train()
     sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    random.seed(int(g["seed"]) + 2)
     h, chunk, preds, labels = m(batch, device=dev)
     assert_close(chunk, g["chunk_emb"], rtol=0, atol=1e-4, what="chunk embedding")
     assert_close(preds["mi"], g["pred_mi"], rtol=1e-4, atol=1e-4)
     assert_close(preds["cmi"], g["pred_cmi"], rtol=1e-4, atol=1e-4)
     assert_close(preds["mfcc"], g["pred_mfcc"], rtol=1e-4, atol=1e-4)
     assert_close(preds["cchunk"][:, :, :400], g["pred_cchunk_head"], rtol=1e-4, atol=1e-4)
+    if "pred_spc" in g.files:
+        assert_close(preds["spc"], g["pred_spc"], rtol=1e-4, atol=1e-4)
     del h, chunk, preds, labels
     with torch.no_grad():      # undo the running-stat update of the extra forward
         for k, v in m.state_dict().items():
             v.copy_(sd0[k])
+    random.seed(int(g["seed"]) + 2)
     losses = tr.train_step(batch)
     gl = dict(zip([str(s) for s in g["loss_names"]], g["loss_values"]))
     for k, v in gl.items():
@@ -145,3 +152,56 @@ def test_full_width_golden_step(dev):
     assert_close(gsq.sqrt(), np.sqrt(g["grad_sq"][keep]), rtol=5e-3, atol=1e-6, what="grad norms")
     psq = torch.tensor([float((params[names[i]].detach().double() ** 2).sum()) for i in keep])
     assert_close(psq.sqrt(), np.sqrt(g["post_sq"][keep]), rtol=1e-4, atol=1e-5, what="post-Adam parameter norms")
+
+
+def _mini_workers_cfg2():
+    """workers.cfg-shaped (BASELINE.json configs[1]): decoder, r-less MLP regressors, spc / mi / cmi."""
+    return {"regr": [
+        {"num_outputs": 1, "dropout": 0, "hidden_layers": 1, "name": "cchunk", "type": "decoder", "hidden_size": 6,
+         "fmaps": [10, 8, 6], "strides": [4, 4, 10], "kwidths": [30, 30, 30], "loss": "L1Loss"},
+        {"num_outputs": 9, "dropout": 0, "hidden_size": 9, "hidden_layers": 1, "name": "lps", "loss": "MSELoss",
+         "skip": False},
+        {"num_outputs": 4, "dropout": 0, "hidden_size": 7, "hidden_layers": 1, "name": "prosody", "loss": "MSELoss",
+         "skip": False}],
+        "cls": [
+        {"num_outputs": 1, "dropout": 0, "hidden_size": 8, "hidden_layers": 1, "name": "spc", "type": "spc",
+         "loss": "BCEWithLogitsLoss", "skip": False},
+        {"num_outputs": 1, "dropout": 0, "hidden_size": 8, "hidden_layers": 1, "name": "mi",
+         "loss": "BCEWithLogitsLoss", "skip": False},
+        {"num_outputs": 1, "dropout": 0, "hidden_size": 8, "hidden_layers": 1, "name": "cmi",
+         "loss": "BCEWithLogitsLoss", "skip": False}]}
+
+
+def test_config2_shaped_step_with_spc(dev):
+    """PASE.cfg-shaped encoder (no QRNN / skips) + workers.cfg-shaped heads incl. the SPC worker, whose
+    frame sampling consumes Python's `random` stream exactly like the reference (minions.py:614-628)."""
+    import random
+    from pase_amd.pase import pase
+    from util import MINI_FE_PLAIN
+    seed_all(7)
+    m = quiet(pase, frontend_cfg=dict(MINI_FE_PLAIN), minions_cfg=with_losses(_mini_workers_cfg2()),
+              cls_lst=["spc", "mi", "cmi"], regr_lst=["cchunk", "lps", "prosody"])
+    randomize_affine(m)
+    m = m.to(dev)
+    P = oracle_params(m)
+    B, T = 2, 8000
+    g = torch.Generator().manual_seed(3)
+    batch = {k: torch.randn(B, 1, T, generator=g) * 0.3 for k in ("chunk", "chunk_ctxt", "chunk_rand", "cchunk")}
+    batch["lps"] = torch.randn(B, 9, T // 160, generator=g)
+    batch["prosody"] = torch.randn(B, 4, T // 160, generator=g)
+    raw = _mini_workers_cfg2()
+    random.seed(11)
+    h, chunk, preds, labels = O.pase_forward(P, MINI_FE_PLAIN, raw, batch, True)
+    lo = O.pase_losses(raw, preds, labels)
+    lo["total"].backward()
+    m.train()
+    random.seed(11)
+    lf = m.loss_and_grads({k: v.to(dev) for k, v in batch.items()})
+    for k, v in lo.items():
+        assert abs(float(lf[k]) - float(v)) <= 1e-4 * max(1.0, abs(float(v))), (k, float(lf[k]), float(v))
+    _check_grads(m, P)
+    # API-compatible path draws the same frames under the same seed
+    m.zero_grad()
+    random.seed(11)
+    h2, chunk2, preds2, labels2 = m({k: v.to(dev) for k, v in batch.items()}, device=dev)
+    assert_close(preds2["spc"], preds["spc"], rtol=1e-3, atol=1e-3)
