@@ -26,6 +26,11 @@ extern "C" {
 
 enum { PASE_PAD_ZERO = 0, PASE_PAD_REFLECT = 1 };
 enum { PASE_EPI_STORE = 0, PASE_EPI_MSE_CTX = 1 };
+/* post-ops of the PASE_EPI_STORE epilogue (on-device target DSP: spectra as DFT-basis convolutions) */
+enum { PASE_POST_NONE = 0,
+       PASE_POST_POW = 1,     /* rows come in (re, im) pairs: out[row/2] = (re^2 + im^2) * post_scale            */
+       PASE_POST_LOGPOW = 2,  /* out[row/2] = post_scale * ln(re^2 + im^2 + post_eps)                          */
+       PASE_POST_LOG = 3 };   /* out[row] = post_scale * ln(v == 0 ? post_eps : v)                             */
 enum { PASE_LOSS_NONE = 0, PASE_LOSS_L1 = 1, PASE_LOSS_MSE = 2, PASE_LOSS_BCE_LOGITS = 3 };
 
 /* ------------------------------------------------------------------------------------------
@@ -62,6 +67,8 @@ typedef struct PaseConvGemm {
     int y_ctot, y_coff, Cout_store, ps, poff, Tout;
     int epilogue, r_ctx, label_D;
     int tile_hint;         /* 0 = auto, 64 = 64x256 block tile, 128 = 128x128                     */
+    int post_op;           /* PASE_POST_* (EPI_STORE, ps == 1, no stat_part / bias for the pair ops)       */
+    float post_scale, post_eps;
     int splitk;            /* 1: none; >1: split the reduction, partial tiles atomically added into a
                               caller-zeroed y (EPI_STORE without stat_part only); 0: library decides --
                               query pase_conv_gemm_splitk() and zero y when it returns > 1        */
@@ -193,6 +200,31 @@ int pase_pack_dgrad(const float* src, float* dst, int R, int O, int k, int st, l
 int pase_adam_step(float* p, const float* g, float* m, float* v, long n, const float* lr, const int* step,
                    float beta1, float beta2, float eps, float grad_mul, void* stream);
 int pase_step_tick(int* step, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * On-device regression targets (pase/transforms.py LPS :439-487, FBanks :489-548, MFCC :671-722,
+ * ZNorm :183-205 -- host numpy / librosa / python_speech_features code in the reference's
+ * DataLoader workers).  The spectra are DFT-basis convolutions on pase_conv_gemm (PASE_POST_*);
+ * these two entry points cover the rest.
+ *   pase_delta_znorm: out (B, (order+1)*D, Fo) = [x, delta_1(x), .., delta_order(x)] z-normalised;
+ *     delta = librosa.feature.delta = Savitzky-Golay width 9 (coef: (order+1, 9, 9) host table,
+ *     pos 4 = interior, other pos = mode='interp' edge fits); columns F..Fo-1 replicate column F-1
+ *     (FBanks' replicate padding, transforms.py:534-538); mean / istd (per output channel) or NULL.
+ *   pase_power_to_db: librosa.power_to_db(S, ref, amin, top_db) with the clamp at the per-utterance
+ *     maximum - top_db; umax_scratch: B unsigned ints.
+ * ------------------------------------------------------------------------------------------ */
+int pase_delta_znorm(const float* x, const float* coef, const float* mean, const float* istd, float* out, int B,
+                     int D, int F, int Fo, int order, int x_ctot, int x_coff, void* stream);
+int pase_power_to_db(const float* x, float* y, unsigned* umax_scratch, long per_utt, int B, float amin,
+                     float ref_db, float top_db, void* stream);
+/* Framing prologue of LPS / FBanks / MFCC (transforms.py:465-466 torch.stft centre padding, :517
+ * logfbank framing + pre-emphasis, :700 librosa stft): y (B, hop, Q) with
+ * y[b][r][q] = xpad[q*hop + r], xpad = x padded by padL on the left (pad_mode PASE_PAD_REFLECT or
+ * PASE_PAD_ZERO; the right side is padded the same way as far as Q*hop reaches), after the optional
+ * pre-emphasis x[n] - preemph*x[n-1] (0 = off).  A hop-strided frame of `win` samples then is a
+ * stride-1 conv over q with Cin = hop and ceil(win/hop) taps, which pase_conv_gemm runs. */
+int pase_frame_prep(const float* x, float* y, int B, int T, int hop, int Q, int padL, int pad_mode,
+                    float preemph, void* stream);
 
 /* sizeof() of the ABI structs (0 = PaseConvGemm, 1 = PaseWgrad, 2 = PaseActBwd), for binding self-checks */
 int pase_abi_sizeof(int which);

@@ -1,0 +1,153 @@
+"""CPU oracle for the regression-target transforms (TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py).
+
+numpy/scipy restatement of pase/transforms.py LPS (:439-487), FBanks (:489-548), MFCC (:671-722) and
+ZNorm (:183-205) on one utterance, following the reference's own order of operations.
+
+Pinning status:
+  * LPS: the STFT is pinned against this image's torch.stft (the function the reference calls; the
+    reference passes the pre-complex calling convention that torch 2.x rejects, so the LIVE transform
+    cannot run here) -- tests/test_oracle_pins.py.
+  * deltas: scipy.signal.savgol_filter IS what librosa 0.6.3 feature.delta calls
+    (width=9, polyorder=order, deriv=order, mode='interp'); scipy is installed, so it is used directly.
+  * DCT: scipy.fftpack.dct(type=2, norm='ortho') used directly (what librosa.feature.mfcc calls).
+  * python_speech_features 0.6 (logfbank) and librosa 0.6.3 (stft/mel/power_to_db) are pinned
+    dependencies of the reference that are NOT installed in this image (requirements.txt:3,7):
+    their published algorithms are restated below -- PARITY UNPINNED for the mel filter banks,
+    psf framing/pre-emphasis and power_to_db.
+"""
+import math
+
+import numpy as np
+import scipy.fftpack
+import scipy.signal
+
+
+def delta(X, order):
+    """librosa.feature.delta(X, order=order): width 9, axis -1, mode 'interp'."""
+    return scipy.signal.savgol_filter(X, 9, deriv=order, polyorder=order, axis=-1, mode="interp")
+
+
+def with_deltas(X, der_order):
+    if der_order <= 0:
+        return X
+    return np.concatenate([X] + [delta(X, n) for n in range(1, der_order + 1)])
+
+
+def stft_rect(wav, n_fft, hop, win):
+    """Legacy torch.stft(wav, n_fft, hop, win): window=None -> ones(win) zero-padded to n_fft centred;
+    center=True with reflect padding of n_fft//2; onesided.  Returns complex (n_fft/2+1, frames)."""
+    x = np.pad(np.asarray(wav, dtype=np.float64), n_fft // 2, mode="reflect")
+    nfr = 1 + (len(x) - n_fft) // hop
+    left = (n_fft - win) // 2
+    w = np.zeros(n_fft)
+    w[left:left + win] = 1.0
+    frames = np.stack([x[t * hop:t * hop + n_fft] * w for t in range(nfr)], axis=1)
+    return np.fft.rfft(frames, axis=0)
+
+
+def lps(wav, n_fft=2048, hop=160, win=400, der_order=2):
+    max_frames = len(wav) // hop
+    X = np.abs(stft_rect(wav, n_fft, hop, win))[:, :max_frames]
+    X = 10 * np.log10(X ** 2 + 10e-20)
+    return with_deltas(X.astype(np.float32), der_order)
+
+
+def psf_get_filterbanks(nfilt, nfft, samplerate):
+    """python_speech_features.base.get_filterbanks (HTK mel, floor()-quantised bin edges)."""
+    hz2mel = lambda hz: 2595 * np.log10(1 + hz / 700.)
+    mel2hz = lambda mel: 700 * (10 ** (mel / 2595.0) - 1)
+    melpoints = np.linspace(hz2mel(0), hz2mel(samplerate / 2), nfilt + 2)
+    bins = np.floor((nfft + 1) * mel2hz(melpoints) / samplerate)
+    fbank = np.zeros([nfilt, nfft // 2 + 1])
+    for j in range(0, nfilt):
+        for i in range(int(bins[j]), int(bins[j + 1])):
+            fbank[j, i] = (i - bins[j]) / (bins[j + 1] - bins[j])
+        for i in range(int(bins[j + 1]), int(bins[j + 2])):
+            fbank[j, i] = (bins[j + 2] - i) / (bins[j + 2] - bins[j + 1])
+    return fbank
+
+
+def psf_logfbank(signal, samplerate, winlen, winstep, nfilt, nfft, preemph=0.97):
+    """python_speech_features.base.logfbank -> fbank -> sigproc.{preemphasis,framesig,powspec}."""
+    signal = np.asarray(signal, dtype=np.float64)
+    signal = np.append(signal[0], signal[1:] - preemph * signal[:-1])
+    # sigproc.round_half_up on the lengths
+    frame_len = int(math.floor(winlen * samplerate + 0.5))
+    frame_step = int(math.floor(winstep * samplerate + 0.5))
+    slen = len(signal)
+    numframes = 1 if slen <= frame_len else 1 + int(math.ceil((1.0 * slen - frame_len) / frame_step))
+    padlen = int((numframes - 1) * frame_step + frame_len)
+    padsignal = np.concatenate((signal, np.zeros((padlen - slen,))))
+    idx = np.arange(frame_len)[None, :] + (np.arange(numframes) * frame_step)[:, None]
+    frames = padsignal[idx]                                  # rectangular window (winfunc = ones)
+    pspec = 1.0 / nfft * np.square(np.absolute(np.fft.rfft(frames, nfft)))
+    feat = np.dot(pspec, psf_get_filterbanks(nfilt, nfft, samplerate).T)
+    feat = np.where(feat == 0, np.finfo(float).eps, feat)
+    return np.log(feat)
+
+
+def fbanks(wav, n_filters=40, n_fft=512, hop=160, win=400, rate=16000, der_order=2):
+    X = psf_logfbank(wav, rate, float(win) / rate, float(hop) / rate, n_filters, n_fft).T
+    expected = len(wav) // hop
+    X = with_deltas(X, der_order).astype(np.float32)
+    if X.shape[1] < expected:
+        X = np.concatenate([X, np.repeat(X[:, -1:], expected - X.shape[1], axis=1)], axis=1)
+    return X
+
+
+def librosa_mel(sr, n_fft, n_mels=128):
+    """librosa.filters.mel(sr, n_fft, n_mels=128, fmin=0, fmax=sr/2, htk=False, norm=1) (0.6.3)."""
+    f_sp = 200.0 / 3
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+
+    def hz_to_mel(f):
+        f = float(f)
+        return min_log_mel + np.log(f / min_log_hz) / logstep if f >= min_log_hz else f / f_sp
+
+    def mel_to_hz(m):
+        m = np.asarray(m, dtype=np.float64)
+        out = f_sp * m
+        log_t = m >= min_log_mel
+        out[log_t] = min_log_hz * np.exp(logstep * (m[log_t] - min_log_mel))
+        return out
+
+    fftfreqs = np.linspace(0, float(sr) / 2, int(1 + n_fft // 2), endpoint=True)
+    mel_f = mel_to_hz(np.linspace(hz_to_mel(0.0), hz_to_mel(sr / 2.0), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = np.subtract.outer(mel_f, fftfreqs)
+    weights = np.zeros((n_mels, int(1 + n_fft // 2)))
+    for i in range(n_mels):
+        lower = -ramps[i] / fdiff[i]
+        upper = ramps[i + 2] / fdiff[i + 1]
+        weights[i] = np.maximum(0, np.minimum(lower, upper))
+    enorm = 2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels])
+    weights *= enorm[:, np.newaxis]
+    return weights
+
+
+def librosa_mfcc(y, sr, n_mfcc, n_fft, hop_length):
+    """librosa.feature.mfcc -> melspectrogram(power=2) -> stft(hann periodic, center, reflect) ->
+    power_to_db(ref=1, amin=1e-10, top_db=80) -> dct(type 2, ortho)[:n_mfcc]."""
+    y = np.asarray(y, dtype=np.float64)
+    yp = np.pad(y, n_fft // 2, mode="reflect")
+    nfr = 1 + (len(yp) - n_fft) // hop_length
+    win = scipy.signal.get_window("hann", n_fft, fftbins=True)
+    frames = np.stack([yp[t * hop_length:t * hop_length + n_fft] * win for t in range(nfr)], axis=1)
+    S = np.abs(np.fft.rfft(frames, axis=0)) ** 2
+    mel = np.dot(librosa_mel(sr, n_fft), S)
+    log_spec = 10.0 * np.log10(np.maximum(1e-10, mel))
+    log_spec -= 10.0 * np.log10(np.maximum(1e-10, 1.0))
+    log_spec = np.maximum(log_spec, log_spec.max() - 80.0)
+    return scipy.fftpack.dct(log_spec, axis=0, type=2, norm="ortho")[:n_mfcc]
+
+
+def mfcc(wav, hop=160, order=13, win=400, der_order=2):
+    max_frames = len(wav) // hop
+    m = librosa_mfcc(wav, 16000, order, win, hop)[:, :max_frames]
+    return with_deltas(m, der_order).astype(np.float32)
+
+
+def znorm(X, mean, std):
+    return (X - np.asarray(mean)[:, None]) / np.asarray(std)[:, None]

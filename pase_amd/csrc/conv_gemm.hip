@@ -369,7 +369,27 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
         }
     }
 
-    if (p.epilogue == PASE_EPI_STORE) {
+    if (p.epilogue == PASE_EPI_STORE && (p.post_op == PASE_POST_POW || p.post_op == PASE_POST_LOGPOW)) {
+        // spectra: accumulator rows r, r+1 (same lane) are the (re, im) parts of one frequency bin
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const int m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + rbase;   // even row
+                if (m >= p.M) continue;          // M is even (host-checked): a pair is valid or absent
+                const int bin = m >> 1;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const float re = acc[a][b][r], im = acc[a][b][r + 1];
+                    float v = re * re + im * im;
+                    v = (p.post_op == PASE_POST_LOGPOW) ? p.post_scale * logf(v + p.post_eps) : v * p.post_scale;
+                    const int pos = cq[b] + p.poff;
+                    if (cok[b] && pos >= 0 && pos < p.Tout)
+                        p.y[((size_t)cs[b] * p.y_ctot + p.y_coff + bin) * (size_t)p.Tout + pos] = v;
+                }
+            }
+        }
+    } else if (p.epilogue == PASE_EPI_STORE) {
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
 #pragma unroll
@@ -383,7 +403,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    const float v = acc[a][b][r] + bv;
+                    float v = acc[a][b][r] + bv;
+                    if (p.post_op == PASE_POST_LOG) v = p.post_scale * logf(v == 0.f ? p.post_eps : v);
                     const int pos = cq[b] * p.ps + ph + p.poff;
                     const bool ok = mok && cok[b] && pos >= 0 && pos < p.Tout;
                     if (ok) {
@@ -499,7 +520,7 @@ HostPlan make_plan(const PaseConvGemm& p) {
     int splitk = 1;
     const int G = pl.n_gc * pl.n_gt;
     if (p.splitk > 1) splitk = p.splitk;
-    else if (p.splitk == 0 && !p.stat_part && p.epilogue == PASE_EPI_STORE && tiles < 192) {
+    else if (p.splitk == 0 && !p.stat_part && p.epilogue == PASE_EPI_STORE && p.post_op == PASE_POST_NONE && tiles < 192) {
         // auto: few output tiles and a long reduction (head / deconv data-gradients) -> fill the chip
         splitk = (int)((384 + tiles - 1) / tiles);
         if (splitk > G / 6) splitk = G / 6;
@@ -526,7 +547,8 @@ extern "C" int pase_conv_gemm(const PaseConvGemm* d, void* stream) {
     if (p.tapstep != 1 && p.tapstep != -1) return -5;
     const HostPlan h = make_plan(p);
     if (h.pl.CB < 1) return -6;
-    if (h.pl.splitk > 1 && (p.stat_part || p.epilogue != PASE_EPI_STORE)) return -7;
+    if (h.pl.splitk > 1 && (p.stat_part || p.epilogue != PASE_EPI_STORE || p.post_op != PASE_POST_NONE)) return -7;
+    if ((p.post_op == PASE_POST_POW || p.post_op == PASE_POST_LOGPOW) && (p.ps != 1 || p.stat_part || (p.M & 1))) return -9;
     if ((long)p.S * p.Ncols >= 0x7fffffffL) return -8;
     if ((long)p.S * p.x_ctot * (long)p.Tin >= 0x7fffffffL) return -8;   // int element offsets in the loader
     hipStream_t st = (hipStream_t)stream;

@@ -1,0 +1,170 @@
+// dsp.hip -- HBM-bound pieces of the on-device regression targets:
+// the spectra themselves are DFT-basis convolutions on pase_conv_gemm (PASE_POST_POW / _LOGPOW / _LOG);
+// here: librosa-style delta features (Savitzky-Golay, width 9, mode='interp') fused with the ZNorm
+// of pase/transforms.py:183-205, and librosa.power_to_db's per-utterance top_db clamp.
+//
+// Reference arithmetic (third-party, not installed here; restated in oracle/dsp_oracle.py):
+//   librosa 0.6.3 feature.delta(X, width=9, order=n) = scipy.signal.savgol_filter(X, 9, polyorder=n,
+//     deriv=n, axis=-1, mode='interp')                       (transforms.py:475-477, :528-530, :709-711)
+//   librosa.power_to_db(S, ref=1, amin=1e-10, top_db=80): 10 log10(max(amin,S)) clipped at max-80.
+#include "hip_compat.h"
+#include "pase_amd.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// out[b, k*D + d, t] = (delta_k(x[b, d, :])[t] - mean[k*D+d]) * istd[k*D+d],  k = 0..order
+// coef: (order+1, 9, 9): row (k, pos, j) = weight of sample j of a 9-window when the output sits at
+// window position pos; pos == 4 is the interior filter, pos < 4 / > 4 the 'interp' edge fits.
+__global__ void __launch_bounds__(NT) delta_znorm_kernel(const float* x, const float* coef, const float* mean,
+                                                         const float* istd, float* out, int B, int D, int F, int Fo,
+                                                         int order, int x_ctot, int x_coff) {
+    const long total = (long)B * D * Fo;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int t = (int)(i % Fo);
+        const int d = (int)((i / Fo) % D);
+        const int b = (int)(i / ((long)Fo * D));
+        const float* row = x + ((size_t)b * x_ctot + x_coff + d) * (size_t)F;
+        // window start and position of t inside it (replicate-pad columns t >= F copy column F-1)
+        const int tt = t < F ? t : F - 1;
+        int w0 = tt - 4, pos = 4;
+        if (F >= 9) {
+            if (w0 < 0) { pos = tt; w0 = 0; }
+            if (w0 + 9 > F) { w0 = F - 9; pos = tt - w0; }
+        }
+        float xs[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int u = w0 + j;
+            xs[j] = (u >= 0 && u < F) ? row[u] : 0.f;
+        }
+        for (int k = 0; k <= order; ++k) {
+            float v;
+            if (k == 0) {
+                v = row[tt];
+            } else {
+                const float* c = coef + ((size_t)k * 9 + pos) * 9;
+                v = 0.f;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) v = fmaf(c[j], xs[j], v);
+            }
+            const int ch = k * D + d;
+            if (mean) v = (v - mean[ch]) * istd[ch];
+            out[((size_t)b * (order + 1) * D + ch) * (size_t)Fo + t] = v;
+        }
+    }
+}
+
+// Framing prologue shared by every spectral target: the waveform, padded (reflect / zero) by padL on the
+// left and optionally pre-emphasised (python_speech_features.sigproc.preemphasis: y[0] = x[0],
+// y[n] = x[n] - c x[n-1]), is laid out hop-major -- y[b][r][q] = xpad[q*hop + r] -- so that a frame of
+// `win` samples at hop `hop` becomes a stride-1 conv over q with `hop` input channels and
+// ceil(win/hop) taps: the strided STFT runs on the same sliding-window implicit GEMM as the encoder.
+__global__ void __launch_bounds__(NT) frame_prep_kernel(const float* x, float* y, int T, int hop, int Q, int padL,
+                                                        int reflect, float coeff, long total) {
+    const int HQ = hop * Q;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int b = (int)(i / HQ);
+        const int rq = (int)(i - (long)b * HQ);
+        const int q = rq / hop, r = rq - q * hop;     // consecutive threads walk the waveform: coalesced reads
+        int u = q * hop + r - padL;
+        float v = 0.f;
+        if (reflect) {
+            if (u < 0) u = -u;
+            if (u >= T) u = 2 * (T - 1) - u;
+        }
+        if (u >= 0 && u < T) {
+            const float* xb = x + (long)b * T;
+            v = xb[u];
+            if (coeff != 0.f && u > 0) v -= coeff * xb[u - 1];
+        }
+        y[((long)b * hop + r) * Q + q] = v;
+    }
+}
+
+__device__ __forceinline__ unsigned f2ord(float f) {   // order-preserving float -> uint
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned u) {
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __uint_as_float(u);
+}
+
+// y = 10 log10(max(amin, x)) - ref_db ; per-utterance running max (ordered-uint atomicMax)
+__global__ void __launch_bounds__(NT) power_to_db_kernel(const float* x, float* y, unsigned* umax, long per_utt,
+                                                         int B, float amin, float ref_db) {
+    __shared__ unsigned sh[NT / 64];
+    const int b = blockIdx.y;
+    const float* xb = x + (size_t)b * per_utt;
+    float* yb = y + (size_t)b * per_utt;
+    float mx = -3.0e38f;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < per_utt; i += (long)gridDim.x * NT) {
+        const float v = 10.f * log10f(fmaxf(amin, xb[i])) - ref_db;
+        yb[i] = v;
+        mx = fmaxf(mx, v);
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = f2ord(mx);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned u = sh[0];
+        for (int w = 1; w < NT / 64; ++w) u = max(u, sh[w]);
+        atomicMax(umax + b, u);
+    }
+}
+
+__global__ void __launch_bounds__(NT) clamp_top_db_kernel(float* y, const unsigned* umax, long per_utt, int B,
+                                                          float top_db) {
+    const int b = blockIdx.y;
+    const float lo = ord2f(umax[b]) - top_db;
+    float* yb = y + (size_t)b * per_utt;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < per_utt; i += (long)gridDim.x * NT)
+        yb[i] = fmaxf(yb[i], lo);
+}
+
+}  // namespace
+
+extern "C" int pase_delta_znorm(const float* x, const float* coef, const float* mean, const float* istd, float* out,
+                                int B, int D, int F, int Fo, int order, int x_ctot, int x_coff, void* stream) {
+    if (order < 0 || order > 2 || Fo < F) return -2;
+    const long total = (long)B * D * Fo;
+    if (total <= 0) return 0;
+    long blocks = (total + NT - 1) / NT;
+    if (blocks > 4096) blocks = 4096;
+    PASE_LAUNCH(delta_znorm_kernel, dim3((unsigned)blocks), dim3(NT), (hipStream_t)stream, x, coef, mean, istd, out, B, D,
+                F, Fo, order, x_ctot, x_coff);
+    PASE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pase_power_to_db(const float* x, float* y, unsigned* umax_scratch, long per_utt, int B, float amin,
+                                float ref_db, float top_db, void* stream) {
+    if (per_utt <= 0 || B <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(umax_scratch, 0, sizeof(unsigned) * (size_t)B, st);
+    if (e != hipSuccess) return (int)e;
+    long bx = (per_utt + NT - 1) / NT;
+    if (bx > 64) bx = 64;
+    PASE_LAUNCH(power_to_db_kernel, dim3((unsigned)bx, (unsigned)B), dim3(NT), st, x, y, umax_scratch, per_utt, B, amin,
+                ref_db);
+    if (top_db > 0.f)
+        PASE_LAUNCH(clamp_top_db_kernel, dim3((unsigned)bx, (unsigned)B), dim3(NT), st, y, umax_scratch, per_utt, B, top_db);
+    PASE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pase_frame_prep(const float* x, float* y, int B, int T, int hop, int Q, int padL, int pad_mode,
+                               float preemph, void* stream) {
+    const long total = (long)B * hop * Q;
+    if (total <= 0) return 0;
+    if (pad_mode == PASE_PAD_REFLECT && (padL >= T || (long)Q * hop - padL > 2L * T - 1)) return -3;
+    long blocks = (total + NT - 1) / NT;
+    if (blocks > 8192) blocks = 8192;
+    PASE_LAUNCH(frame_prep_kernel, dim3((unsigned)blocks), dim3(NT), (hipStream_t)stream, x, y, T, hop, Q, padL,
+                pad_mode == PASE_PAD_REFLECT ? 1 : 0, preemph, total);
+    PASE_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,254 @@
+"""On-device regression targets: mirrors of the host transforms LPS / FBanks / MFCC (+ deltas, ZNorm)
+of pase/transforms.py (:439-487, :489-548, :671-722, :183-205), batched on the GPU.
+
+`pase_frame_prep` lays the (padded, optionally pre-emphasised) waveform out hop-major, which turns the
+hop-strided framing into a stride-1 conv with `hop` input channels; every spectrum then is ONE
+`pase_conv_gemm` launch with a DFT basis as the weight (window, centring and -- for MFCC -- the Hann
+taper folded into the basis) and a power / log-power post-op in the epilogue; mel and DCT projections
+are 1x1 launches; deltas + ZNorm are one `pase_delta_znorm` launch.  Nothing runs on the
+host per step: the basis matrices are built once with numpy.
+
+Third-party arithmetic the reference delegates to (not installed here; restated from the published
+algorithms, parity UNPINNED -- SURVEY.md section 8c): legacy torch.stft (rectangular window centred in
+n_fft, reflect centre padding) for LPS; python_speech_features 0.6 `logfbank` for FBanks; librosa 0.6.3
+`feature.mfcc` (periodic Hann, Slaney mel bank with area normalisation, power_to_db top_db=80, DCT-II
+ortho) and `feature.delta` (Savitzky-Golay width 9) for MFCC / deltas.  Gammatone (gtgram IIR bank) and
+Prosody (SWIPE' pitch) are not built.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import kernels as K
+
+
+def _dft_basis(n_fft, taps, offset, window=None):
+    """(2*(n_fft/2+1), taps): rows (2f, 2f+1) = window[n] * (cos, -sin)(2 pi f (n+offset) / n_fft)."""
+    f = np.arange(n_fft // 2 + 1, dtype=np.float64)[:, None]
+    n = np.arange(taps, dtype=np.float64)[None, :] + offset
+    ang = 2.0 * np.pi * f * n / n_fft
+    w = np.ones(taps) if window is None else np.asarray(window, dtype=np.float64)
+    basis = np.empty((2 * (n_fft // 2 + 1), taps), dtype=np.float64)
+    basis[0::2] = np.cos(ang) * w[None, :]
+    basis[1::2] = -np.sin(ang) * w[None, :]
+    return basis.astype(np.float32)
+
+
+def _hop_major(basis, hop):
+    """(M, win) frame basis -> (M, hop * taps) weight of the stride-1 conv over the hop-major layout:
+    W[f, r, dq] = basis[f, dq*hop + r] (zero past the window)."""
+    M, win = basis.shape
+    taps = (win + hop - 1) // hop
+    w = np.zeros((M, taps * hop), dtype=np.float32)
+    w[:, :win] = basis
+    return np.ascontiguousarray(w.reshape(M, taps, hop).transpose(0, 2, 1)).reshape(M, hop * taps), taps
+
+
+def _spectrum(wav, weight, taps, hop, nframes, padL, pad_mode, preemph, post_op, post_scale, post_eps=0.0):
+    """frames x DFT basis -> (B, bins, nframes) power / log-power spectrum."""
+    B, _, T = wav.shape
+    Q = nframes + taps - 1
+    xq = torch.empty(B, hop, Q, device=wav.device)
+    K.frame_prep(wav, xq, B=B, T=T, hop=hop, Q=Q, padL=padL, pad_mode=pad_mode, preemph=preemph)
+    bins = weight.shape[0] // 2
+    out = torch.empty(B, bins, nframes, device=wav.device)
+    K.conv_gemm(xq, weight, out, S=B, Cin=hop, Tin=Q, M=2 * bins, K=hop * taps, taps=taps, Ncols=nframes,
+                Tout=nframes, Cout_store=bins, y_ctot=bins, post_op=post_op, post_scale=post_scale,
+                post_eps=post_eps, splitk=1)
+    return out
+
+
+def savgol_delta_coefs(order_max=2, width=9):
+    """(order_max+1, 9, 9) table for pase_delta_znorm.  With polyorder == deriv == k the k-th derivative
+    of the least-squares polynomial is constant over the window, so scipy's mode='interp' edge fit
+    uses the same 9 weights as the interior filter (shifted window): every pos row is identical."""
+    j = np.arange(width, dtype=np.float64) - (width - 1) / 2.0
+    tab = np.zeros((order_max + 1, width, width), dtype=np.float64)
+    for k in range(1, order_max + 1):
+        A = np.vander(j, k + 1, increasing=True)          # (9, k+1)
+        coef = np.linalg.pinv(A)[k] * math.factorial(k)    # d^k/dt^k of the fit = k! * a_k
+        tab[k, :, :] = coef[None, :]
+    return tab.astype(np.float32)
+
+
+def psf_mel_filterbank(nfilt, nfft, sr, lowfreq=0.0, highfreq=None):
+    """python_speech_features.base.get_filterbanks."""
+    highfreq = highfreq or sr / 2
+    hz2mel = lambda hz: 2595.0 * np.log10(1 + hz / 700.0)
+    mel2hz = lambda mel: 700.0 * (10 ** (mel / 2595.0) - 1)
+    melpoints = np.linspace(hz2mel(lowfreq), hz2mel(highfreq), nfilt + 2)
+    b = np.floor((nfft + 1) * mel2hz(melpoints) / sr)
+    fb = np.zeros([nfilt, nfft // 2 + 1])
+    for jj in range(nfilt):
+        for i in range(int(b[jj]), int(b[jj + 1])):
+            fb[jj, i] = (i - b[jj]) / (b[jj + 1] - b[jj])
+        for i in range(int(b[jj + 1]), int(b[jj + 2])):
+            fb[jj, i] = (b[jj + 2] - i) / (b[jj + 2] - b[jj + 1])
+    return fb.astype(np.float32)
+
+
+def slaney_mel_filterbank(sr, n_fft, n_mels=128, fmin=0.0, fmax=None):
+    """librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax, htk=False, norm=1)."""
+    fmax = fmax or sr / 2.0
+
+    def hz_to_mel(f):
+        f = np.asanyarray(f, dtype=np.float64)
+        f_sp = 200.0 / 3
+        mels = f / f_sp
+        min_log_hz, logstep = 1000.0, np.log(6.4) / 27.0
+        min_log_mel = min_log_hz / f_sp
+        return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-10) / min_log_hz) / logstep, mels)
+
+    def mel_to_hz(m):
+        m = np.asanyarray(m, dtype=np.float64)
+        f_sp = 200.0 / 3
+        min_log_hz, logstep = 1000.0, np.log(6.4) / 27.0
+        min_log_mel = min_log_hz / f_sp
+        return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+    fftfreqs = np.linspace(0, sr / 2.0, 1 + n_fft // 2)
+    mel_f = mel_to_hz(np.linspace(hz_to_mel(fmin), hz_to_mel(fmax), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = np.subtract.outer(mel_f, fftfreqs)
+    weights = np.zeros((n_mels, 1 + n_fft // 2))
+    for i in range(n_mels):
+        lower = -ramps[i] / fdiff[i]
+        upper = ramps[i + 2] / fdiff[i + 1]
+        weights[i] = np.maximum(0, np.minimum(lower, upper))
+    enorm = 2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels])
+    weights *= enorm[:, None]
+    return weights.astype(np.float32)
+
+
+def dct2_ortho(n_out, n_in):
+    """rows of scipy.fftpack.dct(type=2, norm='ortho') restricted to the first n_out coefficients."""
+    k = np.arange(n_out, dtype=np.float64)[:, None]
+    n = np.arange(n_in, dtype=np.float64)[None, :]
+    m = 2.0 * np.cos(np.pi * k * (2 * n + 1) / (2.0 * n_in))
+    m[0] *= math.sqrt(1.0 / (4 * n_in))
+    m[1:] *= math.sqrt(1.0 / (2 * n_in))
+    return m.astype(np.float32)
+
+
+class _Feature(object):
+    def __init__(self, name, der_order, device):
+        self.name = name
+        self.der_order = der_order
+        self.device = torch.device(device)
+        self.coef = torch.from_numpy(savgol_delta_coefs(2)).to(self.device)
+        self.mean = self.istd = None
+
+    def set_stats(self, mean, std):
+        """ZNorm (transforms.py:183-205): per output channel (x - mean) / std, fused into the delta kernel."""
+        self.mean = torch.as_tensor(mean, dtype=torch.float32).reshape(-1).contiguous().to(self.device)
+        self.istd = (1.0 / torch.as_tensor(std, dtype=torch.float32).reshape(-1)).contiguous().to(self.device)
+
+    def _finish(self, base, F, Fo):
+        B, D = base.shape[0], base.shape[1]
+        out = torch.empty(B, (self.der_order + 1) * D, Fo, device=base.device)
+        K.delta_znorm(base, self.coef, self.mean, self.istd, out, B=B, D=D, F=F, Fo=Fo, order=self.der_order,
+                      x_ctot=D, x_coff=0)
+        return out
+
+
+class LPS(_Feature):
+    """10 log10(|STFT|^2 + 1e-19) with the legacy torch.stft(wav, n_fft, hop, win) semantics."""
+
+    def __init__(self, n_fft=2048, hop=160, win=400, der_order=2, name="lps", device="cuda"):
+        super().__init__(name, der_order, device)
+        self.n_fft, self.hop, self.win = n_fft, hop, win
+        off = (n_fft - win) // 2
+        self.padL = n_fft // 2 - off
+        w, self.taps = _hop_major(_dft_basis(n_fft, win, off), hop)
+        self.basis = torch.from_numpy(w).to(self.device)
+
+    def __call__(self, wav):
+        """wav (B, 1, T) -> (B, (der_order+1)*(n_fft/2+1), T//hop)"""
+        B, _, T = wav.shape
+        F = T // self.hop
+        lps = _spectrum(wav, self.basis, self.taps, self.hop, F, self.padL, K.PAD_REFLECT, 0.0, K.POST_LOGPOW,
+                        10.0 / math.log(10.0), 10e-20)
+        return self._finish(lps, F, F)
+
+
+class FBanks(_Feature):
+    """python_speech_features.logfbank (pre-emphasis 0.97, rectangular frames, |rfft|^2 / nfft, HTK mel
+    triangles, log) -> deltas -> replicate-pad to T//hop frames."""
+
+    def __init__(self, n_filters=40, n_fft=512, hop=160, win=400, rate=16000, der_order=2, name="fbank",
+                 device="cuda"):
+        super().__init__(name, der_order, device)
+        self.n_filters, self.n_fft, self.hop, self.win, self.rate = n_filters, n_fft, hop, win, rate
+        # numpy.fft.rfft(frames, NFFT) truncates longer frames
+        w, self.taps = _hop_major(_dft_basis(n_fft, min(win, n_fft), 0), hop)
+        self.basis = torch.from_numpy(w).to(self.device)
+        self.mel = torch.from_numpy(psf_mel_filterbank(n_filters, n_fft, rate)).to(self.device)
+
+    def __call__(self, wav):
+        B, _, T = wav.shape
+        L, st = self.win, self.hop
+        nf = 1 if T <= L else 1 + int(math.ceil((1.0 * T - L) / st))
+        Fo = T // st
+        bins = self.n_fft // 2 + 1
+        pspec = _spectrum(wav, self.basis, self.taps, st, nf, 0, K.PAD_ZERO, 0.97, K.POST_POW, 1.0 / self.n_fft)
+        feat = torch.empty(B, self.n_filters, nf, device=wav.device)
+        K.conv_gemm(pspec, self.mel, feat, S=B, Cin=bins, Tin=nf, M=self.n_filters, K=bins, taps=1, Ncols=nf, Tout=nf,
+                    post_op=K.POST_LOG, post_scale=1.0, post_eps=float(np.finfo(float).eps), splitk=1)
+        return self._finish(feat, nf, max(Fo, nf))
+
+
+class MFCC(_Feature):
+    """librosa.feature.mfcc(y, sr, n_mfcc=order, n_fft=win, hop_length=hop)[:, :T//hop] -> deltas."""
+
+    def __init__(self, n_fft=2048, hop=160, order=13, sr=16000, win=400, der_order=2, name="mfcc", device="cuda"):
+        super().__init__(name, der_order, device)
+        self.n_fft, self.hop, self.order, self.sr = win, hop, order, 16000    # (sic) n_fft := win, :679-683
+        n = self.n_fft
+        hann = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n) / n)            # periodic ('fftbins') Hann
+        w, self.taps = _hop_major(_dft_basis(n, n, 0, hann), hop)
+        self.basis = torch.from_numpy(w).to(self.device)
+        self.mel = torch.from_numpy(slaney_mel_filterbank(self.sr, n, 128)).to(self.device)
+        self.dct = torch.from_numpy(dct2_ortho(order, 128)).to(self.device)
+
+    def __call__(self, wav):
+        B, _, T = wav.shape
+        n, st = self.n_fft, self.hop
+        nf = 1 + T // st                       # centred STFT
+        F = T // st
+        bins = n // 2 + 1
+        power = _spectrum(wav, self.basis, self.taps, st, nf, n // 2, K.PAD_REFLECT, 0.0, K.POST_POW, 1.0)
+        mel = torch.empty(B, 128, nf, device=wav.device)
+        K.conv_gemm(power, self.mel, mel, S=B, Cin=bins, Tin=nf, M=128, K=bins, taps=1, Ncols=nf, Tout=nf, splitk=1)
+        db = torch.empty_like(mel)
+        umax = torch.empty(B, dtype=torch.int32, device=wav.device)
+        K.power_to_db(mel, db, umax, per_utt=128 * nf, B=B, amin=1e-10, ref_db=0.0, top_db=80.0)
+        mfcc = torch.empty(B, self.order, F, device=wav.device)
+        K.conv_gemm(db, self.dct, mfcc, S=B, Cin=128, Tin=nf, M=self.order, K=128, taps=1, Ncols=F, Tout=F, splitk=1)
+        return self._finish(mfcc, F, F)
+
+
+class DeviceTargets(object):
+    """What train.py:make_transforms (train.py:37-136) composes from the worker names -- LPS / FBanks /
+    MFCC (+ their *_long variants via the per-worker `transform` kwargs) followed by ZNorm -- as a
+    batched on-device producer: targets(cchunk) -> {worker name: (B, D, T//hop)}."""
+
+    def __init__(self, workers_cfg, hop=160, stats=None, device="cuda"):
+        self.feats = {}
+        for w in workers_cfg.get("regr", []):
+            name = w["name"]
+            kw = dict(w.get("transform", {}))
+            if "lps" in name:
+                f = LPS(hop=hop, name=name, device=device, **kw)
+            elif "fbank" in name:
+                f = FBanks(hop=hop, name=name, device=device, **kw)
+            elif "mfcc" in name:
+                f = MFCC(hop=hop, name=name, device=device, **kw)
+            else:
+                continue      # cchunk (the waveform itself), gammatone, prosody: not produced here
+            if stats is not None and name in stats:
+                f.set_stats(stats[name]["mean"], stats[name]["std"])
+            self.feats[name] = f
+
+    def __call__(self, cchunk):
+        return {name: f(cchunk) for name, f in self.feats.items()}

@@ -11,6 +11,7 @@ from . import _lib
 
 PAD_ZERO, PAD_REFLECT = 0, 1
 EPI_STORE, EPI_MSE_CTX = 0, 1
+POST_NONE, POST_POW, POST_LOGPOW, POST_LOG = 0, 1, 2, 3
 
 _fp = C.c_void_p
 
@@ -28,7 +29,8 @@ class PaseConvGemm(C.Structure):
         ("y_ctot", C.c_int), ("y_coff", C.c_int), ("Cout_store", C.c_int), ("ps", C.c_int),
         ("poff", C.c_int), ("Tout", C.c_int),
         ("epilogue", C.c_int), ("r_ctx", C.c_int), ("label_D", C.c_int),
-        ("tile_hint", C.c_int), ("splitk", C.c_int),
+        ("tile_hint", C.c_int), ("post_op", C.c_int), ("post_scale", C.c_float), ("post_eps", C.c_float),
+        ("splitk", C.c_int),
     ]
 
 
@@ -84,8 +86,9 @@ def _conv_desc(x, w, y, *, S, Cin, Tin, M, K, taps, Ncols, Tout, ldw=None, bias=
                x_ctot=None, x_coff=0, tap_major=0, stride=1, tapstep=1, padL=0, pad_mode=PAD_ZERO,
                y_ctot=None, y_coff=0, Cout_store=None, ps=1, poff=0,
                epilogue=EPI_STORE, label=None, grad_out=None, loss_acc=None, grad_scale=0.0,
-               r_ctx=0, label_D=0, tile_hint=0, splitk=0):
+               r_ctx=0, label_D=0, tile_hint=0, splitk=0, post_op=0, post_scale=1.0, post_eps=0.0):
     d = PaseConvGemm()
+    d.post_op, d.post_scale, d.post_eps = post_op, post_scale, post_eps
     d.x, d.w, d.y, d.bias = _ptr(x), _ptr(w), _ptr(y), _ptr(bias)
     d.in_scale, d.in_shift, d.in_alpha = _ptr(in_scale), _ptr(in_shift), _ptr(in_alpha)
     d.stat_part, d.label, d.grad_out = _ptr(stat_part), _ptr(label), _ptr(grad_out)
@@ -205,6 +208,9 @@ _SIMPLE.update({
     "pase_pack_dgrad": [_fp, _fp, _i, _i, _i, _i, _l, _l, _l, _fp],
     "pase_adam_step": [_fp, _fp, _fp, _fp, _l, _fp, _fp, _f, _f, _f, _f, _fp],
     "pase_step_tick": [_fp, _fp],
+    "pase_delta_znorm": [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp],
+    "pase_power_to_db": [_fp, _fp, _fp, _l, _i, _f, _f, _f, _fp],
+    "pase_frame_prep": [_fp, _fp, _i, _i, _i, _i, _i, _i, _f, _fp],
 })
 
 LOSS_NONE, LOSS_L1, LOSS_MSE, LOSS_BCE = 0, 1, 2, 3
@@ -339,3 +345,18 @@ def adam_step(p, g, m, v, lr, step, *, beta1=0.9, beta2=0.999, eps=1e-8, grad_mu
 
 def step_tick(step):
     _check(_lib.lib().pase_step_tick(_ptr(step, torch.int32), _stream()), "pase_step_tick")
+
+
+def delta_znorm(x, coef, mean, istd, out, *, B, D, F, Fo, order, x_ctot=None, x_coff=0):
+    _check(_lib.lib().pase_delta_znorm(_ptr(x), _ptr(coef), _ptr(mean), _ptr(istd), _ptr(out), B, D, F, Fo, order,
+                                       D if x_ctot is None else x_ctot, x_coff, _stream()), "pase_delta_znorm")
+
+
+def power_to_db(x, y, umax, *, per_utt, B, amin=1e-10, ref_db=0.0, top_db=80.0):
+    _check(_lib.lib().pase_power_to_db(_ptr(x), _ptr(y), _ptr(umax, torch.int32), per_utt, B, amin, ref_db, top_db,
+                                       _stream()), "pase_power_to_db")
+
+
+def frame_prep(x, y, *, B, T, hop, Q, padL, pad_mode, preemph=0.0):
+    _check(_lib.lib().pase_frame_prep(_ptr(x), _ptr(y), B, T, hop, Q, padL, pad_mode, preemph, _stream()),
+           "pase_frame_prep")

