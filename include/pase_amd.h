@@ -49,7 +49,11 @@ enum { PASE_LOSS_NONE = 0, PASE_LOSS_L1 = 1, PASE_LOSS_MSE = 2, PASE_LOSS_BCE_LO
  * ------------------------------------------------------------------------------------------ */
 typedef struct PaseConvGemm {
     const float* x;        /* input  (S, x_ctot, Tin); channels [x_coff, x_coff+Cin) are read      */
-    const float* w;        /* A operand, row-major (M, ldw); column k = ci*taps+kk (or kk*Cin+ci)  */
+    const float* w;        /* A operand as the reference stores it, row-major (M, ldw); column k = ci*taps+kk
+                              (or kk*Cin+ci when tap_major): the SOURCE of the pack below, not read by the kernel */
+    const float* wt;       /* K-major pack of A the kernel reads: wt[k*ldwt + m] = A[m, k], k = ci*taps+kk
+                              (pase_pack_wt; a weight that already is K-major, e.g. W (Cout, Cin) as the A of a
+                              1x1 data-gradient, can be passed as is).  16-B aligned, ldwt % 4 == 0, ldwt >= M  */
     float* y;              /* output (S, y_ctot, Tout) (EPI_STORE) / prediction (S, M, Ncols) or NULL (EPI_MSE_CTX) */
     const float* bias;     /* (Cout_store) or NULL                                                */
     const float* in_scale; /* (Cin) on-load affine, NULL = identity                               */
@@ -61,7 +65,7 @@ typedef struct PaseConvGemm {
     double* loss_acc;      /* EPI_MSE_CTX: += sum (pred-tgt)^2  (caller zeroes)                   */
     float grad_scale;
     int S, Cin, Tin, x_ctot, x_coff;
-    int M, K, ldw, taps, tap_major;
+    int M, K, ldw, ldwt, taps, tap_major;
     int stride, tapstep, padL, pad_mode;
     int Ncols;             /* GEMM columns per sequence                                           */
     int y_ctot, y_coff, Cout_store, ps, poff, Tout;
@@ -75,6 +79,11 @@ typedef struct PaseConvGemm {
 } PaseConvGemm;
 
 int pase_conv_gemm(const PaseConvGemm* desc, void* stream);
+/* wt (K, ldwt) <- transpose of the logical A (M, K) held in w (row-major, ldw, optional tap-major columns);
+ * columns M..ldwt-1 are zero-filled.  Weights change every optimizer step, so the training step re-packs
+ * each weight once per use (29.7 M parameters: ~0.1 ms of HBM traffic per step). */
+int pase_pack_wt(const float* w, float* wt, int M, int K, int Cin, int taps, int ldw, int tap_major, int ldwt,
+                 void* stream);
 /* number of column tiles (= first dim of stat_part) the launch described by desc will use */
 int pase_conv_gemm_stat_tiles(const PaseConvGemm* desc);
 /* the split-K factor the launch will actually use (after clamping) */

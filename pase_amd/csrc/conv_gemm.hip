@@ -18,15 +18,27 @@
 //
 // gfx950 mapping.  256 threads = 4 waves; block tile BM x BN; each wave owns a 64x64 sub-tile as 2x2
 // v_mfma_f32_32x32x2_f32 tiles (exact fp32, 64 accumulator VGPRs).  The input is NOT expanded to an
-// im2col tile: per stage the block stages, with fully coalesced row loads, the raw sliding-window
-// SPANS of CB input channels (length (BN-1)*stride + TB, affine+PReLU and padding applied once per
-// element) plus the matching [BM x CB*TB] weight slab into LDS (double-buffered, register
+// im2col tile: per stage the block stages the raw sliding-window SPANS of CB input channels (length
+// (BN-1)*stride + TB, affine+PReLU and padding applied once per element) plus the matching
+// [CB*TB x BM] slab of the K-MAJOR weight pack (pase_pack_wt) into LDS (double-buffered, register
 // prefetch, one barrier per stage).  An MFMA B fragment is then a strided ds_read_b32 straight out
 // of the span: column j, tap kk -> Xs[cl][j*stride + kk]; each lane walks its (channel row, tap)
 // offset incrementally, so neither integer division nor a table lookup sits in the MFMA loop.
-// Loads are issued as raw prefetches one stage ahead and only touched (affine / PReLU, ds_write)
-// after the MFMA loop of the current stage, so HBM/L2 latency hides under the matrix pipe.
+//
+// The per-stage loader is the part that competes with the matrix pipe for issue slots (two
+// workgroups share a CU), so it is kept to a handful of instructions per thread:
+//   * A slab: <= 6 unconditional global_load_dwordx4 from the K-major pack (rows = flat k, BM
+//     contiguous floats per row), written with ds_write_b128; no per-element index arithmetic.
+//   * X spans: every thread owns ONE channel row of the slab (row = tid / TPR) and Q samples of it;
+//     all (sequence, time, padding) arithmetic is done once per tile into per-slot offsets + a mask,
+//     per stage a slot is one global load off a uniform base that advances by CB channels.  The
+//     thread's channel is fixed, so the on-load affine / PReLU needs one (scale, shift, alpha)
+//     triple per stage instead of one per element.
+//   * a ragged last channel group is shifted back to end at Cin (its already-covered rows get zero
+//     weights), so the loader has no channel-validity branches.
 // Two shapes: <128,128> (waves 2x2) and <64,256> (waves 1x4) for the 64-row layers.
+#include <type_traits>
+
 #include "hip_compat.h"
 #include "pase_amd.h"
 
@@ -35,12 +47,19 @@ namespace {
 constexpr int NTHREADS = 256;
 constexpr int KGMAX = 48;     // flat k (channels x taps) per stage
 constexpr int XSMAX = 3072;   // staged span floats per stage
-constexpr int XPT = XSMAX / NTHREADS;
+constexpr int XPT = XSMAX / NTHREADS;   // 12 staged floats per thread per stage
+constexpr int NPAR = 3;       // on-load (scale, shift, alpha) triples prefetched per thread
 
 struct ConvPlan {
-    int CB, TB, SPAN, n_gc, n_gt, mode, tiles_per_seq, splitk, avec;
-    unsigned span_magic;      // ceil(2^32 / SPAN)
+    int CB, TB, SPAN, SPANV, n_gc, n_gt, mode, tiles_per_seq, splitk;
+    int tl;        // log2(threads per slab row)
+    int pmajor;    // 0: slot t = sample c + t*TPR of row tid/TPR;  1 (flat 1x1): slot t = row t*RPP + tid/TPR
+    int nslots;    // slots per thread (Q or PX)
+    int xvec;      // flat mode, float4 slots
+    int PA;        // A slab passes
     unsigned ncols_magic;     // ceil(2^32 / Ncols)
+    unsigned cout_magic;      // ceil(2^32 / Cout_store)
+    unsigned rctx_magic;      // ceil(2^32 / r_ctx)
 };
 // column-tile modes
 //   MODE_FLAT  : 1x1, stride 1, no padding: columns are the flattened (s, q) index, a row of the
@@ -64,18 +83,52 @@ __device__ __forceinline__ unsigned div_magic(unsigned e, unsigned magic) {
     return magic ? (unsigned)(((unsigned long long)e * magic) >> 32) : e;
 }
 
-template <int BM, int BN>
+#ifdef PASE_TRACE   // tools/trace_conv.py only: per-workgroup phase timestamps (100 MHz wall clock)
+#define PASE_TRACE_SLOTS 16384
+__device__ unsigned long long g_trace[PASE_TRACE_SLOTS * 6];
+#define PASE_STAMP(i)                                                                              \
+    do {                                                                                           \
+        if (threadIdx.x == 0 && blockIdx.x < PASE_TRACE_SLOTS) g_trace[blockIdx.x * 6 + (i)] = wall_clock64(); \
+    } while (0)
+#define PASE_TACC_DECL unsigned long long tacc_[4] = {0, 0, 0, 0}, tl_ = 0
+#define PASE_TACC_BEGIN() tl_ = wall_clock64()
+#define PASE_TACC(i) do { const unsigned long long n_ = wall_clock64(); tacc_[i] += n_ - tl_; tl_ = n_; } while (0)
+#define PASE_TACC_DUMP()                                                                        \
+    do {                                                                                        \
+        if (threadIdx.x == 0 && blockIdx.x < PASE_TRACE_SLOTS)                                  \
+            for (int i_ = 0; i_ < 4; ++i_) g_tacc[blockIdx.x * 4 + i_] = tacc_[i_];             \
+    } while (0)
+__device__ unsigned long long g_tacc[PASE_TRACE_SLOTS * 4];
+#else
+#define PASE_STAMP(i)
+#define PASE_TACC_DECL
+#define PASE_TACC_BEGIN()
+#define PASE_TACC(i)
+#define PASE_TACC_DUMP()
+#endif
+
+struct alignas(16) F4 { float x, y, z, w; };
+
+// identity on-load parameters for launches without an affine / PReLU ({scale = alpha = 1}, {shift = 0})
+__device__ const float g_ident[2] = {1.f, 0.f};
+
+// NS = X slots per thread (the plan rounds its slot count up to 3 / 6 / 12), XV = float4 slots (flat 1x1).
+// Both are compile-time so that the per-stage loader is straight-line code: every load is issued
+// unconditionally from a precomputed offset (slots / rows that do not exist re-read a valid address and
+// land in slab padding), which keeps the loads independent of each other in the instruction stream.
+template <int BM, int BN, int NS, int XV>
 __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, ConvPlan pl) {
     constexpr int WAVES_N = BN / 64;
     static_assert((BM / 64) * WAVES_N == 4, "4 waves");
-    constexpr int A_ROWS = BM / 8;   // rows per thread per k slot (scalar path)
-    constexpr int A_VROWS = BM / 16; // rows per thread (float4 path)
-    constexpr int LDA = BM + 1;
-    __shared__ float As[2][KGMAX][LDA];
-    __shared__ float Xs[2][XSMAX];
-    __shared__ int kinfo[2][2];   // per stage: {flat k count, taps in this sub-range}
+    constexpr int TA = BM / 4;             // threads per A slab row (one float4 each)
+    constexpr int RA = NTHREADS / TA;      // slab rows per pass (8 / 16)
+    constexpr int PA_MAX = KGMAX / RA;     // 6 / 3
+    constexpr int LDA = BM + 4;
+    __shared__ __attribute__((aligned(16))) float As[2][KGMAX][LDA];
+    __shared__ __attribute__((aligned(16))) float Xs[2][XSMAX];
     __shared__ float red[WAVES_N][BM][2];
 
+    PASE_STAMP(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = pase_uniform(tid >> 6);   // provably wave-uniform: tile-shape branches stay scalar
@@ -120,138 +173,174 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
     const int g_end = min(G, g_begin + g_per);
     if (g_begin >= g_end) return;   // uniform for the whole block, before any barrier
 
-    float areg[2 * A_ROWS];
-    float xreg[XPT];
-    int xoff[XPT];                 // element offset of slot t relative to channel ci0 of sequence 0
+    // ---- loader state ------------------------------------------------------------------------
+    // A: thread -> (slab row ar + RA*pass, 4 tile columns from acl) of the K-major pack
+    const int ar = tid / TA;
+    const int acl = (tid % TA) * 4;
+    const unsigned a_col = (unsigned)min(m0 + acl, p.ldwt - 4);
+    F4 areg[PA_MAX];
+    // X: thread -> slab row `xrow` (+ t*RPP when pmajor), samples xc + t*TPR (q-major)
+    constexpr int NXR = XV ? 4 * NS : NS;      // staged floats per thread
+    static_assert(NXR <= XPT, "slab");
+    const int TPR = 1 << pl.tl;
+    const int RPP = NTHREADS >> pl.tl;
+    const int xrow = tid >> pl.tl;
+    const int xc = tid & (TPR - 1);
+    const int xs_tbase = xrow * pl.SPAN + (XV ? 4 * xc : xc);
+    const int slot_stride = pl.pmajor ? RPP * pl.SPAN : TPR;   // LDS distance between a thread's slots
+    float xreg[NXR];
+    int xoff[NS];                  // element offset of slot t relative to channel ci0 of sequence 0
     unsigned xmask = 0u;           // slot t holds a real sample (else zero padding / out of range)
-    int kg_next = 0, tbe_next = 0, ci0_next = 0;
+    constexpr int NP = (NS <= NPAR) ? NS : 1;  // (scale, shift, alpha) triples prefetched per stage
+    float par_s[NP], par_h[NP], par_a[NP];
+    const bool has_xf = p.in_scale != nullptr || p.in_alpha != nullptr;
+    const float* sc_p = p.in_scale ? p.in_scale : &g_ident[0];
+    const float* sh_p = p.in_scale ? p.in_shift : &g_ident[1];
+    const float* al_p = p.in_alpha ? p.in_alpha : &g_ident[0];
+    const int aff_on = p.in_scale ? 1 : 0, alpha_on = p.in_alpha ? 1 : 0;
+    // pmajor with more rows per thread than prefetched triples (odd flat shapes): fetched per slot
+    const bool slow_par = pl.pmajor && NS > NPAR;
+    int kg_next = 0, tbe_next = 0, lo_next = 0, ci0s_next = 0;
 
-    // slot t of this thread = element e = tid + 256 t of the [CB][SPAN] slab -> (cl, i) -> (s, u)
+    // (sequence, time) of span sample i for tap-group offset koffs -> element offset / validity
+    auto locate = [&](int i, int koffs, int& off, bool& ok) __attribute__((always_inline)) {
+        int s, u;
+        if (pl.mode == MODE_FLAT) {
+            const unsigned n = (unsigned)(n0 + i);
+            s = (int)div_magic(n, pl.ncols_magic);   // may overshoot by one for huge n*Ncols
+            u = (int)n - s * p.Ncols;
+            if (u < 0) { --s; u += p.Ncols; }
+            ok = (int)n < ntot;
+        } else {
+            const bool segB = i >= SA;
+            s = segB ? s0 + 1 : s0;
+            u = (segB ? i - SA : qA * p.stride + i) - p.padL + koffs;
+            ok = segB ? lenB > 0 : true;
+            if (p.pad_mode == PASE_PAD_REFLECT) {
+                if (u < 0) u = -u;
+                if (u >= p.Tin) u = 2 * (p.Tin - 1) - u;
+            }
+            ok = ok && u >= 0 && u < p.Tin;
+        }
+        ok = ok && i < pl.SPANV;
+        off = s * p.x_ctot * p.Tin + u;
+    };
     auto slot_setup = [&](int kk0, int TBe) __attribute__((always_inline)) {
         xmask = 0u;
         const int koffs = (p.tapstep > 0) ? kk0 : -(kk0 + TBe - 1);
-#pragma unroll
-        for (int t = 0; t < XPT; ++t) {
-            const int e = tid + NTHREADS * t;
-            const int cl = (int)div_magic((unsigned)e, pl.span_magic);
-            const int i = e - cl * pl.SPAN;
-            int s, u;
+        if (pl.pmajor) {
+            int off;
             bool ok;
-            if (pl.mode == MODE_FLAT) {
-                const unsigned n = (unsigned)(n0 + i);
-                s = (int)div_magic(n, pl.ncols_magic);   // may overshoot by one for huge n*Ncols
-                u = (int)n - s * p.Ncols;
-                if (u < 0) { --s; u += p.Ncols; }
-                ok = (int)n < ntot;
-            } else {
-                const bool segB = i >= SA;
-                s = segB ? s0 + 1 : s0;
-                u = (segB ? i - SA : qA * p.stride + i) - p.padL + koffs;
-                ok = segB ? lenB > 0 : true;
-                if (p.pad_mode == PASE_PAD_REFLECT) {
-                    if (u < 0) u = -u;
-                    if (u >= p.Tin) u = 2 * (p.Tin - 1) - u;
-                }
-                ok = ok && u >= 0 && u < p.Tin;
+            locate(XV ? 4 * xc : xc, koffs, off, ok);
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                const int row = xrow + t * RPP;
+                const bool okr = ok && row < pl.CB;
+                xoff[t] = okr ? off + row * p.Tin : 0;
+                if (okr) xmask |= 1u << t;
             }
-            xoff[t] = ok ? (s * p.x_ctot + cl) * p.Tin + u : 0;
-            if (ok) xmask |= 1u << t;
+        } else {
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                int off;
+                bool ok;
+                locate(xc + (t << pl.tl), koffs, off, ok);
+                ok = ok && xrow < pl.CB;
+                xoff[t] = ok ? off + xrow * p.Tin : 0;
+                if (ok) xmask |= 1u << t;
+            }
         }
     };
     const bool slots_invariant = pl.n_gt == 1;
     if (slots_invariant) slot_setup(0, p.taps);
+    constexpr unsigned all_slots = (1u << NS) - 1u;
+    // wave-uniform: no slot of this wave needs zeroing (interior tile)
+    bool x_allvalid = pase_wave_all(xmask == all_slots) != 0;
 
-    auto load_stage = [&](int g) __attribute__((always_inline)) {
-        const int gc = g / pl.n_gt, gt = g - gc * pl.n_gt;
-        const int ci0 = gc * pl.CB, kk0 = gt * pl.TB;
+    int gc_n = g_begin / pl.n_gt, gt_n = g_begin - gc_n * pl.n_gt;   // (gc, gt) of the next stage to load
+
+    auto load_stage = [&]() __attribute__((always_inline)) {
+        const int ci0 = gc_n * pl.CB, kk0 = gt_n * pl.TB;
         const int TBe = min(pl.TB, p.taps - kk0);
-        const int CBe = min(pl.CB, p.Cin - ci0);
-        const int KGe = CBe * TBe;
-        kg_next = KGe;
+        // a ragged last channel group is shifted back so it ends at Cin; rows below `lo` (channels the
+        // previous stage already covered) get zero weights in store_stage
+        const int ci0s = slots_invariant ? min(ci0, p.Cin - pl.CB) : ci0;
+        lo_next = (ci0 - ci0s) * pl.TB;
+        kg_next = slots_invariant ? pl.CB * pl.TB : TBe;
         tbe_next = TBe;
-        ci0_next = ci0;
-        // ---- A slab [BM x KGe], rows K-contiguous in HBM.  Raw prefetch only.
-        if (pl.avec) {
-            // float4 along K: lane group of 16 covers up to 64 k of one row
-            const int k4 = (tid & 15) * 4;
-            const float* wrow = p.w + (size_t)(m0 + (tid >> 4)) * p.ldw + (size_t)ci0 * p.taps + kk0 + k4;
-            const bool kok = k4 < KGe;
+        ci0s_next = ci0s;
+        if (++gt_n == pl.n_gt) { gt_n = 0; ++gc_n; }
+        if (!slots_invariant) {
+            slot_setup(kk0, TBe);
+            x_allvalid = pase_wave_all(xmask == all_slots) != 0;
+        }
+        // ---- straight-line issue: A slab rows k0 + RA*pass of the K-major pack (BM contiguous floats
+        // each; rows past K re-read row K-1 and are zeroed / ignored), then the X slots.  Only raw loads
+        // here (they stay in flight under the MFMAs of the current stage); the on-load affine / PReLU is
+        // applied in store_stage.
+        const int k0 = ci0s * p.taps + kk0 + ar;
+        const float* xb = p.x + (size_t)(p.x_coff + ci0s) * p.Tin;
 #pragma unroll
-            for (int i = 0; i < A_VROWS; ++i) {
-                const int m = m0 + (tid >> 4) + 16 * i;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (kok && m < p.M) v = *reinterpret_cast<const float4*>(wrow + (size_t)16 * i * p.ldw);
-                areg[4 * i + 0] = v.x; areg[4 * i + 1] = v.y; areg[4 * i + 2] = v.z; areg[4 * i + 3] = v.w;
-            }
-        } else {
+        for (int ps = 0; ps < PA_MAX; ++ps) {
+            const unsigned row = (unsigned)min(k0 + RA * ps, p.K - 1);
+            areg[ps] = *reinterpret_cast<const F4*>(p.wt + (row * (unsigned)p.ldwt + a_col));
+        }
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int kl = (tid & 31) + 32 * h;
-                const bool kok = kl < KGe;
-                int ka = 0;
-                if (kok) {
-                    const int cl = kl / TBe, kkl = kl - cl * TBe;
-                    ka = p.tap_major ? (kk0 + kkl) * p.Cin + ci0 + cl : (ci0 + cl) * p.taps + kk0 + kkl;
-                }
-#pragma unroll
-                for (int i = 0; i < A_ROWS; ++i) {
-                    const int m = m0 + (tid >> 5) + 8 * i;
-                    areg[h * A_ROWS + i] = (kok && m < p.M) ? p.w[(size_t)m * p.ldw + ka] : 0.f;
-                }
+        for (int t = 0; t < NS; ++t) {
+            if (XV) {
+                const F4 v = *reinterpret_cast<const F4*>(xb + (unsigned)xoff[t]);
+                xreg[4 * t + 0] = v.x; xreg[4 * t + 1] = v.y; xreg[4 * t + 2] = v.z; xreg[4 * t + 3] = v.w;
+            } else {
+                xreg[t] = xb[(unsigned)xoff[t]];
             }
         }
-        // ---- X spans: CBe rows of SPAN floats, consecutive threads on consecutive samples.  Only the
-        // raw loads are issued here (they stay in flight under the MFMAs of the current stage); the
-        // on-load affine / PReLU is applied in store_stage, after the MFMA loop.
-        if (!slots_invariant) slot_setup(kk0, TBe);
-        const int total = CBe * pl.SPAN;
-        const float* xb = p.x + (size_t)(p.x_coff + ci0) * p.Tin;
 #pragma unroll
-        for (int t = 0; t < XPT; ++t) {
-            const bool ok = ((xmask >> t) & 1u) && (tid + NTHREADS * t) < total;
-            xreg[t] = ok ? xb[xoff[t]] : 0.f;
+        for (int j = 0; j < NP; ++j) {
+            const int ch = min(ci0s + xrow + (pl.pmajor ? j * RPP : 0), p.Cin - 1);
+            par_s[j] = sc_p[ch * aff_on];
+            par_h[j] = sh_p[ch * aff_on];
+            par_a[j] = al_p[ch * alpha_on];
         }
     };
+    auto xform = [&](float v, float sc, float sh, float al) __attribute__((always_inline)) {
+        v = fmaf(v, sc, sh);
+        return v > 0.f ? v : v * al;
+    };
     auto store_stage = [&](int buf) __attribute__((always_inline)) {
-        if (pl.avec) {
-            const int k4 = (tid & 15) * 4;
-            if (k4 < KGMAX) {
+        // ---- A
+        const bool a_zero = lo_next > 0 || (kg_next & 3) != 0;   // uniform
 #pragma unroll
-                for (int i = 0; i < A_VROWS; ++i) {
-                    const int r = (tid >> 4) + 16 * i;
-                    As[buf][k4 + 0][r] = areg[4 * i + 0];
-                    As[buf][k4 + 1][r] = areg[4 * i + 1];
-                    As[buf][k4 + 2][r] = areg[4 * i + 2];
-                    As[buf][k4 + 3][r] = areg[4 * i + 3];
-                }
-            }
-        } else {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int kl = (tid & 31) + 32 * h;
-                if (kl < KGMAX) {
-#pragma unroll
-                    for (int i = 0; i < A_ROWS; ++i) As[buf][kl][(tid >> 5) + 8 * i] = areg[h * A_ROWS + i];
-                }
-            }
+        for (int ps = 0; ps < PA_MAX; ++ps) {
+            F4 v = areg[ps];
+            const int kl = ar + RA * ps;
+            if (a_zero && (kl < lo_next || kl >= kg_next)) v = F4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<F4*>(&As[buf][kl][acl]) = v;
         }
-        if (p.in_scale || p.in_alpha) {
-            const int total = kg_next / tbe_next * pl.SPAN;
+        // ---- X
+        float* xs = &Xs[buf][xs_tbase];
 #pragma unroll
-            for (int t = 0; t < XPT; ++t) {
-                const int e = tid + NTHREADS * t;
-                if (((xmask >> t) & 1u) && e < total) {
-                    const int ci = ci0_next + (int)div_magic((unsigned)e, pl.span_magic);
-                    float v = xreg[t];
-                    if (p.in_scale) v = v * p.in_scale[ci] + p.in_shift[ci];
-                    if (p.in_alpha) v = v > 0.f ? v : v * p.in_alpha[ci];
-                    xreg[t] = v;
+        for (int t = 0; t < NS; ++t) {
+            constexpr int W = XV ? 4 : 1;
+            float v[W];
+#pragma unroll
+            for (int e = 0; e < W; ++e) v[e] = xreg[W * t + e];
+            if (has_xf) {   // uniform
+                float sc = par_s[NP > 1 ? t : 0], sh = par_h[NP > 1 ? t : 0], al = par_a[NP > 1 ? t : 0];
+                if (NP > 1 && !pl.pmajor) { sc = par_s[0]; sh = par_h[0]; al = par_a[0]; }
+                if (slow_par) {
+                    const int ch = min(ci0s_next + xrow + t * RPP, p.Cin - 1);
+                    sc = sc_p[ch * aff_on]; sh = sh_p[ch * aff_on]; al = al_p[ch * alpha_on];
                 }
-            }
-        }
 #pragma unroll
-        for (int t = 0; t < XPT; ++t) Xs[buf][tid + NTHREADS * t] = xreg[t];
-        if (tid == 0) { kinfo[buf][0] = kg_next; kinfo[buf][1] = tbe_next; }
+                for (int e = 0; e < W; ++e) v[e] = xform(v[e], sc, sh, al);
+            }
+            if (!x_allvalid && !((xmask >> t) & 1u)) {
+#pragma unroll
+                for (int e = 0; e < W; ++e) v[e] = 0.f;
+            }
+            if (XV) *reinterpret_cast<F4*>(xs + t * slot_stride) = F4{v[0], v[W > 1 ? 1 : 0], v[W > 2 ? 2 : 0], v[W > 3 ? 3 : 0]};
+            else xs[t * slot_stride] = v[0];
+        }
     };
 
     f32x16 acc[2][2];
@@ -262,35 +351,33 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    // wave-uniform "this 32-wide block has work" flags (ragged tiles: T_out = 200, M = 273, ...)
-    const bool row_ok0 = m0 + wm * 64 < p.M, row_ok1 = m0 + wm * 64 + 32 < p.M;
-    const bool col_ok0 = wn * 64 < ncols_valid, col_ok1 = wn * 64 + 32 < ncols_valid;
-    const bool full_tile = row_ok0 && row_ok1 && col_ok0 && col_ok1;
     // LDS offset of this lane's two columns within a slab row (segment B starts at SA)
     const int j0c = wn * 64 + fr, j1c = wn * 64 + 32 + fr;
     const int xc0 = (pl.mode != MODE_FLAT && j0c >= lenA) ? SA + (j0c - lenA) * xstep : j0c * xstep;
     const int xc1 = (pl.mode != MODE_FLAT && j1c >= lenA) ? SA + (j1c - lenA) * xstep : j1c * xstep;
+    // a padded / look-ahead step must stay inside the part of Xs every stage rewrites
+    const int xo_lim = NXR * NTHREADS - 1 - max(xc0, xc1);
 
-    load_stage(g_begin);
+    load_stage();
+    PASE_STAMP(1);
     store_stage(0);
+    int kg = kg_next, tbe = tbe_next;
     __syncthreads();
+    PASE_STAMP(2);
+    PASE_TACC_DECL;
     for (int g = g_begin; g < g_end; ++g) {
         const int cur = (g - g_begin) & 1;
-        if (g + 1 < g_end) load_stage(g + 1);   // global loads in flight under the MFMAs
-        const int kg = kinfo[cur][0];
-        const int tbe = kinfo[cur][1];
+        PASE_TACC_BEGIN();
+        if (g + 1 < g_end) load_stage();   // global loads in flight under the MFMAs
+        PASE_TACC(0);
         const int nks = (kg + 1) >> 1;
-        // K order inside a stage: channel rows are taken two at a time ("super-row" = 2*tbe flat k, so
-        // an MFMA step never straddles super-rows even for odd tap counts).  Step j of a super-row
-        // gives this lane flat position f = 2j + fk -> row f >= tbe, tap f - row*tbe.  All of it is
-        // scalar loop state plus 3-4 VALU; operands for step ks+1 are fetched from LDS BEFORE the
-        // MFMAs of step ks are issued (register double buffer), so the ds_read latency hides under
-        // the 256 matrix-pipe cycles of the current step.
         // K order inside a stage: channel rows are taken two at a time ("super-row" = 2*tbe flat k,
         // tbe MFMA steps, so a step never straddles super-rows even for odd tap counts).  This lane's
         // flat position in step j is f = 2j + fk.  Its span offset advances by +-2 per step, plus one
         // extra jump D when f crosses from the first to the second row (step j == jc, a per-lane
         // constant) and the same D at the end of the super-row: ~7 VALU per step, no division, no table.
+        // Operands for step ks+1 are fetched from LDS BEFORE the MFMAs of step ks are issued (register
+        // double buffer), so the ds_read latency hides under the 256 matrix-pipe cycles of the step.
         const int ts = p.tapstep;
         int xo = (fk >= tbe) ? ((ts > 0) ? pl.SPAN - tbe : pl.SPAN + 2 * tbe - 1) : ((ts > 0) ? 0 : tbe - 1);
         xo = (ts > 0) ? xo + fk : xo - fk;
@@ -298,7 +385,6 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
         const int xstepk = one_tap ? 2 * pl.SPAN : 2 * ts;
         const int D = one_tap ? 0 : ((ts > 0) ? pl.SPAN - tbe : pl.SPAN + tbe);
         const int jc = one_tap ? -1 : (tbe - fk + 1) / 2 - 1;
-        const int xo_lim = XSMAX - 1 - max(xc0, xc1);        // a padded / look-ahead step must stay inside Xs
         const float* as_ = &As[cur][fk][wm * 64 + fr];
         const float* xs_ = &Xs[cur][0];
         int j = 0;
@@ -346,81 +432,133 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
             PASE_SCHED_BARRIER();
         }
 #undef PASE_STEP_SCHED
-        if (g + 1 < g_end) store_stage(cur ^ 1);
+        PASE_TACC(1);
+        if (g + 1 < g_end) {
+            store_stage(cur ^ 1);
+            kg = kg_next;
+            tbe = tbe_next;
+        }
+        PASE_TACC(2);
         __syncthreads();
+        PASE_TACC(3);
     }
+    PASE_TACC_DUMP();
 
     // ---- epilogue ---------------------------------------------------------------------------
-    // D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    const int rbase = 4 * (lane >> 5);
+    // D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  All offsets are 32-bit element
+    // offsets off a uniform base (host-checked), rows advance by compile-time constants.
+    PASE_STAMP(3);
+    const int rbase = m0 + wm * 64 + 4 * (lane >> 5);
     int cs[2], cq[2];
     bool cok[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        const int j = wn * 64 + b * 32 + fr;
-        cok[b] = j < ncols_valid;
+        const int jj = wn * 64 + b * 32 + fr;
+        cok[b] = jj < ncols_valid;
         if (pl.mode == MODE_FLAT) {
-            const int n = n0 + j;
-            cs[b] = cok[b] ? n / p.Ncols : 0;
-            cq[b] = cok[b] ? n % p.Ncols : 0;
+            const unsigned n = (unsigned)(n0 + jj);
+            int s = (int)div_magic(n, pl.ncols_magic);
+            int u = (int)n - s * p.Ncols;
+            if (u < 0) { --s; u += p.Ncols; }
+            cs[b] = cok[b] ? s : 0;
+            cq[b] = cok[b] ? u : 0;
         } else {
-            cs[b] = j < lenA ? s0 : s0 + 1;
-            cq[b] = j < lenA ? qA + j : j - lenA;
+            cs[b] = jj < lenA ? s0 : s0 + 1;
+            cq[b] = jj < lenA ? qA + jj : jj - lenA;
         }
     }
+    const bool rows_full = m0 + wm * 64 + 64 <= p.M;   // uniform
 
     if (p.epilogue == PASE_EPI_STORE && (p.post_op == PASE_POST_POW || p.post_op == PASE_POST_LOGPOW)) {
         // spectra: accumulator rows r, r+1 (same lane) are the (re, im) parts of one frequency bin
+        int cbase[2];
+        bool colok[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int pos = cq[b] + p.poff;
+            cbase[b] = (cs[b] * p.y_ctot + p.y_coff) * p.Tout + pos;
+            colok[b] = cok[b] && pos >= 0 && pos < p.Tout;
+        }
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const int m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + rbase;   // even row
+                const int m = rbase + a * 32 + (r & 3) + 8 * (r >> 2);   // even row
                 if (m >= p.M) continue;          // M is even (host-checked): a pair is valid or absent
-                const int bin = m >> 1;
+                const int rowoff = (m >> 1) * p.Tout;
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     const float re = acc[a][b][r], im = acc[a][b][r + 1];
                     float v = re * re + im * im;
                     v = (p.post_op == PASE_POST_LOGPOW) ? p.post_scale * logf(v + p.post_eps) : v * p.post_scale;
-                    const int pos = cq[b] + p.poff;
-                    if (cok[b] && pos >= 0 && pos < p.Tout)
-                        p.y[((size_t)cs[b] * p.y_ctot + p.y_coff + bin) * (size_t)p.Tout + pos] = v;
+                    if (colok[b]) p.y[(unsigned)(cbase[b] + rowoff)] = v;
                 }
             }
         }
     } else if (p.epilogue == PASE_EPI_STORE) {
+        const bool pshuf = p.ps != 1;
+        const float* biasp = (p.bias && split == 0) ? p.bias : nullptr;
+        int cbase[2], posb[2];
+        bool colok[2];
+        bool interior = true;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
+        for (int b = 0; b < 2; ++b) {
+            posb[b] = cq[b] * p.ps + p.poff;
+            cbase[b] = (cs[b] * p.y_ctot + p.y_coff) * p.Tout + posb[b];
+            colok[b] = cok[b] && (pshuf || (posb[b] >= 0 && posb[b] < p.Tout));
+            interior = interior && cok[b] && posb[b] >= 0 && posb[b] + p.ps <= p.Tout;
+        }
+        // FAST (wave-uniform): every (row, column, phase) of this wave's 64x64 block is stored, no
+        // post-op -> no predicates at all in the unrolled body.  ATOMIC: split-K partial tile.
+        auto store_rows = [&](auto fast_tag, auto atomic_tag) __attribute__((always_inline)) {
+            constexpr bool FAST = decltype(fast_tag)::value;
+            constexpr bool ATOMIC = decltype(atomic_tag)::value;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ml = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + rbase;  // row in tile
-                const int m = m0 + ml;
-                const bool mok = m < p.M;
-                const int ph = mok ? m / p.Cout_store : 0;
-                const int co = mok ? m - ph * p.Cout_store : 0;
-                const float bv = (mok && p.bias && split == 0) ? p.bias[co] : 0.f;
-                float s1 = 0.f, s2 = 0.f;
+            for (int a = 0; a < 2; ++a) {
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    float v = acc[a][b][r] + bv;
-                    if (p.post_op == PASE_POST_LOG) v = p.post_scale * logf(v == 0.f ? p.post_eps : v);
-                    const int pos = cq[b] * p.ps + ph + p.poff;
-                    const bool ok = mok && cok[b] && pos >= 0 && pos < p.Tout;
-                    if (ok) {
-                        float* dst = p.y + ((size_t)cs[b] * p.y_ctot + p.y_coff + co) * (size_t)p.Tout + pos;
-                        if (pl.splitk > 1) atomicAdd(dst, v);
-                        else *dst = v;
-                        s1 += v;
-                        s2 += v * v;
+                for (int r = 0; r < 16; ++r) {
+                    const int m = rbase + a * 32 + (r & 3) + 8 * (r >> 2);
+                    const bool mok = FAST || m < p.M;
+                    int ph = 0, co = m;
+                    if (pshuf) {   // uniform
+                        ph = (int)div_magic((unsigned)m, pl.cout_magic);
+                        co = m - ph * p.Cout_store;
+                    }
+                    const float bv = (biasp && mok) ? biasp[co] : 0.f;
+                    const int rowoff = co * p.Tout + ph;
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        float v = acc[a][b][r] + bv;
+                        if (!FAST && p.post_op == PASE_POST_LOG) v = p.post_scale * logf(v == 0.f ? p.post_eps : v);
+                        const bool ok = FAST || (mok && colok[b] && (!pshuf || (unsigned)(posb[b] + ph) < (unsigned)p.Tout));
+                        if (ok) {
+                            float* dst = p.y + (unsigned)(cbase[b] + rowoff);
+                            if (ATOMIC) atomicAdd(dst, v);
+                            else *dst = v;
+                            s1 += v;
+                            s2 += v * v;
+                        }
+                    }
+                    if (!ATOMIC && p.stat_part) {   // uniform branch
+                        s1 = pase_half_sum_lane31(s1);
+                        s2 = pase_half_sum_lane31(s2);
+                        if (fr == 31) {
+                            const int ml = m - m0;
+                            red[wn][ml][0] = s1;
+                            red[wn][ml][1] = s2;
+                        }
                     }
                 }
-                if (p.stat_part) {   // uniform branch
-                    s1 = pase_wave_sum32(s1);
-                    s2 = pase_wave_sum32(s2);
-                    if (fr == 0) { red[wn][ml][0] = s1; red[wn][ml][1] = s2; }
-                }
             }
+        };
+        const bool fast = rows_full && p.post_op == PASE_POST_NONE && pase_wave_all(interior) != 0;
+        if (pl.splitk > 1) {
+            if (fast) store_rows(std::true_type{}, std::true_type{});
+            else store_rows(std::false_type{}, std::true_type{});
+        } else {
+            if (fast) store_rows(std::true_type{}, std::false_type{});
+            else store_rows(std::false_type{}, std::false_type{});
         }
         if (p.stat_part) {
             __syncthreads();
@@ -440,32 +578,44 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
     } else {  // PASE_EPI_MSE_CTX: rows m = d*r + j, columns (b, t); target = label[b, d, t + j - r/2]
         float lsum = 0.f;
         const int half = p.r_ctx / 2;
+        int lbase[2], obase[2], tb[2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
+        for (int b = 0; b < 2; ++b) {
+            tb[b] = cq[b] - half;
+            lbase[b] = cs[b] * p.label_D * p.Ncols + tb[b];
+            obase[b] = cs[b] * p.M * p.Ncols + cq[b];
+        }
+        auto mse_rows = [&](auto fast_tag) __attribute__((always_inline)) {
+            constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + rbase;
-                const bool mok = m < p.M;
-                const int d = mok ? m / p.r_ctx : 0;
-                const int j = mok ? m - d * p.r_ctx : 0;
-                const float bv = (mok && p.bias) ? p.bias[m] : 0.f;
+            for (int a = 0; a < 2; ++a) {
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    if (mok && cok[b]) {
-                        const float pred = acc[a][b][r] + bv;
-                        const int tt = cq[b] + j - half;
-                        float tgt = 0.f;
-                        if (tt >= 0 && tt < p.Ncols)
-                            tgt = p.label[((size_t)cs[b] * p.label_D + d) * (size_t)p.Ncols + tt];
-                        const float diff = pred - tgt;
-                        lsum += diff * diff;
-                        const size_t o = ((size_t)cs[b] * p.M + m) * (size_t)p.Ncols + cq[b];
-                        if (p.y) p.y[o] = pred;
-                        if (p.grad_out) p.grad_out[o] = diff * p.grad_scale;
+                for (int r = 0; r < 16; ++r) {
+                    const int m = rbase + a * 32 + (r & 3) + 8 * (r >> 2);
+                    const bool mok = FAST || m < p.M;
+                    const int d = (int)div_magic((unsigned)m, pl.rctx_magic);
+                    const int jj = m - d * p.r_ctx;
+                    const float bv = (mok && p.bias) ? p.bias[m] : 0.f;
+                    const int lrow = d * p.Ncols + jj;
+                    const int orow = m * p.Ncols;
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        if (FAST || (mok && cok[b])) {
+                            const float pred = acc[a][b][r] + bv;
+                            float tgt = 0.f;
+                            if ((unsigned)(tb[b] + jj) < (unsigned)p.Ncols) tgt = p.label[(unsigned)(lbase[b] + lrow)];
+                            const float diff = pred - tgt;
+                            lsum += diff * diff;
+                            const unsigned o = (unsigned)(obase[b] + orow);
+                            if (p.y) p.y[o] = pred;
+                            if (p.grad_out) p.grad_out[o] = diff * p.grad_scale;
+                        }
                     }
                 }
             }
-        }
+        };
+        if (rows_full && pase_wave_all(cok[0] && cok[1]) != 0) mse_rows(std::true_type{});
+        else mse_rows(std::false_type{});
         lsum = pase_wave_sum64(lsum);
         if (lane == 0) red[0][wave][0] = lsum;
         __syncthreads();
@@ -473,6 +623,56 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
             const double t = (double)red[0][0][0] + (double)red[0][1][0] + (double)red[0][2][0] + (double)red[0][3][0];
             atomicAdd(p.loss_acc, t);
         }
+    }
+#ifdef PASE_TRACE
+    __builtin_amdgcn_s_waitcnt(0);   // stores acknowledged
+    PASE_STAMP(4);
+    if (threadIdx.x == 0 && blockIdx.x < PASE_TRACE_SLOTS) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_trace[blockIdx.x * 6 + 5] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
+}
+
+#ifdef PASE_TRACE
+extern "C" int pase_debug_trace(unsigned long long* host, int nslots) {
+    hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * 6 * (size_t)nslots);
+}
+extern "C" int pase_debug_tacc(unsigned long long* host, int nslots) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tacc), sizeof(unsigned long long) * 4 * (size_t)nslots);
+}
+#endif
+
+// ---- K-major weight pack: wt[k, m] = A[m, k], k = ci*taps + kk, A[m, (ci,kk)] = w[m*ldw + (tap_major ?
+// kk*Cin + ci : ci*taps + kk)]; columns m >= M of a row are zero-filled up to ldwt.  32x32 LDS transpose.
+__global__ void __launch_bounds__(256) pack_wt_kernel(const float* w, float* wt, int M, int K, int Cin, int taps,
+                                                      int ldw, int tap_major, int ldwt) {
+    __shared__ float tile[32][33];
+    const int kt = blockIdx.x * 32, mt = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = mt + ty + 8 * i, k = kt + tx;
+        float v = 0.f;
+        if (m < M && k < K) {
+            int src = k;
+            if (tap_major) {
+                const int ci = k / taps, kk = k - ci * taps;
+                src = kk * Cin + ci;
+            }
+            v = w[(size_t)m * ldw + src];
+        }
+        tile[ty + 8 * i][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = kt + ty + 8 * i, m = mt + tx;
+        if (k < K && m < ldwt) wt[(size_t)k * ldwt + m] = tile[tx][ty + 8 * i];
     }
 }
 
@@ -483,6 +683,10 @@ struct HostPlan {
     int n_col_tiles;
 };
 
+unsigned magic_of(int d) {
+    return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned long long)d);
+}
+
 HostPlan make_plan(const PaseConvGemm& p) {
     HostPlan h;
     h.narrow = (p.tile_hint == 64) || (p.tile_hint == 0 && p.M <= 64);
@@ -491,29 +695,50 @@ HostPlan make_plan(const PaseConvGemm& p) {
     ConvPlan& pl = h.pl;
     const bool flat = (p.taps == 1 && p.stride == 1 && p.padL == 0 && p.tapstep == 1);
     pl.mode = flat ? MODE_FLAT : (p.Ncols >= h.BN ? MODE_SEG : MODE_PERSEQ);
+    pl.xvec = 0;
+    pl.pmajor = flat ? 1 : 0;
     if (flat) {
         pl.TB = 1;
-        pl.SPAN = h.BN;
+        pl.SPANV = pl.SPAN = h.BN;
         pl.CB = XSMAX / h.BN;
         if (pl.CB > KGMAX) pl.CB = KGMAX;
+        if (pl.CB > p.Cin) pl.CB = p.Cin;
+        // float4 slots: 4 consecutive columns stay inside one sequence and are 16-B aligned
+        pl.xvec = ((p.Ncols % 4) == 0 && (p.Tin % 4) == 0 && (((unsigned long long)(size_t)p.x) % 16) == 0) ? 1 : 0;
+        const int TPR = pl.xvec ? h.BN / 4 : h.BN;
+        pl.tl = 0;
+        while ((1 << pl.tl) < TPR) ++pl.tl;
+        const int RPP = NTHREADS / TPR;
+        pl.nslots = (pl.CB + RPP - 1) / RPP;
+        if (pl.xvec) pl.nslots = 3;
+        else pl.nslots = pl.nslots <= 3 ? 3 : (pl.nslots <= 6 ? 6 : 12);
     } else {
         pl.TB = p.taps <= KGMAX ? p.taps : 32;
         // a tile may touch two sequences: each segment carries its own halo of TB samples
-        pl.SPAN = (h.BN - 1) * p.stride + (pl.mode == MODE_SEG ? 2 : 1) * pl.TB;
+        pl.SPANV = (h.BN - 1) * p.stride + (pl.mode == MODE_SEG ? 2 : 1) * pl.TB;
         pl.CB = KGMAX / pl.TB;
-        if (pl.CB * pl.SPAN > XSMAX) pl.CB = XSMAX / pl.SPAN;
+        if (pl.CB > p.Cin) pl.CB = p.Cin;
+        // one slab row per thread: TPR = largest power of two with 256/TPR >= CB; Q samples each
+        pl.nslots = XPT + 1;
+        pl.tl = 8;
+        for (; pl.CB >= 1; --pl.CB) {
+            pl.tl = 8;
+            while ((NTHREADS >> pl.tl) < pl.CB) --pl.tl;
+            pl.nslots = (pl.SPANV + (1 << pl.tl) - 1) >> pl.tl;
+            if (pl.nslots <= XPT) break;
+        }
+        if (pl.CB < 1) pl.CB = 0;   // span does not fit: rejected by the caller
+        pl.nslots = pl.nslots <= 3 ? 3 : (pl.nslots <= 6 ? 6 : 12);   // kernel instantiations: 3 / 6 / 12 slots
+        pl.SPAN = pl.nslots << pl.tl;
     }
-    if (pl.CB > p.Cin) pl.CB = p.Cin;
-    if (pl.CB < 1) pl.CB = 0;   // span does not fit: rejected by the caller
     pl.n_gc = pl.CB ? (p.Cin + pl.CB - 1) / pl.CB : 0;
     pl.n_gt = (p.taps + pl.TB - 1) / pl.TB;
+    const int RA = NTHREADS / (BM / 4);
+    pl.PA = (pl.CB * pl.TB + RA - 1) / RA;
     pl.tiles_per_seq = (p.Ncols + h.BN - 1) / h.BN;
-    pl.span_magic = (unsigned)((0x100000000ULL + pl.SPAN - 1) / (unsigned long long)pl.SPAN);
-    pl.ncols_magic = (unsigned)((0x100000000ULL + p.Ncols - 1) / (unsigned long long)p.Ncols);
-    // float4 weight loads: rows 16-B aligned, whole channels per stage, natural (ci, kk) K order
-    pl.avec = (!p.tap_major && pl.n_gt == 1 && (p.ldw % 4) == 0 && ((pl.CB * pl.TB) % 4) == 0 &&
-               (((unsigned long long)(size_t)p.w) % 16) == 0 && pl.CB * pl.TB <= 64 && pl.CB > 0 &&
-               (p.Cin % pl.CB) == 0) ? 1 : 0;
+    pl.ncols_magic = magic_of(p.Ncols);
+    pl.cout_magic = magic_of(p.Cout_store);
+    pl.rctx_magic = magic_of(p.r_ctx);
     const long ntot = (long)p.S * p.Ncols;
     h.n_col_tiles = (pl.mode == MODE_PERSEQ) ? p.S * pl.tiles_per_seq : (int)((ntot + h.BN - 1) / h.BN);
     const long tiles = (long)((p.M + BM - 1) / BM) * h.n_col_tiles;
@@ -538,10 +763,21 @@ HostPlan make_plan(const PaseConvGemm& p) {
 
 }  // namespace
 
+extern "C" int pase_pack_wt(const float* w, float* wt, int M, int K, int Cin, int taps, int ldw, int tap_major,
+                            int ldwt, void* stream) {
+    if (M <= 0 || K <= 0) return 0;
+    if (ldwt < M || (ldwt & 3) || K != Cin * taps) return -4;
+    PASE_LAUNCH(pack_wt_kernel, dim3((unsigned)((K + 31) / 32), (unsigned)((ldwt + 31) / 32)), dim3(256),
+                (hipStream_t)stream, w, wt, M, K, Cin, taps, ldw, tap_major, ldwt);
+    PASE_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int pase_conv_gemm(const PaseConvGemm* d, void* stream) {
     const PaseConvGemm p = *d;
     if (p.M <= 0 || p.K <= 0 || p.S <= 0 || p.Ncols <= 0) return 0;
     if (p.K != p.Cin * p.taps) return -4;
+    if (!p.wt || p.ldwt < p.M || p.ldwt < 4 || (p.ldwt & 3) || (((unsigned long long)(size_t)p.wt) % 16) != 0) return -10;
     if (p.epilogue == PASE_EPI_MSE_CTX && (!p.label || !p.loss_acc || p.r_ctx < 1)) return -2;
     if (p.pad_mode == PASE_PAD_REFLECT && (p.padL >= p.Tin)) return -3;
     if (p.tapstep != 1 && p.tapstep != -1) return -5;
@@ -549,14 +785,28 @@ extern "C" int pase_conv_gemm(const PaseConvGemm* d, void* stream) {
     if (h.pl.CB < 1) return -6;
     if (h.pl.splitk > 1 && (p.stat_part || p.epilogue != PASE_EPI_STORE || p.post_op != PASE_POST_NONE)) return -7;
     if ((p.post_op == PASE_POST_POW || p.post_op == PASE_POST_LOGPOW) && (p.ps != 1 || p.stat_part || (p.M & 1))) return -9;
-    if ((long)p.S * p.Ncols >= 0x7fffffffL) return -8;
-    if ((long)p.S * p.x_ctot * (long)p.Tin >= 0x7fffffffL) return -8;   // int element offsets in the loader
+    // 32-bit element offsets in the loader and the epilogue
+    const long LIM = 0x7fffffffL;
+    if ((long)p.S * p.Ncols >= LIM) return -8;
+    if ((long)p.S * p.x_ctot * (long)p.Tin >= LIM) return -8;
+    if ((long)(p.K + KGMAX) * p.ldwt >= LIM) return -8;
+    if (p.epilogue == PASE_EPI_STORE && (long)p.S * p.y_ctot * (long)p.Tout + (long)p.ps * p.Ncols >= LIM) return -8;
+    if (p.epilogue == PASE_EPI_MSE_CTX &&
+        ((long)p.S * p.M * (long)p.Ncols >= LIM || (long)p.S * p.label_D * (long)p.Ncols >= LIM)) return -8;
+    if (p.ps != 1 && (long)p.M * p.Cout_store >= 0xffffffffL) return -8;      // exact magic division
+    if (p.epilogue == PASE_EPI_MSE_CTX && (long)p.M * p.r_ctx >= 0xffffffffL) return -8;
     hipStream_t st = (hipStream_t)stream;
-    if (h.narrow) {
-        PASE_LAUNCH((conv_gemm_kernel<64, 256>), dim3((unsigned)h.blocks), dim3(NTHREADS), st, p, h.pl);
-    } else {
-        PASE_LAUNCH((conv_gemm_kernel<128, 128>), dim3((unsigned)h.blocks), dim3(NTHREADS), st, p, h.pl);
-    }
+    const dim3 grid((unsigned)h.blocks), block(NTHREADS);
+#define PASE_CONV_LAUNCH(BM_, BN_)                                                                       \
+    do {                                                                                                 \
+        if (h.pl.xvec) PASE_LAUNCH((conv_gemm_kernel<BM_, BN_, 3, 1>), grid, block, st, p, h.pl);        \
+        else if (h.pl.nslots == 3) PASE_LAUNCH((conv_gemm_kernel<BM_, BN_, 3, 0>), grid, block, st, p, h.pl);  \
+        else if (h.pl.nslots == 6) PASE_LAUNCH((conv_gemm_kernel<BM_, BN_, 6, 0>), grid, block, st, p, h.pl);  \
+        else PASE_LAUNCH((conv_gemm_kernel<BM_, BN_, 12, 0>), grid, block, st, p, h.pl);                 \
+    } while (0)
+    if (h.narrow) PASE_CONV_LAUNCH(64, 256);
+    else PASE_CONV_LAUNCH(128, 128);
+#undef PASE_CONV_LAUNCH
     PASE_CHECK_LAUNCH();
     return 0;
 }

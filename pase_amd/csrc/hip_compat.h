@@ -37,6 +37,36 @@ __device__ __forceinline__ int pase_uniform(int v) { return __builtin_amdgcn_rea
 #define PASE_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 #endif
 
+#ifdef PASE_HIPEMU
+__device__ __forceinline__ int pase_wave_all(int pred) {
+    int v = pred ? 1 : 0;
+    for (int m = 1; m < 64; m <<= 1) v &= __shfl_xor(v, m);
+    return v;
+}
+// sum over the 32 lanes sharing (lane>>5); the result is only guaranteed in lane 31 of each half
+__device__ __forceinline__ float pase_half_sum_lane31(float v) {
+    for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+#else
+__device__ __forceinline__ int pase_wave_all(int pred) { return __all(pred); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float pase_dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
+    return v + __int_as_float(moved);
+}
+// DPP tree (no LDS crossbar): quad xor 1, xor 2, row_half_mirror, row_mirror, then row_bcast15 into
+// rows 1 and 3 -> lanes 16-31 / 48-63 hold the sum of their 32-lane half (lane 31 / 63 is the reader)
+__device__ __forceinline__ float pase_half_sum_lane31(float v) {
+    v = pase_dpp_add<0xB1, 0xf>(v);
+    v = pase_dpp_add<0x4E, 0xf>(v);
+    v = pase_dpp_add<0x141, 0xf>(v);
+    v = pase_dpp_add<0x140, 0xf>(v);
+    v = pase_dpp_add<0x142, 0xa>(v);
+    return v;
+}
+#endif
+
 #define PASE_CHECK_LAUNCH()                      \
     do {                                         \
         hipError_t e__ = hipGetLastError();      \

@@ -18,12 +18,13 @@ _fp = C.c_void_p
 
 class PaseConvGemm(C.Structure):
     _fields_ = [
-        ("x", _fp), ("w", _fp), ("y", _fp), ("bias", _fp),
+        ("x", _fp), ("w", _fp), ("wt", _fp), ("y", _fp), ("bias", _fp),
         ("in_scale", _fp), ("in_shift", _fp), ("in_alpha", _fp),
         ("stat_part", _fp), ("label", _fp), ("grad_out", _fp), ("loss_acc", _fp),
         ("grad_scale", C.c_float),
         ("S", C.c_int), ("Cin", C.c_int), ("Tin", C.c_int), ("x_ctot", C.c_int), ("x_coff", C.c_int),
-        ("M", C.c_int), ("K", C.c_int), ("ldw", C.c_int), ("taps", C.c_int), ("tap_major", C.c_int),
+        ("M", C.c_int), ("K", C.c_int), ("ldw", C.c_int), ("ldwt", C.c_int), ("taps", C.c_int),
+        ("tap_major", C.c_int),
         ("stride", C.c_int), ("tapstep", C.c_int), ("padL", C.c_int), ("pad_mode", C.c_int),
         ("Ncols", C.c_int),
         ("y_ctot", C.c_int), ("y_coff", C.c_int), ("Cout_store", C.c_int), ("ps", C.c_int),
@@ -86,8 +87,10 @@ def _conv_desc(x, w, y, *, S, Cin, Tin, M, K, taps, Ncols, Tout, ldw=None, bias=
                x_ctot=None, x_coff=0, tap_major=0, stride=1, tapstep=1, padL=0, pad_mode=PAD_ZERO,
                y_ctot=None, y_coff=0, Cout_store=None, ps=1, poff=0,
                epilogue=EPI_STORE, label=None, grad_out=None, loss_acc=None, grad_scale=0.0,
-               r_ctx=0, label_D=0, tile_hint=0, splitk=0, post_op=0, post_scale=1.0, post_eps=0.0):
+               r_ctx=0, label_D=0, tile_hint=0, splitk=0, post_op=0, post_scale=1.0, post_eps=0.0, wt=None):
     d = PaseConvGemm()
+    if wt is not None:
+        d.wt, d.ldwt = _ptr(wt), wt.shape[1]
     d.post_op, d.post_scale, d.post_eps = post_op, post_scale, post_eps
     d.x, d.w, d.y, d.bias = _ptr(x), _ptr(w), _ptr(y), _ptr(bias)
     d.in_scale, d.in_shift, d.in_alpha = _ptr(in_scale), _ptr(in_shift), _ptr(in_alpha)
@@ -125,16 +128,23 @@ class GemmTimer(object):
 
     def __init__(self):
         self.records = []
+        self.tags = []
 
     def start(self):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream())
         return ev
 
-    def stop(self, family, flops, ev0):
+    def stop(self, family, flops, ev0, tag=None):
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record(torch.cuda.current_stream())
         self.records.append((family, flops, ev0, ev1))
+        self.tags.append(tag)
+
+    def per_launch(self):
+        """[(family, tag, flops, ms)] in launch order (tools/step_breakdown.py)."""
+        torch.cuda.synchronize()
+        return [(f, t, fl, e0.elapsed_time(e1)) for (f, fl, e0, e1), t in zip(self.records, self.tags)]
 
     def summary(self):
         torch.cuda.synchronize()
@@ -150,8 +160,22 @@ class GemmTimer(object):
 GEMM_TIMER = None
 
 
+def pack_wt(w, *, M, K, Cin, taps, ldw=None, tap_major=0):
+    """K-major pack (K, ldwt) of the logical A operand (M, K) held row-major in `w` (pase_pack_wt)."""
+    ldwt = (M + 3) // 4 * 4
+    wt = torch.empty(K, ldwt, device=w.device, dtype=torch.float32)
+    _check(_lib.lib().pase_pack_wt(_ptr(w), _ptr(wt), M, K, Cin, taps, K if ldw is None else ldw, tap_major, ldwt,
+                                   _stream()), "pase_pack_wt")
+    return wt
+
+
 def conv_gemm(x, w, y, **kw):
-    """see include/pase_amd.h PaseConvGemm.  With splitk > 1 the output is zero-filled here first."""
+    """see include/pase_amd.h PaseConvGemm.  With splitk > 1 the output is zero-filled here first.
+    The kernel reads the K-major pack of the weight: pass it as wt= (e.g. straight from pack_dgrad, or a
+    weight that already is K-major) or it is produced here from `w`."""
+    if kw.get("wt") is None:
+        kw["wt"] = pack_wt(w, M=kw["M"], K=kw["K"], Cin=kw["Cin"], taps=kw["taps"], ldw=kw.get("ldw"),
+                           tap_major=kw.get("tap_major", 0))
     d = _conv_desc(x, w, y, **kw)
     if d.splitk != 1:
         if _lib.lib().pase_conv_gemm_splitk(C.byref(d)) > 1:
@@ -159,7 +183,9 @@ def conv_gemm(x, w, y, **kw):
     ev0 = GEMM_TIMER.start() if GEMM_TIMER is not None else None
     _check(_lib.lib().pase_conv_gemm(C.byref(d), _stream()), "pase_conv_gemm")
     if ev0 is not None:
-        GEMM_TIMER.stop("conv_gemm", 2.0 * d.S * d.Ncols * d.M * d.K, ev0)
+        GEMM_TIMER.stop("conv_gemm", 2.0 * d.S * d.Ncols * d.M * d.K, ev0,
+                        "M%d K%d(Cin%d x %d) N%dx%d s%d ps%d epi%d" % (d.M, d.K, d.Cin, d.taps, d.S, d.Ncols, d.stride,
+                                                                    d.ps, d.epilogue))
 
 
 # ======================================================================================
@@ -206,6 +232,7 @@ _SIMPLE.update({
     "pase_sinc_filters": [_fp, _fp, _fp, _fp, _fp, _i, _i, _f, _f, _f, _fp],
     "pase_sinc_filters_bwd": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _f, _f, _f, _fp],
     "pase_pack_dgrad": [_fp, _fp, _i, _i, _i, _i, _l, _l, _l, _fp],
+    "pase_pack_wt": [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp],
     "pase_adam_step": [_fp, _fp, _fp, _fp, _l, _fp, _fp, _f, _f, _f, _f, _fp],
     "pase_step_tick": [_fp, _fp],
     "pase_delta_znorm": [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp],
@@ -242,7 +269,8 @@ def wgrad_gemm(g, z, dw, *, S, M, Tg, Ncols, Cin, Tz, taps, ldw=None, dbias=None
     ev0 = GEMM_TIMER.start() if GEMM_TIMER is not None else None
     _check(_lib.lib().pase_wgrad_gemm(C.byref(d), _stream()), "pase_wgrad_gemm")
     if ev0 is not None:
-        GEMM_TIMER.stop("wgrad_gemm", 2.0 * S * Ncols * M * (Cin * taps + (1 if dbias is not None else 0)), ev0)
+        GEMM_TIMER.stop("wgrad_gemm", 2.0 * S * Ncols * M * (Cin * taps + (1 if dbias is not None else 0)), ev0,
+                        "M%d Kw%d(Cin%d x %d) N%dx%d s%d" % (M, Cin * taps, Cin, taps, S, Ncols, d.stride))
 
 
 def bn_finalize(stat_part, C_, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift,
