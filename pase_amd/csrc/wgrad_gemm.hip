@@ -95,18 +95,46 @@ __global__ void __launch_bounds__(NTHREADS, (ZPT <= ZPT_SMALL ? 2 : 1)) wgrad_ge
     bool gvec_next = false;
     for (int i = tid; i < ZS_ONES; i += NTHREADS) { Zs[0][ZS_DATA + i] = 1.f; Zs[1][ZS_DATA + i] = 1.f; }
 
+    // ---- loader state (fixed for the whole tile) ------------------------------------------------
+    // G slab [BM x 32]: thread -> rows (tid >> 3) + 32*i, time steps k4..k4+3 (float4) when gvec, else
+    // rows (tid >> 5) + 8*i at time step tid & 31.  Rows past M re-read row M-1 (never stored).
+    constexpr int GS = A_ROWS / 4;
     float areg[A_ROWS];
     float zreg[ZPT];
-    unsigned zmask = 0u;
+    const int k4 = (tid & 7) * 4;
+    unsigned goff[GS];
+    float g_al[GS];
+    const bool has_ga = p.g_alpha != nullptr;
+#pragma unroll
+    for (int i = 0; i < GS; ++i) {
+        const int m = min(m0 + (tid >> 3) + 32 * i, p.M - 1);
+        goff[i] = (unsigned)((p.g_coff + m) * p.Tg);
+        g_al[i] = has_ga ? p.g_alpha[m] : 1.f;
+    }
+    // Z spans: slot t = element e = tid + 256 t of the [NC][SPANW] slab; interior offset cl*Tz + i and the
+    // channel's on-load parameters are per-tile constants
     const int ntot = p.S * p.Ncols;
     const int total = NC * pl.SPANW;
-    const int zrow_skip = p.Tz - pl.SPANW;   // slot e -> element offset e + cl * (Tz - SPANW) from the span start
-    int lic = 0;   // laundered zero, refreshed every stage: keeps the per-slot index math INSIDE the
-                   // stage (hoisted out of the loop it would pin ~40 VGPRs for the whole kernel)
-    auto zrel = [&](int t) __attribute__((always_inline)) {
-        const int e = tid + NTHREADS * t + lic;
-        return e + (int)div_magic((unsigned)e, pl.span_magic) * zrow_skip;
-    };
+    unsigned zoff[ZPT];
+    constexpr bool PRE = ZPT <= ZPT_SMALL;       // on-load (scale, shift, alpha) per slot held in registers
+    constexpr int NPRE = PRE ? ZPT : 1;
+    float z_sc[NPRE], z_sh[NPRE], z_al[NPRE];
+    const bool has_aff = p.in_scale != nullptr, has_al = p.in_alpha != nullptr;
+    const bool has_xf = has_aff || has_al;
+#pragma unroll
+    for (int t = 0; t < ZPT; ++t) {
+        const int e = min(tid + NTHREADS * t, max(total - 1, 0));   // slots past the slab re-read its last element
+        const int cl = (int)div_magic((unsigned)e, pl.span_magic);
+        zoff[t] = (unsigned)(cl * p.Tz + (e - cl * pl.SPANW));
+        if (PRE) {
+            const int ci = min(c_lo + cl, p.Cin - 1);
+            z_sc[t] = has_aff ? p.in_scale[ci] : 1.f;
+            z_sh[t] = has_aff ? p.in_shift[ci] : 0.f;
+            z_al[t] = has_al ? p.in_alpha[ci] : 1.f;
+        }
+    }
+    unsigned zmask = 0u;
+    bool zfast_next = true, gkeep_next = true;
 
     auto load_stage = [&](int c) __attribute__((always_inline)) {
         int s, q0;
@@ -118,19 +146,17 @@ __global__ void __launch_bounds__(NTHREADS, (ZPT <= ZPT_SMALL ? 2 : 1)) wgrad_ge
             s = c / pl.chunks_per_seq;
             q0 = (c - s * pl.chunks_per_seq) * BKQ;
         }
-        PASE_LAUNDER(lic);
         // a flat chunk that crosses a sequence boundary takes the per-element path
-        const bool straddle = pl.flat && (q0 + BKQ > p.Ncols);
-        // ---- G slab [BM x 32]: lanes along time.  Raw prefetch only.
+        const bool straddle = pl.flat && (q0 + pl.SPANW > p.Ncols);
+        // ---- G slab.  Raw prefetch only.
         if (pl.gvec && !straddle) {
-            const int k4 = (tid & 7) * 4;
-            const bool ok = q0 + k4 < p.Ncols;       // Ncols % 4 == 0: a float4 is all-valid or all-out
-            const float* grow = p.g + ((size_t)s * p.g_ctot + p.g_coff) * (size_t)p.Tg + q0 + k4;
+            // Ncols % 4 == 0: a float4 is all-valid or all-out; out-of-range ones re-read the row's last
+            // valid float4 and are zeroed in store_piece
+            gkeep_next = q0 + k4 < p.Ncols;
+            const float* gb = p.g + ((unsigned)(s * p.g_ctot * p.Tg) + (unsigned)min(q0 + k4, p.Ncols - 4));
 #pragma unroll
-            for (int i = 0; i < A_ROWS / 4; ++i) {
-                const int m = m0 + (tid >> 3) + 32 * i;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok && m < p.M) v = *reinterpret_cast<const float4*>(grow + (size_t)m * p.Tg);
+            for (int i = 0; i < GS; ++i) {
+                const float4 v = *reinterpret_cast<const float4*>(gb + goff[i]);
                 areg[4 * i + 0] = v.x; areg[4 * i + 1] = v.y; areg[4 * i + 2] = v.z; areg[4 * i + 3] = v.w;
             }
         } else {
@@ -152,23 +178,20 @@ __global__ void __launch_bounds__(NTHREADS, (ZPT <= ZPT_SMALL ? 2 : 1)) wgrad_ge
             }
         }
         // ---- Z spans: NC rows of SPANW floats.  Two paths only: (fast) the whole span is real
-        // data of one sequence -> slot address = span start + e + cl*(Tz - SPANW); (slow) chunk at a
+        // data of one sequence -> unconditional loads off a uniform base; (slow) chunk at a
         // sequence edge / crossing sequences -> per-slot padding + sequence logic.
-        zmask = 0u;
         const int u0 = pl.flat ? q0 : q0 * p.stride - p.padL + (p.tapstep > 0 ? 0 : -(p.taps - 1));
-        const bool fast = pl.flat ? (!straddle && (long)c * BKQ + BKQ <= ntot) : (u0 >= 0 && u0 + pl.SPANW <= p.Tz);
+        const bool fast = pl.flat ? (!straddle && (long)c * BKQ + pl.SPANW <= ntot) : (u0 >= 0 && u0 + pl.SPANW <= p.Tz);
+        zfast_next = fast;
         if (fast) {
             const float* zb = p.z + ((size_t)s * p.z_ctot + p.z_coff + c_lo) * (size_t)p.Tz + u0;
 #pragma unroll
-            for (int t = 0; t < ZPT; ++t) {
-                const bool ok = (tid + NTHREADS * t) < total;
-                zreg[t] = ok ? zb[zrel(t)] : 0.f;
-                if (ok) zmask |= 1u << t;
-            }
+            for (int t = 0; t < ZPT; ++t) zreg[t] = zb[zoff[t]];
         } else {
+            zmask = 0u;
 #pragma unroll
             for (int t = 0; t < ZPT; ++t) {
-                const int e = tid + NTHREADS * t + lic;
+                const int e = tid + NTHREADS * t;
                 float v = 0.f;
                 if (e < total) {
                     const int cl = (int)div_magic((unsigned)e, pl.span_magic);
@@ -206,18 +229,16 @@ __global__ void __launch_bounds__(NTHREADS, (ZPT <= ZPT_SMALL ? 2 : 1)) wgrad_ge
     auto store_piece = [&](int buf, int part) __attribute__((always_inline)) {
         // on-load transforms (g_alpha on G, affine/PReLU on Z) are applied here
         if (gvec_next) {
-            const int k4 = (tid & 7) * 4;
+            const float keep = gkeep_next ? 1.f : 0.f;
 #pragma unroll
-            for (int i = 0; i < A_ROWS / 4; ++i) {
-                if (part >= 0 && (i * NP) / (A_ROWS / 4) != part) continue;
+            for (int i = 0; i < GS; ++i) {
+                if (part >= 0 && (i * NP) / GS != part) continue;
                 const int r = (tid >> 3) + 32 * i;
-                float al = 1.f;
-                if (p.g_alpha && m0 + r < p.M) al = p.g_alpha[m0 + r];
 #pragma unroll
                 for (int cidx = 0; cidx < 4; ++cidx) {
                     float gv = areg[4 * i + cidx];
-                    if (p.g_alpha) gv = gv > 0.f ? gv : gv * al;
-                    As[buf][k4 + cidx][r] = gv;
+                    if (has_ga) gv = gv > 0.f ? gv : gv * g_al[i];
+                    As[buf][k4 + cidx][r] = gv * keep;
                 }
             }
         } else {
@@ -226,7 +247,7 @@ __global__ void __launch_bounds__(NTHREADS, (ZPT <= ZPT_SMALL ? 2 : 1)) wgrad_ge
                 if (part >= 0 && (i * NP) / A_ROWS != part) continue;
                 const int r = (tid >> 5) + 8 * i;
                 float gv = areg[i];
-                if (p.g_alpha && m0 + r < p.M) gv = gv > 0.f ? gv : gv * p.g_alpha[m0 + r];
+                if (has_ga && m0 + r < p.M) gv = gv > 0.f ? gv : gv * p.g_alpha[m0 + r];
                 As[buf][tid & 31][r] = gv;
             }
         }
@@ -234,10 +255,21 @@ __global__ void __launch_bounds__(NTHREADS, (ZPT <= ZPT_SMALL ? 2 : 1)) wgrad_ge
         for (int t = 0; t < ZPT; ++t) {
             if (part >= 0 && (t * NP) / ZPT != part) continue;
             float v = zreg[t];
-            if ((p.in_scale || p.in_alpha) && (zmask & (1u << t))) {
-                const int ci = c_lo + (int)div_magic((unsigned)(tid + NTHREADS * t), pl.span_magic);
-                if (p.in_scale) v = v * p.in_scale[ci] + p.in_shift[ci];
-                if (p.in_alpha) v = v > 0.f ? v : v * p.in_alpha[ci];
+            if (has_xf) {
+                float sc, sh, al;
+                if (PRE) {
+                    sc = z_sc[PRE ? t : 0]; sh = z_sh[PRE ? t : 0]; al = z_al[PRE ? t : 0];
+                } else {
+                    const int e = min(tid + NTHREADS * t, max(total - 1, 0));
+                    const int ci = min(c_lo + (int)div_magic((unsigned)e, pl.span_magic), p.Cin - 1);
+                    sc = has_aff ? p.in_scale[ci] : 1.f;
+                    sh = has_aff ? p.in_shift[ci] : 0.f;
+                    al = has_al ? p.in_alpha[ci] : 1.f;
+                }
+                v = fmaf(v, sc, sh);
+                v = v > 0.f ? v : v * al;
+                // padding / out-of-range samples are zeros of the ACTIVATED tensor
+                if (!zfast_next && !(zmask & (1u << t))) v = 0.f;
             }
             Zs[buf][tid + NTHREADS * t] = v;
         }
@@ -330,6 +362,180 @@ __global__ void __launch_bounds__(NTHREADS, (ZPT <= ZPT_SMALL ? 2 : 1)) wgrad_ge
     }
 }
 
+
+// ---- 1x1 layers (taps == 1): dW[m, j] += sum_n G[m, n] * act(bn(Z[j, n])), n = (s, q) flattened -- a plain
+// "NT" GEMM whose two operands are both contiguous along the reduction.  Dedicated kernel: every thread owns
+// fixed G rows / Z channels for the whole tile (float4 along time), so the per-row PReLU slope and the
+// per-channel affine are loaded once per tile, a stage costs one magic division + 8 unconditional
+// global_load_dwordx4 per thread, and both slabs sit k-major in LDS (pitch BM+1 / BN+1: conflict-free
+// fragment reads).  ~140 VGPRs -> 2 workgroups per CU (the generic kernel needs the 1-wave/SIMD variant here).
+struct alignas(16) WF4 { float x, y, z, w; };
+
+template <int BM, int BN>
+__global__ void __launch_bounds__(NTHREADS, 2) wgrad_flat_kernel(PaseWgrad p, WgradPlan pl) {
+    constexpr int WAVES_N = BN / 64;
+    constexpr int GS = BM / 32;      // G float4 slots per thread (8 threads x float4 = 32 time steps per row)
+    constexpr int ZSL = BN / 32;     // Z float4 slots per thread
+    __shared__ float As[2][BKQ][BM + 1];
+    __shared__ float Zs[2][BKQ][BN + 1];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = pase_uniform(tid >> 6);
+    const int wm = wave / WAVES_N;
+    const int wn = wave % WAVES_N;
+    const int fr = lane & 31;
+    const int fk = lane >> 5;
+
+    const int tiles = pl.n_row_tiles * pl.n_col_tiles;
+    const int tile = blockIdx.x % tiles;
+    const int split = blockIdx.x / tiles;
+    const int mt = tile % pl.n_row_tiles;
+    const int ct = tile / pl.n_row_tiles;
+    const int m0 = mt * BM;
+    const int j0 = ct * BN;
+    const int Kw = p.Cin;
+    const int c_begin = split * pl.kt_per_split;
+    const int c_end = min(pl.n_chunks, c_begin + pl.kt_per_split);
+    if (c_begin >= c_end) return;
+    const int ntot = p.S * p.Ncols;
+
+    // thread -> rows (tid >> 3) + 32*i, time steps k4 .. k4+3 of the chunk
+    const int k4 = (tid & 7) * 4;
+    const int r0 = tid >> 3;
+    unsigned goff[GS], zoff[ZSL];
+    float g_al[GS], z_sc[ZSL], z_sh[ZSL], z_al[ZSL];
+    const bool has_ga = p.g_alpha != nullptr;
+    const bool has_aff = p.in_scale != nullptr, has_al = p.in_alpha != nullptr;
+#pragma unroll
+    for (int i = 0; i < GS; ++i) {
+        const int m = min(m0 + r0 + 32 * i, p.M - 1);          // rows past M re-read row M-1 (never stored)
+        goff[i] = (unsigned)((p.g_coff + m) * p.Tg);
+        g_al[i] = has_ga ? p.g_alpha[m] : 1.f;
+    }
+#pragma unroll
+    for (int i = 0; i < ZSL; ++i) {
+        const int j = min(j0 + r0 + 32 * i, Kw - 1);
+        zoff[i] = (unsigned)((p.z_coff + j) * p.Tz);
+        z_sc[i] = has_aff ? p.in_scale[j] : 1.f;
+        z_sh[i] = has_aff ? p.in_shift[j] : 0.f;
+        z_al[i] = has_al ? p.in_alpha[j] : 1.f;
+    }
+    WF4 areg[GS], zreg[ZSL];
+    bool valid_next = true;
+
+    auto load_stage = [&](int c) __attribute__((always_inline)) {
+        const int n = c * BKQ + k4;                              // 4 consecutive n share a sequence (Ncols % 4 == 0)
+        valid_next = n < ntot;
+        const unsigned nn = (unsigned)min(n, ntot - 4);
+        int s = (int)div_magic(nn, pl.ncols_magic);
+        int q = (int)nn - s * p.Ncols;
+        if (q < 0) { --s; q += p.Ncols; }
+        const float* gb = p.g + (unsigned)(s * p.g_ctot * p.Tg + q);
+        const float* zb = p.z + (unsigned)(s * p.z_ctot * p.Tz + q);
+#pragma unroll
+        for (int i = 0; i < GS; ++i) areg[i] = *reinterpret_cast<const WF4*>(gb + goff[i]);
+#pragma unroll
+        for (int i = 0; i < ZSL; ++i) zreg[i] = *reinterpret_cast<const WF4*>(zb + zoff[i]);
+    };
+    auto prelu = [&](float v, float al) __attribute__((always_inline)) { return v > 0.f ? v : v * al; };
+    auto store_stage = [&](int buf) __attribute__((always_inline)) {
+        const float keep = valid_next ? 1.f : 0.f;               // chunk tail beyond S*Ncols contributes zero
+#pragma unroll
+        for (int i = 0; i < GS; ++i) {
+            const int r = r0 + 32 * i;
+            WF4 v = areg[i];
+            if (has_ga) { v.x = prelu(v.x, g_al[i]); v.y = prelu(v.y, g_al[i]); v.z = prelu(v.z, g_al[i]); v.w = prelu(v.w, g_al[i]); }
+            As[buf][k4 + 0][r] = v.x * keep;
+            As[buf][k4 + 1][r] = v.y * keep;
+            As[buf][k4 + 2][r] = v.z * keep;
+            As[buf][k4 + 3][r] = v.w * keep;
+        }
+#pragma unroll
+        for (int i = 0; i < ZSL; ++i) {
+            const int r = r0 + 32 * i;
+            WF4 v = zreg[i];
+            if (has_aff || has_al) {
+                v.x = prelu(fmaf(v.x, z_sc[i], z_sh[i]), z_al[i]); v.y = prelu(fmaf(v.y, z_sc[i], z_sh[i]), z_al[i]);
+                v.z = prelu(fmaf(v.z, z_sc[i], z_sh[i]), z_al[i]); v.w = prelu(fmaf(v.w, z_sc[i], z_sh[i]), z_al[i]);
+            }
+            Zs[buf][k4 + 0][r] = v.x;
+            Zs[buf][k4 + 1][r] = v.y;
+            Zs[buf][k4 + 2][r] = v.z;
+            Zs[buf][k4 + 3][r] = v.w;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const bool do_rowsum = p.dbias && ct == 0;
+    float rowsum = 0.f;
+
+    load_stage(c_begin);
+    store_stage(0);
+    __syncthreads();
+    for (int c = c_begin; c < c_end; ++c) {
+        const int cur = (c - c_begin) & 1;
+        const bool has_next = c + 1 < c_end;
+        if (has_next) load_stage(c + 1);
+        const float* as_ = &As[cur][fk][wm * 64 + fr];
+        const float* zs_ = &Zs[cur][fk][wn * 64 + fr];
+        auto fetch = [&](int ks, float& a0, float& a1, float& b0, float& b1) __attribute__((always_inline)) {
+            const int kc = min(ks, BKQ / 2 - 1);      // the one fetch past the end stays in bounds
+            a0 = as_[kc * 2 * (BM + 1)];
+            a1 = as_[kc * 2 * (BM + 1) + 32];
+            b0 = zs_[kc * 2 * (BN + 1)];
+            b1 = zs_[kc * 2 * (BN + 1) + 32];
+        };
+        float pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1;
+        fetch(0, pa0, pa1, pb0, pb1);
+#pragma unroll
+        for (int it = 0; it < BKQ / 4; ++it) {       // 8 iterations x 2 k-steps, fully unrolled
+            const int ks = it * 2;
+            fetch(ks + 1, qa0, qa1, qb0, qb1);
+            PASE_SCHED_BARRIER();
+            acc[0][0] = pase_mfma_32x32x2(pa0, pb0, acc[0][0]);
+            acc[0][1] = pase_mfma_32x32x2(pa0, pb1, acc[0][1]);
+            acc[1][0] = pase_mfma_32x32x2(pa1, pb0, acc[1][0]);
+            acc[1][1] = pase_mfma_32x32x2(pa1, pb1, acc[1][1]);
+            PASE_SCHED_BARRIER();
+            fetch(ks + 2, pa0, pa1, pb0, pb1);
+            PASE_SCHED_BARRIER();
+            acc[0][0] = pase_mfma_32x32x2(qa0, qb0, acc[0][0]);
+            acc[0][1] = pase_mfma_32x32x2(qa0, qb1, acc[0][1]);
+            acc[1][0] = pase_mfma_32x32x2(qa1, qb0, acc[1][0]);
+            acc[1][1] = pase_mfma_32x32x2(qa1, qb1, acc[1][1]);
+            PASE_SCHED_BARRIER();
+        }
+        if (do_rowsum && tid < BM) {
+#pragma unroll 8
+            for (int kq = 0; kq < BKQ; ++kq) rowsum += As[cur][kq][tid];
+        }
+        if (has_next) store_stage(cur ^ 1);
+        __syncthreads();
+    }
+    if (do_rowsum && tid < BM && m0 + tid < p.M) atomicAdd(p.dbias + m0 + tid, rowsum);
+
+    const int rbase = m0 + wm * 64 + 4 * (lane >> 5);
+    const int jb = j0 + wn * 64 + fr;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = rbase + a * 32 + (r & 3) + 8 * (r >> 2);
+            if (m >= p.M) continue;
+            const unsigned rowoff = (unsigned)(m * p.ldw);
+            if (jb < Kw) atomicAdd(p.dw + (rowoff + (unsigned)jb), acc[a][0][r]);
+            if (jb + 32 < Kw) atomicAdd(p.dw + (rowoff + (unsigned)(jb + 32)), acc[a][1][r]);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
@@ -343,7 +549,15 @@ extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
     bool narrow = p.M <= 64;
     WgradPlan pl;
     pl.flat = (p.taps == 1 && p.stride == 1 && p.padL == 0 && p.tapstep == 1) ? 1 : 0;
-    pl.SPANW = pl.flat ? BKQ : (BKQ - 1) * p.stride + p.taps;
+    // dedicated 1x1 kernel: float4 along time on both operands, 32-bit element offsets
+    const bool flat_fast = pl.flat && (p.Ncols % 4) == 0 && (p.Tg % 4) == 0 && (p.Tz % 4) == 0 &&
+                           (((unsigned long long)(size_t)p.g) % 16) == 0 && (((unsigned long long)(size_t)p.z) % 16) == 0 &&
+                           (long)p.S * p.g_ctot * (long)p.Tg < 0x7fffffffL && (long)p.S * p.z_ctot * (long)p.Tz < 0x7fffffffL &&
+                           (long)p.M * p.ldw < 0x7fffffffL && (long)p.S * p.Ncols >= 4;
+    if (flat_fast) narrow = false;
+    // flat (1x1): one extra (unused) sample per channel row makes the LDS row pitch odd -- the 32 lanes of a
+    // B fragment read 32 different rows at the same k, which with a pitch of 32 is one bank
+    pl.SPANW = pl.flat ? BKQ + 1 : (BKQ - 1) * p.stride + p.taps;
     auto need = [&](int bn) {
         long max_nc = (bn - 1) / p.taps + 2;     // channels a tile of bn (ci,kk) columns can touch
         if (max_nc > p.Cin) max_nc = p.Cin;
@@ -354,7 +568,7 @@ extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
     const bool small = need(narrow ? 256 : 128) <= ZPT_SMALL * NTHREADS;
     const int BMv = narrow ? 64 : 128, BNv = narrow ? 256 : 128;
     if ((BKQ - 1) * (pl.flat ? 1 : p.stride) + 1 > ZS_ONES) return -6;
-    pl.bias_rowsum = (p.dbias && ((p.Cin * p.taps) % BNv) == 0) ? 1 : 0;
+    pl.bias_rowsum = (p.dbias && (flat_fast || ((p.Cin * p.taps) % BNv) == 0)) ? 1 : 0;
     const int Nw = p.Cin * p.taps + ((p.dbias && !pl.bias_rowsum) ? 1 : 0);
     pl.n_row_tiles = (p.M + BMv - 1) / BMv;
     pl.n_col_tiles = (Nw + BNv - 1) / BNv;
@@ -363,7 +577,8 @@ extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
     pl.n_chunks = pl.flat ? (int)((kred + BKQ - 1) / BKQ) : p.S * pl.chunks_per_seq;
     pl.span_magic = (unsigned)((0x100000000ULL + pl.SPANW - 1) / (unsigned long long)pl.SPANW);
     pl.ncols_magic = (unsigned)((0x100000000ULL + p.Ncols - 1) / (unsigned long long)p.Ncols);
-    pl.gvec = ((p.Tg % 4) == 0 && (p.Ncols % 4) == 0 && (((unsigned long long)(size_t)p.g) % 16) == 0) ? 1 : 0;
+    pl.gvec = ((p.Tg % 4) == 0 && (p.Ncols % 4) == 0 && (((unsigned long long)(size_t)p.g) % 16) == 0 &&
+               (long)p.S * p.g_ctot * (long)p.Tg < 0x7fffffffL) ? 1 : 0;
     const int tiles = pl.n_row_tiles * pl.n_col_tiles;
     int splitk = p.splitk;
     if (splitk <= 0) {
@@ -376,6 +591,11 @@ extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
     pl.kt_per_split = (pl.n_chunks + splitk - 1) / splitk;
     splitk = (pl.n_chunks + pl.kt_per_split - 1) / pl.kt_per_split;
     const dim3 grid((unsigned)(tiles * splitk)), block(NTHREADS);
+    if (flat_fast) {
+        PASE_LAUNCH((wgrad_flat_kernel<128, 128>), grid, block, st, p, pl);
+        PASE_CHECK_LAUNCH();
+        return 0;
+    }
     if (narrow && small)       PASE_LAUNCH((wgrad_gemm_kernel<64, 256, ZPT_SMALL>), grid, block, st, p, pl);
     else if (narrow)           PASE_LAUNCH((wgrad_gemm_kernel<64, 256, ZPT_LARGE>), grid, block, st, p, pl);
     else if (small)            PASE_LAUNCH((wgrad_gemm_kernel<128, 128, ZPT_SMALL>), grid, block, st, p, pl);

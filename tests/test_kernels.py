@@ -46,6 +46,30 @@ def test_wgrad_flat_1x1_and_narrow(dev):
         assert_close(db, g.sum((0, 2)), rtol=1e-4, atol=1e-3)
 
 
+def test_wgrad_flat_vector_kernel(dev):
+    """1x1 layers with T % 4 == 0 take the dedicated NT kernel: ragged M / Cin, chunk tail (S*T % 32 != 0),
+    channel slices of wider tensors, on-load PReLU on G and affine + PReLU on Z, bias from G row sums."""
+    torch.manual_seed(7)
+    for (S, Cin, Cout, T, gx, zx) in [(3, 84, 273, 200, 0, 0), (2, 130, 150, 36, 5, 7), (5, 256, 64, 20, 0, 3),
+                                     (1, 12, 300, 4, 2, 0)]:
+        xw = torch.randn(S, Cin + zx + 2, T)
+        gw = torch.randn(S, Cout + gx + 3, T)
+        sc, sh, al = torch.rand(Cin) + 0.5, torch.randn(Cin), torch.rand(Cin) * 0.5
+        ga = torch.rand(Cout) * 0.5
+        x = xw[:, zx:zx + Cin] * sc[None, :, None] + sh[None, :, None]
+        x = torch.where(x > 0, x, x * al[None, :, None])
+        g = gw[:, gx:gx + Cout]
+        g = torch.where(g > 0, g, g * ga[None, :, None])
+        ref = torch.einsum("sot,sct->oc", g.double(), x.double()).float()
+        dw = torch.zeros(Cout, Cin, device=dev)
+        db = torch.zeros(Cout, device=dev)
+        K.wgrad_gemm(gw.to(dev), xw.to(dev), dw, S=S, M=Cout, Tg=T, Ncols=T, Cin=Cin, Tz=T, taps=1, dbias=db,
+                     g_ctot=gw.shape[1], g_coff=gx, z_ctot=xw.shape[1], z_coff=zx, in_scale=sc.to(dev),
+                     in_shift=sh.to(dev), in_alpha=al.to(dev), g_alpha=ga.to(dev))
+        assert_close(dw, ref, rtol=1e-4, atol=2e-3, what="dW %s" % ((S, Cin, Cout, T),))
+        assert_close(db, g.sum((0, 2)), rtol=1e-4, atol=2e-3, what="db")
+
+
 def test_wgrad_conv_transpose_roles_swapped(dev):
     """nn.ConvTranspose1d weight gradient: G = PReLU(layer input) at the low rate, Z = dY."""
     torch.manual_seed(2)
