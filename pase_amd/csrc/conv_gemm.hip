@@ -110,7 +110,9 @@ __device__ unsigned long long g_tacc[PASE_TRACE_SLOTS * 4];
 struct alignas(16) F4 { float x, y, z, w; };
 
 // identity on-load parameters for launches without an affine / PReLU ({scale = alpha = 1}, {shift = 0})
-__device__ const float g_ident[2] = {1.f, 0.f};
+// (plain global memory, not constant address space: a pointer selected between it and a kernel argument
+// must stay a GLOBAL pointer -- a generic one turns the loads into flat_load and every wait into vmcnt(0))
+__device__ float g_ident[2] = {1.f, 0.f};
 
 // NS = X slots per thread (the plan rounds its slot count up to 3 / 6 / 12), XV = float4 slots (flat 1x1).
 // Both are compile-time so that the per-stage loader is straight-line code: every load is issued
@@ -187,20 +189,20 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
     const int xrow = tid >> pl.tl;
     const int xc = tid & (TPR - 1);
     const int xs_tbase = xrow * pl.SPAN + (XV ? 4 * xc : xc);
-    const int slot_stride = pl.pmajor ? RPP * pl.SPAN : TPR;   // LDS distance between a thread's slots
+    constexpr bool PM = XV != 0;   // row-major slots (flat 1x1, always float4) vs sample-major slots
+    const int slot_stride = PM ? RPP * pl.SPAN : TPR;   // LDS distance between a thread's slots
     float xreg[NXR];
     int xoff[NS];                  // element offset of slot t relative to channel ci0 of sequence 0
     unsigned xmask = 0u;           // slot t holds a real sample (else zero padding / out of range)
-    constexpr int NP = (NS <= NPAR) ? NS : 1;  // (scale, shift, alpha) triples prefetched per stage
+    static_assert(!PM || NS <= NPAR, "row-major slots prefetch one parameter triple per slot");
+    constexpr int NP = PM ? NS : 1;            // (scale, shift, alpha) triples prefetched per stage
     float par_s[NP], par_h[NP], par_a[NP];
     const bool has_xf = p.in_scale != nullptr || p.in_alpha != nullptr;
     const float* sc_p = p.in_scale ? p.in_scale : &g_ident[0];
     const float* sh_p = p.in_scale ? p.in_shift : &g_ident[1];
     const float* al_p = p.in_alpha ? p.in_alpha : &g_ident[0];
     const int aff_on = p.in_scale ? 1 : 0, alpha_on = p.in_alpha ? 1 : 0;
-    // pmajor with more rows per thread than prefetched triples (odd flat shapes): fetched per slot
-    const bool slow_par = pl.pmajor && NS > NPAR;
-    int kg_next = 0, tbe_next = 0, lo_next = 0, ci0s_next = 0;
+    int kg_next = 0, tbe_next = 0, lo_next = 0;
 
     // (sequence, time) of span sample i for tap-group offset koffs -> element offset / validity
     auto locate = [&](int i, int koffs, int& off, bool& ok) __attribute__((always_inline)) {
@@ -228,10 +230,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
     auto slot_setup = [&](int kk0, int TBe) __attribute__((always_inline)) {
         xmask = 0u;
         const int koffs = (p.tapstep > 0) ? kk0 : -(kk0 + TBe - 1);
-        if (pl.pmajor) {
+        if (PM) {
             int off;
             bool ok;
-            locate(XV ? 4 * xc : xc, koffs, off, ok);
+            locate(4 * xc, koffs, off, ok);
 #pragma unroll
             for (int t = 0; t < NS; ++t) {
                 const int row = xrow + t * RPP;
@@ -268,7 +270,6 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
         lo_next = (ci0 - ci0s) * pl.TB;
         kg_next = slots_invariant ? pl.CB * pl.TB : TBe;
         tbe_next = TBe;
-        ci0s_next = ci0s;
         if (++gt_n == pl.n_gt) { gt_n = 0; ++gc_n; }
         if (!slots_invariant) {
             slot_setup(kk0, TBe);
@@ -296,7 +297,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
         }
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-            const int ch = min(ci0s + xrow + (pl.pmajor ? j * RPP : 0), p.Cin - 1);
+            const int ch = min(ci0s + xrow + j * RPP, p.Cin - 1);
             par_s[j] = sc_p[ch * aff_on];
             par_h[j] = sh_p[ch * aff_on];
             par_a[j] = al_p[ch * alpha_on];
@@ -325,12 +326,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
 #pragma unroll
             for (int e = 0; e < W; ++e) v[e] = xreg[W * t + e];
             if (has_xf) {   // uniform
-                float sc = par_s[NP > 1 ? t : 0], sh = par_h[NP > 1 ? t : 0], al = par_a[NP > 1 ? t : 0];
-                if (NP > 1 && !pl.pmajor) { sc = par_s[0]; sh = par_h[0]; al = par_a[0]; }
-                if (slow_par) {
-                    const int ch = min(ci0s_next + xrow + t * RPP, p.Cin - 1);
-                    sc = sc_p[ch * aff_on]; sh = sh_p[ch * aff_on]; al = al_p[ch * alpha_on];
-                }
+                const float sc = par_s[PM ? t : 0], sh = par_h[PM ? t : 0], al = par_a[PM ? t : 0];
 #pragma unroll
                 for (int e = 0; e < W; ++e) v[e] = xform(v[e], sc, sh, al);
             }
@@ -399,6 +395,19 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
             xo += xstepk + ((j == jc) ? D : 0) + endj;
             j = (j == tbe - 1) ? 0 : j + 1;
         };
+#ifndef PASE_LOOP_VARIANT
+#define PASE_LOOP_VARIANT 0
+#endif
+#if PASE_LOOP_VARIANT == 2
+        for (int ks = 0; ks < nks; ++ks) {
+            float a0, a1, b0, b1;
+            fetch(ks, a0, a1, b0, b1);
+            acc[0][0] = pase_mfma_32x32x2(a0, b0, acc[0][0]);
+            acc[0][1] = pase_mfma_32x32x2(a0, b1, acc[0][1]);
+            acc[1][0] = pase_mfma_32x32x2(a1, b0, acc[1][0]);
+            acc[1][1] = pase_mfma_32x32x2(a1, b1, acc[1][1]);
+        }
+#else
         // ping-pong operand registers (P/Q), two k-steps per iteration: no register copies, so the
         // wait before a step's MFMAs covers only that step's own ds_reads
         float pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1;
@@ -408,11 +417,15 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
         // Interleave: the index arithmetic + ds_reads of the NEXT step are spread between the four MFMAs
         // of the current step (a wave that has issued a 64-cycle MFMA cannot issue the next one for
         // ~60 cycles anyway), instead of sitting in a serial block behind them.
+#if PASE_LOOP_VARIANT == 1
+#define PASE_STEP_SCHED()
+#else
 #define PASE_STEP_SCHED()                                             \
         PASE_SGB(0x008, 1); PASE_SGB(0x002, 3); PASE_SGB(0x100, 1);   \
         PASE_SGB(0x008, 1); PASE_SGB(0x002, 3); PASE_SGB(0x100, 1);   \
         PASE_SGB(0x008, 1); PASE_SGB(0x002, 3); PASE_SGB(0x100, 1);   \
         PASE_SGB(0x008, 1); PASE_SGB(0x002, 3);
+#endif
         for (int ks = 0; ks < nks2; ks += 2) {
             fetch(ks + 1, qa0, qa1, qb0, qb1);
             // All MFMAs are issued unconditionally: rows / columns beyond the tile edge multiply
@@ -432,6 +445,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
             PASE_SCHED_BARRIER();
         }
 #undef PASE_STEP_SCHED
+#endif
         PASE_TACC(1);
         if (g + 1 < g_end) {
             store_stage(cur ^ 1);
@@ -693,25 +707,23 @@ HostPlan make_plan(const PaseConvGemm& p) {
     const int BM = h.narrow ? 64 : 128;
     h.BN = h.narrow ? 256 : 128;
     ConvPlan& pl = h.pl;
-    const bool flat = (p.taps == 1 && p.stride == 1 && p.padL == 0 && p.tapstep == 1);
+    // flat (1x1 as a plain GEMM over the flattened (s, q) columns) needs float4 slots: 4 consecutive columns
+    // stay inside one sequence and are 16-B aligned.  Other 1x1 shapes run as a one-tap convolution.
+    const bool flat = (p.taps == 1 && p.stride == 1 && p.padL == 0 && p.tapstep == 1) && (p.Ncols % 4) == 0 &&
+                      (p.Tin % 4) == 0 && (((unsigned long long)(size_t)p.x) % 16) == 0;
     pl.mode = flat ? MODE_FLAT : (p.Ncols >= h.BN ? MODE_SEG : MODE_PERSEQ);
-    pl.xvec = 0;
-    pl.pmajor = flat ? 1 : 0;
+    pl.xvec = flat ? 1 : 0;
+    pl.pmajor = pl.xvec;
     if (flat) {
         pl.TB = 1;
         pl.SPANV = pl.SPAN = h.BN;
         pl.CB = XSMAX / h.BN;
         if (pl.CB > KGMAX) pl.CB = KGMAX;
         if (pl.CB > p.Cin) pl.CB = p.Cin;
-        // float4 slots: 4 consecutive columns stay inside one sequence and are 16-B aligned
-        pl.xvec = ((p.Ncols % 4) == 0 && (p.Tin % 4) == 0 && (((unsigned long long)(size_t)p.x) % 16) == 0) ? 1 : 0;
-        const int TPR = pl.xvec ? h.BN / 4 : h.BN;
+        const int TPR = h.BN / 4;
         pl.tl = 0;
         while ((1 << pl.tl) < TPR) ++pl.tl;
-        const int RPP = NTHREADS / TPR;
-        pl.nslots = (pl.CB + RPP - 1) / RPP;
-        if (pl.xvec) pl.nslots = 3;
-        else pl.nslots = pl.nslots <= 3 ? 3 : (pl.nslots <= 6 ? 6 : 12);
+        pl.nslots = 3;
     } else {
         pl.TB = p.taps <= KGMAX ? p.taps : 32;
         // a tile may touch two sequences: each segment carries its own halo of TB samples

@@ -352,7 +352,10 @@ def encoder_backward(fe, ctx, demb, sink):
         # Linear over [x_t ; x_{t-1}] (tap-major columns): one wgrad per tap into the two column halves
         dwq = sink.buf(layer.linear.weight)
         conv_wgrad(dgates, inp, dwq, sink.buf(layer.linear.bias), taps=1, padL=0, pad_mode=K.PAD_ZERO)
-        conv_wgrad(dgates, inp, dwq, None, taps=1, padL=1, pad_mode=K.PAD_ZERO, dw_col_off=cin)
+        # x_{t-1} tap: sum_q dG[q] x[q-1] = sum_q dG[q+1] x[q] -- shift the GRADIENT left by one (its padding is a
+        # true zero; the input's would have to be a zero of the activated tensor) and stay on the 1x1 kernel
+        dg_next = torch.nn.functional.pad(dgates[:, :, 1:], (0, 1))
+        conv_wgrad(dg_next, inp, dwq, None, taps=1, padL=0, pad_mode=K.PAD_ZERO, dw_col_off=cin)
         # dX[s,ci,u] = sum_{o,r} Wq[o, r*cin+ci] * dG[s,o,u+r]
         wp = _new((cin, 3 * H * 2), x)
         K.pack_dgrad(layer.linear.weight, wp, R=3 * H, O=cin, k=2, st=1, s_red=2 * cin, s_out=1, s_k=cin)

@@ -10,12 +10,13 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-SO = os.path.join(ROOT, "tools", "_trace", "libpase_trace.so")
+SO = os.environ.get("PASE_TRACE_SO", os.path.join(ROOT, "tools", "_trace", "libpase_trace.so"))
+EXTRA = os.environ.get("PASE_TRACE_DEFS", "").split()
 
 if sys.argv[1] == "build":
     from pase_amd import build as B
     srcs = B._sources()
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DPASE_TRACE",
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DPASE_TRACE"] + EXTRA + [
            "-I", B.INCLUDE, "-I", B.CSRC, "-Wno-unused-result", "-o", SO] + srcs
     subprocess.check_call(cmd)
     print(SO)
