@@ -203,6 +203,10 @@ int pase_sinc_filters_bwd(const float* low_hz_, const float* band_hz_, const flo
  * conv / the forward of nn.ConvTranspose1d (phase decomposition). */
 int pase_pack_dgrad(const float* src, float* dst, int R, int O, int k, int st, long s_red, long s_out, long s_k,
                     void* stream);
+/* same pack written K-major for pase_conv_gemm's `wt` operand: dst ((R*ceil(k/st)), ldt),
+ * dst[(red*taps_p + j)*ldt + (p*O + o)]; ldt % 4 == 0, ldt >= st*O, pad columns zero-filled */
+int pase_pack_dgrad_t(const float* src, float* dst, int R, int O, int k, int st, long s_red, long s_out,
+                      long s_k, int ldt, void* stream);
 
 /* torch.optim.Adam (defaults; WorkerScheduler/trainer.py:91,111,134) over flat buffers; lr and step
  * are device scalars so a captured hipGraph stays valid.  grad_mul pre-scales g (1/world_size). */

@@ -758,8 +758,9 @@ HostPlan make_plan(const PaseConvGemm& p) {
     const int G = pl.n_gc * pl.n_gt;
     if (p.splitk > 1) splitk = p.splitk;
     else if (p.splitk == 0 && !p.stat_part && p.epilogue == PASE_EPI_STORE && p.post_op == PASE_POST_NONE && tiles < 192) {
-        // auto: few output tiles and a long reduction (head / deconv data-gradients) -> fill the chip
-        splitk = (int)((384 + tiles - 1) / tiles);
+        // auto: few output tiles and a long reduction (head / deconv data-gradients) -> fill the chip's
+        // 512 workgroup slots (2 per CU) as exactly as the tile count allows
+        splitk = (int)(512 / tiles);
         if (splitk > G / 6) splitk = G / 6;
         if (splitk < 1) splitk = 1;
     }

@@ -86,12 +86,11 @@ def conv_dgrad(dy, w_nat, *, R, O, k, stride, Tin, padL, padR, s_red, s_out, s_k
     dXpad[s,o,u] = sum_{red,kk} W[red,o,kk] * dy[s,red,(u-kk)/stride]  (phase decomposition)."""
     S, _, Tg = dy.shape
     taps_p = -(-k // stride)
-    wp = _new((stride * O, R * taps_p), dy)
-    K.pack_dgrad(w_nat, wp, R=R, O=O, k=k, st=stride, s_red=s_red, s_out=s_out, s_k=s_k)
+    wt = K.pack_dgrad_t(w_nat, R=R, O=O, k=k, st=stride, s_red=s_red, s_out=s_out, s_k=s_k)
     Tp = Tin + padL + padR
     Ncols = -(-Tp // stride)
     dx = _new((S, O, Tp), dy)
-    K.conv_gemm(dy, wp, dx, S=S, Cin=R, Tin=Tg, M=stride * O, K=R * taps_p, taps=taps_p, Ncols=Ncols, Tout=Tp,
+    K.conv_gemm(dy, None, dx, wt=wt, S=S, Cin=R, Tin=Tg, M=stride * O, K=R * taps_p, taps=taps_p, Ncols=Ncols, Tout=Tp,
                 stride=1, tapstep=-1, padL=0, pad_mode=K.PAD_ZERO, Cout_store=O, ps=stride, poff=0)
     return dx
 
@@ -112,11 +111,10 @@ def deconv_fwd(a: Act, w_nat, bias, *, Cout, k, stride):
     S, Tin = a.S, a.T
     pad = max(0, (stride - k) // -2)
     taps_p = -(-k // stride)
-    wp = _new((stride * Cout, a.C * taps_p), a.t)
-    K.pack_dgrad(w_nat, wp, R=a.C, O=Cout, k=k, st=stride, s_red=Cout * k, s_out=k, s_k=1)
+    wt = K.pack_dgrad_t(w_nat, R=a.C, O=Cout, k=k, st=stride, s_red=Cout * k, s_out=k, s_k=1)
     Tout = (Tin - 1) * stride - 2 * pad + k
     y = _new((S, Cout, Tout), a.t)
-    K.conv_gemm(a.t, wp, y, S=S, Cin=a.C, Tin=Tin, M=stride * Cout, K=a.C * taps_p, taps=taps_p,
+    K.conv_gemm(a.t, None, y, wt=wt, S=S, Cin=a.C, Tin=Tin, M=stride * Cout, K=a.C * taps_p, taps=taps_p,
                 Ncols=Tin + taps_p - 1, Tout=Tout, bias=bias, in_scale=a.scale, in_shift=a.shift, in_alpha=a.alpha,
                 x_ctot=a.ctot, x_coff=a.coff, stride=1, tapstep=-1, padL=0, pad_mode=K.PAD_ZERO, Cout_store=Cout,
                 ps=stride, poff=-pad)
@@ -357,10 +355,9 @@ def encoder_backward(fe, ctx, demb, sink):
         dg_next = torch.nn.functional.pad(dgates[:, :, 1:], (0, 1))
         conv_wgrad(dg_next, inp, dwq, None, taps=1, padL=0, pad_mode=K.PAD_ZERO, dw_col_off=cin)
         # dX[s,ci,u] = sum_{o,r} Wq[o, r*cin+ci] * dG[s,o,u+r]
-        wp = _new((cin, 3 * H * 2), x)
-        K.pack_dgrad(layer.linear.weight, wp, R=3 * H, O=cin, k=2, st=1, s_red=2 * cin, s_out=1, s_k=cin)
+        wt = K.pack_dgrad_t(layer.linear.weight, R=3 * H, O=cin, k=2, st=1, s_red=2 * cin, s_out=1, s_k=cin)
         dxl = _new((S, cin, F_), x)
-        K.conv_gemm(dgates, wp, dxl, S=S, Cin=3 * H, Tin=F_, M=cin, K=3 * H * 2, taps=2, Ncols=F_, Tout=F_,
+        K.conv_gemm(dgates, None, dxl, wt=wt, S=S, Cin=3 * H, Tin=F_, M=cin, K=3 * H * 2, taps=2, Ncols=F_, Tout=F_,
                     stride=1, tapstep=1, padL=0, pad_mode=K.PAD_ZERO)
         dsrc, dsrc_ctot, dsrc_coff = dxl, cin, 0
     # ---- conv blocks, last to first -----------------------------------------------------------------

@@ -232,6 +232,7 @@ _SIMPLE.update({
     "pase_sinc_filters": [_fp, _fp, _fp, _fp, _fp, _i, _i, _f, _f, _f, _fp],
     "pase_sinc_filters_bwd": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _f, _f, _f, _fp],
     "pase_pack_dgrad": [_fp, _fp, _i, _i, _i, _i, _l, _l, _l, _fp],
+    "pase_pack_dgrad_t": [_fp, _fp, _i, _i, _i, _i, _l, _l, _l, _i, _fp],
     "pase_pack_wt": [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp],
     "pase_adam_step": [_fp, _fp, _fp, _fp, _l, _fp, _fp, _f, _f, _f, _f, _fp],
     "pase_step_tick": [_fp, _fp],
@@ -363,6 +364,20 @@ def sinc_filters_bwd(low, band, n_, window_, dfilt, dlow, dband, *, C_, Kw, min_
 def pack_dgrad(src, dst, *, R, O, k, st, s_red, s_out, s_k):
     _check(_lib.lib().pase_pack_dgrad(_ptr(src), _ptr(dst), R, O, k, st, s_red, s_out, s_k, _stream()),
            "pase_pack_dgrad")
+
+
+def pack_dgrad_t(src, *, R, O, k, st, s_red, s_out, s_k):
+    """K-major data-gradient / transposed-conv weight pack, ready to be conv_gemm's wt= operand.
+    A 1x1 weight stored (R, O) row-major already IS that pack: it is returned as is when aligned."""
+    taps_p = -(-k // st)
+    if (k == 1 and st == 1 and s_red == O and s_out == 1 and O % 4 == 0 and src.data_ptr() % 16 == 0
+            and src.is_contiguous()):
+        return src.view(R, O)
+    ldt = (st * O + 3) // 4 * 4
+    dst = torch.empty(R * taps_p, ldt, device=src.device, dtype=torch.float32)
+    _check(_lib.lib().pase_pack_dgrad_t(_ptr(src), _ptr(dst), R, O, k, st, s_red, s_out, s_k, ldt, _stream()),
+           "pase_pack_dgrad_t")
+    return dst
 
 
 def adam_step(p, g, m, v, lr, step, *, beta1=0.9, beta2=0.999, eps=1e-8, grad_mul=1.0):
