@@ -127,11 +127,14 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
     constexpr int PA_MAX = KGMAX / RA;     // 6 / 3
     constexpr int LDA = BM + 4;
     __shared__ __attribute__((aligned(16))) float As[2][KGMAX][LDA];
-    __shared__ __attribute__((aligned(16))) float Xs[2][XSMAX];
+    // 4 guard floats (zero) in front of each X buffer: the one zero-weight tap a reversed-tap single-row stage
+    // with an odd tap count reads at span offset -1 must be finite
+    __shared__ __attribute__((aligned(16))) float XsG[2][XSMAX + 4];
     __shared__ float red[WAVES_N][BM][2];
 
     PASE_STAMP(0);
     const int tid = threadIdx.x;
+    if (tid < 8) XsG[tid >> 2][tid & 3] = 0.f;
     const int lane = tid & 63;
     const int wave = pase_uniform(tid >> 6);   // provably wave-uniform: tile-shape branches stay scalar
     const int wm = wave / WAVES_N;
@@ -318,7 +321,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
             *reinterpret_cast<F4*>(&As[buf][kl][acl]) = v;
         }
         // ---- X
-        float* xs = &Xs[buf][xs_tbase];
+        float* xs = &XsG[buf][4 + xs_tbase];
 #pragma unroll
         for (int t = 0; t < NS; ++t) {
             constexpr int W = XV ? 4 : 1;
@@ -351,8 +354,6 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
     const int j0c = wn * 64 + fr, j1c = wn * 64 + 32 + fr;
     const int xc0 = (pl.mode != MODE_FLAT && j0c >= lenA) ? SA + (j0c - lenA) * xstep : j0c * xstep;
     const int xc1 = (pl.mode != MODE_FLAT && j1c >= lenA) ? SA + (j1c - lenA) * xstep : j1c * xstep;
-    // a padded / look-ahead step must stay inside the part of Xs every stage rewrites
-    const int xo_lim = NXR * NTHREADS - 1 - max(xc0, xc1);
 
     load_stage();
     PASE_STAMP(1);
@@ -366,68 +367,60 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
         PASE_TACC_BEGIN();
         if (g + 1 < g_end) load_stage();   // global loads in flight under the MFMAs
         PASE_TACC(0);
-        const int nks = (kg + 1) >> 1;
-        // K order inside a stage: channel rows are taken two at a time ("super-row" = 2*tbe flat k,
-        // tbe MFMA steps, so a step never straddles super-rows even for odd tap counts).  This lane's
-        // flat position in step j is f = 2j + fk.  Its span offset advances by +-2 per step, plus one
-        // extra jump D when f crosses from the first to the second row (step j == jc, a per-lane
-        // constant) and the same D at the end of the super-row: ~7 VALU per step, no division, no table.
-        // Operands for step ks+1 are fetched from LDS BEFORE the MFMAs of step ks are issued (register
-        // double buffer), so the ds_read latency hides under the 256 matrix-pipe cycles of the step.
+        // K order inside a stage.  An MFMA step consumes two flat k values (fk = 0 / 1).  With two or more
+        // channel rows per stage (CB is even then) the pair is (row 2p, tap j) / (row 2p+1, tap j); with a
+        // single row it is taps (2s, 2s+1) (an odd tap count ends on a zero-weight tap).  Either way the
+        // LDS offsets of a step are [per-lane constant] + [uniform scalar walk]: the walk is SALU only and
+        // the per-step VALU work is the three address adds of the ds_reads -- index arithmetic in this
+        // loop competes directly with MFMA issue (tools/mfma_probe: -15 % for a 10-instruction walk).
         const int ts = p.tapstep;
-        int xo = (fk >= tbe) ? ((ts > 0) ? pl.SPAN - tbe : pl.SPAN + 2 * tbe - 1) : ((ts > 0) ? 0 : tbe - 1);
-        xo = (ts > 0) ? xo + fk : xo - fk;
-        const bool one_tap = tbe == 1;                       // rows of one tap: plain 2*SPAN stride
-        const int xstepk = one_tap ? 2 * pl.SPAN : 2 * ts;
-        const int D = one_tap ? 0 : ((ts > 0) ? pl.SPAN - tbe : pl.SPAN + tbe);
-        const int jc = one_tap ? -1 : (tbe - fk + 1) / 2 - 1;
-        const float* as_ = &As[cur][fk][wm * 64 + fr];
-        const float* xs_ = &Xs[cur][0];
-        int j = 0;
-        auto fetch = [&](int ks, float& a0, float& a1, float& b0, float& b1) __attribute__((always_inline)) {
-            const int ka = min(ks * 2, KGMAX - 2) * LDA;   // (the one fetch past the end stays in bounds)
-            const int xoc = min(xo, xo_lim);
-            a0 = as_[ka];
-            a1 = as_[ka + 32];
-            b0 = xs_[xoc + xc0];
-            b1 = xs_[xoc + xc1];
-            const int endj = (j == tbe - 1) ? D : 0;       // uniform
-            xo += xstepk + ((j == jc) ? D : 0) + endj;
-            j = (j == tbe - 1) ? 0 : j + 1;
+        const bool pair_rows = pl.CB > 1;                       // uniform
+        const int nks = pair_rows ? (kg >> 1) : ((tbe + 1) >> 1);
+        const int stepX = pair_rows ? ts : 2 * ts;
+        const int stepA = pair_rows ? LDA : 2 * LDA;
+        const int period = pair_rows ? tbe : 0x7fffffff;        // steps until the walk moves to the next row pair
+        const int wrapX = 2 * pl.SPAN - tbe * ts;
+        const int wrapA = tbe * LDA;
+        const int tap0 = ts > 0 ? 0 : tbe - 1;
+        const int lx = pair_rows ? fk * pl.SPAN + tap0 : tap0 + fk * ts;
+        const float* aL = &As[cur][pair_rows ? fk * tbe : fk][wm * 64 + fr];
+        const float* x0L = &XsG[cur][4 + lx + xc0];
+        const float* x1L = &XsG[cur][4 + lx + xc1];
+        int sx = 0, sa = 0, j = 0;
+        auto fetch = [&](float& a0, float& a1, float& b0, float& b1) __attribute__((always_inline)) {
+            a0 = aL[sa];
+            a1 = aL[sa + 32];
+            b0 = x0L[sx];
+            b1 = x1L[sx];
+            ++j;
+            const bool wrap = j == period;                      // uniform
+            sx += stepX + (wrap ? wrapX : 0);
+            sa += stepA + (wrap ? wrapA : 0);
+            j = wrap ? 0 : j;
         };
-#ifndef PASE_LOOP_VARIANT
-#define PASE_LOOP_VARIANT 0
-#endif
-#if PASE_LOOP_VARIANT == 2
-        for (int ks = 0; ks < nks; ++ks) {
-            float a0, a1, b0, b1;
-            fetch(ks, a0, a1, b0, b1);
-            acc[0][0] = pase_mfma_32x32x2(a0, b0, acc[0][0]);
-            acc[0][1] = pase_mfma_32x32x2(a0, b1, acc[0][1]);
-            acc[1][0] = pase_mfma_32x32x2(a1, b0, acc[1][0]);
-            acc[1][1] = pase_mfma_32x32x2(a1, b1, acc[1][1]);
-        }
-#else
         // ping-pong operand registers (P/Q), two k-steps per iteration: no register copies, so the
-        // wait before a step's MFMAs covers only that step's own ds_reads
+        // wait before a step's MFMAs covers only that step's own ds_reads.  The operands of step ks+1 are
+        // fetched from LDS BEFORE the MFMAs of step ks are issued; the fetch past the last step is unused.
         float pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1;
-        fetch(0, pa0, pa1, pb0, pb1);
-        const int nks2 = (nks + 1) & ~1;     // an odd step count is padded with a zero-weight step (A rows
-                                             // beyond kg are zero-filled) so the loop body is branch-free
-        // Interleave: the index arithmetic + ds_reads of the NEXT step are spread between the four MFMAs
-        // of the current step (a wave that has issued a 64-cycle MFMA cannot issue the next one for
-        // ~60 cycles anyway), instead of sitting in a serial block behind them.
-#if PASE_LOOP_VARIANT == 1
-#define PASE_STEP_SCHED()
-#else
+        fetch(pa0, pa1, pb0, pb1);
+        int nloop = nks;
+        if (nks & 1) {   // odd step count: peel one step so the unrolled loop stays branch-free
+            fetch(qa0, qa1, qb0, qb1);
+            acc[0][0] = pase_mfma_32x32x2(pa0, pb0, acc[0][0]);
+            acc[0][1] = pase_mfma_32x32x2(pa0, pb1, acc[0][1]);
+            acc[1][0] = pase_mfma_32x32x2(pa1, pb0, acc[1][0]);
+            acc[1][1] = pase_mfma_32x32x2(pa1, pb1, acc[1][1]);
+            pa0 = qa0; pa1 = qa1; pb0 = qb0; pb1 = qb1;
+            --nloop;
+        }
+        // Interleave: the ds_reads of the NEXT step are spread between the four MFMAs of the current step
 #define PASE_STEP_SCHED()                                             \
-        PASE_SGB(0x008, 1); PASE_SGB(0x002, 3); PASE_SGB(0x100, 1);   \
-        PASE_SGB(0x008, 1); PASE_SGB(0x002, 3); PASE_SGB(0x100, 1);   \
-        PASE_SGB(0x008, 1); PASE_SGB(0x002, 3); PASE_SGB(0x100, 1);   \
-        PASE_SGB(0x008, 1); PASE_SGB(0x002, 3);
-#endif
-        for (int ks = 0; ks < nks2; ks += 2) {
-            fetch(ks + 1, qa0, qa1, qb0, qb1);
+        PASE_SGB(0x008, 1); PASE_SGB(0x100, 1);                       \
+        PASE_SGB(0x008, 1); PASE_SGB(0x100, 1);                       \
+        PASE_SGB(0x008, 1); PASE_SGB(0x100, 1);                       \
+        PASE_SGB(0x008, 1);
+        for (int ks = 0; ks < nloop; ks += 2) {
+            fetch(qa0, qa1, qb0, qb1);
             // All MFMAs are issued unconditionally: rows / columns beyond the tile edge multiply
             // zero-filled A rows or finite staged data and are discarded in the epilogue.
             acc[0][0] = pase_mfma_32x32x2(pa0, pb0, acc[0][0]);
@@ -436,7 +429,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
             acc[1][1] = pase_mfma_32x32x2(pa1, pb1, acc[1][1]);
             PASE_STEP_SCHED();
             PASE_SCHED_BARRIER();
-            fetch(ks + 2, pa0, pa1, pb0, pb1);
+            fetch(pa0, pa1, pb0, pb1);
             acc[0][0] = pase_mfma_32x32x2(qa0, qb0, acc[0][0]);
             acc[0][1] = pase_mfma_32x32x2(qa0, qb1, acc[0][1]);
             acc[1][0] = pase_mfma_32x32x2(qa1, qb0, acc[1][0]);
@@ -445,7 +438,6 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
             PASE_SCHED_BARRIER();
         }
 #undef PASE_STEP_SCHED
-#endif
         PASE_TACC(1);
         if (g + 1 < g_end) {
             store_stage(cur ^ 1);
@@ -720,6 +712,7 @@ HostPlan make_plan(const PaseConvGemm& p) {
         pl.CB = XSMAX / h.BN;
         if (pl.CB > KGMAX) pl.CB = KGMAX;
         if (pl.CB > p.Cin) pl.CB = p.Cin;
+        if (pl.CB > 1) pl.CB &= ~1;
         const int TPR = h.BN / 4;
         pl.tl = 0;
         while ((1 << pl.tl) < TPR) ++pl.tl;
@@ -730,13 +723,16 @@ HostPlan make_plan(const PaseConvGemm& p) {
         pl.SPANV = (h.BN - 1) * p.stride + (pl.mode == MODE_SEG ? 2 : 1) * pl.TB;
         pl.CB = KGMAX / pl.TB;
         if (pl.CB > p.Cin) pl.CB = p.Cin;
-        // one slab row per thread: TPR = largest power of two with 256/TPR >= CB; Q samples each
+        // one slab row per thread: TPR = largest power of two with 256/TPR >= CB; Q samples each.  CB is kept
+        // even (the MFMA loop pairs channel rows) unless it is 1; one slack sample per row (SPANV + 1) keeps the
+        // zero-weight tap of an odd single-row stage inside the slab.
         pl.nslots = XPT + 1;
         pl.tl = 8;
         for (; pl.CB >= 1; --pl.CB) {
+            if (pl.CB > 1 && (pl.CB & 1)) continue;
             pl.tl = 8;
             while ((NTHREADS >> pl.tl) < pl.CB) --pl.tl;
-            pl.nslots = (pl.SPANV + (1 << pl.tl) - 1) >> pl.tl;
+            pl.nslots = (pl.SPANV + 1 + (1 << pl.tl) - 1) >> pl.tl;
             if (pl.nslots <= XPT) break;
         }
         if (pl.CB < 1) pl.CB = 0;   // span does not fit: rejected by the caller

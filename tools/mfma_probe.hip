@@ -35,9 +35,22 @@ __global__ void __launch_bounds__(256, 2) probe(const float* __restrict__ g, flo
         }
         const float* as_ = &As[cur][fk][wm * 64 + fr];
         const float* xs_ = &Xs[cur][(wn * 64 + fr) * 2 + fk];
+        int xo = fk, j = 0;
+        const int tbe = 11 + (stages & 1), D = 100 + (stages & 3), jc = (tbe - fk + 1) / 2 - 1, xo_lim = 2800 - fr;
+        (void)xo_lim; (void)jc; (void)D; (void)tbe; (void)j; (void)xo;
         for (int ks = 0; ks < ksteps; ++ks) {
             float a0 = ra0, a1 = ra1, b0 = rb0, b1 = rb1;
-            if (MODE >= 1) { a0 = as_[ks * 2 * 129]; a1 = as_[ks * 2 * 129 + 32]; b0 = xs_[ks * 2]; b1 = xs_[ks * 2 + 64]; }
+            if (MODE >= 1 && MODE < 4) { a0 = as_[ks * 2 * 129]; a1 = as_[ks * 2 * 129 + 32]; b0 = xs_[ks * 2]; b1 = xs_[ks * 2 + 64]; }
+            if (MODE >= 4) {
+                // conv_gemm-style per-lane offset walk: clamp, two conditional jumps, wrap counter
+                const int ka = min(ks * 2, 46) * 129;
+                const int xoc = min(xo, xo_lim);
+                a0 = as_[ka]; a1 = as_[ka + 32]; b0 = xs_[xoc]; b1 = xs_[xoc + 64];
+                const int endj = (j == tbe - 1) ? D : 0;
+                xo += 2 + ((j == jc) ? D : 0) + endj;
+                if (MODE >= 5) xo &= 1023;
+                j = (j == tbe - 1) ? 0 : j + 1;
+            }
             acc[0][0] = MFMA(a0, b0, acc[0][0]);
             acc[0][1] = MFMA(a0, b1, acc[0][1]);
             acc[1][0] = MFMA(a1, b0, acc[1][0]);
@@ -84,6 +97,7 @@ int main() {
         run<1>("P1 +LDS reads     ", g, out, blocks);
         run<2>("P2 +restage+barrier", g, out, blocks);
         run<3>("P3 +global prefetch", g, out, blocks);
+        run<4>("P4 P3 w/ offset walk", g, out, blocks);
     }
     return 0;
 }
