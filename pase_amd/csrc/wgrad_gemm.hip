@@ -582,10 +582,21 @@ extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
     const int tiles = pl.n_row_tiles * pl.n_col_tiles;
     int splitk = p.splitk;
     if (splitk <= 0) {
-        splitk = (1024 + tiles - 1) / tiles;              // ~2 resident waves of workgroups (2 WG/CU)
+        // 512 workgroup slots (2 per CU).  Workgroups of one launch cost the same, so the grid runs in rounds
+        // of 512; a nearly empty last round costs as much as a half-full one (measured: a lone workgroup on
+        // a CU runs 1.85x faster than two co-resident ones).  Pick the split that minimises
+        // rounds x (reduction share + atomic tile flush) per workgroup.
         const int max_split = (pl.n_chunks + 3) / 4;      // at least 4 stages (256 MFMAs/wave) per split
-        if (splitk > max_split) splitk = max_split;
-        if (splitk < 1) splitk = 1;
+        double best = 1e30;
+        splitk = 1;
+        const double flush = 3.0 / (double)pl.n_chunks;   // atomic tile flush ~ 3 stages of work
+        for (int sk = 1; sk <= max_split && sk <= 2048; ++sk) {
+            const long W = (long)tiles * sk;
+            const long full = W / 512, tail = W % 512;
+            const double tc = tail == 0 ? 0.0 : (tail <= 256 ? 0.55 : 1.0);
+            const double est = ((double)full + tc) * (1.0 / sk + flush);   // rounds x (work + flush) per workgroup
+            if (est < best - 1e-12) { best = est; splitk = sk; }
+        }
     }
     if (splitk > pl.n_chunks) splitk = pl.n_chunks;
     pl.kt_per_split = (pl.n_chunks + splitk - 1) / splitk;
