@@ -753,12 +753,22 @@ HostPlan make_plan(const PaseConvGemm& p) {
     int splitk = 1;
     const int G = pl.n_gc * pl.n_gt;
     if (p.splitk > 1) splitk = p.splitk;
-    else if (p.splitk == 0 && !p.stat_part && p.epilogue == PASE_EPI_STORE && p.post_op == PASE_POST_NONE && tiles < 192) {
-        // auto: few output tiles and a long reduction (head / deconv data-gradients) -> fill the chip's
-        // 512 workgroup slots (2 per CU) as exactly as the tile count allows
-        splitk = (int)(512 / tiles);
-        if (splitk > G / 6) splitk = G / 6;
-        if (splitk < 1) splitk = 1;
+    else if (p.splitk == 0 && !p.stat_part && p.epilogue == PASE_EPI_STORE && p.post_op == PASE_POST_NONE && G >= 12) {
+        // auto (data-gradients, transposed convs, plain 1x1s): the grid runs in rounds of 512 workgroup slots
+        // (2 per CU) and a nearly empty last round costs as much as a half-full one (a lone workgroup on a CU
+        // runs 1.85x faster than two co-resident ones).  Pick the split minimising
+        // rounds x (reduction share + atomic tile flush) per workgroup; the flush (64 atomics per lane on a
+        // caller-zeroed output) is worth ~4 stages.
+        const double flush = 4.0 / (double)G;
+        double best = 1e30;
+        const int max_split = G / 6 < 1 ? 1 : G / 6;
+        for (int sk = 1; sk <= max_split && sk <= 64; ++sk) {
+            const long W = tiles * sk;
+            const long full = W / 512, tail = W % 512;
+            const double tc = tail == 0 ? 0.0 : (tail <= 256 ? 0.55 : 1.0);
+            const double est = ((double)full + tc) * (1.0 / sk + (sk > 1 ? flush : 0.0));
+            if (est < best * 0.97) { best = est; splitk = sk; }     // a larger split must win by 3 %
+        }
     }
     if (splitk > G) splitk = G > 0 ? G : 1;
     if (splitk > 1) {   // every split must own at least one stage
