@@ -239,6 +239,31 @@ int pase_power_to_db(const float* x, float* y, unsigned* umax_scratch, long per_
 int pase_frame_prep(const float* x, float* y, int B, int T, int hop, int Q, int padL, int pad_mode,
                     float preemph, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * On-device batch producer: what the reference's DataLoader workers do
+ * per utterance in numpy / scipy, for the whole batch on resident waveforms.  Random decisions are made by the
+ * caller and passed as index arrays (device memory).
+ * ------------------------------------------------------------------------------------------ */
+/* SingleChunkWav.select_chunk / MIChunkWav (pase/transforms.py:309-356,388-436): out[n, :] = wav_{src[n]}[beg[n] :
+ * beg[n]+T]; waveform u lives at pool[off[u] : off[u]+len[u]]; a waveform with len <= T is taken from 0 and
+ * right-padded by reflection (torch F.pad mode='reflect'). */
+int pase_chunk_gather(const float* pool, const long long* off, const int* len, const int* src, const int* beg,
+                      float* out, int N, int T, void* stream);
+/* norm_and_scale (pase/transforms.py:148-151), in place on (N, T): x / max|x| * u[n] */
+int pase_peak_scale(float* x, const float* u, int N, int T, void* stream);
+/* Reverb.__call__ (pase/transforms.py:1071-1103), in place on x (B, T): full = scipy.signal.convolve(x_b,
+ * IR, 'full'); shifted left by the IR's peak position, trimmed to T, scaled by sqrt(sum x^2 / sum full^2).
+ * IR i = irs[ir_off[i] : +ir_len[i]] (already truncated / peak-normalised by the caller, load_IR :1027-1044),
+ * ir_pmax[i] = argmax|IR_i|; ir_idx[b] < 0 leaves utterance b untouched.  Scratch: full (B, T+max_ir_len-1)
+ * floats, energies (2B) doubles. */
+int pase_reverb(float* x, const float* irs, const long long* ir_off, const int* ir_len, const int* ir_pmax,
+                const int* ir_idx, float* full, double* energies, int B, int T, int max_ir_len, void* stream);
+/* SimpleAdditive.__call__ (pase/transforms.py:1633-1675), in place on x (B, T): noise crop
+ * npool[noff[i] + nbeg[b] : +T] (zero beyond nlen[i]), K = sqrt(Ex / (10^(snr/10) En)), x <- (x + K n) *
+ * sqrt(Ex / (E(x + K n) + 1e-14)); nidx[b] < 0 or a silent crop leaves utterance b untouched. */
+int pase_add_noise(float* x, const float* npool, const long long* noff, const int* nlen, const int* nidx,
+                   const int* nbeg, const float* snr, int B, int T, void* stream);
+
 /* sizeof() of the ABI structs (0 = PaseConvGemm, 1 = PaseWgrad, 2 = PaseActBwd), for binding self-checks */
 int pase_abi_sizeof(int which);
 

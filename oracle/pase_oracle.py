@@ -264,6 +264,19 @@ def spc_samples(x, ctxt_frames=5, seq_pad=16):
     return torch.cat((pos, neg), 0).unsqueeze(2)
 
 
+def gap_samples(x):
+    """GapMinion.forward sampling (Minions/minions.py:672-693): two np.random.randint draws of size B, the
+    frame pair concatenated on channels, label = LongTensor(|a-b|/(T-1)) (truncation as written)."""
+    import numpy as np
+    B, T = x.size(0), x.size(2)
+    aidx = np.random.randint(0, T, size=B)
+    bidx = np.random.randint(0, T, size=B)
+    xa = torch.stack([x[i, :, int(a)] for i, a in enumerate(aidx)], 0)
+    xb = torch.stack([x[i, :, int(b)] for i, b in enumerate(bidx)], 0)
+    dists = torch.tensor([float(int(abs(int(a) - int(b)) / (T - 1))) for a, b in zip(aidx, bidx)])
+    return torch.cat((xa, xb), 1).unsqueeze(2), dists.view(-1, 1, 1)
+
+
 def make_labels(y):
     """cls_minions.py:47-51."""
     bsz, slen = y.size(0) // 2, y.size(2)
@@ -286,6 +299,11 @@ def pase_forward(P, fe_cfg, workers_cfg, batch, training=True, stats_out=None):
         labels[w["name"]] = batch[w["name"]]
     for i, w in enumerate(workers_cfg.get("cls", [])):
         pre = "classification_workers.%d.minion." % i
+        if w["name"] == "gap":
+            x, lab = gap_samples(chunk)
+            preds[w["name"]] = mlp_minion(P, pre, x, w.get("hidden_layers", 2))
+            labels[w["name"]] = lab
+            continue
         if w["name"] == "spc":
             x = spc_samples(chunk, w.get("ctxt_frames", 5), w.get("seq_pad", 16))
         else:

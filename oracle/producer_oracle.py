@@ -1,0 +1,65 @@
+"""CPU oracle for the batch producer (TEST INFRASTRUCTURE ONLY): numpy / scipy restatement of
+pase/transforms.py select_chunk (:309-356), norm_and_scale (:148-151), Reverb.__call__ (:1071-1103) with
+load_IR's preparation (:1039-1042), SimpleAdditive.__call__ (:1633-1675), one utterance at a time and with the
+random decisions passed in.  scipy.signal.convolve is the function the reference calls (scipy is installed), so
+the convolution itself is the live third-party code; the class bodies cannot be imported (pase/transforms.py
+fails on its soundfile / librosa / gammatone imports), hence the restatement."""
+import numpy as np
+import scipy.signal
+
+
+def select_chunk(wav, T, beg):
+    wav = np.asarray(wav, dtype=np.float32)
+    if len(wav) <= T:
+        P = T - len(wav)
+        return np.pad(wav, (0, P), mode="reflect")
+    return wav[beg:beg + T]
+
+
+def norm_and_scale(wav, u):
+    return wav / np.max(np.abs(wav)) * np.float32(u)
+
+
+def prepare_ir(ir, max_reverb_len=24000):
+    ir = np.asarray(ir, dtype=np.float64)[:max_reverb_len]
+    if np.max(ir) > 0:
+        ir = ir / np.abs(np.max(ir))
+    return ir, int(np.argmax(np.abs(ir)))
+
+
+def shift(xs, n):
+    e = np.empty_like(xs)
+    if n >= 0:
+        e[:n] = 0.0
+        e[n:] = xs[:-n] if n > 0 else xs     # (the reference's xs[:-0] is empty: n == 0 is defined here as no shift)
+    else:
+        e[n:] = 0.0
+        e[:n] = xs[-n:]
+    return e
+
+
+def reverb(wav, ir, p_max):
+    ir = ir.astype(np.float32)
+    wav = np.asarray(wav).reshape(-1)
+    Ex = np.dot(wav, wav)
+    wav = wav.astype(np.float32)
+    rev = scipy.signal.convolve(wav, ir, mode="full").reshape(-1)
+    Er = np.dot(rev, rev)
+    rev = shift(rev, -p_max)
+    ratio = np.sqrt(Ex / Er) if Er > 0 else 1.0
+    return (ratio * rev[:wav.shape[0]]).astype(np.float32)
+
+
+def additive(wav, noise_full, n_beg, snr):
+    wav = np.asarray(wav, dtype=np.float32).reshape(-1)
+    sel = np.asarray(noise_full, dtype=np.float64)
+    if len(sel) < len(wav):
+        sel = np.concatenate([sel, np.zeros(len(wav) - len(sel))])
+    T = len(wav)
+    noise = sel[n_beg:n_beg + T].astype(np.float32)
+    Ex, En = np.dot(wav, wav), np.dot(noise, noise)
+    if not En > 0:
+        return wav
+    Kf = np.sqrt(Ex / ((10 ** (snr / 10.)) * En))
+    noisy = wav + Kf * noise
+    return (np.sqrt(Ex / (np.dot(noisy, noisy) + 1e-14)) * noisy).astype(np.float32)

@@ -233,6 +233,10 @@ _SIMPLE.update({
     "pase_sinc_filters_bwd": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _f, _f, _f, _fp],
     "pase_pack_dgrad": [_fp, _fp, _i, _i, _i, _i, _l, _l, _l, _fp],
     "pase_pack_dgrad_t": [_fp, _fp, _i, _i, _i, _i, _l, _l, _l, _i, _fp],
+    "pase_chunk_gather": [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _fp],
+    "pase_peak_scale": [_fp, _fp, _i, _i, _fp],
+    "pase_reverb": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp],
+    "pase_add_noise": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _fp],
     "pase_pack_wt": [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp],
     "pase_adam_step": [_fp, _fp, _fp, _fp, _l, _fp, _fp, _f, _f, _f, _f, _fp],
     "pase_step_tick": [_fp, _fp],
@@ -403,3 +407,28 @@ def power_to_db(x, y, umax, *, per_utt, B, amin=1e-10, ref_db=0.0, top_db=80.0):
 def frame_prep(x, y, *, B, T, hop, Q, padL, pad_mode, preemph=0.0):
     _check(_lib.lib().pase_frame_prep(_ptr(x), _ptr(y), B, T, hop, Q, padL, pad_mode, preemph, _stream()),
            "pase_frame_prep")
+
+
+# ======================================================================================
+# batch producer
+# ======================================================================================
+def chunk_gather(pool, off, length, src, beg, out, *, N, T):
+    _check(_lib.lib().pase_chunk_gather(_ptr(pool), _ptr(off, torch.int64), _ptr(length, torch.int32),
+                                        _ptr(src, torch.int32), _ptr(beg, torch.int32), _ptr(out), N, T, _stream()),
+           "pase_chunk_gather")
+
+
+def peak_scale(x, u, *, N, T):
+    _check(_lib.lib().pase_peak_scale(_ptr(x), _ptr(u), N, T, _stream()), "pase_peak_scale")
+
+
+def reverb(x, irs, ir_off, ir_len, ir_pmax, ir_idx, full, energies, *, B, T, max_ir_len):
+    _check(_lib.lib().pase_reverb(_ptr(x), _ptr(irs), _ptr(ir_off, torch.int64), _ptr(ir_len, torch.int32),
+                                  _ptr(ir_pmax, torch.int32), _ptr(ir_idx, torch.int32), _ptr(full),
+                                  _ptr(energies, torch.float64), B, T, max_ir_len, _stream()), "pase_reverb")
+
+
+def add_noise(x, npool, noff, nlen, nidx, nbeg, snr, *, B, T):
+    _check(_lib.lib().pase_add_noise(_ptr(x), _ptr(npool), _ptr(noff, torch.int64), _ptr(nlen, torch.int32),
+                                     _ptr(nidx, torch.int32), _ptr(nbeg, torch.int32), _ptr(snr), B, T, _stream()),
+           "pase_add_noise")

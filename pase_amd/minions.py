@@ -6,6 +6,7 @@ reference's state_dict; arithmetic on the HIP kernels via pase_amd.engine.
 import json
 import random
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -157,6 +158,37 @@ class SPCMinion(MLPMinion):
         return y
 
 
+class GapMinion(MLPMinion):
+    """Gap worker (Minions/minions.py:651-704): two random frames per batch item (np.random.randint, same
+    draws as the reference), concatenated to (B, 2*emb, 1) and pushed through the MLP to regress their
+    normalised distance.  The reference builds the label with torch.LongTensor(dists) (:693), which
+    truncates |a-b|/(T-1) to 0 (or 1 when the frames are the two ends); that is mirrored."""
+
+    def sample(self, B, T):
+        aidx = np.random.randint(0, T, size=B)
+        bidx = np.random.randint(0, T, size=B)
+        return aidx, bidx
+
+    @staticmethod
+    def labels(aidx, bidx, T, device):
+        d = np.abs(aidx - bidx) / float(T - 1)
+        return torch.as_tensor(np.trunc(d), dtype=torch.float32, device=device).view(-1, 1, 1)
+
+    @staticmethod
+    def gather(x, aidx, bidx):
+        ar = torch.arange(x.size(0), device=x.device)
+        xa = x[ar, :, torch.as_tensor(aidx, device=x.device)]
+        xb = x[ar, :, torch.as_tensor(bidx, device=x.device)]
+        return torch.cat((xa, xb), dim=1).unsqueeze(2)
+
+    def forward(self, x, alpha=1, device=None):
+        aidx, bidx = self.sample(x.size(0), x.size(2))
+        y = self._run(self.gather(x, aidx, bidx).contiguous())
+        if self.skip:
+            raise NotImplementedError("pase_amd GapMinion: skip=True")
+        return y, self.labels(aidx, bidx, x.size(2), x.device)
+
+
 def minion_maker(cfg):
     """minions.py:11-35 (mlp / decoder; the wavernn / spc / gap / gru / regularizer types are not
     reachable from cfg/workers/workers+.cfg)."""
@@ -173,6 +205,8 @@ def minion_maker(cfg):
         return DecoderMinion(**cfg)
     if mtype == "spc":
         return SPCMinion(**cfg)
+    if mtype == "gap":
+        return GapMinion(**cfg)
     raise NotImplementedError("pase_amd minion_maker: minion type {}".format(mtype))
 
 
@@ -236,6 +270,21 @@ class SPC(Model):
         return y, make_labels(y).to(device)
 
 
+class Gap(Model):
+    """cls_minions.py:117-131."""
+
+    def __init__(self, cfg, emb_dim):
+        super().__init__(name=cfg["name"])
+        cfg["num_inputs"] = 2 * emb_dim
+        self.minion = minion_maker(cfg)
+        self.loss = self.minion.loss
+        self.loss_weight = self.minion.loss_weight
+
+    def forward(self, x, alpha=1, device=None):
+        y, label = self.minion(x, alpha)
+        return y, label.float().to(device)
+
+
 def cls_worker_maker(cfg, emb_dim):
     """cls_minions.py:10-27 (spc / gap are workers.cfg-only / unshipped; not in the PASE+ path)."""
     print("=" * 50)
@@ -248,5 +297,5 @@ def cls_worker_maker(cfg, emb_dim):
     if cfg["name"] == "spc":
         return SPC(cfg, emb_dim)
     if cfg["name"] == "gap":
-        raise NotImplementedError("pase_amd: the gap worker has no shipped cfg and is not built")
+        return Gap(cfg, emb_dim)
     return minion_maker(cfg)

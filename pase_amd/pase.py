@@ -61,7 +61,7 @@ class pase(Model):
             preds[worker.name] = worker(chunk, alpha)
             labels[worker.name] = x[worker.name].to(device).detach()
         for worker in self.classification_workers:
-            if worker.name == "spc":
+            if worker.name == "spc" or worker.name == "gap":
                 y, label = worker(chunk, alpha, device=device)
             else:
                 y, label = worker(h, alpha, device=device)
@@ -147,6 +147,25 @@ class pase(Model):
                 demb[:B, :, t] += pos[:, :E] + neg[:, :E]
                 demb[:B, :, ft:ft + N] += pos[:, E:].reshape(B, E, N)
                 demb[:B, :, pt - N:pt] += neg[:, E:].reshape(B, E, N)
+                l = wctx.loss_acc[0] * (worker.loss_weight / wctx.numel)
+                losses[worker.name] = l
+                total = total + l
+                del wctx, dsrc
+                continue
+            if worker.name == "gap":
+                # Gap reads two frames of the chunk embedding per item (pase.py:346-347, minions.py:672-689)
+                aidx, bidx = mn.sample(B, F_)
+                xin = mn.gather(chunk, aidx, bidx).contiguous()
+                label = mn.labels(aidx, bidx, F_, emb.device)
+                wctx = engine.worker_forward(list(mn.blocks), mn.W, Act(xin, C=xin.shape[1]),
+                                             loss=dict(name=loss.loss_name, r=loss.r, target=label,
+                                                       weight=worker.loss_weight), want_pred=False)
+                dsrc = engine.worker_backward(list(mn.blocks), mn.W, wctx, wctx.dpred, sink)
+                dx = dsrc.dense(xin.shape[1], 1)[:, :, 0]
+                ar = torch.arange(B, device=emb.device)
+                dv = demb[:B]          # (i, :, a_i) is unique per item; a_i == b_i is handled by the two statements
+                dv[ar, :, torch.as_tensor(aidx, device=emb.device)] += dx[:, :E]
+                dv[ar, :, torch.as_tensor(bidx, device=emb.device)] += dx[:, E:]
                 l = wctx.loss_acc[0] * (worker.loss_weight / wctx.numel)
                 losses[worker.name] = l
                 total = total + l

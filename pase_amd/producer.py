@@ -1,0 +1,148 @@
+"""On-device batch producer: the dataset / transform side of the training step (SURVEY.md section 8 rows a19,
+a26, a27; (f)-2, (f)-3), batched on the GPU over HBM-resident waveforms.
+
+Mirrors, per batch instead of per utterance:
+  * MIChunkWav / SingleChunkWav (pase/transforms.py:295-436): random fixed-size crops of (utterance,
+    same-context utterance, random other utterance), reflect padding of short files, optional
+    norm_and_scale (:148-151);
+  * the dataset's package layout + DictCollater (pase/dataset.py:21-89,428-513): every waveform key is a
+    (B, 1, T) tensor, `cchunk` is the clean copy of `chunk` taken BEFORE the distortions (:496);
+  * Reverb (:1001-1103) and SimpleAdditive (:1590-1680) applied to `chunk` with the reference's Bernoulli
+    gating (PCompose, :208-237).
+Random DECISIONS (utterance ids, crop starts, which IR / noise / SNR, the U(0,1) scales) are drawn on the host
+with numpy exactly where the reference draws them; every `__call__` also accepts them explicitly so parity
+tests can replay the reference's draws.  The arithmetic runs in pase_amd/csrc/producer.hip.
+"""
+import numpy as np
+import torch
+
+from . import kernels as K
+
+
+def _dev_i32(a, device):
+    return torch.as_tensor(np.asarray(a, dtype=np.int32), device=device)
+
+
+class WavPool(object):
+    """Waveforms (1-D float arrays) concatenated in one HBM buffer."""
+
+    def __init__(self, wavs, device="cuda"):
+        self.device = torch.device(device)
+        lens = [int(len(w)) for w in wavs]
+        offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64) if lens else np.zeros(0, np.int64)
+        self.lens_host = np.asarray(lens, dtype=np.int64)
+        flat = np.concatenate([np.asarray(w, dtype=np.float32).reshape(-1) for w in wavs]) if lens else np.zeros(0, np.float32)
+        self.pool = torch.from_numpy(flat).to(self.device)
+        self.off = torch.from_numpy(offs).to(self.device)
+        self.len = torch.from_numpy(np.asarray(lens, dtype=np.int32)).to(self.device)
+
+    def __len__(self):
+        return len(self.lens_host)
+
+
+class DeviceChunker(object):
+    """MIChunkWav over a resident pool: __call__ -> {'chunk','chunk_ctxt','chunk_rand'} as (B, 1, T)."""
+
+    def __init__(self, pool, chunk_size, random_scale=False, rng=None):
+        self.pool, self.T, self.random_scale = pool, int(chunk_size), random_scale
+        self.rng = rng if rng is not None else np.random
+
+    def draw(self, B):
+        """The reference's draws: dataset __getitem__ picks the utterance and a different random one
+        (dataset.py:482-484); select_chunk draws np.random.randint(0, len - T) per crop (transforms.py:350)."""
+        n = len(self.pool)
+        utt = self.rng.randint(0, n, size=B)
+        rand = np.array([self.rng.choice([i for i in range(n) if i != u]) if n > 1 else u for u in utt])
+        src = np.stack([utt, utt, rand], 0)                   # chunk, chunk_ctxt (same context), chunk_rand
+        L = self.pool.lens_host[src]
+        beg = np.where(L > self.T, (self.rng.random_sample(src.shape) * np.maximum(L - self.T, 1)).astype(np.int64), 0)
+        scale = self.rng.random_sample(src.shape).astype(np.float32) if self.random_scale else None
+        return src, beg, scale
+
+    def __call__(self, B=None, src=None, beg=None, scale=None):
+        if src is None:
+            src, beg, scale = self.draw(B)
+        src = np.asarray(src)
+        N = src.size
+        out = torch.empty(N, self.T, device=self.pool.device)
+        K.chunk_gather(self.pool.pool, self.pool.off, self.pool.len, _dev_i32(src.reshape(-1), self.pool.device),
+                       _dev_i32(np.asarray(beg).reshape(-1), self.pool.device), out, N=N, T=self.T)
+        if scale is not None:
+            K.peak_scale(out, torch.as_tensor(np.asarray(scale, dtype=np.float32).reshape(-1), device=out.device),
+                         N=N, T=self.T)
+        Bn = src.shape[1]
+        out = out.view(3, Bn, 1, self.T)
+        return {"chunk": out[0], "chunk_ctxt": out[1], "chunk_rand": out[2]}
+
+
+class DeviceReverb(object):
+    """Reverb (pase/transforms.py:1001-1103) for a batch; IRs truncated to max_reverb_len and divided by
+    |max| at load time like load_IR (:1039-1042)."""
+
+    def __init__(self, irs, max_reverb_len=24000, device="cuda"):
+        prepared, pmax = [], []
+        for ir in irs:
+            ir = np.asarray(ir, dtype=np.float64).reshape(-1)[:max_reverb_len]
+            if np.max(ir) > 0:
+                ir = ir / np.abs(np.max(ir))
+            prepared.append(ir.astype(np.float32))
+            pmax.append(int(np.argmax(np.abs(ir))))
+        self.irs = WavPool(prepared, device)
+        self.pmax = _dev_i32(pmax, device)
+        self.max_len = int(max(len(i) for i in prepared))
+        self.n = len(prepared)
+
+    def __call__(self, chunk, ir_idx):
+        """chunk (B, 1, T) modified in place; ir_idx[b] = IR index, -1 = leave utterance b clean."""
+        B, _, T = chunk.shape
+        full = torch.empty(B, T + self.max_len - 1, device=chunk.device)
+        energies = torch.empty(2 * B, dtype=torch.float64, device=chunk.device)
+        K.reverb(chunk, self.irs.pool, self.irs.off, self.irs.len, self.pmax, _dev_i32(ir_idx, chunk.device), full,
+                 energies, B=B, T=T, max_ir_len=self.max_len)
+        return chunk
+
+
+class DeviceAdditive(object):
+    """SimpleAdditive (pase/transforms.py:1590-1680) for a batch of resident noises."""
+
+    def __init__(self, noises, snr_levels=(0, 5, 10), device="cuda"):
+        self.noises = WavPool(noises, device)
+        self.snr_levels = list(snr_levels)
+
+    def __call__(self, chunk, noise_idx, noise_beg, snr):
+        B, _, T = chunk.shape
+        K.add_noise(chunk, self.noises.pool, self.noises.off, self.noises.len, _dev_i32(noise_idx, chunk.device),
+                    _dev_i32(noise_beg, chunk.device),
+                    torch.as_tensor(np.asarray(snr, dtype=np.float32), device=chunk.device), B=B, T=T)
+        return chunk
+
+
+class DeviceBatchProducer(object):
+    """dataset.__getitem__ + DictCollater for one batch: chunks, clean copy, gated distortions, and (when a
+    DeviceTargets is attached) the regression labels computed from the clean chunk."""
+
+    def __init__(self, chunker, reverb=None, reverb_p=0.5, additive=None, additive_p=0.5, targets=None, rng=None):
+        self.chunker, self.reverb, self.additive, self.targets = chunker, reverb, additive, targets
+        self.reverb_p, self.additive_p = reverb_p, additive_p
+        self.rng = rng if rng is not None else np.random
+
+    def __call__(self, B):
+        batch = self.chunker(B)
+        batch = {k: v.contiguous() for k, v in batch.items()}
+        batch["cchunk"] = batch["chunk"].clone()                       # dataset.py:496, before the distortions
+        T = batch["chunk"].shape[-1]
+        if self.reverb is not None:
+            gate = self.rng.random_sample(B) < self.reverb_p           # PCompose: one Bernoulli per transform
+            idx = np.where(gate, self.rng.randint(0, self.reverb.n, size=B), -1)
+            self.reverb(batch["chunk"], idx)
+        if self.additive is not None:
+            gate = self.rng.random_sample(B) < self.additive_p
+            nn = len(self.additive.noises)
+            idx = self.rng.randint(0, nn, size=B)
+            nl = self.additive.noises.lens_host[idx]
+            beg = np.where(nl > T, (self.rng.random_sample(B) * np.maximum(nl - T, 1)).astype(np.int64), 0)
+            snr = np.asarray(self.additive.snr_levels, dtype=np.float32)[self.rng.randint(0, len(self.additive.snr_levels), size=B)]
+            self.additive(batch["chunk"], np.where(gate, idx, -1), beg, snr)
+        if self.targets is not None:
+            batch.update(self.targets(batch["cchunk"]))
+        return batch

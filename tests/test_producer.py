@@ -1,0 +1,105 @@
+"""On-device batch producer (chunking, norm_and_scale, Reverb, SimpleAdditive) vs the numpy/scipy oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import producer_oracle as O
+from pase_amd import producer as P
+
+
+def _pool(rng, lens):
+    return [(0.3 * rng.standard_normal(n)).astype(np.float32) for n in lens]
+
+
+def test_chunker_matches_select_chunk(dev):
+    rng = np.random.RandomState(0)
+    wavs = _pool(rng, [5000, 1300, 900, 2400])        # 900 <= T: reflect-padded from 0
+    T = 1200
+    pool = P.WavPool(wavs, dev)
+    ch = P.DeviceChunker(pool, T, random_scale=True, rng=np.random.RandomState(1))
+    src, beg, scale = ch.draw(5)
+    out = ch(src=src, beg=beg, scale=scale)
+    for k, name in enumerate(("chunk", "chunk_ctxt", "chunk_rand")):
+        assert out[name].shape == (5, 1, T)
+        for b in range(5):
+            want = O.norm_and_scale(O.select_chunk(wavs[src[k, b]], T, int(beg[k, b])), scale[k, b])
+            np.testing.assert_allclose(out[name][b, 0].cpu().numpy(), want, rtol=1e-6, atol=1e-7)
+    assert (src[0] == src[1]).all() and (src[2] != src[0]).all()
+
+
+@pytest.mark.parametrize("T,irlens", [(700, [90, 300, 1]), (2300, [1100, 40])])
+def test_reverb_matches_scipy(dev, T, irlens):
+    rng = np.random.RandomState(2)
+    B = 4
+    x = (0.2 * rng.standard_normal((B, 1, T))).astype(np.float32)
+    irs = []
+    for L in irlens:
+        ir = rng.standard_normal(L) * np.exp(-np.arange(L) / max(L / 5.0, 1.0))
+        ir[min(7, L - 1)] = 2.5                       # a clear direct-path peak at a non-zero delay
+        irs.append(ir)
+    rv = P.DeviceReverb(irs, max_reverb_len=1000, device=dev)
+    idx = np.array([0, -1, len(irs) - 1, 1 % len(irs)])
+    got = rv(torch.from_numpy(x.copy()).to(dev), idx).cpu().numpy()
+    for b in range(B):
+        if idx[b] < 0:
+            np.testing.assert_array_equal(got[b, 0], x[b, 0])
+            continue
+        ir, pm = O.prepare_ir(irs[idx[b]], 1000)
+        want = O.reverb(x[b, 0], ir, pm)
+        np.testing.assert_allclose(got[b, 0], want, rtol=2e-4, atol=2e-5 * np.abs(want).max())
+
+
+def test_additive_matches_reference_formula(dev):
+    rng = np.random.RandomState(3)
+    B, T = 5, 1500
+    x = (0.2 * rng.standard_normal((B, 1, T))).astype(np.float32)
+    noises = [0.05 * rng.standard_normal(4000), 0.1 * rng.standard_normal(900), np.zeros(2000)]
+    ad = P.DeviceAdditive(noises, device=dev)
+    idx = np.array([0, 1, 2, -1, 0])
+    beg = np.array([100, 0, 10, 0, 2499])
+    snr = np.array([0.0, 5.0, 10.0, 5.0, 10.0], dtype=np.float32)
+    got = ad(torch.from_numpy(x.copy()).to(dev), idx, beg, snr).cpu().numpy()
+    for b in range(B):
+        want = x[b, 0] if idx[b] < 0 else O.additive(x[b, 0], noises[idx[b]], int(beg[b]), float(snr[b]))
+        np.testing.assert_allclose(got[b, 0], want, rtol=1e-5, atol=1e-6)
+
+
+def test_batch_producer_contract(dev):
+    """dataset.__getitem__ + DictCollater layout: (B, 1, T) waveforms, cchunk = clean chunk, distortions on
+    `chunk` only, energy preserved by both distortions."""
+    rng = np.random.RandomState(4)
+    pool = P.WavPool(_pool(rng, [4000, 5000, 3000]), dev)
+    T = 1600
+    prod = P.DeviceBatchProducer(
+        P.DeviceChunker(pool, T, rng=np.random.RandomState(5)),
+        reverb=P.DeviceReverb([np.r_[0.0, 1.0, 0.5 * rng.standard_normal(200) * np.exp(-np.arange(200) / 40.0)]],
+                              device=dev), reverb_p=1.0,
+        additive=P.DeviceAdditive([0.1 * rng.standard_normal(6000)], device=dev), additive_p=1.0,
+        rng=np.random.RandomState(6))
+    batch = prod(4)
+    assert set(batch) == {"chunk", "chunk_ctxt", "chunk_rand", "cchunk"}
+    for v in batch.values():
+        assert v.shape == (4, 1, T) and v.dtype == torch.float32
+    e_clean = (batch["cchunk"] ** 2).sum(-1)
+    e_dist = (batch["chunk"] ** 2).sum(-1)
+    assert not torch.allclose(batch["chunk"], batch["cchunk"])
+    # additive renormalises to the (reverberated) input energy; reverb scales the FULL convolution to the clean
+    # energy, so the trimmed chunk keeps most of it
+    assert (e_dist <= e_clean * 1.001).all() and (e_dist >= 0.5 * e_clean).all()
+
+
+@pytest.mark.gpu
+def test_reverb_full_size_24000_taps():
+    """The BASELINE configs[3] size: 32 000-sample chunks, impulse responses truncated at 24 000 taps."""
+    rng = np.random.RandomState(8)
+    T, L, B = 32000, 24000, 3
+    x = (0.1 * rng.standard_normal((B, 1, T))).astype(np.float32)
+    irs = [np.r_[np.zeros(123), 1.0, 0.2 * rng.standard_normal(L + 500) * np.exp(-np.arange(L + 500) / 4000.0)],
+           np.r_[0.0, 0.0, 1.0, 0.5 * rng.standard_normal(3000) * np.exp(-np.arange(3000) / 600.0)]]
+    rv = P.DeviceReverb(irs, device="cuda")
+    idx = np.array([0, 1, 0])
+    got = rv(torch.from_numpy(x.copy()).cuda(), idx).cpu().numpy()
+    for b in range(B):
+        ir, pm = O.prepare_ir(irs[idx[b]])
+        want = O.reverb(x[b, 0], ir, pm)
+        np.testing.assert_allclose(got[b, 0], want, rtol=1e-3, atol=1e-4 * np.abs(want).max())
