@@ -111,6 +111,11 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--chunk", type=int, default=32000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--producer", action="store_true",
+                    help="BASELINE.json configs[3] shape: every step's batch is produced ON DEVICE inside the timed "
+                         "region (random crops of a resident waveform pool, Reverb / additive-noise gating on "
+                         "`chunk`, LPS / FBANK / MFCC targets from the clean chunk); default is configs[2] "
+                         "(batch and targets resident in HBM)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -136,6 +141,28 @@ def main():
                      lr_mode="poly", device=dev)
     B, T = args.batch, args.chunk
     batch = synthetic_batch(1234 + rank, B, T, raw, dev)
+    next_batch = lambda: batch
+    if args.producer:
+        import numpy as np
+        from pase_amd import dsp, producer as PR
+        rs = np.random.RandomState(1234 + rank)
+        pool = PR.WavPool([(0.1 * rs.standard_normal(16000 * 6)).clip(-1, 1).astype(np.float32) for _ in range(64)], dev)
+        irs = [np.r_[np.zeros(40), 1.0, 0.3 * rs.standard_normal(23959) * np.exp(-np.arange(23959) / 4000.0)]
+               for _ in range(8)]                                     # synthetic exponentially-decaying IRs, 24 000 taps
+        noises = [0.05 * rs.standard_normal(16000 * 10) for _ in range(8)]
+        tg = dsp.DeviceTargets(raw, device=dev)
+        for n_, f_ in tg.feats.items():
+            D_ = next(w["num_outputs"] for w in raw["regr"] if w["name"] == n_)
+            f_.set_stats(torch.zeros(D_), torch.ones(D_))
+        prod = PR.DeviceBatchProducer(PR.DeviceChunker(pool, T, rng=rs), PR.DeviceReverb(irs, device=dev), 0.5,
+                                      PR.DeviceAdditive(noises, device=dev), 0.5, tg, rng=rs)
+        extra = {k: v for k, v in batch.items() if k not in ("chunk", "chunk_ctxt", "chunk_rand", "cchunk")}
+
+        def next_batch():
+            b = prod(B)
+            for k, v in extra.items():          # gammatone / prosody targets are not produced on device
+                b.setdefault(k, v)
+            return b
 
     def sync():
         if world > 1:
@@ -143,13 +170,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        losses = tr.train_step(batch)
+        losses = tr.train_step(next_batch())
     sync()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.time()
     ev0.record()
     for _ in range(args.steps):
-        losses = tr.train_step(batch)
+        losses = tr.train_step(next_batch())
     ev1.record()
     sync()
     dt = time.time() - t0
@@ -196,9 +223,14 @@ def main():
             "encoder_frames_per_s": round(utt_s * 3 * (T // 160), 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "PASE+.cfg + workers+.cfg self-supervised train step (BASELINE.json configs[2])",
+            "config": {"workload": ("PASE+.cfg + workers+.cfg train step with the batch produced on device each step: crops "
+                                    "of a resident pool, Reverb(24000-tap synthetic IRs, p=0.5) + additive noise (p=0.5), "
+                                    "LPS/FBANK/MFCC targets from the clean chunk (BASELINE.json configs[3] shape)")
+                       if args.producer else
+                       "PASE+.cfg + workers+.cfg self-supervised train step (BASELINE.json configs[2])",
                        "batch_per_gpu": B, "global_batch": B * world, "chunk_samples": T,
-                       "targets": "given (N(0,1) tensors resident in HBM)", "parallelism": "dp%d" % world,
+                       "targets": ("lps/lps_long/fbank/fbank_long/mfcc/mfcc_long computed on device; gtn/prosody N(0,1)"
+                                   if args.producer else "given (N(0,1) tensors resident in HBM)"), "parallelism": "dp%d" % world,
                        "final_total_loss": round(total_loss, 5)},
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (all launches of one step)",
                          "achieved": round(cg_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
