@@ -61,7 +61,7 @@ if kt:
                                "sum_kernel_us": round(tot, 1),
                                "families": [{"kernel": k, "calls": v[0], "total_us": round(v[1], 1),
                                              "avg_us": round(v[1] / v[0], 1), "pct": round(100 * v[1] / tot, 2)}
-                                            for k, v in sorted(fam.items(), key=lambda x: -x[1][1])[:16]]}
+                                            for k, v in sorted(fam.items(), key=lambda x: -x[1][1])[:28]]}
 # --- HBM traffic (FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x,
 #     MI355X_MICROARCH.md section HBM -> both the raw and the corrected figure are given)
 fe, wr = counters("pmc_fetch"), counters("pmc_write")
@@ -73,7 +73,7 @@ if fe and wr:
         tr.append({"kernel": k, "fetch_MB_raw": round(f_kib * 1024 / 1e6, 1), "fetch_MB_x2": round(2 * f_kib * 1024 / 1e6, 1),
                    "write_MB": round(w_kib * 1024 / 1e6, 1)})
     tr.sort(key=lambda x: -(x["fetch_MB_x2"] + x["write_MB"]))
-    out["hbm_traffic_per_step"] = tr[:12]
+    out["hbm_traffic_per_step"] = tr[:24]
 sq = counters("pmc_sq")
 if sq:
     rows = []
