@@ -48,7 +48,10 @@ constexpr int NTHREADS = 256;
 constexpr int KGMAX = 48;     // flat k (channels x taps) per stage
 constexpr int XSMAX = 3072;   // staged span floats per stage
 constexpr int XPT = XSMAX / NTHREADS;   // 12 staged floats per thread per stage
-constexpr int NPAR = 3;       // on-load (scale, shift, alpha) triples prefetched per thread
+constexpr int NPAR = 4;       // on-load (scale, shift, alpha) triples prefetched per thread
+// flat 1x1 instantiation (float4 slots): 32 k per stage x BN columns = 4096 staged floats and a 32-row weight
+// slab -- more columns of X per stage than the span layout needs, fewer rows of A, same LDS footprint
+constexpr int KG_FLAT = 32, XS_FLAT = 4096, NS_FLAT = 4;
 
 struct ConvPlan {
     int CB, TB, SPAN, SPANV, n_gc, n_gt, mode, tiles_per_seq, splitk;
@@ -124,12 +127,14 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
     static_assert((BM / 64) * WAVES_N == 4, "4 waves");
     constexpr int TA = BM / 4;             // threads per A slab row (one float4 each)
     constexpr int RA = NTHREADS / TA;      // slab rows per pass (8 / 16)
-    constexpr int PA_MAX = KGMAX / RA;     // 6 / 3
+    constexpr int KG_T = XV ? KG_FLAT : KGMAX;
+    constexpr int XS_T = XV ? XS_FLAT : XSMAX;
+    constexpr int PA_MAX = KG_T / RA;      // 6 / 3 (4 / 2 flat)
     constexpr int LDA = BM + 4;
-    __shared__ __attribute__((aligned(16))) float As[2][KGMAX][LDA];
+    __shared__ __attribute__((aligned(16))) float As[2][KG_T][LDA];
     // 4 guard floats (zero) in front of each X buffer: the one zero-weight tap a reversed-tap single-row stage
     // with an odd tap count reads at span offset -1 must be finite
-    __shared__ __attribute__((aligned(16))) float XsG[2][XSMAX + 4];
+    __shared__ __attribute__((aligned(16))) float XsG[2][XS_T + 4];
     __shared__ float red[WAVES_N][BM][2];
 
     PASE_STAMP(0);
@@ -186,7 +191,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
     F4 areg[PA_MAX];
     // X: thread -> slab row `xrow` (+ t*RPP when pmajor), samples xc + t*TPR (q-major)
     constexpr int NXR = XV ? 4 * NS : NS;      // staged floats per thread
-    static_assert(NXR <= XPT, "slab");
+    static_assert(NXR * NTHREADS <= XS_T, "slab");
     const int TPR = 1 << pl.tl;
     const int RPP = NTHREADS >> pl.tl;
     const int xrow = tid >> pl.tl;
@@ -709,14 +714,14 @@ HostPlan make_plan(const PaseConvGemm& p) {
     if (flat) {
         pl.TB = 1;
         pl.SPANV = pl.SPAN = h.BN;
-        pl.CB = XSMAX / h.BN;
-        if (pl.CB > KGMAX) pl.CB = KGMAX;
+        pl.CB = XS_FLAT / h.BN;
+        if (pl.CB > KG_FLAT) pl.CB = KG_FLAT;
         if (pl.CB > p.Cin) pl.CB = p.Cin;
         if (pl.CB > 1) pl.CB &= ~1;
         const int TPR = h.BN / 4;
         pl.tl = 0;
         while ((1 << pl.tl) < TPR) ++pl.tl;
-        pl.nslots = 3;
+        pl.nslots = NS_FLAT;
     } else {
         pl.TB = p.taps <= KGMAX ? p.taps : 32;
         // a tile may touch two sequences: each segment carries its own halo of TB samples
@@ -818,7 +823,7 @@ extern "C" int pase_conv_gemm(const PaseConvGemm* d, void* stream) {
     const dim3 grid((unsigned)h.blocks), block(NTHREADS);
 #define PASE_CONV_LAUNCH(BM_, BN_)                                                                       \
     do {                                                                                                 \
-        if (h.pl.xvec) PASE_LAUNCH((conv_gemm_kernel<BM_, BN_, 3, 1>), grid, block, st, p, h.pl);        \
+        if (h.pl.xvec) PASE_LAUNCH((conv_gemm_kernel<BM_, BN_, NS_FLAT, 1>), grid, block, st, p, h.pl);        \
         else if (h.pl.nslots == 3) PASE_LAUNCH((conv_gemm_kernel<BM_, BN_, 3, 0>), grid, block, st, p, h.pl);  \
         else if (h.pl.nslots == 6) PASE_LAUNCH((conv_gemm_kernel<BM_, BN_, 6, 0>), grid, block, st, p, h.pl);  \
         else PASE_LAUNCH((conv_gemm_kernel<BM_, BN_, 12, 0>), grid, block, st, p, h.pl);                 \
