@@ -160,7 +160,7 @@ def main():
 
         def next_batch():
             b = prod(B)
-            for k, v in extra.items():          # gammatone / prosody targets are not produced on device
+            for k, v in extra.items():          # the prosody target (SWIPE' f0) is not produced on device
                 b.setdefault(k, v)
             return b
 
@@ -227,11 +227,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("PASE+.cfg + workers+.cfg train step with the batch produced on device each step: crops "
                                     "of a resident pool, Reverb(24000-tap synthetic IRs, p=0.5) + additive noise (p=0.5), "
-                                    "LPS/FBANK/MFCC targets from the clean chunk (BASELINE.json configs[3] shape)")
+                                    "LPS/FBANK/gammatone/MFCC targets from the clean chunk (BASELINE.json configs[3] shape)")
                        if args.producer else
                        "PASE+.cfg + workers+.cfg self-supervised train step (BASELINE.json configs[2])",
                        "batch_per_gpu": B, "global_batch": B * world, "chunk_samples": T,
-                       "targets": ("lps/lps_long/fbank/fbank_long/mfcc/mfcc_long computed on device; gtn/prosody N(0,1)"
+                       "targets": ("lps/lps_long/fbank/fbank_long/gtn/gtn_long/mfcc/mfcc_long computed on device; prosody N(0,1)"
                                    if args.producer else "given (N(0,1) tensors resident in HBM)"), "parallelism": "dp%d" % world,
                        "final_total_loss": round(total_loss, 5)},
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (all launches of one step)",

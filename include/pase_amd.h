@@ -239,6 +239,14 @@ int pase_power_to_db(const float* x, float* y, unsigned* umax_scratch, long per_
 int pase_frame_prep(const float* x, float* y, int B, int T, int hop, int Q, int padL, int pad_mode,
                     float preemph, void* stream);
 
+/* Gammatone (pase/transforms.py:550-613 -> gammatone.gtgram.gtgram): 4th-order gammatone filterbank as four
+ * cascaded biquads per channel (coef (C, 10) doubles in gammatone.filters.make_erb_filters' column order),
+ * squared and summed over blocks of g samples -> blocks (B*C, ceil(T/g)); pase_gammatone_frames turns block
+ * sums into out (rows, ncol) = log(sqrt(mean over nwin samples from c*hop) + eps) (g divides nwin and hop). */
+int pase_gammatone_blocks(const float* x, const double* coef, float* blocks, int B, int C, int T, int g, void* stream);
+int pase_gammatone_frames(const float* blocks, float* out, int rows, int T, int g, int nwin, int hop, int ncol,
+                          float eps, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * On-device batch producer: what the reference's DataLoader workers do
  * per utterance in numpy / scipy, for the whole batch on resident waveforms.  Random decisions are made by the

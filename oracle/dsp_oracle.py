@@ -151,3 +151,74 @@ def mfcc(wav, hop=160, order=13, win=400, der_order=2):
 
 def znorm(X, mean, std):
     return (X - np.asarray(mean)[:, None]) / np.asarray(std)[:, None]
+
+
+# ---- Gammatone (pase/transforms.py:550-613; gammatone package absent: restated, PARITY UNPINNED) -------------
+def gt_erb_space(low_freq, high_freq, num):
+    """gammatone.filters.erb_space (centre frequencies from high to low)."""
+    ear_q, min_bw = 9.26449, 24.7
+    return (-ear_q * min_bw + np.exp((np.arange(1, num + 1) / num) * (-np.log(high_freq + ear_q * min_bw)
+                                                                     + np.log(low_freq + ear_q * min_bw)))
+            * (high_freq + ear_q * min_bw))
+
+
+def gt_make_erb_filters(fs, centre_freqs, width=1.0):
+    """gammatone.filters.make_erb_filters."""
+    T = 1 / fs
+    ear_q, min_bw, order = 9.26449, 24.7, 1
+    erb = width * ((centre_freqs / ear_q) ** order + min_bw ** order) ** (1 / order)
+    B = 1.019 * 2 * np.pi * erb
+    arg = 2 * centre_freqs * np.pi * T
+    vec = np.exp(2j * arg)
+    A0, A2, B0 = T, 0, 1
+    B1 = -2 * np.cos(arg) / np.exp(B * T)
+    B2 = np.exp(-2 * B * T)
+    rt_pos, rt_neg = np.sqrt(3 + 2 ** 1.5), np.sqrt(3 - 2 ** 1.5)
+    common = -T * np.exp(-(B * T))
+    k11 = np.cos(arg) + rt_pos * np.sin(arg)
+    k12 = np.cos(arg) - rt_pos * np.sin(arg)
+    k13 = np.cos(arg) + rt_neg * np.sin(arg)
+    k14 = np.cos(arg) - rt_neg * np.sin(arg)
+    A11, A12, A13, A14 = common * k11, common * k12, common * k13, common * k14
+    gain_arg = np.exp(1j * arg - B * T)
+    gain = np.abs((vec - gain_arg * k11) * (vec - gain_arg * k12) * (vec - gain_arg * k13) * (vec - gain_arg * k14)
+                  * (T * np.exp(B * T) / (-1 / np.exp(B * T) + 1 + vec * (1 - np.exp(B * T)))) ** 4)
+    allfilts = np.ones_like(centre_freqs)
+    return np.column_stack([A0 * allfilts, A11, A12, A13, A14, A2 * allfilts, B0 * allfilts, B1, B2, gain])
+
+
+def gt_erb_filterbank(wave, coefs):
+    """gammatone.filters.erb_filterbank: four scipy.signal.lfilter passes per channel, then / gain."""
+    output = np.zeros((coefs.shape[0], wave.shape[0]))
+    gain = coefs[:, 9]
+    As = [coefs[:, (0, k, 5)] for k in (1, 2, 3, 4)]
+    Bs = coefs[:, 6:9]
+    for idx in range(coefs.shape[0]):
+        y = wave
+        for A in As:
+            y = scipy.signal.lfilter(A[idx], Bs[idx], y)
+        output[idx, :] = y / gain[idx]
+    return output
+
+
+def gtgram(wave, fs, window_time, hop_time, channels, f_min):
+    """gammatone.gtgram.gtgram: sqrt of the mean squared filter output per window."""
+    xe = np.power(gt_erb_filterbank(np.asarray(wave, dtype=np.float64),
+                                    gt_make_erb_filters(fs, gt_erb_space(f_min, fs / 2, channels))), 2)
+    nwin = int(math.floor(window_time * fs + 0.5))
+    hop_samples = int(math.floor(hop_time * fs + 0.5))
+    columns = 1 + int(np.floor((xe.shape[1] - nwin) / hop_samples))
+    y = np.zeros((channels, columns))
+    for c in range(columns):
+        y[:, c] = np.sqrt(xe[:, c * hop_samples + np.arange(nwin)].mean(axis=1))
+    return y
+
+
+def gammatone(wav, f_min=500, n_channels=40, hop=160, win=400, der_order=2, rate=16000):
+    gtn = np.log(gtgram(np.asarray(wav, dtype=np.float32), rate, float(win) / rate, float(hop) / rate, n_channels,
+                        f_min) + 1e-10)
+    gtn = with_deltas(gtn, der_order).astype(np.float32)
+    expected = len(wav) // hop
+    if gtn.shape[1] < expected:
+        gtn = np.concatenate([gtn, np.repeat(gtn[:, -1:], expected - gtn.shape[1], axis=1)], axis=1)
+    return gtn

@@ -228,6 +228,70 @@ class MFCC(_Feature):
         return self._finish(mfcc, F, F)
 
 
+def erb_space(low_freq, high_freq, num):
+    """gammatone.filters.erb_space: `num` centre frequencies from high_freq down to low_freq on the ERB scale."""
+    ear_q, min_bw = 9.26449, 24.7
+    frac = np.arange(1, num + 1) / float(num)
+    return -ear_q * min_bw + np.exp(frac * (-np.log(high_freq + ear_q * min_bw) + np.log(low_freq + ear_q * min_bw))) * (
+        high_freq + ear_q * min_bw)
+
+
+def make_erb_filters(fs, centre_freqs, width=1.0):
+    """gammatone.filters.make_erb_filters (Slaney 1993, Auditory Toolbox MakeERBFilters): rows
+    [A0, A11, A12, A13, A14, A2, B0, B1, B2, gain] of the four cascaded second-order sections."""
+    T = 1.0 / fs
+    ear_q, min_bw, order = 9.26449, 24.7, 1
+    cf = np.asarray(centre_freqs, dtype=np.float64)
+    erb = width * ((cf / ear_q) ** order + min_bw ** order) ** (1.0 / order)
+    B = 1.019 * 2 * np.pi * erb
+    arg = 2 * cf * np.pi * T
+    vec = np.exp(2j * arg)
+    A0, A2, B0 = T, 0.0, 1.0
+    B1 = -2 * np.cos(arg) / np.exp(B * T)
+    B2 = np.exp(-2 * B * T)
+    rt_pos, rt_neg = np.sqrt(3 + 2 ** 1.5), np.sqrt(3 - 2 ** 1.5)
+    common = -T * np.exp(-(B * T))
+    k11 = np.cos(arg) + rt_pos * np.sin(arg)
+    k12 = np.cos(arg) - rt_pos * np.sin(arg)
+    k13 = np.cos(arg) + rt_neg * np.sin(arg)
+    k14 = np.cos(arg) - rt_neg * np.sin(arg)
+    gain_arg = np.exp(1j * arg - B * T)
+    gain = np.abs((vec - gain_arg * k11) * (vec - gain_arg * k12) * (vec - gain_arg * k13) * (vec - gain_arg * k14)
+                  * (T * np.exp(B * T) / (-1 / np.exp(B * T) + 1 + vec * (1 - np.exp(B * T)))) ** 4)
+    ones = np.ones_like(cf)
+    return np.column_stack([A0 * ones, common * k11, common * k12, common * k13, common * k14, A2 * ones, B0 * ones,
+                            B1, B2, gain])
+
+
+class Gammatone(_Feature):
+    """gammatone.gtgram.gtgram(wav, rate, win/rate, hop/rate, n_channels, f_min) -> log(. + 1e-10) -> deltas ->
+    replicate-pad (pase/transforms.py:550-613).  Third-party arithmetic restated from the published Slaney ERB
+    filter design (package absent: parity unpinned)."""
+
+    def __init__(self, f_min=500, n_channels=40, hop=160, win=400, der_order=2, rate=16000, name="gtn", device="cuda"):
+        super().__init__(name, der_order, device)
+        self.hop, self.win, self.C, self.rate = hop, win, n_channels, rate
+        self.erb = torch.from_numpy(make_erb_filters(rate, erb_space(f_min, rate / 2.0, n_channels))).to(self.device)
+        self.g = math.gcd(win, hop)
+
+    def __call__(self, wav, blocks=None, g=None):
+        """`blocks` / `g`: block sums shared with another Gammatone of the same filterbank (DeviceTargets)."""
+        B, _, T = wav.shape
+        if blocks is None:
+            g = self.g
+            blocks = self.block_sums(wav, g)
+        ncol = 1 + (T - self.win) // self.hop
+        gt = torch.empty(B, self.C, ncol, device=wav.device)
+        K.gammatone_frames(blocks, gt, rows=B * self.C, T=T, g=g, nwin=self.win, hop=self.hop, ncol=ncol, eps=1e-10)
+        return self._finish(gt, ncol, max(T // self.hop, ncol))
+
+    def block_sums(self, wav, g):
+        B, _, T = wav.shape
+        blocks = torch.empty(B * self.C, (T + g - 1) // g, device=wav.device)
+        K.gammatone_blocks(wav, self.erb, blocks, B=B, C_=self.C, T=T, g=g)
+        return blocks
+
+
 class DeviceTargets(object):
     """What train.py:make_transforms (train.py:37-136) composes from the worker names -- LPS / FBanks /
     MFCC (+ their *_long variants via the per-worker `transform` kwargs) followed by ZNorm -- as a
@@ -244,11 +308,25 @@ class DeviceTargets(object):
                 f = FBanks(hop=hop, name=name, device=device, **kw)
             elif "mfcc" in name:
                 f = MFCC(hop=hop, name=name, device=device, **kw)
+            elif "gtn" in name:
+                f = Gammatone(hop=hop, name=name, device=device, **kw)
             else:
-                continue      # cchunk (the waveform itself), gammatone, prosody: not produced here
+                continue      # cchunk (the waveform itself), prosody: not produced here
             if stats is not None and name in stats:
                 f.set_stats(stats[name]["mean"], stats[name]["std"])
             self.feats[name] = f
 
     def __call__(self, cchunk):
-        return {name: f(cchunk) for name, f in self.feats.items()}
+        out = {}
+        # Gammatone features that share a filterbank (gtn / gtn_long differ only in the window) share the IIR pass
+        gts = [f for f in self.feats.values() if isinstance(f, Gammatone)]
+        shared = {}
+        if len(gts) > 1 and all((f.C, f.rate) == (gts[0].C, gts[0].rate) and torch.equal(f.erb, gts[0].erb) for f in gts):
+            g = 0
+            for f in gts:
+                g = math.gcd(g, f.g)
+            blocks = gts[0].block_sums(cchunk, g)
+            shared = {f.name: (blocks, g) for f in gts}
+        for name, f in self.feats.items():
+            out[name] = f(cchunk, *shared[name]) if name in shared else f(cchunk)
+        return out

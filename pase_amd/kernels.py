@@ -237,6 +237,8 @@ _SIMPLE.update({
     "pase_peak_scale": [_fp, _fp, _i, _i, _fp],
     "pase_reverb": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp],
     "pase_add_noise": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _fp],
+    "pase_gammatone_blocks": [_fp, _fp, _fp, _i, _i, _i, _i, _fp],
+    "pase_gammatone_frames": [_fp, _fp, _i, _i, _i, _i, _i, _i, _f, _fp],
     "pase_pack_wt": [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp],
     "pase_adam_step": [_fp, _fp, _fp, _fp, _l, _fp, _fp, _f, _f, _f, _f, _fp],
     "pase_step_tick": [_fp, _fp],
@@ -432,3 +434,13 @@ def add_noise(x, npool, noff, nlen, nidx, nbeg, snr, *, B, T):
     _check(_lib.lib().pase_add_noise(_ptr(x), _ptr(npool), _ptr(noff, torch.int64), _ptr(nlen, torch.int32),
                                      _ptr(nidx, torch.int32), _ptr(nbeg, torch.int32), _ptr(snr), B, T, _stream()),
            "pase_add_noise")
+
+
+def gammatone_blocks(x, coef, blocks, *, B, C_, T, g):
+    _check(_lib.lib().pase_gammatone_blocks(_ptr(x), _ptr(coef, torch.float64), _ptr(blocks), B, C_, T, g, _stream()),
+           "pase_gammatone_blocks")
+
+
+def gammatone_frames(blocks, out, *, rows, T, g, nwin, hop, ncol, eps):
+    _check(_lib.lib().pase_gammatone_frames(_ptr(blocks), _ptr(out), rows, T, g, nwin, hop, ncol, eps, _stream()),
+           "pase_gammatone_frames")

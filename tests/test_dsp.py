@@ -46,11 +46,14 @@ CASES = [
     ("fbank", dict(n_filters=12, n_fft=128, hop=160, win=100), 1600),
     ("fbank_trunc", dict(n_filters=12, n_fft=128, hop=160, win=200), 1600),
     ("mfcc", dict(hop=160, order=7, win=128), 1600),
+    ("gtn", dict(n_channels=9, hop=160, win=400), 3200),
+    ("gtn_long", dict(n_channels=6, hop=160, win=1024, f_min=300), 3200),
 ]
 FULL = [
     ("lps", dict(), 32000), ("lps_long", dict(win=512), 32000),
     ("fbank", dict(), 32000), ("fbank_long", dict(win=1024, n_fft=1024), 32000),
     ("mfcc", dict(), 32000), ("mfcc_long", dict(win=2048, order=20), 32000),
+    ("gtn", dict(), 32000), ("gtn_long", dict(win=2048), 32000),
 ]
 
 
@@ -58,6 +61,8 @@ def _run(dev, name, kw, T, B, znorm):
     wav = _wav(B, T, seed=len(name))
     if name.startswith("lps"):
         f, ofn = dsp.LPS(device=dev, **kw), O.lps
+    elif name.startswith("gtn"):
+        f, ofn = dsp.Gammatone(device=dev, **kw), O.gammatone
     elif name.startswith("fbank"):
         f, ofn = dsp.FBanks(device=dev, **kw), O.fbanks
     else:
@@ -146,3 +151,15 @@ def test_trainer_step_with_device_targets(dev):
         losses.append({k: float(v) for k, v in lo.items()})
     for k, v in losses[0].items():
         assert abs(losses[1][k] - v) <= 1e-3 * max(1.0, abs(v)), (k, losses[1][k], v)
+
+
+def test_device_targets_share_gammatone_filterbank(dev):
+    """gtn / gtn_long (workers+.cfg) differ only in the window: DeviceTargets runs the IIR bank once."""
+    cfg = {"regr": [{"name": "gtn", "num_outputs": 18, "transform": {"n_channels": 6}},
+                    {"name": "gtn_long", "num_outputs": 18, "transform": {"n_channels": 6, "win": 1024}}]}
+    tg = dsp.DeviceTargets(cfg, device=dev)
+    wav = _wav(2, 3200, seed=5)
+    got = tg(wav.to(dev))
+    for name, kw in (("gtn", dict(n_channels=6)), ("gtn_long", dict(n_channels=6, win=1024))):
+        want = np.stack([O.gammatone(wav[b, 0].numpy(), **kw) for b in range(2)])
+        _check(got[name], want, np.full(want.shape, 2e-3), name)

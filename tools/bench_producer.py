@@ -42,7 +42,7 @@ x = chunker(B)["chunk"].contiguous()
 res = {"chunk_gather+scale (3B crops)": timed(lambda: chunker(B)),
        "reverb all B, IR %d taps" % L: timed(lambda: rv(x.clone(), np.arange(B) % 8)),
        "additive all B": timed(lambda: ad(x.clone(), np.arange(B) % 8, np.zeros(B, int), np.full(B, 5.0))),
-       "targets (lps/fbank/mfcc x2)": timed(lambda: tg(x))}
+       "targets (lps/fbank/gtn/mfcc x2)": timed(lambda: tg(x))}
 prod = P.DeviceBatchProducer(chunker, rv, 0.5, ad, 0.5, tg, rng=np.random.RandomState(2))
 res["full producer (p=0.5 gates)"] = timed(lambda: prod(B))
 gf = 2.0 * (T + L - 1) * L * B / 1e9
