@@ -179,3 +179,46 @@ def test_dsp_oracle_mel_banks_are_well_formed():
     x = np.random.default_rng(1).normal(size=(128, 5))
     np.testing.assert_allclose(dsp.dct2_ortho(13, 128).astype(np.float64) @ x,
                                scipy.fftpack.dct(x, axis=0, type=2, norm="ortho")[:13], atol=1e-5)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="live reference tree not present")
+def test_checkpoint_wire_format_round_trip_with_live_reference(tmp_path):
+    """SURVEY (f)-4: a checkpoint written by pase_amd's Saver loads into the REFERENCE WaveFe through the
+    reference's own load_pretrained (modules.py:267-301), and a reference checkpoint loads into pase_amd --
+    same keys, same shapes, same tensors (PASE+-shaped encoder incl. QRNN and dense skips)."""
+    from oracle import ref_shim
+    ref_shim.install()
+    from pase.models.frontend import wf_builder as ref_builder
+    import pase_amd.frontend as mine
+    from pase_amd.modules import Saver
+    cfg = dict(kwidths=[51, 20, 11, 11, 11, 11, 11, 11], strides=[1, 10, 2, 1, 2, 1, 2, 2],
+               fmaps=[8, 8, 12, 12, 16, 16, 20, 20], emb_dim=24, rnn_dim=20, denseskips=True, norm_out=True,
+               rnn_pool=True, rnn_layers=1)
+    seed_all(5)
+    a = quiet(mine.wf_builder, dict(cfg))
+    seed_all(6)
+    ref = quiet(ref_builder, dict(cfg))
+    assert list(a.state_dict().keys()) == list(ref.state_dict().keys())
+    # pase_amd -> reference: Saver file ('state_dict' wrapper, trainer.py:267-272 convention)
+    sv = Saver(a, str(tmp_path), max_ckpts=2, prefix="PASE-")
+    quiet(sv.save, "PASE", 3)
+    ck = [f for f in os.listdir(tmp_path) if f.endswith(".ckpt") and "weights" in f]
+    assert ck, os.listdir(tmp_path)
+    quiet(ref.load_pretrained, os.path.join(str(tmp_path), ck[0]), load_last=True, verbose=False)
+    for k, v in a.state_dict().items():
+        assert torch.equal(ref.state_dict()[k], v), k
+    # reference -> pase_amd: bare state_dict file
+    seed_all(7)
+    ref2 = quiet(ref_builder, dict(cfg))
+    p2 = os.path.join(str(tmp_path), "ref.ckpt")
+    torch.save(ref2.state_dict(), p2)
+    quiet(a.load_pretrained, p2, load_last=True, verbose=False)
+    for k, v in ref2.state_dict().items():
+        assert torch.equal(a.state_dict()[k], v), k
+    # and the two then compute the same thing on CPU through the oracle parameters
+    x = torch.randn(2, 1, 1600) * 0.2
+    ref2.eval()
+    with torch.no_grad():
+        yr = ref2(x)
+    yo = O.encoder_forward(oracle_params(a), cfg, x, False)
+    assert_close(yo, yr, rtol=1e-5, atol=1e-5)
