@@ -152,3 +152,60 @@ def test_channel_slices_and_large_taps(dev):
                 pad_mode=K.PAD_ZERO)
     torch.testing.assert_close(yw.cpu()[:, 1:1 + Cout], ref, rtol=2e-5, atol=2e-5)
     assert float(yw.cpu()[:, 0].abs().max()) == 0.0
+
+
+def test_reversed_taps_single_row_odd_count(dev):
+    """tapstep = -1 with more taps than a stage holds per row pair (taps 27 > 24 -> one channel row per stage,
+    taps paired, odd count -> the zero-weight tap reads the guard sample in front of the span)."""
+    torch.manual_seed(6)
+    S, Cin, Cout, T, k = 2, 3, 7, 90, 27
+    x = torch.randn(S, Cin, T)
+    w = torch.randn(Cout, Cin, k) * 0.2
+    # out[q] = sum_kk w[kk] x[q - kk]  (causal, reversed taps, zero history)
+    ref = F.conv1d(F.pad(x, (k - 1, 0)), w.flip(2))
+    y = torch.zeros(S, Cout, T, device=dev)
+    K.conv_gemm(x.to(dev), w.reshape(Cout, -1).contiguous().to(dev), y, S=S, Cin=Cin, Tin=T, M=Cout, K=Cin * k,
+                taps=k, Ncols=T, Tout=T, tapstep=-1, padL=0, pad_mode=K.PAD_ZERO)
+    torch.testing.assert_close(y.cpu(), ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("Cin,T", [(50, 40), (21, 64), (1, 8), (70, 37)])
+def test_flat_1x1_paths(dev, Cin, T):
+    """1x1 layers: float4 flat path (T % 4 == 0: ragged last channel group shifted back, odd Cin, on-load affine +
+    PReLU per row) and the one-tap convolution fallback (T = 37)."""
+    torch.manual_seed(7)
+    S, Cout = 3, 150
+    x = torch.randn(S, Cin, T)
+    w = torch.randn(Cout, Cin) * 0.2
+    b = torch.randn(Cout)
+    sc, sh, al = torch.rand(Cin) + 0.5, torch.randn(Cin) * 0.2, torch.rand(Cin) * 0.5
+    xin = x * sc[None, :, None] + sh[None, :, None]
+    xin = torch.where(xin > 0, xin, xin * al[None, :, None])
+    ref = torch.einsum("ok,skt->sot", w, xin) + b[None, :, None]
+    y = torch.zeros(S, Cout, T, device=dev)
+    K.conv_gemm(x.to(dev), w.to(dev), y, S=S, Cin=Cin, Tin=T, M=Cout, K=Cin, taps=1, Ncols=T, Tout=T, bias=b.to(dev),
+                in_scale=sc.to(dev), in_shift=sh.to(dev), in_alpha=al.to(dev), splitk=1)
+    torch.testing.assert_close(y.cpu(), ref, rtol=3e-5, atol=3e-5)
+
+
+def test_auto_splitk_with_pixel_shuffle_and_direct_kmajor_weight(dev):
+    """library-chosen split-K (splitk=0) on a transposed conv (atomic partial tiles + bias from split 0), and a
+    weight that already is K-major passed as wt= without a pack."""
+    torch.manual_seed(8)
+    S, Cin, Cout, k, st, T = 2, 200, 6, 8, 4, 9
+    x = torch.randn(S, Cin, T)
+    w = torch.randn(Cin, Cout, k) * 0.1
+    b = torch.randn(Cout)
+    pad = (k - st) // 2
+    ref = F.conv_transpose1d(x, w, b, stride=st, padding=pad)
+    from pase_amd import engine as E
+    y = E.deconv_fwd(E.Act(x.to(dev), C=Cin), w.to(dev), b.to(dev), Cout=Cout, k=k, stride=st)
+    torch.testing.assert_close(y.cpu(), ref, rtol=1e-4, atol=1e-4)
+    # A = W^T of a 1x1 data-gradient: W (R=12, O=8) row-major is its own K-major pack
+    W = torch.randn(12, 8)
+    g = torch.randn(2, 12, 20)
+    wt = K.pack_dgrad_t(W.to(dev), R=12, O=8, k=1, st=1, s_red=8, s_out=1, s_k=1)
+    assert wt.data_ptr() == wt.data_ptr() and tuple(wt.shape) == (12, 8)
+    dx = torch.zeros(2, 8, 20, device=dev)
+    K.conv_gemm(g.to(dev), None, dx, wt=wt, S=2, Cin=12, Tin=20, M=8, K=12, taps=1, Ncols=20, Tout=20, splitk=1)
+    torch.testing.assert_close(dx.cpu(), torch.einsum("ro,srt->sot", W, g), rtol=2e-5, atol=2e-5)
