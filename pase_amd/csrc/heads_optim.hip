@@ -36,7 +36,21 @@ __global__ void __launch_bounds__(NT) head1_fwd_kernel(const float* z, const flo
         const int s = (int)(i / T), t = (int)(i % T);
         const float* zp = z + (size_t)s * C * T + t;
         float acc = bias ? bias[0] : 0.f;
-        for (int c = 0; c < C; ++c) {
+        // channels are T floats apart: eight independent loads in flight, accumulated in channel order
+        int c = 0;
+        for (; c + 8 <= C; c += 8) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = zp[(size_t)(c + e) * T];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float u = v[e];
+                if (in_scale) u = u * in_scale[c + e] + in_shift[c + e];
+                if (in_alpha) u = u > 0.f ? u : u * in_alpha[c + e];
+                acc = fmaf(w[c + e], u, acc);
+            }
+        }
+        for (; c < C; ++c) {
             float v = zp[(size_t)c * T];
             if (in_scale) v = v * in_scale[c] + in_shift[c];
             if (in_alpha) v = v > 0.f ? v : v * in_alpha[c];
