@@ -121,21 +121,25 @@ __device__ float g_ident[2] = {1.f, 0.f};
 // Both are compile-time so that the per-stage loader is straight-line code: every load is issued
 // unconditionally from a precomputed offset (slots / rows that do not exist re-read a valid address and
 // land in slab padding), which keeps the loads independent of each other in the instruction stream.
-template <int BM, int BN, int NS, int XV>
-__global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, ConvPlan pl) {
+// OCC = workgroups per CU the instantiation is sized for: 3 needs <= 53 KB of LDS (44-row weight slab, 3-slot span
+// slab: the 11-tap and 30-tap layers) and <= 168 VGPRs.
+template <int BM, int BN, int NS, int XV, int OCC = 2>
+__global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p, ConvPlan pl) {
     constexpr int WAVES_N = BN / 64;
     static_assert((BM / 64) * WAVES_N == 4, "4 waves");
     constexpr int TA = BM / 4;             // threads per A slab row (one float4 each)
     constexpr int RA = NTHREADS / TA;      // slab rows per pass (8 / 16)
-    constexpr int KG_T = XV ? KG_FLAT : KGMAX;
-    constexpr int XS_T = XV ? XS_FLAT : XSMAX;
-    constexpr int PA_MAX = KG_T / RA;      // 6 / 3 (4 / 2 flat)
+    constexpr int KG_T = XV ? KG_FLAT : (OCC == 3 ? 44 : KGMAX);
+    constexpr int XS_T = XV ? XS_FLAT : (OCC == 3 ? NS * NTHREADS : XSMAX);
+    constexpr int PA_MAX = (KG_T + RA - 1) / RA;      // 6 / 3 (4 / 2 flat)
     constexpr int LDA = BM + 4;
     __shared__ __attribute__((aligned(16))) float As[2][KG_T][LDA];
     // 4 guard floats (zero) in front of each X buffer: the one zero-weight tap a reversed-tap single-row stage
     // with an odd tap count reads at span offset -1 must be finite
     __shared__ __attribute__((aligned(16))) float XsG[2][XS_T + 4];
-    __shared__ float red[WAVES_N][BM][2];
+    // epilogue scratch (BN partial sums / loss partials) reuses the weight slab: it is dead after the last stage
+    float (*red)[BM][2] = reinterpret_cast<float (*)[BM][2]>(&As[0][0][0]);
+    static_assert(sizeof(float) * WAVES_N * BM * 2 <= sizeof(As), "epilogue scratch");
 
     PASE_STAMP(0);
     const int tid = threadIdx.x;
@@ -323,7 +327,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) conv_gemm_kernel(PaseConvGemm p, 
             F4 v = areg[ps];
             const int kl = ar + RA * ps;
             if (a_zero && (kl < lo_next || kl >= kg_next)) v = F4{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<F4*>(&As[buf][kl][acl]) = v;
+            if (PA_MAX * RA == KG_T || kl < KG_T) *reinterpret_cast<F4*>(&As[buf][kl][acl]) = v;
         }
         // ---- X
         float* xs = &XsG[buf][4 + xs_tbase];
@@ -767,9 +771,11 @@ HostPlan make_plan(const PaseConvGemm& p) {
         const double flush = 4.0 / (double)G;
         double best = 1e30;
         const int max_split = G / 6 < 1 ? 1 : G / 6;
+        // workgroup slots: 2 per CU, 3 for the small-footprint instantiation (see PASE_CONV_LAUNCH)
+        const long slots = (!h.narrow && !pl.xvec && pl.nslots == 3 && pl.CB * pl.TB <= 44) ? 768 : 512;
         for (int sk = 1; sk <= max_split && sk <= 64; ++sk) {
             const long W = tiles * sk;
-            const long full = W / 512, tail = W % 512;
+            const long full = W / slots, tail = W % slots;
             const double tc = tail == 0 ? 0.0 : (tail <= 256 ? 0.55 : 1.0);
             const double est = ((double)full + tc) * (1.0 / sk + (sk > 1 ? flush : 0.0));
             if (est < best * 0.97) { best = est; splitk = sk; }     // a larger split must win by 3 %
@@ -824,6 +830,8 @@ extern "C" int pase_conv_gemm(const PaseConvGemm* d, void* stream) {
 #define PASE_CONV_LAUNCH(BM_, BN_)                                                                       \
     do {                                                                                                 \
         if (h.pl.xvec) PASE_LAUNCH((conv_gemm_kernel<BM_, BN_, NS_FLAT, 1>), grid, block, st, p, h.pl);        \
+        else if (h.pl.nslots == 3 && BM_ == 128 && h.pl.CB * h.pl.TB <= 44)                              \
+            PASE_LAUNCH((conv_gemm_kernel<128, 128, 3, 0, 3>), grid, block, st, p, h.pl);                \
         else if (h.pl.nslots == 3) PASE_LAUNCH((conv_gemm_kernel<BM_, BN_, 3, 0>), grid, block, st, p, h.pl);  \
         else if (h.pl.nslots == 6) PASE_LAUNCH((conv_gemm_kernel<BM_, BN_, 6, 0>), grid, block, st, p, h.pl);  \
         else PASE_LAUNCH((conv_gemm_kernel<BM_, BN_, 12, 0>), grid, block, st, p, h.pl);                 \
