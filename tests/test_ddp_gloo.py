@@ -92,3 +92,70 @@ def test_two_rank_step_matches_manual_average():
                 torch.testing.assert_close(p.detach(), r0["params"][n], rtol=0, atol=5e-6, msg=n)
     finally:
         _lib.use_library(None, "cuda")
+
+
+def _gpu_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0 if rank == 0 else 999)
+    from pase_amd.trainer import trainer
+    tr = quiet(trainer, frontend_cfg=dict(MINI_FE), minions_cfg=with_losses(mini_workers()),
+               cfg=dict(fe_lr=1e-3, min_lr=5e-4, epoch=1, bpe=4), lr_mode="poly", device=dev)
+    assert tr.world == 2
+    tot = []
+    for step in range(2):
+        losses = tr.train_step({k: v.to(dev) for k, v in _batch(100 + 10 * step + rank).items()})
+        tot.append(float(losses["total"]))
+    assert tr._side is not None        # the worker-buffer all-reduce ran on the side stream under the encoder backward
+    sd = {n: p.detach().cpu().clone() for n, p in tr.model.named_parameters()}
+    torch.save({"params": sd, "total": tot}, os.path.join(outdir, "rank%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_step_on_gpu_side_stream_overlap():
+    """The CUDA path of trainer._step_ddp (side-stream all-reduce of the worker buffers issued from the
+    before_encoder_backward hook) on the real library: two ranks share cuda:0 and exchange over gloo (RCCL refuses
+    two ranks on one device; the collective backend is the only difference to the 8-GPU run).  Ranks must stay
+    bit-identical and match a single process that averages the two per-rank gradients."""
+    from pase_amd import engine
+    port = 29500 + (os.getpid() % 2000)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_gpu_worker, args=(2, port, d), nprocs=2, join=True)
+        r0 = torch.load(os.path.join(d, "rank0.pt"))
+        r1 = torch.load(os.path.join(d, "rank1.pt"))
+    for n in r0["params"]:
+        assert torch.equal(r0["params"][n], r1["params"][n]), "ranks diverged on " + n
+    dev = torch.device("cuda", 0)
+    from pase_amd.trainer import trainer
+    seed_all(0)
+    tr = quiet(trainer, frontend_cfg=dict(MINI_FE), minions_cfg=with_losses(mini_workers()),
+               cfg=dict(fe_lr=1e-3, min_lr=5e-4, epoch=1, bpe=4), lr_mode="poly", device=dev)
+    for step in range(2):
+        grads = []
+        snap = {k: v.clone() for k, v in tr.model.state_dict().items()}
+        for r in range(2):
+            with torch.no_grad():                      # BN running stats advance per rank: restore between ranks
+                for k, v in tr.model.state_dict().items():
+                    v.copy_(snap[k])
+            for opt in tr.optimizers():
+                opt.zero_grad()
+            tr.model.train()
+            tr.model.loss_and_grads({k: v.to(dev) for k, v in _batch(100 + 10 * step + r).items()},
+                                    engine.GradSink(direct=True))
+            grads.append([opt.flat_g.clone() for opt in tr.optimizers()])
+        with torch.no_grad():
+            for k, v in tr.model.state_dict().items():
+                if "running" not in k and "num_batches" not in k:
+                    v.copy_(snap[k])
+        for i, opt in enumerate(tr.optimizers()):
+            opt.flat_g.copy_(grads[0][i] + grads[1][i])
+            opt.step(grad_mul=0.5)
+    for n, p in tr.model.named_parameters():
+        if not is_noise_grad(n):
+            torch.testing.assert_close(p.detach().cpu(), r0["params"][n], rtol=0, atol=2e-5, msg=n)
