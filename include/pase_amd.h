@@ -266,6 +266,15 @@ int pase_peak_scale(float* x, const float* u, int N, int T, void* stream);
  * floats, energies (2B) doubles. */
 int pase_reverb(float* x, const float* irs, const long long* ir_off, const int* ir_len, const int* ir_pmax,
                 const int* ir_idx, float* full, double* energies, int B, int T, int max_ir_len, void* stream);
+/* The same FIR with the filter-distortion conventions: BandDrop / Downsample (pase/transforms.py:1113-1300) shift
+ * by round(len/2) (ir_shift[i], computed by the caller with the reference's Python round) and take the energy
+ * ratio on the shifted, trimmed signal (trimmed_energy = 1); trimmed_energy = 0 is pase_reverb. */
+int pase_fir_distort(float* x, const float* irs, const long long* ir_off, const int* ir_len, const int* ir_shift,
+                     const int* ir_idx, float* full, double* energies, int B, int T, int max_ir_len,
+                     int trimmed_energy, void* stream);
+/* Clipping.__call__ (pase/transforms.py:1514-1535), in place: clamp utterance b to [f * min, f * max], f = factor[b]
+ * (<= 0: untouched) */
+int pase_clip(float* x, const float* factor, int B, int T, void* stream);
 /* SimpleAdditive.__call__ (pase/transforms.py:1633-1675), in place on x (B, T): noise crop
  * npool[noff[i] + nbeg[b] : +T] (zero beyond nlen[i]), K = sqrt(Ex / (10^(snr/10) En)), x <- (x + K n) *
  * sqrt(Ex / (E(x + K n) + 1e-14)); nidx[b] < 0 or a silent crop leaves utterance b untouched. */

@@ -63,3 +63,24 @@ def additive(wav, noise_full, n_beg, snr):
     Kf = np.sqrt(Ex / ((10 ** (snr / 10.)) * En))
     noisy = wav + Kf * noise
     return (np.sqrt(Ex / (np.dot(noisy, noisy) + 1e-14)) * noisy).astype(np.float32)
+
+
+def fir_filter_distortion(wav, filt):
+    """BandDrop / Downsample.__call__ (pase/transforms.py:1162-1196, 1256-1296)."""
+    filt = np.asarray(filt, dtype=np.float64)
+    filt = (filt / np.abs(np.max(filt))).astype(np.float32)
+    wav = np.asarray(wav).reshape(-1)
+    Ex = np.dot(wav, wav)
+    wav = wav.astype(np.float32)
+    sig = scipy.signal.convolve(wav, filt, mode="full").reshape(-1)
+    sig = shift(sig, -round(filt.shape[0] / 2))
+    sig = sig[:wav.shape[0]]
+    Ef = np.dot(sig, sig)
+    ratio = np.sqrt(Ex / Ef) if Ef > 0 else 1.0
+    return (ratio * sig).astype(np.float32)
+
+
+def clipping(wav, cf):
+    wav = np.asarray(wav, dtype=np.float32)
+    clip = np.maximum(wav, cf * np.min(wav))
+    return np.minimum(clip, cf * np.max(wav))

@@ -147,20 +147,50 @@ __global__ void __launch_bounds__(NT) fir_full_kernel(const float* x, const floa
     if (tid == 0) atomicAdd(Er + b, e);
 }
 
-// rev = Eratio * shift(full, -p_max)[:T]  (transforms.py:1088-1098); utterances with ir_idx < 0 are left as is
+// rev = Eratio * shift(full, -p_max)[:T]  (transforms.py:1088-1098); utterances with ir_idx < 0 are left as is.
+// trimmed_energy (BandDrop / Downsample, :1275-1289): the energy ratio is taken on the shifted, trimmed signal,
+// so this pass writes it unscaled and fir_rescale_kernel applies the ratio afterwards.
 __global__ void __launch_bounds__(NT) reverb_finish_kernel(float* x, const float* full, const int* ir_len,
                                                            const int* ir_pmax, const int* ir_idx, const double* Ex,
-                                                           const double* Er, int T, int full_stride) {
+                                                           const double* Er, int T, int full_stride,
+                                                           int trimmed_energy) {
     const int b = blockIdx.y;
     const int ii = ir_idx[b];
     if (ii < 0) return;
     const int nfull = T + ir_len[ii] - 1;
     const int p = ir_pmax[ii];
-    const float ratio = Er[b] > 0.0 ? (float)sqrt(Ex[b] / Er[b]) : 1.f;
+    const float ratio = trimmed_energy ? 1.f : (Er[b] > 0.0 ? (float)sqrt(Ex[b] / Er[b]) : 1.f);
     for (int t = blockIdx.x * NT + threadIdx.x; t < T; t += gridDim.x * NT) {
         const int n = t + p;
         x[(size_t)b * T + t] = n < nfull ? ratio * full[(size_t)b * full_stride + n] : 0.f;
     }
+}
+
+__global__ void __launch_bounds__(NT) fir_rescale_kernel(float* x, const int* ir_idx, const double* Ex, int T) {
+    __shared__ double sh[NT / 64];
+    const int b = blockIdx.x;
+    if (ir_idx[b] < 0) return;
+    float* row = x + (size_t)b * T;
+    double e = 0.0;
+    for (int t = threadIdx.x; t < T; t += NT) e += (double)row[t] * (double)row[t];
+    e = block_sum_d(e, sh);
+    const float ratio = e > 0.0 ? (float)sqrt(Ex[b] / e) : 1.f;
+    for (int t = threadIdx.x; t < T; t += NT) row[t] *= ratio;
+}
+
+// Clipping.__call__ (transforms.py:1514-1535): clamp to [cf * min(x), cf * max(x)]; cf[b] <= 0 leaves b untouched
+__global__ void __launch_bounds__(NT) clip_kernel(float* x, const float* cf, int T) {
+    __shared__ float sh[NT / 64];
+    const int b = blockIdx.x;
+    const float f = cf[b];
+    if (!(f > 0.f)) return;
+    float* row = x + (size_t)b * T;
+    float mx = -3.4e38f, mn = 3.4e38f;
+    for (int t = threadIdx.x; t < T; t += NT) { mx = fmaxf(mx, row[t]); mn = fminf(mn, row[t]); }
+    mx = block_max_f(mx, sh);
+    mn = -block_max_f(-mn, sh);
+    const float lo = f * mn, hi = f * mx;
+    for (int t = threadIdx.x; t < T; t += NT) row[t] = fminf(fmaxf(row[t], lo), hi);
 }
 
 // SimpleAdditive.__call__ (transforms.py:1633-1675): noise crop, K = sqrt(Ex / (10^(snr/10) En)),
@@ -214,9 +244,9 @@ extern "C" int pase_peak_scale(float* x, const float* u, int N, int T, void* str
     return 0;
 }
 
-extern "C" int pase_reverb(float* x, const float* irs, const long long* ir_off, const int* ir_len,
-                           const int* ir_pmax, const int* ir_idx, float* full, double* energies, int B, int T,
-                           int max_ir_len, void* stream) {
+extern "C" int pase_fir_distort(float* x, const float* irs, const long long* ir_off, const int* ir_len,
+                                const int* ir_shift, const int* ir_idx, float* full, double* energies, int B, int T,
+                                int max_ir_len, int trimmed_energy, void* stream) {
     if (B <= 0 || T <= 0) return 0;
     if (max_ir_len < 1) return -2;
     hipStream_t st = (hipStream_t)stream;
@@ -228,7 +258,23 @@ extern "C" int pase_reverb(float* x, const float* irs, const long long* ir_off, 
     PASE_LAUNCH(fir_full_kernel, dim3((unsigned)((full_stride + FIR_TILE - 1) / FIR_TILE), (unsigned)B), dim3(NT), st,
                 (const float*)x, irs, ir_len, ir_off, ir_idx, full, Er, T, full_stride);
     PASE_LAUNCH(reverb_finish_kernel, dim3((unsigned)((T + NT * 4 - 1) / (NT * 4)), (unsigned)B), dim3(NT), st, x,
-                (const float*)full, ir_len, ir_pmax, ir_idx, (const double*)Ex, (const double*)Er, T, full_stride);
+                (const float*)full, ir_len, ir_shift, ir_idx, (const double*)Ex, (const double*)Er, T, full_stride,
+                trimmed_energy);
+    if (trimmed_energy)
+        PASE_LAUNCH(fir_rescale_kernel, dim3((unsigned)B), dim3(NT), st, x, ir_idx, (const double*)Ex, T);
+    PASE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pase_reverb(float* x, const float* irs, const long long* ir_off, const int* ir_len,
+                           const int* ir_pmax, const int* ir_idx, float* full, double* energies, int B, int T,
+                           int max_ir_len, void* stream) {
+    return pase_fir_distort(x, irs, ir_off, ir_len, ir_pmax, ir_idx, full, energies, B, T, max_ir_len, 0, stream);
+}
+
+extern "C" int pase_clip(float* x, const float* factor, int B, int T, void* stream) {
+    if (B <= 0 || T <= 0) return 0;
+    PASE_LAUNCH(clip_kernel, dim3((unsigned)B), dim3(NT), (hipStream_t)stream, x, factor, T);
     PASE_CHECK_LAUNCH();
     return 0;
 }

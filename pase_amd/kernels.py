@@ -236,6 +236,8 @@ _SIMPLE.update({
     "pase_chunk_gather": [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _fp],
     "pase_peak_scale": [_fp, _fp, _i, _i, _fp],
     "pase_reverb": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp],
+    "pase_fir_distort": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp],
+    "pase_clip": [_fp, _fp, _i, _i, _fp],
     "pase_add_noise": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _fp],
     "pase_gammatone_blocks": [_fp, _fp, _fp, _i, _i, _i, _i, _fp],
     "pase_gammatone_frames": [_fp, _fp, _i, _i, _i, _i, _i, _i, _f, _fp],
@@ -444,3 +446,14 @@ def gammatone_blocks(x, coef, blocks, *, B, C_, T, g):
 def gammatone_frames(blocks, out, *, rows, T, g, nwin, hop, ncol, eps):
     _check(_lib.lib().pase_gammatone_frames(_ptr(blocks), _ptr(out), rows, T, g, nwin, hop, ncol, eps, _stream()),
            "pase_gammatone_frames")
+
+
+def fir_distort(x, irs, ir_off, ir_len, ir_shift, ir_idx, full, energies, *, B, T, max_ir_len, trimmed_energy):
+    _check(_lib.lib().pase_fir_distort(_ptr(x), _ptr(irs), _ptr(ir_off, torch.int64), _ptr(ir_len, torch.int32),
+                                       _ptr(ir_shift, torch.int32), _ptr(ir_idx, torch.int32), _ptr(full),
+                                       _ptr(energies, torch.float64), B, T, max_ir_len, trimmed_energy, _stream()),
+           "pase_fir_distort")
+
+
+def clip(x, factor, *, B, T):
+    _check(_lib.lib().pase_clip(_ptr(x), _ptr(factor), B, T, _stream()), "pase_clip")

@@ -102,6 +102,49 @@ class DeviceReverb(object):
         return chunk
 
 
+class DeviceFilter(object):
+    """BandDrop / Downsample (pase/transforms.py:1113-1300): FIR with a filter divided by |max| at load time
+    (:1140,1241), delay compensation by round(len / 2) (Python's round, as written), trim, energy matched on the
+    trimmed signal."""
+
+    def __init__(self, filters, device="cuda"):
+        prepared, shifts = [], []
+        for f in filters:
+            f = np.asarray(f, dtype=np.float64).reshape(-1)
+            f = f / np.abs(np.max(f))
+            prepared.append(f.astype(np.float32))
+            shifts.append(int(round(f.shape[0] / 2)))
+        self.filters = WavPool(prepared, device)
+        self.shift = _dev_i32(shifts, device)
+        self.max_len = int(max(len(f) for f in prepared))
+        self.n = len(prepared)
+
+    def __call__(self, chunk, filt_idx):
+        B, _, T = chunk.shape
+        full = torch.empty(B, T + self.max_len - 1, device=chunk.device)
+        energies = torch.empty(2 * B, dtype=torch.float64, device=chunk.device)
+        K.fir_distort(chunk, self.filters.pool, self.filters.off, self.filters.len, self.shift,
+                      _dev_i32(filt_idx, chunk.device), full, energies, B=B, T=T, max_ir_len=self.max_len,
+                      trimmed_energy=1)
+        return chunk
+
+
+BandDrop = Downsample = DeviceFilter
+
+
+class DeviceClipping(object):
+    """Clipping (pase/transforms.py:1514-1535)."""
+
+    def __init__(self, clip_factors=(0.3, 0.4, 0.5)):
+        self.clip_factors = list(clip_factors)
+
+    def __call__(self, chunk, factor):
+        """factor[b] = clip factor drawn for utterance b, <= 0 = leave untouched"""
+        B, _, T = chunk.shape
+        K.clip(chunk, torch.as_tensor(np.asarray(factor, dtype=np.float32), device=chunk.device), B=B, T=T)
+        return chunk
+
+
 class DeviceAdditive(object):
     """SimpleAdditive (pase/transforms.py:1590-1680) for a batch of resident noises."""
 
@@ -121,9 +164,13 @@ class DeviceBatchProducer(object):
     """dataset.__getitem__ + DictCollater for one batch: chunks, clean copy, gated distortions, and (when a
     DeviceTargets is attached) the regression labels computed from the clean chunk."""
 
-    def __init__(self, chunker, reverb=None, reverb_p=0.5, additive=None, additive_p=0.5, targets=None, rng=None):
+    def __init__(self, chunker, reverb=None, reverb_p=0.5, additive=None, additive_p=0.5, targets=None, rng=None,
+                 clipping=None, clip_p=0.2, bandrop=None, bandrop_p=0.35, downsample=None, downsample_p=0.25):
         self.chunker, self.reverb, self.additive, self.targets = chunker, reverb, additive, targets
         self.reverb_p, self.additive_p = reverb_p, additive_p
+        self.clipping, self.clip_p = clipping, clip_p
+        self.bandrop, self.bandrop_p = bandrop, bandrop_p
+        self.downsample, self.downsample_p = downsample, downsample_p
         self.rng = rng if rng is not None else np.random
 
     def __call__(self, B):
@@ -143,6 +190,15 @@ class DeviceBatchProducer(object):
             beg = np.where(nl > T, (self.rng.random_sample(B) * np.maximum(nl - T, 1)).astype(np.int64), 0)
             snr = np.asarray(self.additive.snr_levels, dtype=np.float32)[self.rng.randint(0, len(self.additive.snr_levels), size=B)]
             self.additive(batch["chunk"], np.where(gate, idx, -1), beg, snr)
+        # config_distortions order (pase/transforms.py:83-141): reverb, [overlap], noises, clip, [chop], bandrop, downsample
+        if self.clipping is not None:
+            gate = self.rng.random_sample(B) < self.clip_p
+            cf = np.asarray(self.clipping.clip_factors, dtype=np.float32)[self.rng.randint(0, len(self.clipping.clip_factors), size=B)]
+            self.clipping(batch["chunk"], np.where(gate, cf, 0.0))
+        for filt, prob in ((self.bandrop, self.bandrop_p), (self.downsample, self.downsample_p)):
+            if filt is not None:
+                gate = self.rng.random_sample(B) < prob
+                filt(batch["chunk"], np.where(gate, self.rng.randint(0, filt.n, size=B), -1))
         if self.targets is not None:
             batch.update(self.targets(batch["cchunk"]))
         return batch

@@ -49,6 +49,24 @@ def test_reverb_matches_scipy(dev, T, irlens):
         np.testing.assert_allclose(got[b, 0], want, rtol=2e-4, atol=2e-5 * np.abs(want).max())
 
 
+def test_filter_distortions_and_clipping(dev):
+    rng = np.random.RandomState(9)
+    B, T = 4, 1800
+    x = (0.2 * rng.standard_normal((B, 1, T))).astype(np.float32)
+    filts = [np.sinc(np.arange(-50, 51) / 2.0) * np.hamming(101), rng.standard_normal(64)]   # odd and even lengths
+    fd = P.DeviceFilter(filts, device=dev)
+    idx = np.array([0, 1, -1, 0])
+    got = fd(torch.from_numpy(x.copy()).to(dev), idx).cpu().numpy()
+    for b in range(B):
+        want = x[b, 0] if idx[b] < 0 else O.fir_filter_distortion(x[b, 0], filts[idx[b]])
+        np.testing.assert_allclose(got[b, 0], want, rtol=2e-4, atol=2e-5 * np.abs(want).max())
+    cf = np.array([0.3, 0.0, 0.5, 0.1], dtype=np.float32)
+    got = P.DeviceClipping()(torch.from_numpy(x.copy()).to(dev), cf).cpu().numpy()
+    for b in range(B):
+        want = x[b, 0] if cf[b] <= 0 else O.clipping(x[b, 0], cf[b])
+        np.testing.assert_array_equal(got[b, 0], want)
+
+
 def test_additive_matches_reference_formula(dev):
     rng = np.random.RandomState(3)
     B, T = 5, 1500
