@@ -272,6 +272,13 @@ int pase_reverb(float* x, const float* irs, const long long* ir_off, const int* 
 int pase_fir_distort(float* x, const float* irs, const long long* ir_off, const int* ir_len, const int* ir_shift,
                      const int* ir_idx, float* full, double* energies, int B, int T, int max_ir_len,
                      int trimmed_energy, void* stream);
+/* SimpleAdditiveShift (overlapped speech, pase/transforms.py:1684-1766): out[b, t] = 0 for t < shift[b], else
+ * wav_{src[b]}[beg[b] + t - shift[b]] (zero past the file end; src[b] < 0 leaves row b untouched);
+ * pase_zero_front re-zeroes the first shift[b] samples after the optional reverberation of that crop.  The mix
+ * itself is pase_add_noise with the crop buffer as the noise pool. */
+int pase_overlap_gather(const float* pool, const long long* off, const int* len, const int* src, const int* beg,
+                        const int* shift, float* out, int B, int T, void* stream);
+int pase_zero_front(float* x, const int* shift, int B, int T, void* stream);
 /* Clipping.__call__ (pase/transforms.py:1514-1535), in place: clamp utterance b to [f * min, f * max], f = factor[b]
  * (<= 0: untouched) */
 int pase_clip(float* x, const float* factor, int B, int T, void* stream);

@@ -84,3 +84,22 @@ def clipping(wav, cf):
     wav = np.asarray(wav, dtype=np.float32)
     clip = np.maximum(wav, cf * np.min(wav))
     return np.minimum(clip, cf * np.max(wav))
+
+
+def overlap(wav, speech, n_beg, shift_n, snr, ir=None, p_max=0):
+    """SimpleAdditiveShift.__call__ (pase/transforms.py:1714-1766) with the draws passed in."""
+    wav = np.asarray(wav, dtype=np.float32).reshape(-1)
+    T = len(wav) - shift_n
+    sel = np.asarray(speech, dtype=np.float64)
+    if len(sel) < T:
+        sel = np.concatenate([sel, np.zeros(T - len(sel))])
+        n_beg = 0
+    noise = sel[n_beg:n_beg + T].astype(np.float32)
+    if ir is not None:
+        noise = reverb(noise, ir, p_max)
+    pad_len = len(wav) - len(noise)
+    noise = np.concatenate([np.zeros(pad_len, dtype=np.float32), noise])
+    Ex, En = np.dot(wav, wav), np.dot(noise, noise)
+    Kf = np.sqrt(Ex / ((10 ** (snr / 10.)) * En)) if En > 0 else 1.0
+    noisy = wav + Kf * noise
+    return (np.sqrt(Ex / (np.dot(noisy, noisy) + 1e-14)) * noisy).astype(np.float32)

@@ -51,6 +51,29 @@ __global__ void __launch_bounds__(NT) chunk_gather_kernel(const float* pool, con
     }
 }
 
+// SimpleAdditiveShift's interfering-speech crop (transforms.py:1718-1750): out[b, t] = 0 for t < shift[b], else
+// wav_{src[b]}[beg[b] + t - shift[b]] (zero past the end of a short file): the crop of length T - shift, front-padded.
+__global__ void __launch_bounds__(NT) overlap_gather_kernel(const float* pool, const long long* off, const int* len,
+                                                            const int* src, const int* beg, const int* shift,
+                                                            float* out, int T) {
+    const int n = blockIdx.y;
+    const int u = src[n];
+    if (u < 0) return;
+    const float* w = pool + off[u];
+    const int L = len[u], b0 = beg[n], sh = shift[n];
+    for (int t = blockIdx.x * NT + threadIdx.x; t < T; t += gridDim.x * NT) {
+        const int i = b0 + t - sh;
+        out[(size_t)n * T + t] = (t >= sh && i < L) ? w[i] : 0.f;
+    }
+}
+
+// zero the first shift[b] samples (the reference front-pads AFTER reverberating the crop)
+__global__ void __launch_bounds__(NT) zero_front_kernel(float* x, const int* shift, int T) {
+    const int n = blockIdx.y;
+    const int sh = min(shift[n], T);
+    for (int t = blockIdx.x * NT + threadIdx.x; t < sh; t += gridDim.x * NT) x[(size_t)n * T + t] = 0.f;
+}
+
 // norm_and_scale (transforms.py:148-151): x / max|x| * u, one block per chunk
 __global__ void __launch_bounds__(NT) peak_scale_kernel(float* x, const float* u, int T) {
     __shared__ float sh[NT / 64];
@@ -233,6 +256,23 @@ extern "C" int pase_chunk_gather(const float* pool, const long long* off, const 
     if (N <= 0 || T <= 0) return 0;
     PASE_LAUNCH(chunk_gather_kernel, dim3((unsigned)((T + NT * 4 - 1) / (NT * 4)), (unsigned)N), dim3(NT),
                 (hipStream_t)stream, pool, off, len, src, beg, out, T);
+    PASE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pase_overlap_gather(const float* pool, const long long* off, const int* len, const int* src,
+                                   const int* beg, const int* shift, float* out, int B, int T, void* stream) {
+    if (B <= 0 || T <= 0) return 0;
+    PASE_LAUNCH(overlap_gather_kernel, dim3((unsigned)((T + NT * 4 - 1) / (NT * 4)), (unsigned)B), dim3(NT),
+                (hipStream_t)stream, pool, off, len, src, beg, shift, out, T);
+    PASE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pase_zero_front(float* x, const int* shift, int B, int T, void* stream) {
+    if (B <= 0 || T <= 0) return 0;
+    PASE_LAUNCH(zero_front_kernel, dim3((unsigned)((T + NT * 4 - 1) / (NT * 4)), (unsigned)B), dim3(NT),
+                (hipStream_t)stream, x, shift, T);
     PASE_CHECK_LAUNCH();
     return 0;
 }

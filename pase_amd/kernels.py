@@ -238,6 +238,8 @@ _SIMPLE.update({
     "pase_reverb": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp],
     "pase_fir_distort": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _fp],
     "pase_clip": [_fp, _fp, _i, _i, _fp],
+    "pase_overlap_gather": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _fp],
+    "pase_zero_front": [_fp, _fp, _i, _i, _fp],
     "pase_add_noise": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _fp],
     "pase_gammatone_blocks": [_fp, _fp, _fp, _i, _i, _i, _i, _fp],
     "pase_gammatone_frames": [_fp, _fp, _i, _i, _i, _i, _i, _i, _f, _fp],
@@ -457,3 +459,13 @@ def fir_distort(x, irs, ir_off, ir_len, ir_shift, ir_idx, full, energies, *, B, 
 
 def clip(x, factor, *, B, T):
     _check(_lib.lib().pase_clip(_ptr(x), _ptr(factor), B, T, _stream()), "pase_clip")
+
+
+def overlap_gather(pool, off, length, src, beg, shift, out, *, B, T):
+    _check(_lib.lib().pase_overlap_gather(_ptr(pool), _ptr(off, torch.int64), _ptr(length, torch.int32),
+                                          _ptr(src, torch.int32), _ptr(beg, torch.int32), _ptr(shift, torch.int32),
+                                          _ptr(out), B, T, _stream()), "pase_overlap_gather")
+
+
+def zero_front(x, shift, *, B, T):
+    _check(_lib.lib().pase_zero_front(_ptr(x), _ptr(shift, torch.int32), B, T, _stream()), "pase_zero_front")

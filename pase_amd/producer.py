@@ -160,17 +160,51 @@ class DeviceAdditive(object):
         return chunk
 
 
+class DeviceOverlap(object):
+    """SimpleAdditiveShift (pase/transforms.py:1684-1766): another utterance, cropped to T - shift samples,
+    optionally reverberated (overlap_reverb), front-padded by `shift` and mixed in at a drawn SNR with the
+    energy renormalisation of SimpleAdditive.  Also returns the reference's `overlap` label (fraction of
+    overlapped samples per hop)."""
+
+    def __init__(self, speech_pool, snr_levels=(5, 7.5, 10), reverb=None):
+        self.pool, self.snr_levels, self.reverb = speech_pool, list(snr_levels), reverb
+
+    def __call__(self, chunk, src, beg, shift, snr, ir_idx=None, hop=160):
+        """src[b] < 0 leaves utterance b untouched; ir_idx: IR per utterance for the interfering crop (or None)."""
+        B, _, T = chunk.shape
+        dev = chunk.device
+        src = np.asarray(src)
+        sh = np.where(src >= 0, np.asarray(shift), T)
+        noise = torch.zeros(B, 1, T, device=dev)
+        K.overlap_gather(self.pool.pool, self.pool.off, self.pool.len, _dev_i32(src, dev), _dev_i32(beg, dev),
+                         _dev_i32(sh, dev), noise, B=B, T=T)
+        if self.reverb is not None and ir_idx is not None:
+            # Reverb of the (T - shift)-sample crop == Reverb of its front-padded version with the pre-echo that
+            # leaks in front of `shift` removed (the reference pads after reverberating)
+            self.reverb(noise, np.where(src >= 0, np.asarray(ir_idx), -1))
+            K.zero_front(noise, _dev_i32(sh, dev), B=B, T=T)
+        off = torch.arange(B, dtype=torch.int64, device=dev) * T
+        K.add_noise(chunk, noise.view(-1), off, torch.full((B,), T, dtype=torch.int32, device=dev),
+                    _dev_i32(np.where(src >= 0, np.arange(B), -1), dev), _dev_i32(np.zeros(B), dev),
+                    torch.as_tensor(np.asarray(snr, dtype=np.float32), device=dev), B=B, T=T)
+        t = torch.arange(T, device=dev)[None, :]
+        mask = (t >= torch.as_tensor(sh, device=dev)[:, None]).float()
+        return chunk, mask.view(B, T // hop, hop).mean(2)
+
+
 class DeviceBatchProducer(object):
     """dataset.__getitem__ + DictCollater for one batch: chunks, clean copy, gated distortions, and (when a
     DeviceTargets is attached) the regression labels computed from the clean chunk."""
 
     def __init__(self, chunker, reverb=None, reverb_p=0.5, additive=None, additive_p=0.5, targets=None, rng=None,
-                 clipping=None, clip_p=0.2, bandrop=None, bandrop_p=0.35, downsample=None, downsample_p=0.25):
+                 clipping=None, clip_p=0.2, bandrop=None, bandrop_p=0.35, downsample=None, downsample_p=0.25,
+                 overlap=None, overlap_p=0.1):
         self.chunker, self.reverb, self.additive, self.targets = chunker, reverb, additive, targets
         self.reverb_p, self.additive_p = reverb_p, additive_p
         self.clipping, self.clip_p = clipping, clip_p
         self.bandrop, self.bandrop_p = bandrop, bandrop_p
         self.downsample, self.downsample_p = downsample, downsample_p
+        self.overlap, self.overlap_p = overlap, overlap_p
         self.rng = rng if rng is not None else np.random
 
     def __call__(self, B):
@@ -182,6 +216,16 @@ class DeviceBatchProducer(object):
             gate = self.rng.random_sample(B) < self.reverb_p           # PCompose: one Bernoulli per transform
             idx = np.where(gate, self.rng.randint(0, self.reverb.n, size=B), -1)
             self.reverb(batch["chunk"], idx)
+        if self.overlap is not None:
+            gate = self.rng.random_sample(B) < self.overlap_p
+            src = self.rng.randint(0, len(self.overlap.pool), size=B)
+            shift = self.rng.randint(0, int(0.75 * T), size=B)
+            nl = self.overlap.pool.lens_host[src]
+            need = T - shift
+            beg = np.where(nl > need, (self.rng.random_sample(B) * np.maximum(nl - need, 1)).astype(np.int64), 0)
+            snr = np.asarray(self.overlap.snr_levels, dtype=np.float32)[self.rng.randint(0, len(self.overlap.snr_levels), size=B)]
+            ir = self.rng.randint(0, self.overlap.reverb.n, size=B) if self.overlap.reverb is not None else None
+            _, batch["overlap"] = self.overlap(batch["chunk"], np.where(gate, src, -1), beg, shift, snr, ir)
         if self.additive is not None:
             gate = self.rng.random_sample(B) < self.additive_p
             nn = len(self.additive.noises)

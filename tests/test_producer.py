@@ -67,6 +67,29 @@ def test_filter_distortions_and_clipping(dev):
         np.testing.assert_array_equal(got[b, 0], want)
 
 
+def test_overlap_speech_with_reverberated_interferer(dev):
+    rng = np.random.RandomState(10)
+    B, T = 4, 1600
+    x = (0.2 * rng.standard_normal((B, 1, T))).astype(np.float32)
+    speech = _pool(rng, [5000, 700, 2600])
+    irs = [np.r_[0.0, 0.0, 0.3, 1.0, 0.4 * rng.standard_normal(120) * np.exp(-np.arange(120) / 30.0)]]
+    rv = P.DeviceReverb(irs, device=dev)
+    ov = P.DeviceOverlap(P.WavPool(speech, dev), reverb=rv)
+    src = np.array([0, 1, -1, 2])
+    shift = np.array([300, 1000, 0, 0])
+    beg = np.array([1234, 0, 0, 17])          # utterance 1: file (700) longer than T - shift (600): crop from `beg`
+    beg[1] = 50
+    snr = np.array([5.0, 7.5, 10.0, 10.0], dtype=np.float32)
+    got, label = ov(torch.from_numpy(x.copy()).to(dev), src, beg, shift, snr, ir_idx=np.zeros(B, int))
+    got = got.cpu().numpy()
+    ir, pm = O.prepare_ir(irs[0])
+    for b in range(B):
+        want = x[b, 0] if src[b] < 0 else O.overlap(x[b, 0], speech[src[b]], int(beg[b]), int(shift[b]), float(snr[b]),
+                                                    ir, pm)
+        np.testing.assert_allclose(got[b, 0], want, rtol=2e-4, atol=2e-5 * np.abs(want).max())
+    assert label.shape == (B, T // 160) and float(label[2].sum()) == 0.0 and float(label[3].min()) == 1.0
+
+
 def test_additive_matches_reference_formula(dev):
     rng = np.random.RandomState(3)
     B, T = 5, 1500
