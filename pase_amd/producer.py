@@ -52,7 +52,9 @@ class DeviceChunker(object):
         (dataset.py:482-484); select_chunk draws np.random.randint(0, len - T) per crop (transforms.py:350)."""
         n = len(self.pool)
         utt = self.rng.randint(0, n, size=B)
-        rand = np.array([self.rng.choice([i for i in range(n) if i != u]) if n > 1 else u for u in utt])
+        # a different utterance, uniformly (random.choice over the other indices, dataset.py:482-484)
+        rand = self.rng.randint(0, max(n - 1, 1), size=B)
+        rand = np.where(n > 1, rand + (rand >= utt), utt)
         src = np.stack([utt, utt, rand], 0)                   # chunk, chunk_ctxt (same context), chunk_rand
         L = self.pool.lens_host[src]
         beg = np.where(L > self.T, (self.rng.random_sample(src.shape) * np.maximum(L - self.T, 1)).astype(np.int64), 0)
