@@ -330,3 +330,24 @@ class DeviceTargets(object):
         for name, f in self.feats.items():
             out[name] = f(cchunk, *shared[name]) if name in shared else f(cchunk)
         return out
+
+
+class TargetStats(object):
+    """ZNorm statistics with make_trainset_statistics.py's definition (:96-101): over all collected utterances,
+    mean = mean_u(mean_t x), std = std_u(std_t x) (unbiased, torch.std) -- per feature channel.  Accumulates the
+    per-utterance moments batch by batch on the device instead of concatenating the features of an epoch."""
+
+    def __init__(self):
+        self.means, self.stds = {}, {}
+
+    def update(self, targets):
+        for k, v in targets.items():          # v: (B, D, F) un-normalised feature
+            self.means.setdefault(k, []).append(v.mean(dim=2))
+            self.stds.setdefault(k, []).append(v.std(dim=2))
+
+    def finalize(self):
+        stats = {}
+        for k in self.means:
+            m, sd = torch.cat(self.means[k]), torch.cat(self.stds[k])
+            stats[k] = {"mean": m.mean(dim=0).cpu(), "std": sd.std(dim=0).cpu()}
+        return stats

@@ -163,3 +163,18 @@ def test_device_targets_share_gammatone_filterbank(dev):
     for name, kw in (("gtn", dict(n_channels=6)), ("gtn_long", dict(n_channels=6, win=1024))):
         want = np.stack([O.gammatone(wav[b, 0].numpy(), **kw) for b in range(2)])
         _check(got[name], want, np.full(want.shape, 2e-3), name)
+
+
+def test_target_stats_match_trainset_statistics_definition(dev):
+    """make_trainset_statistics.py:96-101 on the concatenated features == batch-wise accumulation."""
+    g = torch.Generator().manual_seed(3)
+    batches = [{"lps": torch.randn(4, 6, 20, generator=g) * 3 + 1, "mfcc": torch.randn(4, 3, 20, generator=g)}
+               for _ in range(3)]
+    st = dsp.TargetStats()
+    for b in batches:
+        st.update({k: v.to(dev) for k, v in b.items()})
+    got = st.finalize()
+    for k in ("lps", "mfcc"):
+        v = torch.cat([b[k] for b in batches])
+        np.testing.assert_allclose(got[k]["mean"].numpy(), torch.mean(torch.mean(v, dim=2), dim=0).numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(got[k]["std"].numpy(), torch.std(torch.std(v, dim=2), dim=0).numpy(), rtol=1e-5, atol=1e-6)
