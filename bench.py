@@ -103,6 +103,47 @@ def cpu_baseline(raw, fe_cfg, seconds_budget=25.0):
                       % (B, T, n, cores, avail)}
 
 
+def torch_rocm_baseline(raw, fe_cfg, device, B, T, steps=3):
+    """SURVEY 8(d) comparator "reference module code on stock PyTorch-ROCm ops": the same torch restatement of the
+    reference step (oracle/pase_oracle.py -- MIOpen / rocBLAS kernels through torch.nn.functional, autograd,
+    torch.optim.Adam) timed on this GPU at the bench's own batch size.  A reported baseline like cpu_baseline;
+    it is not on the product path."""
+    from oracle import pase_oracle as O
+    from pase_amd.pase import pase
+    from pase_amd.utils import strip_transforms, worker_parser
+    torch.manual_seed(2)
+    with contextlib.redirect_stdout(io.StringIO()):
+        wk = strip_transforms(worker_parser(os.path.join(ROOT, "cfg", "workers", "workers+.cfg")))
+        model = pase(frontend_cfg=dict(fe_cfg), minions_cfg=wk, cls_lst=["mi", "cmi"],
+                     regr_lst=[w["name"] for w in raw["regr"]])
+    P = {k: v.detach().clone().to(device) for k, v in model.state_dict().items()}
+    del model
+    names = [n for n in P if P[n].is_floating_point() and "running" not in n]
+    for n in names:
+        P[n].requires_grad_(True)
+    opt = torch.optim.Adam([P[n] for n in names], lr=5e-4)
+    batch = synthetic_batch(99, B, T, raw, device)
+
+    def step():
+        opt.zero_grad()
+        so = {}
+        h, chunk, preds, labels = O.pase_forward(P, fe_cfg, raw, batch, True, so)
+        O.pase_losses(raw, preds, labels)["total"].backward()
+        opt.step()
+
+    step()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / steps
+    return {"value": round(B / dt, 3), "unit": "utterances/s", "ms_per_step": round(dt * 1e3, 2),
+            "kind": "port on torch ROCm ops", "sample": "oracle/pase_oracle.py on %s, B=%d x %d samples, %d timed steps "
+            "after 1 warm-up (QRNN recurrence as a %d-step Python loop: torchqrnn's CUDA kernel does not exist on ROCm)"
+            % (torch.cuda.get_device_name(0), B, T, steps, T // 160)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,6 +152,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--chunk", type=int, default=32000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--torch-gpu-baseline", action="store_true",
+                    help="also time the torch-op restatement of the reference step on this GPU (stock PyTorch-ROCm "
+                         "kernels) and report it as `torch_rocm_baseline`")
     ap.add_argument("--producer", action="store_true",
                     help="BASELINE.json configs[3] shape: every step's batch is produced ON DEVICE inside the timed "
                          "region (random crops of a resident waveform pool, Reverb / additive-noise gating on "
@@ -259,6 +303,13 @@ def main():
             except Exception as e:  # the baseline leg must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "utterances/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
+        if world == 1 and args.torch_gpu_baseline:
+            try:
+                del tr, batch
+                torch.cuda.empty_cache()
+                out["torch_rocm_baseline"] = torch_rocm_baseline(raw, fe_cfg, dev, B, T)
+            except Exception as e:
+                out["torch_rocm_baseline"] = {"value": None, "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

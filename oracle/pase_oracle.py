@@ -55,6 +55,7 @@ def sinc_init(out_channels=64, sr=16000, min_low=50, min_band=50):
 def sinc_filters(low_hz_, band_hz_, K=251, sr=16000, min_low=50, min_band=50):
     """(C,1,K) band-pass bank, modules.py:895-915."""
     window, n_ = sinc_constants(K, sr)
+    window, n_ = window.to(low_hz_.device), n_.to(low_hz_.device)
     low = min_low + torch.abs(low_hz_)
     high = torch.clamp(low + min_band + torch.abs(band_hz_), min_low, sr / 2)
     band = (high - low)[:, 0]
@@ -274,13 +275,13 @@ def gap_samples(x):
     xa = torch.stack([x[i, :, int(a)] for i, a in enumerate(aidx)], 0)
     xb = torch.stack([x[i, :, int(b)] for i, b in enumerate(bidx)], 0)
     dists = torch.tensor([float(int(abs(int(a) - int(b)) / (T - 1))) for a, b in zip(aidx, bidx)])
-    return torch.cat((xa, xb), 1).unsqueeze(2), dists.view(-1, 1, 1)
+    return torch.cat((xa, xb), 1).unsqueeze(2), dists.view(-1, 1, 1).to(x.device)
 
 
 def make_labels(y):
     """cls_minions.py:47-51."""
     bsz, slen = y.size(0) // 2, y.size(2)
-    return torch.cat((torch.ones(bsz, 1, slen), torch.zeros(bsz, 1, slen)), 0)
+    return torch.cat((torch.ones(bsz, 1, slen, device=y.device), torch.zeros(bsz, 1, slen, device=y.device)), 0)
 
 
 def pase_forward(P, fe_cfg, workers_cfg, batch, training=True, stats_out=None):
