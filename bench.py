@@ -103,6 +103,31 @@ def cpu_baseline(raw, fe_cfg, seconds_budget=25.0):
                       % (B, T, n, cores, avail)}
 
 
+def cpu_targets_baseline(raw, T=32000):
+    """SURVEY 8(d), mode (ii): the CPU restatement of the target transforms (oracle/dsp_oracle.py: numpy / scipy,
+    what the reference's DataLoader workers run through librosa / python_speech_features / gammatone), one
+    utterance, one thread."""
+    import numpy as np
+    from oracle import dsp_oracle as D
+    x = (0.1 * np.random.RandomState(0).standard_normal(T)).astype(np.float32)
+    fns = {"lps": D.lps, "fbank": D.fbanks, "gtn": D.gammatone, "mfcc": D.mfcc}
+    per = {}
+    t_all = 0.0
+    for w in raw["regr"]:
+        base = next((k for k in fns if k in w["name"]), None)
+        if base is None:
+            continue
+        kw = dict(w.get("transform", {}))
+        t0 = time.time()
+        fns[base](x, **kw)
+        per[w["name"]] = round(time.time() - t0, 3)
+        t_all += per[w["name"]]
+    return {"value": round(1.0 / t_all, 3), "unit": "utterances/s", "cores": 1, "kind": "port",
+            "seconds_per_utterance": per,
+            "sample": "oracle/dsp_oracle.py: LPS / FBANK / gammatone / MFCC (+ _long variants) of one %d-sample "
+                      "utterance, single thread" % T}
+
+
 def torch_rocm_baseline(raw, fe_cfg, device, B, T, steps=3):
     """SURVEY 8(d) comparator "reference module code on stock PyTorch-ROCm ops": the same torch restatement of the
     reference step (oracle/pase_oracle.py -- MIOpen / rocBLAS kernels through torch.nn.functional, autograd,
@@ -303,6 +328,11 @@ def main():
             except Exception as e:  # the baseline leg must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "utterances/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
+        if world == 1 and args.producer and not args.no_cpu_baseline:
+            try:
+                out["cpu_targets_baseline"] = cpu_targets_baseline(raw, T)
+            except Exception as e:
+                out["cpu_targets_baseline"] = {"value": None, "sample": "failed: %r" % (e,)}
         if world == 1 and args.torch_gpu_baseline:
             try:
                 del tr, batch
