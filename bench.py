@@ -170,6 +170,8 @@ def torch_rocm_baseline(raw, fe_cfg, device, B, T, steps=3):
 
 
 def main():
+    # the host driver only supports dmabuf IPC: RCCL / cross-process CUDA tensors need this (set before any HIP init)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
