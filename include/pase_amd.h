@@ -201,6 +201,11 @@ int pase_sinc_filters_bwd(const float* low_hz_, const float* band_hz_, const flo
 /* dst[(p*O + o), (red*taps_p + j)] = src[red*s_red + o*s_out + (p + st*j)*s_k]  (0 beyond k),
  * taps_p = ceil(k/st): the A operand that turns pase_conv_gemm into the data-gradient of a strided
  * conv / the forward of nn.ConvTranspose1d (phase decomposition). */
+/* g_k[c] += (float) sums[c*ld + col_k], k < 3 (NULL buffers skipped): one launch commits the fp64 per-channel sums
+ * of pase_act_bwd_reduce / pase_head1_bwd into the BatchNorm / PReLU / bias gradient buffers (what autograd's
+ * AccumulateGrad does for those parameters in the reference) */
+int pase_commit_cols(const double* sums, int ld, int C, float* g0, int c0, float* g1, int c1, float* g2, int c2,
+                     void* stream);
 int pase_pack_dgrad(const float* src, float* dst, int R, int O, int k, int st, long s_red, long s_out, long s_k,
                     void* stream);
 /* same pack written K-major for pase_conv_gemm's `wt` operand: dst ((R*ceil(k/st)), ldt),

@@ -270,6 +270,18 @@ __global__ void __launch_bounds__(NT) pack_dgrad_t_kernel(const float* src, floa
     }
 }
 
+// Parameter-gradient commit: g_k[c] += (float)sums[c*ld + col_k] for up to three (buffer, column) pairs in one launch
+// (the fp64 per-channel sums of pase_act_bwd_reduce / pase_head1_bwd -> dbeta / dgamma / dalpha / dbias buffers).
+__global__ void __launch_bounds__(NT) commit_cols_kernel(const double* sums, int ld, int C, float* g0, int c0, float* g1,
+                                                         int c1, float* g2, int c2) {
+    const int c = blockIdx.x * NT + threadIdx.x;
+    if (c >= C) return;
+    const double* row = sums + (size_t)c * ld;
+    if (g0) g0[c] += (float)row[c0];
+    if (g1) g1[c] += (float)row[c1];
+    if (g2) g2[c] += (float)row[c2];
+}
+
 // ---- Adam (torch.optim.Adam defaults; WorkerScheduler/trainer.py:91,111,134) ----------------------
 // One launch per logical optimizer over its flat parameter / gradient / moment buffers.  `step` and
 // `lr` live in device memory so a captured hipGraph replays correctly as they change.
@@ -380,6 +392,15 @@ extern "C" int pase_pack_dgrad_t(const float* src, float* dst, int R, int O, int
     if (total <= 0) return 0;
     PASE_LAUNCH(pack_dgrad_t_kernel, dim3(grid_for(total)), dim3(NT), (hipStream_t)stream, src, dst, R, O, k, st,
                 taps_p, s_red, s_out, s_k, ldt);
+    PASE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pase_commit_cols(const double* sums, int ld, int C, float* g0, int c0, float* g1, int c1, float* g2,
+                                int c2, void* stream) {
+    if (C <= 0) return 0;
+    PASE_LAUNCH(commit_cols_kernel, dim3((unsigned)((C + NT - 1) / NT)), dim3(NT), (hipStream_t)stream, sums, ld, C, g0,
+                c0, g1, c1, g2, c2);
     PASE_CHECK_LAUNCH();
     return 0;
 }

@@ -187,6 +187,10 @@ class GradSink:
     def get(self, p):
         return self.store.get(p)
 
+    def add_cols(self, sums, ld, C, pairs):
+        """param.grad[c] += sums[c*ld + col] for up to three (param or None, col) pairs, one launch."""
+        K.commit_cols(sums, ld, C, [(None if p is None else self.buf(p).view(-1), col) for p, col in pairs])
+
 
 # =========================================================================================
 # encoder (WaveFe)
@@ -376,11 +380,10 @@ def encoder_backward(fe, ctx, demb, sink):
                                 alpha=blk.act.weight, mean=rec["mean"], rstd=rec["rstd"], dsrc=dsrc,
                                 dsrc_ctot=dsrc_ctot, dsrc_coff=dsrc_coff, Tp=dsrc_Tp, padL=dsrc_padL,
                                 pad_mode=dsrc_mode, **kw)
-        sums_f = sums.float()
-        if rec["has_bn"] and blk.norm.affine:
-            sink.add(blk.norm.bias, sums_f[:, 0].contiguous())
-            sink.add(blk.norm.weight, sums_f[:, 1].contiguous())
-        sink.add(blk.act.weight, sums_f[:, 2].contiguous())
+        bn_aff = rec["has_bn"] and blk.norm.affine
+        no_bn_bias = (not rec["has_bn"]) and not blk.sincnet          # bias gradient = sum dz when no BatchNorm follows
+        sink.add_cols(sums, 3, C, [(blk.norm.bias if bn_aff else (blk.conv.bias if no_bn_bias else None), 0),
+                                   (blk.norm.weight if bn_aff else None, 1), (blk.act.weight, 2)])
         inp = rec["inp"]
         taps = rec["taps"]
         if blk.sincnet:
@@ -397,8 +400,6 @@ def encoder_backward(fe, ctx, demb, sink):
             dbias = sink.buf(blk.conv.bias) if rec["has_bn"] else None
             conv_wgrad(dy, inp, sink.buf(blk.conv.weight).view(C, -1), dbias, taps=taps, stride=blk.stride,
                        padL=rec["padL"], pad_mode=K.PAD_REFLECT)
-            if not rec["has_bn"]:
-                sink.add(blk.conv.bias, sums_f[:, 0].contiguous())
         if n > 0:
             cin = inp.C
             dsrc = conv_dgrad(dy, blk.conv.weight, R=C, O=cin, k=taps, stride=blk.stride, Tin=inp.T,
@@ -517,11 +518,9 @@ def worker_backward(layers, out_conv, ctx, dpred, sink, need_dinput=True):
         sums = _zeros((C * 3 + 1,), x, torch.float64)
         dz = _new((B, C, T), x)
         K.head1_bwd(cur.t, cur.alpha, out_conv.weight.view(-1), dpred.contiguous(), dz, sums, S=B, C_=C, T=T)
-        sf = sums.float()
-        s3 = sf[:C * 3].view(C, 3)
-        sink.add(out_conv.weight, s3[:, 0].contiguous())
-        sink.add(out_conv.bias, sf[C * 3:])
-        dalpha, dzsum = s3[:, 1].contiguous(), s3[:, 2].contiguous()
+        sink.add_cols(sums, 3, C, [(out_conv.weight, 0)])
+        sink.add_cols(sums[C * 3:], 1, 1, [(out_conv.bias, 0)])
+        psums, pcols = sums, (1, 2)             # (dalpha, sum dz) columns for the layer below
         have_dz = True
     else:
         dpred = dpred.contiguous()
@@ -535,16 +534,15 @@ def worker_backward(layers, out_conv, ctx, dpred, sink, need_dinput=True):
             dz, sums = act_backward(z, C=C, T=Tz, S=B, has_bn=False, alpha=blk.act.weight, dsrc=dsrc.t,
                                     dsrc_ctot=dsrc.ctot, dsrc_coff=dsrc.coff, Tp=dsrc.Tp, padL=dsrc.padL,
                                     pad_mode=dsrc.pad_mode)
-            sf = sums.float()
-            dzsum, dalpha = sf[:, 0].contiguous(), sf[:, 2].contiguous()
+            psums, pcols = sums, (2, 0)
         have_dz = False
-        sink.add(blk.act.weight, dalpha)
+        # PReLU slope gradient + the bias gradient (= sum dz) of this layer's conv, one launch
+        sink.add_cols(psums, 3, C, [(blk.act.weight, pcols[0]), ((blk.deconv if kind == "deconv" else blk.W).bias, pcols[1])])
         if kind == "deconv":
             dc = blk.deconv
             k, st = blk.kwidth, blk.stride
             pad = max(0, (st - k) // -2)
             cin = inp.C
-            sink.add(dc.bias, dzsum)
             # dW[ci, co, kk] = sum_{s,t} act(in)[s,ci,t] * dz[s,co,t*st + kk - pad]
             if inp.scale is not None:
                 raise NotImplementedError("deconv wgrad with an affine on-load input")
@@ -559,7 +557,6 @@ def worker_backward(layers, out_conv, ctx, dpred, sink, need_dinput=True):
         else:
             k = blk.context
             cin = inp.C
-            sink.add(blk.W.bias, dzsum)
             conv_wgrad(dz, inp, sink.buf(blk.W.weight).view(C, -1), None, taps=k, padL=k // 2, pad_mode=K.PAD_ZERO)
             last = blk is layers[0]
             if need_dinput or not last:
@@ -614,9 +611,7 @@ def mlp_group_step(workers, a: Act, targets, sink):
         dA = conv_dgrad(dpred, oc.weight, R=nout, O=h, k=1, stride=1, Tin=F_, padL=0, padR=0, s_red=h, s_out=1, s_k=1)
         _, sums = act_backward(z_all, C=h, T=F_, S=B, has_bn=False, alpha=blk.act.weight, dsrc=dA, dsrc_ctot=h, Tp=F_,
                                y_ctot=htot, y_coff=off, dy_out=dz_all)
-        sf = sums.float()
-        sink.add(blk.act.weight, sf[:, 2].contiguous())
-        sink.add(blk.W.bias, sf[:, 0].contiguous())
+        sink.add_cols(sums, 3, h, [(blk.act.weight, 2), (blk.W.bias, 0)])
         del dpred, dA
     # stacked first layer: one wgrad, one dgrad
     dw1 = _zeros((htot, cin), x)

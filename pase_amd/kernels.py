@@ -243,6 +243,7 @@ _SIMPLE.update({
     "pase_add_noise": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _fp],
     "pase_gammatone_blocks": [_fp, _fp, _fp, _i, _i, _i, _i, _fp],
     "pase_gammatone_frames": [_fp, _fp, _i, _i, _i, _i, _i, _i, _f, _fp],
+    "pase_commit_cols": [_fp, _i, _i, _fp, _i, _fp, _i, _fp, _i, _fp],
     "pase_pack_wt": [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp],
     "pase_adam_step": [_fp, _fp, _fp, _fp, _l, _fp, _fp, _f, _f, _f, _f, _fp],
     "pase_step_tick": [_fp, _fp],
@@ -469,3 +470,12 @@ def overlap_gather(pool, off, length, src, beg, shift, out, *, B, T):
 
 def zero_front(x, shift, *, B, T):
     _check(_lib.lib().pase_zero_front(_ptr(x), _ptr(shift, torch.int32), B, T, _stream()), "pase_zero_front")
+
+
+def commit_cols(sums, ld, C_, pairs):
+    """pairs: up to three (grad buffer or None, column) -- g[c] += sums[c*ld + column]"""
+    pairs = [(g, c) for g, c in pairs if g is not None]
+    pairs += [(None, 0)] * (3 - len(pairs))
+    (g0, c0), (g1, c1), (g2, c2) = pairs[:3]
+    _check(_lib.lib().pase_commit_cols(_ptr(sums, torch.float64), ld, C_, _ptr(g0), c0, _ptr(g1), c1, _ptr(g2), c2,
+                                       _stream()), "pase_commit_cols")
