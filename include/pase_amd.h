@@ -143,6 +143,7 @@ int pase_bn_act_apply(const float* y, float* out, const float* scale, const floa
  *   reduce: sums[c] = { sum dz, sum dz*xhat, sum dA*z*[z<=0] }  (doubles, caller zeroes)
  *           -> dbeta = sums[.,0], dgamma = sums[.,1], dalpha = sums[.,2]
  *   apply : dy = scale*(dz - sums0/N - xhat*sums1/N)  (has_bn)   or   dy = dz
+ *   With has_bn == 0 and dy != NULL the reduce pass already writes dy = dz: the apply pass is not needed.
  * ------------------------------------------------------------------------------------------ */
 typedef struct PaseActBwd {
     const float* y;        /* (S, y_ctot, T) raw layer output; channels [y_coff, y_coff+C)          */

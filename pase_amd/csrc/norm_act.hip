@@ -143,6 +143,8 @@ __global__ void __launch_bounds__(NT) act_bwd_reduce_kernel(PaseActBwd p, int ch
     const float al = p.alpha ? p.alpha[c] : 1.f;
     const float mean = p.mean ? p.mean[c] : 0.f, rstd = p.rstd ? p.rstd[c] : 1.f;
     const float* yrow = p.y + ((size_t)s * p.y_ctot + p.y_coff + c) * (size_t)p.T;
+    // without a BatchNorm dy = dz does not depend on the sums: written here, no apply pass (one read of y / dA less)
+    float* drow = (!p.has_bn && p.dy) ? p.dy + ((size_t)s * p.y_ctot + p.y_coff + c) * (size_t)p.T : nullptr;
     const int per = (p.T + chunks - 1) / chunks;
     const int t0 = ch * per, t1 = min(p.T, t0 + per);
     double s_dz = 0.0, s_dzx = 0.0, s_da = 0.0;
@@ -151,6 +153,7 @@ __global__ void __launch_bounds__(NT) act_bwd_reduce_kernel(PaseActBwd p, int ch
         const float z = yv * a + b;
         const float dA = grad_post_act(p, s, c, t);
         const float dz = z > 0.f ? dA : dA * al;
+        if (drow) drow[t] = dz;
         const float xhat = (yv - mean) * rstd;
         s_dz += (double)dz;
         s_dzx += (double)(dz * xhat);

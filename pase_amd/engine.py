@@ -157,7 +157,8 @@ def act_backward(y, *, C, T, S, has_bn, scale=None, shift=None, alpha=None, mean
               pool_d=pool_d, scale=scale, shift=shift, alpha=alpha, mean=mean, rstd=rstd, sums=sums, dy=dy,
               has_bn=1 if has_bn else 0)
     K.act_bwd_reduce(y, **kw)
-    K.act_bwd_apply(y, **kw)
+    if has_bn:                       # without a BatchNorm the reduce pass has already written dy = dz
+        K.act_bwd_apply(y, **kw)
     return dy, sums
 
 

@@ -232,6 +232,26 @@ def test_act_backward_reflect_fold_and_pool_branch(dev):
     assert_close(sums[:, 2], al.grad, rtol=1e-4, atol=1e-5, what="dalpha")
 
 
+def test_act_backward_without_batchnorm_is_single_pass(dev):
+    """PReLU only (decoder / worker hidden layers): the reduce pass writes dy = dz itself (zero-padded dA in padded
+    coordinates, channel slice of a wider buffer)."""
+    torch.manual_seed(9)
+    S, C, T, pL = 2, 5, 37, 3
+    yw = torch.randn(S, C + 3, T)
+    y = yw[:, 2:2 + C].clone().requires_grad_(True)
+    al = (torch.rand(C) * 0.5).requires_grad_(True)
+    g = torch.randn(S, C, T + 2 * pL)
+    (F.pad(F.prelu(y, al), (pL, pL)) * g).sum().backward()
+    sums = torch.zeros(C, 3, dtype=torch.float64, device=dev)
+    dyw = torch.full((S, C + 3, T), 7.0, device=dev)
+    K.act_bwd_reduce(yw.to(dev), S=S, C_=C, T=T, y_ctot=C + 3, y_coff=2, dsrc=g.to(dev), Tp=T + 2 * pL, padL=pL,
+                     pad_mode=K.PAD_ZERO, alpha=al.detach().to(dev), sums=sums, dy=dyw, has_bn=0)
+    assert_close(dyw[:, 2:2 + C], y.grad, rtol=1e-5, atol=1e-6, what="dy")
+    assert float((dyw[:, :2] - 7.0).abs().max()) == 0.0
+    assert_close(sums[:, 2], al.grad, rtol=1e-4, atol=1e-5, what="dalpha")
+    assert_close(sums[:, 0], y.grad.sum((0, 2)), rtol=1e-4, atol=1e-5, what="sum dz")
+
+
 @pytest.mark.parametrize("loss_name,lt", [("L1Loss", K.LOSS_L1), ("BCEWithLogitsLoss", K.LOSS_BCE)])
 def test_head1_forward_backward(dev, loss_name, lt):
     torch.manual_seed(8)
