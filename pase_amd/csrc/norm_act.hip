@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(NT) bn_finalize_kernel(const float* stat_part,
 }
 
 // ---- E2: dense-skip pooling  P[s, c, f] = mean_i act(bn(y[s, c, f*d + i])) ----------------------
-// G lanes cooperate on one output (G = 64 for d >= 64 so the 786 MB block-0 tensor is read coalesced)
+// G lanes cooperate on one output (16 lanes x 64-B segments for the 160-sample windows of the 786 MB block-0 tensor)
 template <int G>
 __global__ void __launch_bounds__(NT) bn_act_pool_kernel(const float* y, float* out, const float* scale,
                                                          const float* shift, const float* alpha, int S, int C,
@@ -221,7 +221,7 @@ extern "C" int pase_bn_act_pool(const float* y, float* out, const float* scale, 
     const long nout = (long)S * C * F;
     if (nout <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    if (d >= 64) {
+    if (d >= 512) {      // (one wave per output only pays for long windows: 160-sample windows run 4 outputs per wave)
         const long blocks = (nout * 64 + NT - 1) / NT;
         PASE_LAUNCH((bn_act_pool_kernel<64>), dim3((unsigned)blocks), dim3(NT), st, y, out, scale, shift, alpha, S, C, T, F, d, o_ctot, o_coff);
     } else if (d >= 16) {
