@@ -169,6 +169,35 @@ def torch_rocm_baseline(raw, fe_cfg, device, B, T, steps=3):
             % (torch.cuda.get_device_name(0), B, T, steps, T // 160)}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: spawn N ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in the env, exactly what torch.distributed.run would set); rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0:                     # one rank died: the others would wait on it forever
+                rc = rc or code
+                for q in alive:
+                    q.terminate()
+    sys.exit(rc)
+
+
 def main():
     # the host driver only supports dmabuf IPC: RCCL / cross-process CUDA tensors need this (set before any HIP init)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -179,6 +208,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--chunk", type=int, default=32000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the second timed leg (batch handed over as host buffers)")
     ap.add_argument("--torch-gpu-baseline", action="store_true",
                     help="also time the torch-op restatement of the reference step on this GPU (stock PyTorch-ROCm "
                          "kernels) and report it as `torch_rocm_baseline`")
@@ -189,16 +219,30 @@ def main():
                          "(batch and targets resident in HBM)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)         # plain `python bench.py --gpus N`: spawn one rank per GPU ourselves
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py ...")
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU path")
+    # one process per GPU over RCCL.  With fewer GPUs than ranks (a 1-GPU box) the ranks share devices and the
+    # exchange falls back to gloo: a functional smoke of the N>1 code path, flagged in the JSON line, not a number.
+    shared = ndev < world
+    local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        if shared:
+            backend = "gloo"
+            dist.init_process_group("gloo")
+        else:
+            backend = "nccl"
+            dist.init_process_group("nccl", device_id=dev)
 
     from pase_amd import _lib
     _lib.lib()   # fail loudly if the HIP library is missing
@@ -259,6 +303,39 @@ def main():
     utt_s = B * world * args.steps / dt
     total_loss = float(losses["total"])
 
+    # ---- the same K steps with the batch handed over as HOST buffers: every step's 4 waveform tensors + 9 target
+    # tensors (205 MB at bs32) cross PCIe inside the timed region, through the pinned ring / copy stream of
+    # pase_amd.producer.PinnedBatchFeeder (SURVEY 8d step definition; reference modules.py:16-31, pase.py:338)
+    h2d = None
+    if not args.producer and not args.no_h2d:
+        from pase_amd.producer import PinnedBatchFeeder
+        ring = []
+        for j in range(3):
+            hb = synthetic_batch(4000 + 17 * rank + j, B, T, raw, torch.device("cpu"))
+            ring.append({k: v.pin_memory() for k, v in hb.items()})
+        cnt = [0]
+
+        def host_source():
+            cnt[0] += 1
+            return ring[cnt[0] % len(ring)]
+        feeder = PinnedBatchFeeder(host_source, dev, depth=2)
+        for _ in range(max(1, min(2, args.warmup))):
+            tr.train_step(feeder.next())
+        sync()
+        t0 = time.time()
+        for _ in range(args.steps):
+            tr.train_step(feeder.next())
+        sync()
+        dth = time.time() - t0
+        if world > 1:
+            t = torch.tensor([dth], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dth = float(t.item())
+        h2d = {"included": True, "value": round(B * world * args.steps / dth, 3), "unit": "utterances/s",
+               "ms_per_step": round(dth / args.steps * 1e3, 3), "MB_per_step_per_gpu": round(feeder.bytes_per_batch / 1e6, 1),
+               "how": "pinned host ring -> copy stream -> double-buffered device slots, overlapped with the previous step"}
+        del feeder, ring
+
     # ---- dominant-kernel roofline, measured live: two extra steps with every MFMA-kernel launch
     # bracketed by HIP events on the launch stream (outside the timed region above)
     from pase_amd import kernels as K
@@ -269,9 +346,16 @@ def main():
     fams = K.GEMM_TIMER.summary()
     K.GEMM_TIMER = None
     traffic = None
+    traffic_src = None
     try:
-        with open(os.path.join(ROOT, "profiles", "summary_r01.json")) as f:
+        # HBM traffic cannot be counted from inside the run (PMC passes need rocprofv3): it comes from this round's
+        # profile summary, and ONLY if that profile was taken of the very library that is loaded now (source digest)
+        from pase_amd import build as _B
+        with open(os.path.join(ROOT, "profiles", "summary_r02.json")) as f:
             prof = json.load(f)
+        if prof.get("lib_digest") != _B.hip_digest():
+            raise ValueError("profile is of another build")
+        traffic_src = "profiles/summary_r02.json"
         # PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs) summed over every conv_gemm
         # instantiation, GB per launch; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B
         # requests as 64 B)
@@ -304,11 +388,13 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "chunk_samples": T,
                        "targets": ("lps/lps_long/fbank/fbank_long/gtn/gtn_long/mfcc/mfcc_long computed on device; prosody N(0,1)"
                                    if args.producer else "given (N(0,1) tensors resident in HBM)"), "parallelism": "dp%d" % world,
-                       "final_total_loss": round(total_loss, 5)},
+                       "final_total_loss": round(total_loss, 5), "inputs": "resident in HBM (see `h2d` for the "
+                       "host-buffer leg)", "collective_backend": backend},
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (all launches of one step)",
                          "achieved": round(cg_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(cg_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "traffic_unit": "GB per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/summary_r01.json)",
+                         "traffic_unit": "GB per launch (PMC FETCH_SIZE x2 + WRITE_SIZE); null when no PMC profile of "
+                                         "exactly this build exists", "traffic_source": traffic_src,
                          "launches_per_step": cg["launches"] // extra,
                          "avg_launch_ms": round(cg["ms"] / cg["launches"], 4),
                          "algorithmic_gflop_per_launch": round(cg["flops"] / cg["launches"] / 1e9, 2),
@@ -324,6 +410,11 @@ def main():
                               "note": "canonical algorithmic FLOPs (122.0 GFLOP per utterance, SURVEY 8d: minimal "
                                       "algorithm, dense skips pooled first) x utterances/s per GPU"},
         }
+        if h2d is not None:
+            out["h2d"] = h2d
+        if shared and world > 1:
+            out["invalid_as_scaling_number"] = ("%d ranks share %d GPU(s) over gloo: functional smoke of the N>1 path only"
+                                                % (world, ndev))
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(raw, fe_cfg)

@@ -142,8 +142,9 @@ int pase_bn_act_apply(const float* y, float* out, const float* scale, const floa
  * (autograd of fuse_skip's mean, frontend.py:225-226).
  *   reduce: sums[c] = { sum dz, sum dz*xhat, sum dA*z*[z<=0] }  (doubles, caller zeroes)
  *           -> dbeta = sums[.,0], dgamma = sums[.,1], dalpha = sums[.,2]
- *   apply : dy = scale*(dz - sums0/N - xhat*sums1/N)  (has_bn)   or   dy = dz
- *   With has_bn == 0 and dy != NULL the reduce pass already writes dy = dz: the apply pass is not needed.
+ *   apply : dy = scale*(dz - sums0/N - xhat*sums1/N)  (has_bn == 1, batch statistics)
+ *           dy = scale*dz  (has_bn == 2: frozen / eval-mode statistics)   or   dy = dz  (has_bn == 0)
+ *   With has_bn != 1 and dy != NULL the reduce pass already writes dy: the apply pass is not needed.
  * ------------------------------------------------------------------------------------------ */
 typedef struct PaseActBwd {
     const float* y;        /* (S, y_ctot, T) raw layer output; channels [y_coff, y_coff+C)          */
@@ -157,7 +158,7 @@ typedef struct PaseActBwd {
     int dsrc_ctot, dsrc_coff, Tp, padL, pad_mode;
     int dpool_ctot, dpool_coff, pool_F, pool_d;
     float pool_inv;        /* 1 / pool_d                                                          */
-    int has_bn;
+    int has_bn;            /* 0 none, 1 BatchNorm with batch statistics, 2 BatchNorm with frozen statistics */
 } PaseActBwd;
 int pase_act_bwd_reduce(const PaseActBwd* desc, void* stream);
 int pase_act_bwd_apply(const PaseActBwd* desc, void* stream);

@@ -105,9 +105,11 @@ def synthetic_batch(seed, B, T, workers_cfg):
     return batch
 
 
-def gen_pase_step(seed, B, T, fe_name="PASE+.cfg", wk_name="workers+.cfg", out="pase_plus_step.npz"):
+def _ref_step(seed, B, T, fe_name, wk_name):
     """One reference training step (trainer.py:229-232 -> worker_scheduler._base_scheduler) of a
-    frontend cfg + workers cfg on a seeded synthetic batch: losses, gradient norms, post-Adam norms."""
+    frontend cfg + workers cfg on a seeded synthetic batch.  Returns (model, param checksums, losses,
+    chunk, preds); _base_scheduler has stepped the optimizers, so `.grad` holds the step's gradients
+    and the parameters are post-Adam."""
     from pase.models.pase import pase
     from pase.utils import worker_parser
     from pase.models.WorkerScheduler.worker_scheduler import backprop_scheduler
@@ -133,6 +135,12 @@ def gen_pase_step(seed, B, T, fe_name="PASE+.cfg", wk_name="workers+.cfg", out="
     random.seed(seed + 2)          # the SPC worker draws its frames from Python's `random`
     h, chunk, preds, labels = model.forward(batch, 1, "cpu")
     losses, _ = sched(preds, labels, cls_opt, regr_opt, fe_opt, device="cpu")
+    return model, (names, sums, sq), losses, chunk, preds
+
+
+def gen_pase_step(seed, B, T, fe_name="PASE+.cfg", wk_name="workers+.cfg", out="pase_plus_step.npz"):
+    """losses, gradient norms, post-Adam norms of one reference step."""
+    model, (names, sums, sq), losses, chunk, preds = _ref_step(seed, B, T, fe_name, wk_name)
     gnames = [n for n, p in model.named_parameters()]
     gsq = np.array([float((p.grad.double() ** 2).sum()) for n, p in model.named_parameters()])
     gsum = np.array([float(p.grad.double().sum()) for n, p in model.named_parameters()])
@@ -151,14 +159,48 @@ def gen_pase_step(seed, B, T, fe_name="PASE+.cfg", wk_name="workers+.cfg", out="
              pred_cchunk_head=preds["cchunk"].detach().numpy()[:, :, :400], **extra)
 
 
+GRAD_SAMPLES = 2048
+
+
+def grad_sample_index(numel, n=GRAD_SAMPLES):
+    """Flat indices at which element-wise gradients are stored: every element of small tensors, an
+    evenly strided comb (odd stride so it walks all rows / columns / taps) of large ones."""
+    if numel <= n:
+        return np.arange(numel)
+    st = numel // n
+    st += (st % 2 == 0)
+    return (np.arange(n) * st) % numel
+
+
+def gen_pase_step_grads(seed, B, T, fe_name="PASE+.cfg", wk_name="workers+.cfg", out="pase_plus_step_grads.npz"):
+    """ELEMENT-WISE reference gradients of the same step as gen_pase_step (same seeds => same step): for
+    every parameter, the gradient at grad_sample_index(numel) flat positions, plus each tensor's max |grad|."""
+    model, _cs, losses, chunk, preds = _ref_step(seed, B, T, fe_name, wk_name)
+    gnames, vals, offs, gmax = [], [], [0], []
+    for n, p in model.named_parameters():
+        g = p.grad.detach().reshape(-1).numpy()
+        idx = grad_sample_index(g.size)
+        gnames.append(n)
+        vals.append(g[idx].astype(np.float32))
+        offs.append(offs[-1] + idx.size)
+        gmax.append(float(np.abs(g).max()))
+    np.savez(os.path.join(GOLD, out), seed=seed, B=B, T=T, grad_names=np.array(gnames),
+             grad_values=np.concatenate(vals), grad_offsets=np.array(offs), grad_absmax=np.array(gmax),
+             n_samples=GRAD_SAMPLES, loss_total=float(losses["total"]))
+
+
 if __name__ == "__main__":
     ref_shim.install()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
+    if sys.argv[1:] == ["grads"]:          # only the element-wise gradient file
+        gen_pase_step_grads(seed=2, B=2, T=8000)
+        sys.exit(0)
     gen_sinc()
     gen_wavefe("pase_plus", "PASE+.cfg", seed=2, S=3, T=8000)
     gen_wavefe("pase", "PASE.cfg", seed=3, S=3, T=8000)
     gen_pase_step(seed=2, B=2, T=8000)
     gen_pase_step(seed=4, B=2, T=8000, fe_name="PASE.cfg", wk_name="workers.cfg", out="pase_step_cfg2.npz")
+    gen_pase_step_grads(seed=2, B=2, T=8000)
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)))

@@ -38,9 +38,23 @@ def lib():
             raise PaseLibraryError(
                 "pase_amd: %s is missing. Build it with `python -m pase_amd.build hip` "
                 "(or __graft_entry__.build()); there is no CPU fallback." % HIP_SO)
+        _check_fresh()
         _lib = ctypes.CDLL(HIP_SO)
         _declare(_lib)
     return _lib
+
+
+def _check_fresh():
+    """A stale binary with the same ABI but older kernel semantics would load silently: compare the build
+    stamp with the digest of the current sources (pase_amd/build.py) and refuse to run on a mismatch."""
+    from . import build
+    stamp = HIP_SO + ".sha256"
+    if not os.path.exists(stamp):
+        return                      # a hand-built library: nothing to compare against
+    want = build.hip_digest()
+    if open(stamp).read().strip() != want:
+        raise PaseLibraryError("pase_amd: %s is older than pase_amd/csrc (source digest mismatch); rebuild with "
+                               "`python -m pase_amd.build hip`" % HIP_SO)
 
 
 def _declare(l):

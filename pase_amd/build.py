@@ -46,12 +46,21 @@ def _run(cmd):
     return r.stdout
 
 
+def _hip_flags():
+    return ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", INCLUDE, "-I", CSRC,
+            "-Wno-unused-result"]
+
+
+def hip_digest():
+    # path-independent (the gpurun snapshot lives under a scratch root): file contents + the flags without the -I paths
+    return _digest(_sources() + _deps(), " ".join(f for f in _hip_flags() if f not in (INCLUDE, CSRC)))
+
+
 def build_hip(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
     srcs = _sources()
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", INCLUDE, "-I", CSRC,
-             "-Wno-unused-result"]
-    digest = _digest(srcs + _deps(), " ".join(flags))
+    flags = _hip_flags()
+    digest = hip_digest()
     if not force and _up_to_date(HIP_SO, digest):
         return HIP_SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -81,7 +90,8 @@ def build_emu(force=False):
     emu_srcs = [os.path.join(EMU_DIR, "hipemu.cpp")]
     flags = ["-O2", "-std=c++17", "-fPIC", "-shared", "-DPASE_HIPEMU", "-I", INCLUDE, "-I", CSRC, "-I", EMU_DIR,
              "-pthread", "-Wno-unused-result", "-fno-strict-aliasing"]
-    digest = _digest(srcs + _deps() + emu_srcs + [os.path.join(EMU_DIR, "hipemu.h")], " ".join(flags))
+    digest = _digest(srcs + _deps() + emu_srcs + [os.path.join(EMU_DIR, "hipemu.h")],
+                     " ".join(f for f in flags if f not in (INCLUDE, CSRC, EMU_DIR)))
     if not force and _up_to_date(EMU_SO, digest):
         return EMU_SO
     objs = []

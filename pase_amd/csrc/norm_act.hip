@@ -143,8 +143,10 @@ __global__ void __launch_bounds__(NT) act_bwd_reduce_kernel(PaseActBwd p, int ch
     const float al = p.alpha ? p.alpha[c] : 1.f;
     const float mean = p.mean ? p.mean[c] : 0.f, rstd = p.rstd ? p.rstd[c] : 1.f;
     const float* yrow = p.y + ((size_t)s * p.y_ctot + p.y_coff + c) * (size_t)p.T;
-    // without a BatchNorm dy = dz does not depend on the sums: written here, no apply pass (one read of y / dA less)
-    float* drow = (!p.has_bn && p.dy) ? p.dy + ((size_t)s * p.y_ctot + p.y_coff + c) * (size_t)p.T : nullptr;
+    // without a BatchNorm (has_bn 0: dy = dz) or behind a FROZEN one (has_bn 2, eval-mode statistics: dy = scale * dz)
+    // dy does not depend on the sums: written here, no apply pass (one read of y / dA less)
+    float* drow = (p.has_bn != 1 && p.dy) ? p.dy + ((size_t)s * p.y_ctot + p.y_coff + c) * (size_t)p.T : nullptr;
+    const float dmul = p.has_bn == 2 ? a : 1.f;
     const int per = (p.T + chunks - 1) / chunks;
     const int t0 = ch * per, t1 = min(p.T, t0 + per);
     double s_dz = 0.0, s_dzx = 0.0, s_da = 0.0;
@@ -153,7 +155,7 @@ __global__ void __launch_bounds__(NT) act_bwd_reduce_kernel(PaseActBwd p, int ch
         const float z = yv * a + b;
         const float dA = grad_post_act(p, s, c, t);
         const float dz = z > 0.f ? dA : dA * al;
-        if (drow) drow[t] = dz;
+        if (drow) drow[t] = dz * dmul;
         const float xhat = (yv - mean) * rstd;
         s_dz += (double)dz;
         s_dzx += (double)(dz * xhat);
@@ -178,7 +180,7 @@ __global__ void __launch_bounds__(NT) act_bwd_apply_kernel(PaseActBwd p, int chu
     const float al = p.alpha ? p.alpha[c] : 1.f;
     const float mean = p.mean ? p.mean[c] : 0.f, rstd = p.rstd ? p.rstd[c] : 1.f;
     float m1 = 0.f, m2 = 0.f;
-    if (p.has_bn) {
+    if (p.has_bn == 1) {
         const double n = (double)p.S * (double)p.T;
         m1 = (float)(p.sums[(size_t)c * 3 + 0] / n);
         m2 = (float)(p.sums[(size_t)c * 3 + 1] / n);
@@ -193,9 +195,11 @@ __global__ void __launch_bounds__(NT) act_bwd_apply_kernel(PaseActBwd p, int chu
         const float dA = grad_post_act(p, s, c, t);
         const float dz = z > 0.f ? dA : dA * al;
         float out = dz;
-        if (p.has_bn) {
+        if (p.has_bn == 1) {
             const float xhat = (yv - mean) * rstd;
             out = a * (dz - m1 - xhat * m2);
+        } else if (p.has_bn == 2) {
+            out = a * dz;
         }
         drow[t] = out;
     }

@@ -126,7 +126,10 @@ def bn_train(stat, C, count, norm, like):
     scale, shift, mean, rstd = (_new((C,), like) for _ in range(4))
     gamma = norm.weight if norm.affine else None
     beta = norm.bias if norm.affine else None
-    mom = norm.momentum if norm.momentum is not None else 0.0
+    if norm.momentum is None:
+        # torch semantics: cumulative moving average with factor 1/num_batches_tracked (a device counter here)
+        raise NotImplementedError("pase_amd: BatchNorm1d(momentum=None) (cumulative average) is not supported")
+    mom = norm.momentum
     K.bn_finalize(stat, C, count, gamma, beta, norm.eps, mom, norm.running_mean, norm.running_var, scale, shift,
                   mean, rstd)
     if norm.num_batches_tracked is not None:
@@ -149,15 +152,16 @@ def act_backward(y, *, C, T, S, has_bn, scale=None, shift=None, alpha=None, mean
                  dsrc_ctot=None, dsrc_coff=0, Tp=None, padL=0, pad_mode=K.PAD_ZERO, dpool=None, dpool_ctot=0,
                  dpool_coff=0, pool_F=0, pool_d=1, y_ctot=None, y_coff=0, dy_out=None):
     """Backward of a = PReLU(BN(y)): returns (dy, sums) with sums (C,3) double =
-    {dbeta | sum dz, dgamma, dalpha}."""
+    {dbeta | sum dz, dgamma, dalpha}.  has_bn: False/0 none, True/1 batch statistics, 2 frozen (eval-mode)
+    statistics, whose backward is dy = scale*dz (torch's batch_norm backward with training=False)."""
     sums = _zeros((C, 3), y, torch.float64)
     dy = dy_out if dy_out is not None else _new(tuple(y.shape), y)
     kw = dict(S=S, C_=C, T=T, y_ctot=y_ctot, y_coff=y_coff, dsrc=dsrc, dsrc_ctot=dsrc_ctot, dsrc_coff=dsrc_coff, Tp=Tp, padL=padL,
               pad_mode=pad_mode, dpool=dpool, dpool_ctot=dpool_ctot, dpool_coff=dpool_coff, pool_F=pool_F,
               pool_d=pool_d, scale=scale, shift=shift, alpha=alpha, mean=mean, rstd=rstd, sums=sums, dy=dy,
-              has_bn=1 if has_bn else 0)
+              has_bn=int(has_bn))
     K.act_bwd_reduce(y, **kw)
-    if has_bn:                       # without a BatchNorm the reduce pass has already written dy = dz
+    if int(has_bn) == 1:             # without a BatchNorm / behind a frozen one the reduce pass has already written dy
         K.act_bwd_apply(y, **kw)
     return dy, sums
 
@@ -208,6 +212,7 @@ def encoder_forward(fe, x, training, need_ctx=True):
     S = x.shape[0]
     ctx = EncoderCtx()
     ctx.x = x
+    ctx.training = bool(training)
     ctx.blocks = []
     cur = Act(x, C=x.shape[1])
     for n, blk in enumerate(fe.blocks):
@@ -313,16 +318,18 @@ def encoder_forward(fe, x, training, need_ctx=True):
     return out, ctx
 
 
-def encoder_backward(fe, ctx, demb, sink):
-    """Accumulates d(loss)/d(param) into `sink` given demb = d(loss)/d(emb)."""
+def encoder_backward(fe, ctx, demb, sink, want_dx=False):
+    """Accumulates d(loss)/d(param) into `sink` given demb = d(loss)/d(emb); with want_dx also returns
+    d(loss)/d(input waveform) (S, num_inputs, T)."""
     demb = demb.contiguous()
     x = ctx.x
     S, F_ = x.shape[0], ctx.F
     emb = fe.W.out_channels
+    bn_mode = 1 if ctx.training else 2     # eval-mode forward => frozen-statistics backward (dy = scale*dz)
     # ---- norm_out (BatchNorm1d affine=False) -----------------------------------------------------
     if ctx.out_bn is not None:
         scale, shift, mean, rstd = ctx.out_bn
-        dyemb, _ = act_backward(ctx.yemb, C=emb, T=F_, S=S, has_bn=True, scale=scale, shift=shift, mean=mean,
+        dyemb, _ = act_backward(ctx.yemb, C=emb, T=F_, S=S, has_bn=bn_mode, scale=scale, shift=shift, mean=mean,
                                 rstd=rstd, dsrc=demb)
     else:
         dyemb = demb
@@ -377,7 +384,7 @@ def encoder_backward(fe, ctx, demb, sink):
         if fe.denseskips_on and n < nb - 1:
             off, d = ctx.skip_off[n]
             kw = dict(dpool=dacat, dpool_ctot=ccat, dpool_coff=off, pool_F=F_, pool_d=d)
-        dy, sums = act_backward(y, C=C, T=Tn, S=S, has_bn=rec["has_bn"], scale=rec["scale"], shift=rec["shift"],
+        dy, sums = act_backward(y, C=C, T=Tn, S=S, has_bn=bn_mode if rec["has_bn"] else 0, scale=rec["scale"], shift=rec["shift"],
                                 alpha=blk.act.weight, mean=rec["mean"], rstd=rec["rstd"], dsrc=dsrc,
                                 dsrc_ctot=dsrc_ctot, dsrc_coff=dsrc_coff, Tp=dsrc_Tp, padL=dsrc_padL,
                                 pad_mode=dsrc_mode, **kw)
@@ -401,12 +408,24 @@ def encoder_backward(fe, ctx, demb, sink):
             dbias = sink.buf(blk.conv.bias) if rec["has_bn"] else None
             conv_wgrad(dy, inp, sink.buf(blk.conv.weight).view(C, -1), dbias, taps=taps, stride=blk.stride,
                        padL=rec["padL"], pad_mode=K.PAD_REFLECT)
-        if n > 0:
+        if n > 0 or want_dx:
             cin = inp.C
-            dsrc = conv_dgrad(dy, blk.conv.weight, R=C, O=cin, k=taps, stride=blk.stride, Tin=inp.T,
+            w_nat = rec["filt"] if blk.sincnet else blk.conv.weight
+            dsrc = conv_dgrad(dy, w_nat, R=C, O=cin, k=taps, stride=blk.stride, Tin=inp.T,
                               padL=rec["padL"], padR=rec["padR"], s_red=cin * taps, s_out=taps, s_k=1)
             dsrc_ctot, dsrc_coff = cin, 0
             dsrc_Tp, dsrc_padL, dsrc_mode = dsrc.shape[2], rec["padL"], K.PAD_REFLECT
+    if not want_dx:
+        return None
+    # gradient w.r.t. the input waveform (saliency / adversarial use through the drop-in alias): fold the reflect
+    # padding of block 0 back onto the interior (autograd of F.pad(mode='reflect')); a rare path, plain slicing
+    pL, pR, T0 = ctx.blocks[0]["padL"], ctx.blocks[0]["padR"], x.shape[2]
+    dx = dsrc[:, :, pL:pL + T0].clone()
+    if pL > 0:
+        dx[:, :, 1:pL + 1] += dsrc[:, :, :pL].flip(2)
+    if pR > 0:
+        dx[:, :, T0 - 1 - pR:T0 - 1] += dsrc[:, :, pL + T0:].flip(2)
+    return dx
 
 
 # =========================================================================================

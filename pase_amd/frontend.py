@@ -50,10 +50,10 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         sink = engine.GradSink(direct=False)
-        engine.encoder_backward(ctx.fe, ctx.ectx, dout, sink)
+        dx = engine.encoder_backward(ctx.fe, ctx.ectx, dout, sink, want_dx=ctx.needs_input_grad[1])
         grads = tuple(sink.get(p) if ctx.needs_input_grad[2 + i] else None for i, p in enumerate(ctx.params))
         ctx.ectx = None
-        return (None, None) + grads
+        return (None, dx) + grads
 
 
 class WaveFe(Model):
@@ -116,7 +116,7 @@ class WaveFe(Model):
     def encode(self, x):
         """(S, 1, T) fp32 on the kernel device -> (S, emb_dim, T // 160)."""
         params = [p for p in nn.Module.parameters(self) if p.requires_grad]
-        if torch.is_grad_enabled() and len(params) > 0:
+        if torch.is_grad_enabled() and (len(params) > 0 or x.requires_grad):
             return _EncoderFn.apply(self, x, *params)
         out, _ = engine.encoder_forward(self, x, self.training)
         return out

@@ -248,3 +248,75 @@ class DeviceBatchProducer(object):
         if self.targets is not None:
             batch.update(self.targets(batch["cchunk"]))
         return batch
+
+
+class PinnedBatchFeeder(object):
+    """Host -> HBM leg of the step for host-produced batches (what `format_frontend_chunk`'s `.to(device)`,
+    pase/models/modules.py:16-31, and the label `.to(device)` of pase/models/pase.py:338 do synchronously in the
+    reference): a ring of page-locked host slots, `depth` device slots and ONE copy stream.  `next()` hands out
+    the device batch whose copy was issued a step earlier (the compute stream waits on its event, the host
+    never blocks) and immediately issues the copy of the following batch, so the 205 MB / step of PASE+ bs32
+    travel over PCIe (SDMA engines, no CUs) underneath the previous step's kernels.
+
+    `source` is any callable returning a dict of CPU tensors (a DataLoader iterator's `next`, or the bench's
+    synthetic generator).  A device slot is recycled only after the compute stream has consumed it
+    (per-slot 'free' event recorded when the NEXT batch is requested)."""
+
+    def __init__(self, source, device="cuda", depth=2):
+        if depth < 2:
+            raise ValueError("PinnedBatchFeeder needs depth >= 2 (one slot in flight, one being consumed)")
+        self.source = source
+        self.device = torch.device(device)
+        self.depth = int(depth)
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.host = [None] * self.depth          # pinned staging slots
+        self.dev = [None] * self.depth
+        self.ready = [None] * self.depth         # copy finished
+        self.free = [None] * self.depth          # compute finished with the slot
+        self.i = 0
+        self.bytes_per_batch = 0
+        self._issue(0)
+
+    def _issue(self, slot):
+        batch = self.source()
+        if self.dev[slot] is None:
+            self.dev[slot] = {k: torch.empty(v.shape, dtype=v.dtype, device=self.device) for k, v in batch.items()}
+            self.host[slot] = {}
+            self.bytes_per_batch = sum(v.numel() * v.element_size() for v in batch.values())
+        hs, ds = self.host[slot], self.dev[slot]
+        if self.ready[slot] is not None:
+            self.ready[slot].synchronize()       # the previous copy OUT of this slot's pinned staging has finished
+        src = {}
+        for k, v in batch.items():
+            if v.is_pinned():                    # a loader that fills page-locked memory: DMA straight from it
+                src[k] = v
+            else:                                # pageable -> pinned staging (host memcpy)
+                if k not in hs:
+                    hs[k] = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                hs[k].copy_(v)
+                src[k] = hs[k]
+        with torch.cuda.stream(self.copy_stream):
+            if self.free[slot] is not None:
+                self.copy_stream.wait_event(self.free[slot])
+            for k in src:
+                ds[k].copy_(src[k], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        self.ready[slot] = ev
+
+    def next(self):
+        slot = self.i % self.depth
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(self.ready[slot])
+        out = self.dev[slot]
+        # the slot handed out the call before is free once everything enqueued so far has run
+        prev = (self.i - 1) % self.depth
+        if self.i > 0:
+            fe = torch.cuda.Event()
+            fe.record(cur)
+            self.free[prev] = fe
+        self.i += 1
+        self._issue(self.i % self.depth)
+        return out
+
+    __call__ = next

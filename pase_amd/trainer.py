@@ -185,6 +185,7 @@ class trainer(object):
         self.epoch_beg = 0
         self.alphaSG = 1
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
         self._side = None
         self.device_targets = None
         if self.world > 1:
@@ -285,13 +286,23 @@ class trainer(object):
     def save_epoch(self, e, step):
         """trainer.py:263-272: FE_e{e}.ckpt (bare frontend state_dict, what load_pretrained
         consumes) + one rotating Saver checkpoint per module."""
-        os.makedirs(self.save_path, exist_ok=True)
-        torch.save(self.model.frontend.state_dict(), os.path.join(self.save_path, "FE_e{}.ckpt".format(e)))
-        for saver in self.savers:
-            saver.save(saver.prefix[:-1], step)
+        if self.world > 1:
+            # BN running statistics are per rank (local batch statistics): checkpoint rank 0's view of the model,
+            # written by rank 0 only -- concurrent writers would tear the files and double-rotate the index
+            for b in self.model.buffers():
+                dist.broadcast(b, src=0)
+        if self.rank == 0:
+            os.makedirs(self.save_path, exist_ok=True)
+            torch.save(self.model.frontend.state_dict(), os.path.join(self.save_path, "FE_e{}.ckpt".format(e)))
+            for saver in self.savers:
+                saver.save(saver.prefix[:-1], step)
+        if self.world > 1:
+            dist.barrier()
 
     def resume_training(self, device=None):
         """trainer.py:339-363: every Saver's latest checkpoint, equal steps, epoch_beg = step // bpe."""
+        if self.world > 1:
+            dist.barrier()          # rank 0 has finished writing; every rank then loads the same files
         steps = []
         for saver in self.savers:
             cur = saver.read_latest_checkpoint()
@@ -318,7 +329,8 @@ class trainer(object):
                 losses = self.train_step(batch, device)
                 if bidx % self.log_freq == 0 or bidx >= self.bpe:
                     lrs = self.adjust_lr(bidx, e, losses)
-                    print("epoch {} batch {}/{}: ".format(e, bidx, self.bpe) +
-                          " ".join("{}={:.4f}".format(k, float(v)) for k, v in losses.items()) +
-                          " lr_fe={:.6f}".format(lrs["frontend"]))
+                    if self.rank == 0:
+                        print("epoch {} batch {}/{}: ".format(e, bidx, self.bpe) +
+                              " ".join("{}={:.4f}".format(k, float(v)) for k, v in losses.items()) +
+                              " lr_fe={:.6f}".format(lrs["frontend"]))
             self.save_epoch(e, e * self.bpe + bidx)

@@ -112,3 +112,49 @@ def test_readme_shapes(dev):
             y = fe(torch.randn(1, 1, 100000, device=dev))
         assert tuple(y.shape) == (1, emb, 625)
         assert bool(torch.isfinite(y).all())
+
+
+@pytest.mark.parametrize("cfg", [MINI_FE, MINI_FE_PLAIN], ids=["plus", "plain"])
+def test_eval_mode_backward_frozen_bn_and_input_gradient(dev, cfg):
+    """fe.eval(); loss(fe(x)).backward(): BatchNorm with FROZEN statistics backpropagates dy = scale*dz (fine-tuning
+    through a frozen frontend).  In this mode the conv biases in front of a BatchNorm and W.bias have NON-ZERO
+    gradients, so the bias-gradient kernel path (excluded from the train-mode comparisons by is_noise_grad) is
+    checked here -- every parameter, no exclusions -- together with the gradient w.r.t. the input waveform."""
+    fe = _build(cfg, dev, seed=5)
+    with torch.no_grad():
+        for n, b in fe.named_buffers():
+            if n.endswith("running_mean"):
+                b.normal_(0, 0.1)
+            if n.endswith("running_var"):
+                b.uniform_(0.5, 1.5)
+    P = oracle_params(fe)
+    fe.eval()
+    x = (torch.randn(4, 1, 1600) * 0.3).requires_grad_(True)
+    xd = x.detach().to(dev).requires_grad_(True)
+    y = fe(xd)
+    yo = O.encoder_forward(P, cfg, x, False)
+    assert_close(y, yo, rtol=1e-4, atol=1e-4, what="eval forward")
+    g = torch.randn_like(yo)
+    (yo * g).sum().backward()
+    (y * g.to(dev)).sum().backward()
+    for n, p in fe.named_parameters():
+        ref = P[n].grad
+        assert float(ref.abs().max()) > 0, n
+        assert_close(p.grad, ref, rtol=1e-3, atol=1e-4 * max(1.0, float(ref.abs().max())), what=n)
+    assert_close(xd.grad, x.grad, rtol=1e-3, atol=1e-4 * max(1.0, float(x.grad.abs().max())), what="d/d waveform")
+    sd = fe.state_dict()
+    for k in sd:
+        if "running" in k:
+            assert_close(sd[k], P[k], rtol=0, atol=0, what=k)     # eval forward leaves the statistics alone
+
+
+def test_train_mode_input_gradient(dev):
+    fe = _build(MINI_FE, dev, seed=6)
+    P = oracle_params(fe)
+    fe.train()
+    x = (torch.randn(3, 1, 1600) * 0.3).requires_grad_(True)
+    xd = x.detach().to(dev).requires_grad_(True)
+    g = torch.randn(3, 12, 10)
+    (O.encoder_forward(P, MINI_FE, x, True, {}) * g).sum().backward()
+    (fe(xd) * g.to(dev)).sum().backward()
+    assert_close(xd.grad, x.grad, rtol=1e-3, atol=1e-4 * max(1.0, float(x.grad.abs().max())), what="d/d waveform")

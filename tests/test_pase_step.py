@@ -152,6 +152,23 @@ def test_full_width_golden_step(dev, gold, fe, wk):
     assert_close(gsq.sqrt(), np.sqrt(g["grad_sq"][keep]), rtol=5e-3, atol=1e-6, what="grad norms")
     psq = torch.tensor([float((params[names[i]].detach().double() ** 2).sum()) for i in keep])
     assert_close(psq.sqrt(), np.sqrt(g["post_sq"][keep]), rtol=1e-4, atol=1e-5, what="post-Adam parameter norms")
+    # ELEMENT-WISE gradients against the live reference's (oracle/make_golden.py:gen_pase_step_grads): every
+    # parameter, sampled at grad_sample_index(numel) -- catches sign / permutation errors confined to wide tiles
+    gfile = os.path.join(GOLD, gold.replace(".npz", "_grads.npz"))
+    if os.path.exists(gfile):
+        from util import grad_sample_index
+        gg = np.load(gfile)
+        offs = gg["grad_offsets"]
+        checked = 0
+        for i, n in enumerate(str(s) for s in gg["grad_names"]):
+            if is_noise_grad(n):
+                continue
+            ref = gg["grad_values"][offs[i]:offs[i + 1]]
+            got = params[n].grad.detach().reshape(-1)[torch.as_tensor(grad_sample_index(params[n].numel(), int(gg["n_samples"])),
+                                                                      device=dev)]
+            assert_close(got, ref, rtol=2e-3, atol=2e-4 * float(gg["grad_absmax"][i]), what="grad " + n)
+            checked += 1
+        assert checked >= 100
 
 
 def _mini_workers_cfg2():

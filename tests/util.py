@@ -111,3 +111,12 @@ def is_noise_grad(name):
     import re
     n = name.replace("frontend.", "")
     return bool(re.fullmatch(r"blocks\.\d+\.conv\.bias", n)) or n == "W.bias"
+
+
+def grad_sample_index(numel, n=2048):
+    """same comb as oracle/make_golden.py:grad_sample_index"""
+    if numel <= n:
+        return np.arange(numel)
+    st = numel // n
+    st += (st % 2 == 0)
+    return (np.arange(n) * st) % numel
