@@ -4,9 +4,10 @@ numpy/scipy restatement of pase/transforms.py LPS (:439-487), FBanks (:489-548),
 ZNorm (:183-205) on one utterance, following the reference's own order of operations.
 
 Pinning status:
-  * LPS: the STFT is pinned against this image's torch.stft (the function the reference calls; the
-    reference passes the pre-complex calling convention that torch 2.x rejects, so the LIVE transform
-    cannot run here) -- tests/test_oracle_pins.py.
+  * LPS and ZNorm: PINNED against the LIVE pase.transforms.LPS / ZNorm classes (tests/test_transform_pins.py;
+    oracle/ref_shim.py adapts the pre-complex torch.stft calling convention the reference uses, which torch 2.x
+    rejects, and routes the absent librosa 0.6.3 `feature.delta` to the scipy call it forwards to); the STFT is
+    additionally pinned against this image's torch.stft -- tests/test_oracle_pins.py.
   * deltas: scipy.signal.savgol_filter IS what librosa 0.6.3 feature.delta calls
     (width=9, polyorder=order, deriv=order, mode='interp'); scipy is installed, so it is used directly.
   * DCT: scipy.fftpack.dct(type=2, norm='ortho') used directly (what librosa.feature.mfcc calls).

@@ -1,9 +1,13 @@
 """CPU oracle for the batch producer (TEST INFRASTRUCTURE ONLY): numpy / scipy restatement of
 pase/transforms.py select_chunk (:309-356), norm_and_scale (:148-151), Reverb.__call__ (:1071-1103) with
-load_IR's preparation (:1039-1042), SimpleAdditive.__call__ (:1633-1675), one utterance at a time and with the
-random decisions passed in.  scipy.signal.convolve is the function the reference calls (scipy is installed), so
-the convolution itself is the live third-party code; the class bodies cannot be imported (pase/transforms.py
-fails on its soundfile / librosa / gammatone imports), hence the restatement."""
+load_IR's preparation (:1039-1042), SimpleAdditive.__call__ (:1633-1675), SimpleAdditiveShift (:1714-1766),
+Clipping (:1514-1535), BandDrop / Downsample (:1162-1196, :1256-1296), one utterance at a time and with the
+random decisions passed in.
+
+PINNED: tests/test_transform_pins.py runs the LIVE classes (oracle/ref_shim.install_transforms() stubs the absent
+third-party imports of pase/transforms.py) under recorded random draws -- alone and chained through
+config_distortions / PCompose -- and requires these functions to reproduce their outputs; the same live outputs
+are committed as tests/golden/transforms_live.npz (oracle/live_transforms.py) for the GPU box."""
 import numpy as np
 import scipy.signal
 
@@ -103,3 +107,10 @@ def overlap(wav, speech, n_beg, shift_n, snr, ir=None, p_max=0):
     Kf = np.sqrt(Ex / ((10 ** (snr / 10.)) * En)) if En > 0 else 1.0
     noisy = wav + Kf * noise
     return (np.sqrt(Ex / (np.dot(noisy, noisy) + 1e-14)) * noisy).astype(np.float32)
+
+
+def overlap_label(T, shift_n, hop):
+    """The 'overlap' label SimpleAdditiveShift writes (pase/transforms.py:1738-1748): per-sample mask
+    [zeros(pad_len) | ones(len(noise))] with pad_len = shift, averaged over hop-sized blocks."""
+    mask = np.concatenate([np.zeros(shift_n, dtype=np.float32), np.ones(T - shift_n, dtype=np.float32)])
+    return mask[:(T // hop) * hop].reshape(-1, hop).mean(1)

@@ -90,6 +90,79 @@ def _stub(name, **attrs):
     return m
 
 
+def _legacy_stft(orig):
+    """torch.stft as torch<=1.7 defaulted: called WITHOUT return_complex it returned a real (..., 2) tensor.
+    pase/transforms.py:467-469 (LPS) relies on that; torch 2.x rejects the call.  Same arithmetic
+    (centred, reflect-padded, rectangular window of win_length zero-padded to n_fft), legacy return layout."""
+    def stft(input, n_fft, hop_length=None, win_length=None, window=None, center=True, pad_mode="reflect",
+             normalized=False, onesided=None, return_complex=None):
+        if return_complex is not None:
+            return orig(input, n_fft, hop_length, win_length, window, center, pad_mode, normalized, onesided,
+                        return_complex)
+        if window is None:
+            window = torch.ones(win_length if win_length is not None else n_fft, dtype=input.dtype, device=input.device)
+        return torch.view_as_real(orig(input, n_fft, hop_length, win_length, window, center, pad_mode, normalized,
+                                       onesided, True))
+    stft._pase_legacy = True
+    return stft
+
+
+def _librosa_delta(data, width=9, order=1, axis=-1, mode="interp", **kw):
+    """librosa 0.6.3 feature.delta (the version requirements.txt:3 pins): a Savitzky-Golay filter,
+    `scipy.signal.savgol_filter(data, width, deriv=order, axis=axis, mode=mode, polyorder=order)`.
+    librosa itself is absent here; scipy (the function it forwards to) is live."""
+    import scipy.signal
+    return scipy.signal.savgol_filter(data, width, deriv=order, axis=axis, mode=mode, polyorder=order, **kw)
+
+
+def _sf_read(filename, *a, **k):
+    """soundfile.read stand-in for the parity tests' float32 .wav fixtures: (float64 samples, rate)."""
+    import numpy as np
+    import scipy.io.wavfile
+    rate, x = scipy.io.wavfile.read(filename)
+    assert x.dtype == np.float32, "the fixtures are IEEE-float wavs (no PCM scaling to restate)"
+    return x.astype(np.float64), rate
+
+
+class _Compose(object):
+    """torchvision.transforms.Compose: apply in order."""
+
+    def __init__(self, transforms):
+        self.transforms = transforms
+
+    def __call__(self, x):
+        for t in self.transforms:
+            x = t(x)
+        return x
+
+
+def install_transforms():
+    """On top of install(): make `import pase.transforms` / `import pase.dataset` work, so that the chunkers,
+    distortions, ZNorm, LPS and DictCollater run LIVE (pase/transforms.py:4-29, pase/dataset.py:7 imports).
+    Third-party packages that are absent are stubbed; the ones whose arithmetic the pinned classes need get
+    working stand-ins built on the live scipy / torch functions they forward to:
+      torchvision.transforms.Compose (plain composition), soundfile.read (float wav fixtures through
+      scipy.io.wavfile), librosa.feature.delta (scipy savgol, librosa 0.6.3 definition), legacy torch.stft.
+    gammatone / pysptk / python_speech_features / ahoproc_tools / torchaudio stay inert: the classes that call
+    them (Gammatone, Prosody, FBanks, MFCC) remain 'parity unpinned' (SURVEY 8c)."""
+    install()
+    g = _stub("gammatone")
+    g.gtgram = _stub("gammatone.gtgram", gtgram=None)
+    _stub("pysptk", swipe=None)
+    _stub("python_speech_features", logfbank=None)
+    lb = _stub("librosa")
+    lb.feature = _stub("librosa.feature", delta=_librosa_delta)
+    tv = sys.modules["torchvision"]
+    tv.transforms = _stub("torchvision.transforms", Compose=_Compose)
+    ah = _stub("ahoproc_tools")
+    ah.interpolate = _stub("ahoproc_tools.interpolate", interpolation=None)
+    ah.io = _stub("ahoproc_tools.io")
+    _stub("torchaudio")
+    sys.modules["soundfile"].read = _sf_read
+    if not getattr(torch.stft, "_pase_legacy", False):
+        torch.stft = _legacy_stft(torch.stft)
+
+
 def install():
     """Make `import pase.models.frontend` etc. work from /root/reference."""
     import os

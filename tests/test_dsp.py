@@ -178,3 +178,20 @@ def test_target_stats_match_trainset_statistics_definition(dev):
         v = torch.cat([b[k] for b in batches])
         np.testing.assert_allclose(got[k]["mean"].numpy(), torch.mean(torch.mean(v, dim=2), dim=0).numpy(), rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(got[k]["std"].numpy(), torch.std(torch.std(v, dim=2), dim=0).numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_lps_and_znorm_vs_live_reference(dev):
+    """Device LPS / lps_long (+deltas) and ZNorm vs the LIVE pase.transforms.LPS / ZNorm outputs committed in
+    tests/golden/transforms_live.npz (oracle/live_transforms.py: legacy torch.stft adapter + scipy savgol for the
+    absent librosa 0.6.3 `delta`)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "transforms_live.npz"))
+    wav = torch.from_numpy(g["clean"].copy()).reshape(1, 1, -1)
+    for nm, win in (("lps", 400), ("lps_long", 512)):
+        f = dsp.LPS(n_fft=2048, hop=160, win=win, name=nm, device=dev)
+        want = g[nm][None]
+        _check(f(wav.to(dev)), want, _lps_tolerance(want, 1025), nm)
+    f = dsp.LPS(n_fft=2048, hop=160, win=400, device=dev)
+    f.set_stats(g["znorm_mean"], g["znorm_std"])
+    want = g["lps_znorm"][None]
+    _check(f(wav.to(dev)), want, _lps_tolerance(g["lps"][None], 1025) / g["znorm_std"][None, :, None], "lps+znorm")

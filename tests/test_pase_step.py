@@ -262,3 +262,23 @@ def test_step_with_gap_worker(dev):
     h2, chunk2, preds2, labels2 = m({k: v.to(dev) for k, v in batch.items()}, device=dev)
     assert_close(preds2["gap"], preds["gap"], rtol=1e-3, atol=1e-3)
     assert_close(labels2["gap"], labels["gap"], rtol=0, atol=0)
+
+
+def test_gap_worker_vs_live_reference(dev):
+    """The Gap worker against the LIVE reference's output (cls_minions.py:117-131 -> minions.py:651-704, run in
+    oracle/live_transforms.py with the legacy LongTensor adapter): same parameters, same numpy seed -> same frame
+    pairs, prediction and truncated labels."""
+    from pase_amd.minions import cls_worker_maker
+    g = np.load(os.path.join(GOLD, "transforms_live.npz"))
+    cfg = {"num_outputs": 1, "dropout": 0, "hidden_size": 16, "hidden_layers": 1, "name": "gap", "type": "gap",
+           "loss": "MSELoss", "skip": False}
+    w = quiet(cls_worker_maker, with_losses({"cls": [cfg]})["cls"][0], 12)
+    sd = {str(n): torch.from_numpy(g["gap_p_" + str(n)]) for n in g["gap_param_names"]}
+    assert set(sd) == set(k for k, _ in w.named_parameters())
+    w.load_state_dict(sd)
+    w = w.to(dev)
+    np.random.seed(701)
+    with torch.no_grad():
+        y, lab = w(torch.from_numpy(g["gap_x"]).to(dev), 1, device=dev)
+    assert_close(y, g["gap_y"], rtol=1e-4, atol=1e-5, what="gap prediction")
+    assert_close(lab, g["gap_label"], rtol=0, atol=0, what="gap label")

@@ -144,3 +144,97 @@ def test_reverb_full_size_24000_taps():
         ir, pm = O.prepare_ir(irs[idx[b]])
         want = O.reverb(x[b, 0], ir, pm)
         np.testing.assert_allclose(got[b, 0], want, rtol=1e-3, atol=1e-4 * np.abs(want).max())
+
+
+# ------------------------------------------------------------------------------------------------------------
+# device producers vs the LIVE reference's outputs (tests/golden/transforms_live.npz, written by
+# oracle/live_transforms.py from pase/transforms.py classes run under recorded random draws)
+# ------------------------------------------------------------------------------------------------------------
+import os  # noqa: E402
+
+_G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "transforms_live.npz"))
+
+
+def _close(got, want, what, rtol=2e-4):
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=2e-5 * max(np.abs(want).max(), 1e-3), err_msg=what)
+
+
+def test_live_reference_chunker(dev):
+    g = _G
+    wavs = [g["wav%d" % i] for i in range(3)]
+    T = g["mi0_chunk"].shape[0]
+    pairs = g["chunk_pairs"]
+    ch = P.DeviceChunker(P.WavPool(wavs, dev), T, random_scale=True)
+    src = np.stack([pairs[:, 0], pairs[:, 0], pairs[:, 1]], 0)
+    beg = np.stack([g["mi%d_beg" % ci] for ci in range(3)], 1)
+    scale = np.stack([g["mi%d_scale" % ci] for ci in range(3)], 1)
+    out = ch(src=src, beg=beg, scale=scale)
+    for ci in range(3):
+        for k in ("chunk", "chunk_ctxt", "chunk_rand"):
+            _close(out[k][ci, 0].cpu().numpy(), g["mi%d_%s" % (ci, k)], "MIChunkWav %d %s" % (ci, k), rtol=1e-6)
+
+
+def _clean(dev, n):
+    return torch.from_numpy(np.repeat(_G["clean"][None, None, :], n, 0).copy()).to(dev)
+
+
+def test_live_reference_distortions(dev):
+    g = _G
+    irs = [g["irs0"], g["irs1"]]
+    rv = P.DeviceReverb(irs, max_reverb_len=int(g["reverb_max_len"]), device=dev)
+    got = rv(_clean(dev, 2), np.array([int(g["reverb0_ir"]), int(g["reverb1_ir"])])).cpu().numpy()
+    for ci in range(2):
+        _close(got[ci, 0], g["reverb%d" % ci], "Reverb %d" % ci)
+    ad = P.DeviceAdditive([g["noises0"], g["noises1"]], device=dev)
+    dr = np.stack([g["additive%d_draw" % ci] for ci in range(3)], 0)
+    got = ad(_clean(dev, 3), dr[:, 0].astype(int), dr[:, 1].astype(int), dr[:, 2].astype(np.float32)).cpu().numpy()
+    for ci in range(3):
+        _close(got[ci, 0], g["additive%d" % ci], "SimpleAdditive %d" % ci)
+    ov = P.DeviceOverlap(P.WavPool([g["speech0"], g["speech1"]], dev), reverb=rv)
+    dr = np.stack([g["overlap%d_draw" % ci] for ci in range(3)], 0)
+    got, lab = ov(_clean(dev, 3), dr[:, 0].astype(int), dr[:, 1].astype(int), dr[:, 2].astype(int),
+                  dr[:, 4].astype(np.float32), ir_idx=dr[:, 3].astype(int))
+    for ci in range(3):
+        _close(got[ci, 0].cpu().numpy(), g["overlap%d" % ci], "SimpleAdditiveShift %d" % ci)
+        np.testing.assert_allclose(lab[ci].cpu().numpy(), g["overlap%d_label" % ci], atol=1e-6)
+    got = P.DeviceClipping()(_clean(dev, 1), np.array([float(g["clipping_cf"])])).cpu().numpy()
+    np.testing.assert_array_equal(got[0, 0], g["clipping"])
+    got = P.DeviceFilter([g["bandrop0"]], device=dev)(_clean(dev, 1), np.array([0])).cpu().numpy()
+    _close(got[0, 0], g["bandrop"], "BandDrop")
+    got = P.DeviceFilter([g["downsample0"]], device=dev)(_clean(dev, 1), np.array([0])).cpu().numpy()
+    _close(got[0, 0], g["downsample"], "Downsample")
+
+
+def test_live_reference_full_distortion_chain(dev):
+    """config_distortions (transforms.py:38-146) -> PCompose gating -> six distortions in the reference's order, four
+    utterances with the reference's own random decisions: DeviceBatchProducer.apply_chain on one batch."""
+    g = _G
+    B = 4
+    prod = P.DeviceBatchProducer(
+        None, reverb=P.DeviceReverb([g["irs0"], g["irs1"]], device=dev),
+        overlap=P.DeviceOverlap(P.WavPool([g["speech0"], g["speech1"]], dev)),
+        additive=P.DeviceAdditive([g["noises0"], g["noises1"]], device=dev), clipping=P.DeviceClipping(),
+        bandrop=P.DeviceFilter([g["bandrop0"]], device=dev), downsample=P.DeviceFilter([g["downsample0"]], device=dev))
+    dr = np.stack([g["chain%d_draw" % ci] for ci in range(B)], 0)
+    d = dict(reverb_ir=dr[:, 0].astype(int), ov_src=dr[:, 1].astype(int), ov_beg=dr[:, 2].astype(int),
+             ov_shift=dr[:, 3].astype(int), ov_snr=dr[:, 4].astype(np.float32), add_idx=dr[:, 5].astype(int),
+             add_beg=dr[:, 6].astype(int), add_snr=dr[:, 7].astype(np.float32), clip=dr[:, 8].astype(np.float32),
+             bandrop=dr[:, 9].astype(int), downsample=dr[:, 10].astype(int))
+    batch = prod.apply_chain({"chunk": _clean(dev, B)}, d)
+    for ci in range(B):
+        _close(batch["chunk"][ci, 0].cpu().numpy(), g["chain%d" % ci], "chain %d" % ci, rtol=5e-4)
+        np.testing.assert_allclose(batch["overlap"][ci].cpu().numpy(), g["chain%d_label" % ci], atol=1e-6)
+
+
+def test_live_reference_dictcollater_layout(dev):
+    """The producer's batch dict has DictCollater's layout (dataset.py:21-89) for the keys it emits."""
+    g = _G
+    rng = np.random.RandomState(4)
+    pool = P.WavPool([g["wav0"], g["wav1"], g["wav2"]], dev)
+    prod = P.DeviceBatchProducer(P.DeviceChunker(pool, 1600, rng=rng), overlap=P.DeviceOverlap(P.WavPool([g["speech0"]], dev)),
+                                 overlap_p=1.0, rng=rng)
+    batch = prod(3)
+    for k in ("chunk", "chunk_ctxt", "chunk_rand", "cchunk"):
+        assert tuple(batch[k].shape) == g["collate_" + k].shape
+    # (the reference collates `overlap` as (B, 1, F); the label is consumed as (B, F) by the overlap worker's loss here)
+    assert tuple(batch["overlap"].shape) == (3, g["collate_overlap"].shape[2])
