@@ -237,6 +237,16 @@ int pase_delta_znorm(const float* x, const float* coef, const float* mean, const
                      int D, int F, int Fo, int order, int x_ctot, int x_coff, void* stream);
 int pase_power_to_db(const float* x, float* y, unsigned* umax_scratch, long per_utt, int B, float amin,
                      float ref_db, float top_db, void* stream);
+/* Prosody target, energy + zero-crossing rows (pase/transforms.py:967-978: librosa.feature.rmse with
+ * pad_mode='constant' and librosa.feature.zero_crossing_rate, both centred frames of `win` samples every `hop`):
+ * out[b, out_coff, f] = sqrt(mean(x_zero-padded^2)), out[b, out_coff+1, f] = sign-bit changes inside the
+ * edge-padded frame / win (|x| <= 1e-10 counts as +0).  x (B, T), out (B, out_ctot, F). */
+int pase_zcr_rms(const float* x, float* out, int B, int T, int F, int hop, int win, int out_ctot, int out_coff,
+                 void* stream);
+/* Prosody target, pitch rows (pase/transforms.py:948-961): f0 (B, F) in Hz with 0 on unvoiced frames ->
+ * out[b, out_coff] = log(f0 + 1e-10) with unvoiced stretches interpolated (ahoproc_tools interpolation(lf0, -1)),
+ * out[b, out_coff+1] = voiced flag; an all-unvoiced chunk gets log(f0_min) / 0. */
+int pase_lf0_interp(const float* f0, float* out, int B, int F, int out_ctot, int out_coff, float f0_min, void* stream);
 /* Framing prologue of LPS / FBanks / MFCC (transforms.py:465-466 torch.stft centre padding, :517
  * logfbank framing + pre-emphasis, :700 librosa stft): y (B, hop, Q) with
  * y[b][r][q] = xpad[q*hop + r], xpad = x padded by padL on the left (pad_mode PASE_PAD_REFLECT or

@@ -223,3 +223,78 @@ def gammatone(wav, f_min=500, n_channels=40, hop=160, win=400, der_order=2, rate
     if gtn.shape[1] < expected:
         gtn = np.concatenate([gtn, np.repeat(gtn[:, -1:], expected - gtn.shape[1], axis=1)], axis=1)
     return gtn
+
+
+# ---------------------------------------------------------------------------------------------
+# Prosody (pase/transforms.py:919-999): rows [lf0, uv, egy, zcr] + deltas.
+# PARITY UNPINNED for every third-party piece (none is installed here): pysptk.swipe (the f0 tracker; f0 is an INPUT
+# of these functions), ahoproc_tools.interpolate.interpolation (un-pinned git dependency, requirements.txt:17;
+# restated from the published package, its quirk of flagging the last voiced frame before a gap as unvoiced kept),
+# librosa 0.6.3 feature.rmse / zero_crossing_rate / util.frame (restated from the published source).
+# ---------------------------------------------------------------------------------------------
+def ahoproc_interpolation(signal, unvoiced_symbol):
+    """ahoproc_tools.interpolate.interpolation: returns (interpolated signal, voiced flag)."""
+    signal = np.asarray(signal, dtype=np.float64)
+    tb = [None, None]
+    fb = [None, None]
+    prev = signal[0]
+    isig = signal.copy()
+    uv = np.ones(signal.shape, dtype=np.int8)
+    for t in range(1, signal.shape[0]):
+        if signal[t] > unvoiced_symbol and prev <= unvoiced_symbol and tb == [None, None]:
+            isig[:t] = signal[t]                      # leading unvoiced stretch: first voiced value
+            uv[:t] = 0
+        elif signal[t] <= unvoiced_symbol and prev > unvoiced_symbol:
+            tb[0], fb[0] = t - 1, prev
+        elif signal[t] > unvoiced_symbol and prev <= unvoiced_symbol:
+            tb[1], fb[1] = t, signal[t]
+            n = tb[1] - tb[0]
+            isig[tb[0]:tb[1]] = fb[0] + np.arange(n) * ((fb[1] - fb[0]) / n)
+            uv[tb[0]:tb[1]] = 0
+            tb, fb = [None, None], [None, None]
+        prev = signal[t]
+    if tb[0] is not None:
+        isig[tb[0]:] = fb[0]                          # trailing unvoiced stretch: last voiced value
+        uv[tb[0]:] = 0
+    if np.all(isig <= unvoiced_symbol):
+        uv = np.zeros(signal.shape, dtype=np.int8)
+    return isig, uv
+
+
+def librosa_frame(y, frame_length, hop_length):
+    n = 1 + (len(y) - frame_length) // hop_length
+    return np.stack([y[i * hop_length:i * hop_length + frame_length] for i in range(n)], 1)     # (frame_length, n)
+
+
+def librosa_rmse(y, frame_length, hop_length, pad_mode="reflect"):
+    y = np.pad(np.asarray(y), int(frame_length // 2), mode=pad_mode)
+    x = librosa_frame(y, frame_length, hop_length)
+    return np.sqrt(np.mean(np.abs(x) ** 2, axis=0, keepdims=True))
+
+
+def librosa_zero_crossing_rate(y, frame_length, hop_length, threshold=1e-10):
+    y = np.pad(np.asarray(y), int(frame_length // 2), mode="edge")
+    x = librosa_frame(y, frame_length, hop_length).copy()
+    x[np.abs(x) <= threshold] = 0
+    sign = np.signbit(x)
+    cross = np.concatenate([np.zeros((1, x.shape[1]), dtype=bool), sign[1:] != sign[:-1]], 0)    # pad=False
+    return np.mean(cross, axis=0, keepdims=True)
+
+
+def prosody(wav, f0, hop=160, win=320, f0_min=60, f0_max=300, der_order=2):
+    """Prosody.__call__ (transforms.py:931-990) given the tracker's f0 contour (Hz, 0 = unvoiced)."""
+    wav = np.asarray(wav)
+    max_frames = wav.shape[0] // hop
+    f0 = np.asarray(f0, dtype=np.float64)
+    if len(f0) < max_frames:
+        pad = max_frames - len(f0)
+        f0 = np.concatenate((f0, f0[-pad:]), axis=0)
+    lf0 = np.log(f0 + 1e-10)
+    lf0, uv = ahoproc_interpolation(lf0, -1)
+    lf0 = lf0.astype(np.float32)[None, :max_frames]
+    uv = uv.astype(np.float32)[None, :max_frames]
+    if uv.sum() == 0:
+        lf0 = np.ones_like(uv) * np.float32(np.log(f0_min))
+    zcr = librosa_zero_crossing_rate(wav, win, hop).astype(np.float32)[:, :max_frames]
+    egy = librosa_rmse(wav, win, hop, pad_mode="constant").astype(np.float32)[:, :max_frames]
+    return with_deltas(np.concatenate((lf0, uv, egy, zcr), 0), der_order)

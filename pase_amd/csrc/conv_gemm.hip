@@ -123,7 +123,10 @@ __device__ float g_ident[2] = {1.f, 0.f};
 // land in slab padding), which keeps the loads independent of each other in the instruction stream.
 // OCC = workgroups per CU the instantiation is sized for: 3 needs <= 53 KB of LDS (44-row weight slab, 3-slot span
 // slab: the 11-tap and 30-tap layers) and <= 168 VGPRs.
-template <int BM, int BN, int NS, int XV, int OCC = 2>
+// XFM (flat instantiation only; -1 = decided at run time): the row-major float4 slots of the flat 1x1 path carry one
+// (scale, shift, alpha) triple PER SLOT, i.e. 12 extra loads per stage next to the 8 operand loads -- specialised away
+// when the launch has no on-load transform (0: every data-gradient) or only a PReLU slope (1: the worker heads).
+template <int BM, int BN, int NS, int XV, int OCC = 2, int XFM = -1>
 __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p, ConvPlan pl) {
     constexpr int WAVES_N = BN / 64;
     static_assert((BM / 64) * WAVES_N == 4, "4 waves");
@@ -209,7 +212,7 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
     static_assert(!PM || NS <= NPAR, "row-major slots prefetch one parameter triple per slot");
     constexpr int NP = PM ? NS : 1;            // (scale, shift, alpha) triples prefetched per stage
     float par_s[NP], par_h[NP], par_a[NP];
-    const bool has_xf = p.in_scale != nullptr || p.in_alpha != nullptr;
+    const bool has_xf = XFM >= 0 ? XFM > 0 : (p.in_scale != nullptr || p.in_alpha != nullptr);
     const float* sc_p = p.in_scale ? p.in_scale : &g_ident[0];
     const float* sh_p = p.in_scale ? p.in_shift : &g_ident[1];
     const float* al_p = p.in_alpha ? p.in_alpha : &g_ident[0];
@@ -307,12 +310,16 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
                 xreg[t] = xb[(unsigned)xoff[t]];
             }
         }
+        if (XFM != 0) {
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const int ch = min(ci0s + xrow + j * RPP, p.Cin - 1);
-            par_s[j] = sc_p[ch * aff_on];
-            par_h[j] = sh_p[ch * aff_on];
-            par_a[j] = al_p[ch * alpha_on];
+            for (int j = 0; j < NP; ++j) {
+                const int ch = min(ci0s + xrow + j * RPP, p.Cin - 1);
+                if (XFM != 1) {
+                    par_s[j] = sc_p[ch * aff_on];
+                    par_h[j] = sh_p[ch * aff_on];
+                }
+                par_a[j] = al_p[ch * alpha_on];
+            }
         }
     };
     auto xform = [&](float v, float sc, float sh, float al) __attribute__((always_inline)) {
@@ -337,7 +344,11 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
             float v[W];
 #pragma unroll
             for (int e = 0; e < W; ++e) v[e] = xreg[W * t + e];
-            if (has_xf) {   // uniform
+            if (XFM == 1) {
+                const float al = par_a[PM ? t : 0];
+#pragma unroll
+                for (int e = 0; e < W; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * al;
+            } else if (has_xf) {   // uniform
                 const float sc = par_s[PM ? t : 0], sh = par_h[PM ? t : 0], al = par_a[PM ? t : 0];
 #pragma unroll
                 for (int e = 0; e < W; ++e) v[e] = xform(v[e], sc, sh, al);
@@ -829,7 +840,11 @@ extern "C" int pase_conv_gemm(const PaseConvGemm* d, void* stream) {
     const dim3 grid((unsigned)h.blocks), block(NTHREADS);
 #define PASE_CONV_LAUNCH(BM_, BN_)                                                                       \
     do {                                                                                                 \
-        if (h.pl.xvec) PASE_LAUNCH((conv_gemm_kernel<BM_, BN_, NS_FLAT, 1>), grid, block, st, p, h.pl);        \
+        if (h.pl.xvec && !p.in_scale && !p.in_alpha)                                                     \
+            PASE_LAUNCH((conv_gemm_kernel<BM_, BN_, NS_FLAT, 1, 2, 0>), grid, block, st, p, h.pl);       \
+        else if (h.pl.xvec && !p.in_scale)                                                               \
+            PASE_LAUNCH((conv_gemm_kernel<BM_, BN_, NS_FLAT, 1, 2, 1>), grid, block, st, p, h.pl);       \
+        else if (h.pl.xvec) PASE_LAUNCH((conv_gemm_kernel<BM_, BN_, NS_FLAT, 1, 2, 2>), grid, block, st, p, h.pl);  \
         else if (h.pl.nslots == 3 && BM_ == 128 && h.pl.CB * h.pl.TB <= 44)                              \
             PASE_LAUNCH((conv_gemm_kernel<128, 128, 3, 0, 3>), grid, block, st, p, h.pl);                \
         else if (h.pl.nslots == 3) PASE_LAUNCH((conv_gemm_kernel<BM_, BN_, 3, 0>), grid, block, st, p, h.pl);  \

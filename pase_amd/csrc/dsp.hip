@@ -56,6 +56,85 @@ __global__ void __launch_bounds__(NT) delta_znorm_kernel(const float* x, const f
     }
 }
 
+// Framed energy and zero-crossing rate of the Prosody target (pase/transforms.py:967-978):
+//   librosa.feature.rmse(y, frame_length=win, hop_length=hop, center=True, pad_mode='constant'):
+//       sqrt(mean(x^2)) over frames of the signal ZERO-padded by win/2 on both sides;
+//   librosa.feature.zero_crossing_rate(y, frame_length=win, hop_length=hop, center=True):
+//       signal EDGE-padded by win/2; |y| <= 1e-10 counts as +0; a crossing = np.signbit differs between
+//       consecutive samples INSIDE the frame (the frame's first sample compares with nothing: pad=False);
+//       rate = crossings / win.
+// out (B, out_ctot, F): row out_coff = energy, row out_coff + 1 = zcr (the reference's [.., egy, zcr] order).
+// One wave per frame, lanes stride over the window.
+__global__ void __launch_bounds__(NT) zcr_rms_kernel(const float* x, float* out, int B, int T, int F, int hop, int win,
+                                                     int out_ctot, int out_coff) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long fr = (long)blockIdx.x * (NT / 64) + wave;
+    if (fr >= (long)B * F) return;
+    const int b = (int)(fr / F), f = (int)(fr % F);
+    const float* xr = x + (size_t)b * T;
+    const int u0 = f * hop - win / 2;
+    float e = 0.f;
+    int zc = 0;
+    for (int i = lane; i < win; i += 64) {
+        const int u = u0 + i;
+        const float v = (u >= 0 && u < T) ? xr[u] : 0.f;                 // zero padding (energy)
+        e = fmaf(v, v, e);
+        if (i > 0) {
+            float a = xr[min(max(u - 1, 0), T - 1)], c = xr[min(max(u, 0), T - 1)];   // edge padding (zcr)
+            a = fabsf(a) <= 1e-10f ? 0.f : a;
+            c = fabsf(c) <= 1e-10f ? 0.f : c;
+            zc += ((a < 0.f) != (c < 0.f)) ? 1 : 0;       // np.signbit after the threshold (no -0 / NaN left)
+        }
+    }
+    e = pase_wave_sum64(e);
+    float z = pase_wave_sum64((float)zc);
+    if (lane == 0) {
+        float* o = out + ((size_t)b * out_ctot + out_coff) * (size_t)F + f;
+        o[0] = sqrtf(e / (float)win);
+        o[F] = z / (float)win;
+    }
+}
+
+// log-f0 contour of the Prosody target (pase/transforms.py:948-961): lf0 = log(f0 + 1e-10) (f0 = 0 on unvoiced
+// frames), then ahoproc_tools.interpolate.interpolation(lf0, -1): unvoiced stretches (lf0 <= -1) are bridged
+// linearly between their voiced neighbours, a leading stretch takes the first voiced value, a trailing one the
+// last voiced value; uv = 1 on voiced frames; an all-unvoiced chunk gets lf0 = log(f0_min), uv = 0.
+// One thread per utterance (F = 200 frames, sequential by nature).  out rows: out_coff = lf0, out_coff+1 = uv.
+__global__ void lf0_interp_kernel(const float* f0, float* out, int B, int F, int out_ctot, int out_coff, float f0_min) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* f = f0 + (size_t)b * F;
+    float* lf = out + ((size_t)b * out_ctot + out_coff) * (size_t)F;
+    float* uv = lf + F;
+    const double us = -1.0;
+    auto L = [&](int t) { return log((double)f[t] + 1e-10); };
+    for (int t = 0; t < F; ++t) { lf[t] = (float)L(t); uv[t] = 1.f; }
+    int tb0 = -1;              // tbound[0]
+    double fb0 = 0.0;          // fbound[0]
+    bool have_b0 = false;      // tbound != [None, None]
+    double prev = L(0);
+    for (int t = 1; t < F; ++t) {
+        const double cur = L(t);
+        if (cur > us && prev <= us && !have_b0) {
+            // leading unvoiced stretch: constant first voiced value
+            for (int i = 0; i < t; ++i) { lf[i] = (float)cur; uv[i] = 0.f; }
+        } else if (cur <= us && prev > us) {
+            tb0 = t - 1; fb0 = prev; have_b0 = true;
+        } else if (cur > us && prev <= us) {
+            const double slope = (cur - fb0) / (double)(t - tb0);
+            for (int i = tb0; i < t; ++i) { lf[i] = (float)(fb0 + (double)(i - tb0) * slope); uv[i] = 0.f; }
+            have_b0 = false; tb0 = -1;
+        }
+        prev = cur;
+    }
+    if (have_b0) for (int i = tb0; i < F; ++i) { lf[i] = (float)fb0; uv[i] = 0.f; }
+    bool all_unv = true;
+    float uvsum = 0.f;
+    for (int t = 0; t < F; ++t) { all_unv = all_unv && !((double)lf[t] > us); uvsum += uv[t]; }
+    if (all_unv) { for (int t = 0; t < F; ++t) uv[t] = 0.f; uvsum = 0.f; }
+    if (uvsum == 0.f) for (int t = 0; t < F; ++t) lf[t] = logf(f0_min);
+}
+
 // Framing prologue shared by every spectral target: the waveform, padded (reflect / zero) by padL on the
 // left and optionally pre-emphasised (python_speech_features.sigproc.preemphasis: y[0] = x[0],
 // y[n] = x[n] - c x[n-1]), is laid out hop-major -- y[b][r][q] = xpad[q*hop + r] -- so that a frame of
@@ -136,6 +215,27 @@ extern "C" int pase_delta_znorm(const float* x, const float* coef, const float* 
     if (blocks > 4096) blocks = 4096;
     PASE_LAUNCH(delta_znorm_kernel, dim3((unsigned)blocks), dim3(NT), (hipStream_t)stream, x, coef, mean, istd, out, B, D,
                 F, Fo, order, x_ctot, x_coff);
+    PASE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pase_zcr_rms(const float* x, float* out, int B, int T, int F, int hop, int win, int out_ctot,
+                            int out_coff, void* stream) {
+    if (B <= 0 || F <= 0) return 0;
+    if (win < 2 || hop < 1 || T < 1 || out_coff + 2 > out_ctot) return -2;
+    const long frames = (long)B * F;
+    PASE_LAUNCH(zcr_rms_kernel, dim3((unsigned)((frames + NT / 64 - 1) / (NT / 64))), dim3(NT), (hipStream_t)stream, x, out,
+                B, T, F, hop, win, out_ctot, out_coff);
+    PASE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pase_lf0_interp(const float* f0, float* out, int B, int F, int out_ctot, int out_coff, float f0_min,
+                               void* stream) {
+    if (B <= 0 || F <= 0) return 0;
+    if (out_coff + 2 > out_ctot) return -2;
+    PASE_LAUNCH(lf0_interp_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), (hipStream_t)stream, f0, out, B, F, out_ctot,
+                out_coff, f0_min);
     PASE_CHECK_LAUNCH();
     return 0;
 }

@@ -292,6 +292,35 @@ class Gammatone(_Feature):
         return blocks
 
 
+class Prosody(_Feature):
+    """Prosody target (pase/transforms.py:919-999): rows [lf0, uv, energy, zcr] (+ deltas, ZNorm).  The energy and
+    zero-crossing rows and the lf0 interpolation / voiced flag run on the device (pase_zcr_rms, pase_lf0_interp);
+    the f0 contour itself (Hz per hop, 0 = unvoiced: what pysptk.swipe(..., otype='f0') returns) comes from `f0`
+    -- a (B, F) tensor the caller provides, or the device tracker when one is attached (`tracker(wav) -> f0`)."""
+
+    def __init__(self, hop=160, win=320, f0_min=60, f0_max=300, der_order=2, sr=16000, name="prosody", device="cuda",
+                 tracker=None):
+        super().__init__(name, der_order, device)
+        self.hop, self.win, self.f0_min, self.f0_max, self.sr = hop, win, f0_min, f0_max, sr
+        self.tracker = tracker
+
+    def __call__(self, wav, f0=None):
+        """wav (B, 1, T), f0 (B, >= T//hop) -> (B, 4*(der_order+1), T//hop)"""
+        B, _, T = wav.shape
+        F = T // self.hop
+        if f0 is None:
+            if self.tracker is None:
+                raise ValueError("pase_amd Prosody: no f0 contour given and no device tracker attached")
+            f0 = self.tracker(wav)
+        f0 = f0[:, :F].contiguous().float()
+        if f0.shape[1] < F:       # transforms.py:951-953: a short contour repeats its tail
+            f0 = torch.cat((f0, f0[:, f0.shape[1] - (F - f0.shape[1]):]), 1).contiguous()
+        base = torch.empty(B, 4, F, device=wav.device)
+        K.lf0_interp(f0, base, B=B, F=F, out_ctot=4, out_coff=0, f0_min=float(self.f0_min))
+        K.zcr_rms(wav.contiguous(), base, B=B, T=T, F=F, hop=self.hop, win=self.win, out_ctot=4, out_coff=2)
+        return self._finish(base, F, F)
+
+
 class DeviceTargets(object):
     """What train.py:make_transforms (train.py:37-136) composes from the worker names -- LPS / FBanks /
     MFCC (+ their *_long variants via the per-worker `transform` kwargs) followed by ZNorm -- as a

@@ -166,6 +166,22 @@ def act_backward(y, *, C, T, S, has_bn, scale=None, shift=None, alpha=None, mean
     return dy, sums
 
 
+_WIDE_HEAD_ELEMS = 16 * 1024 * 1024     # prediction elements above which a head fills the chip by itself
+_SIDE = {}
+
+
+def side_streams(like, n):
+    """n side HIP streams on `like`'s device (none on the CPU emulator; PASE_SIDE_STREAMS=0 serialises
+    everything on the current stream)."""
+    import os
+    if not like.is_cuda or os.environ.get("PASE_SIDE_STREAMS", "1") == "0":
+        return []
+    key = (like.device.index, n)
+    if key not in _SIDE:
+        _SIDE[key] = [torch.cuda.Stream(device=like.device) for _ in range(n)]
+    return _SIDE[key]
+
+
 class GradSink:
     """Where parameter gradients go.  direct=True: accumulate straight into param.grad (the fused
     trainer zeroes one flat buffer per step and lets the wgrad kernels add into views of it);
@@ -605,7 +621,9 @@ def mlp_group_step(workers, a: Act, targets, sink):
     z_all, _ = conv_fwd(a, w1cat, b1cat, Cout=htot, taps=1, Tout=F_)
     dz_all = _new((B, htot, F_), x)
     out = {}
-    for w, h, off in zip(workers, hs, offs):
+
+    def head(w, h, off):
+        """one worker's head: projection + fused loss, weight / data gradients, PReLU backward into dz_all"""
         blk, oc = w.blocks[0], w.W
         nout = oc.out_channels
         loss = w.loss
@@ -632,7 +650,31 @@ def mlp_group_step(workers, a: Act, targets, sink):
         _, sums = act_backward(z_all, C=h, T=F_, S=B, has_bn=False, alpha=blk.act.weight, dsrc=dA, dsrc_ctot=h, Tp=F_,
                                y_ctot=htot, y_coff=off, dy_out=dz_all)
         sink.add_cols(sums, 3, h, [(blk.act.weight, 2), (blk.W.bias, 0)])
-        del dpred, dA
+
+    # The wide heads (LPS: 21 525 rows) fill the chip on their own; the narrow ones (84 ... 840 rows) launch
+    # 10-100 workgroups each and would leave most of the 256 CUs idle if serialised behind each other: they go to
+    # side HIP streams and run underneath the wide ones (fork after the stacked first layer, join before the stacked
+    # backward).  Every head writes disjoint slices (its own parameter gradients, its channel range of dz_all).
+    items = list(zip(workers, hs, offs))
+    narrow = [it for it in items if it[0].W.out_channels * F_ * B < _WIDE_HEAD_ELEMS]
+    side = side_streams(x, 3) if (len(narrow) > 1 and K.GEMM_TIMER is None) else []
+    if side:
+        main = torch.cuda.current_stream()
+        fork = main.record_event()
+        for i, it in enumerate(narrow):
+            st = side[i % len(side)]
+            if i < len(side):
+                st.wait_event(fork)
+            with torch.cuda.stream(st):
+                head(*it)
+        for it in items:
+            if not any(it is n for n in narrow):
+                head(*it)
+        for st in side[:len(narrow)]:
+            main.wait_event(st.record_event())
+    else:
+        for it in items:
+            head(*it)
     # stacked first layer: one wgrad, one dgrad
     dw1 = _zeros((htot, cin), x)
     conv_wgrad(dz_all, a, dw1, None, taps=1)

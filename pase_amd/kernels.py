@@ -250,6 +250,8 @@ _SIMPLE.update({
     "pase_delta_znorm": [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp],
     "pase_power_to_db": [_fp, _fp, _fp, _l, _i, _f, _f, _f, _fp],
     "pase_frame_prep": [_fp, _fp, _i, _i, _i, _i, _i, _i, _f, _fp],
+    "pase_zcr_rms": [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp],
+    "pase_lf0_interp": [_fp, _fp, _i, _i, _i, _i, _f, _fp],
 })
 
 LOSS_NONE, LOSS_L1, LOSS_MSE, LOSS_BCE = 0, 1, 2, 3
@@ -409,6 +411,15 @@ def delta_znorm(x, coef, mean, istd, out, *, B, D, F, Fo, order, x_ctot=None, x_
 def power_to_db(x, y, umax, *, per_utt, B, amin=1e-10, ref_db=0.0, top_db=80.0):
     _check(_lib.lib().pase_power_to_db(_ptr(x), _ptr(y), _ptr(umax, torch.int32), per_utt, B, amin, ref_db, top_db,
                                        _stream()), "pase_power_to_db")
+
+
+def zcr_rms(x, out, *, B, T, F, hop, win, out_ctot, out_coff):
+    _check(_lib.lib().pase_zcr_rms(_ptr(x), _ptr(out), B, T, F, hop, win, out_ctot, out_coff, _stream()), "pase_zcr_rms")
+
+
+def lf0_interp(f0, out, *, B, F, out_ctot, out_coff, f0_min):
+    _check(_lib.lib().pase_lf0_interp(_ptr(f0), _ptr(out), B, F, out_ctot, out_coff, f0_min, _stream()),
+           "pase_lf0_interp")
 
 
 def frame_prep(x, y, *, B, T, hop, Q, padL, pad_mode, preemph=0.0):

@@ -69,62 +69,12 @@ class pase(Model):
             labels[worker.name] = label
         return h, chunk, preds, labels
 
-    # ------------------------------------------------------------------------------------------
-    # fused training schedule: forward + all losses + backward in one hand-scheduled pass
-    # (what trainer.train_ -> model.forward -> backprop_scheduler._base_scheduler do through
-    # autograd in the reference: trainer.py:229-232, worker_scheduler.py:43-75)
-    # ------------------------------------------------------------------------------------------
-    def loss_and_grads(self, batch, sink=None, device=None, before_encoder_backward=None):
-        """Returns {worker: loss_weight*loss, 'total': sum} (0-dim float64 device tensors) and
-        accumulates every parameter gradient into `sink` (default: param.grad)."""
-        if sink is None:
-            sink = engine.GradSink(direct=True)
-        fe = self.frontend
-        keys = [k for k in ("chunk", "chunk_ctxt", "chunk_rand") if k in batch]
-        if len(keys) != 3:
-            raise ValueError("pase_amd: the fused step needs chunk / chunk_ctxt / chunk_rand")
-        x = torch.cat([batch[k] for k in keys], dim=0)
-        if device is not None:
-            x = x.to(device)
-        emb, ectx = engine.encoder_forward(fe, x, training=fe.training)
-        B = batch["chunk"].shape[0]
+    def _cls_step(self, emb, B, demb, sink, losses):
+        """Forward + loss + backward of the contrastive / classification workers (pase.py:345-354); their
+        gradient w.r.t. the embeddings is accumulated into `demb`.  Returns their summed weighted loss."""
         E, F_ = emb.shape[1], emb.shape[2]
-        demb = torch.zeros_like(emb)
-        losses = {}
-        total = torch.zeros((), dtype=torch.float64, device=emb.device)
         chunk = emb[:B]
-        # one-hidden-layer MLP workers share their input: run their first layers stacked
-        from .minions import MLPMinion
-        group = [w for w in self.regression_workers
-                 if isinstance(w, MLPMinion) and len(w.blocks) == 1 and w.blocks[0].context == 1
-                 and w.W.kernel_size[0] == 1 and w.W.out_channels > 1]
-        if len(group) > 1:
-            tg = {w.name: (batch[w.name].to(device) if device is not None else batch[w.name]) for w in group}
-            res, dx = engine.mlp_group_step(group, Act(chunk, C=E), tg, sink)
-            demb[:B] += dx
-            for w in group:
-                acc, numel = res[w.name]
-                l = acc[0] * (w.loss_weight / numel)
-                losses[w.name] = l
-                total = total + l
-        else:
-            group = []
-        for worker in self.regression_workers:
-            if any(worker is g for g in group):
-                continue
-            loss = worker.loss
-            tgt = batch[worker.name]
-            if device is not None:
-                tgt = tgt.to(device)
-            wctx = engine.worker_forward(list(worker.blocks), worker.W, Act(chunk, C=E),
-                                         loss=dict(name=loss.loss_name, r=loss.r, target=tgt,
-                                                   weight=worker.loss_weight), want_pred=False)
-            dsrc = engine.worker_backward(list(worker.blocks), worker.W, wctx, wctx.dpred, sink)
-            demb[:B] += dsrc.dense(E, F_)
-            l = wctx.loss_acc[0] * (worker.loss_weight / wctx.numel)
-            losses[worker.name] = l
-            total = total + l
-            del wctx, dsrc
+        total = torch.zeros((), dtype=torch.float64, device=emb.device)
         h = (emb[:B], emb[B:2 * B], emb[2 * B:3 * B])
         for worker in self.classification_workers:
             mn = worker.minion
@@ -208,6 +158,82 @@ class pase(Model):
             losses[worker.name] = l
             total = total + l
             del wctx, dsrc
+        return total
+
+    # ------------------------------------------------------------------------------------------
+    # fused training schedule: forward + all losses + backward in one hand-scheduled pass
+    # (what trainer.train_ -> model.forward -> backprop_scheduler._base_scheduler do through
+    # autograd in the reference: trainer.py:229-232, worker_scheduler.py:43-75)
+    # ------------------------------------------------------------------------------------------
+    def loss_and_grads(self, batch, sink=None, device=None, before_encoder_backward=None):
+        """Returns {worker: loss_weight*loss, 'total': sum} (0-dim float64 device tensors) and
+        accumulates every parameter gradient into `sink` (default: param.grad)."""
+        if sink is None:
+            sink = engine.GradSink(direct=True)
+        fe = self.frontend
+        keys = [k for k in ("chunk", "chunk_ctxt", "chunk_rand") if k in batch]
+        if len(keys) != 3:
+            raise ValueError("pase_amd: the fused step needs chunk / chunk_ctxt / chunk_rand")
+        x = torch.cat([batch[k] for k in keys], dim=0)
+        if device is not None:
+            x = x.to(device)
+        emb, ectx = engine.encoder_forward(fe, x, training=fe.training)
+        B = batch["chunk"].shape[0]
+        E, F_ = emb.shape[1], emb.shape[2]
+        demb = torch.zeros_like(emb)
+        losses = {}
+        total = torch.zeros((), dtype=torch.float64, device=emb.device)
+        chunk = emb[:B]
+        # The contrastive workers are a few dozen 50-100-workgroup launches: they run on a side HIP stream underneath
+        # the regression workers (own gradient buffer, merged after the join) instead of serialising behind them.
+        side = engine.side_streams(emb, 4)
+        cls_stream = side[3] if (side and engine.K.GEMM_TIMER is None and len(self.classification_workers) > 0) else None
+        losses_cls = {}
+        if cls_stream is not None:
+            main = torch.cuda.current_stream()
+            cls_stream.wait_event(main.record_event())
+            with torch.cuda.stream(cls_stream):
+                demb_cls = torch.zeros_like(emb)
+                total_cls = self._cls_step(emb, B, demb_cls, sink, losses_cls)
+        # one-hidden-layer MLP workers share their input: run their first layers stacked
+        from .minions import MLPMinion
+        group = [w for w in self.regression_workers
+                 if isinstance(w, MLPMinion) and len(w.blocks) == 1 and w.blocks[0].context == 1
+                 and w.W.kernel_size[0] == 1 and w.W.out_channels > 1]
+        if len(group) > 1:
+            tg = {w.name: (batch[w.name].to(device) if device is not None else batch[w.name]) for w in group}
+            res, dx = engine.mlp_group_step(group, Act(chunk, C=E), tg, sink)
+            demb[:B] += dx
+            for w in group:
+                acc, numel = res[w.name]
+                l = acc[0] * (w.loss_weight / numel)
+                losses[w.name] = l
+                total = total + l
+        else:
+            group = []
+        for worker in self.regression_workers:
+            if any(worker is g for g in group):
+                continue
+            loss = worker.loss
+            tgt = batch[worker.name]
+            if device is not None:
+                tgt = tgt.to(device)
+            wctx = engine.worker_forward(list(worker.blocks), worker.W, Act(chunk, C=E),
+                                         loss=dict(name=loss.loss_name, r=loss.r, target=tgt,
+                                                   weight=worker.loss_weight), want_pred=False)
+            dsrc = engine.worker_backward(list(worker.blocks), worker.W, wctx, wctx.dpred, sink)
+            demb[:B] += dsrc.dense(E, F_)
+            l = wctx.loss_acc[0] * (worker.loss_weight / wctx.numel)
+            losses[worker.name] = l
+            total = total + l
+            del wctx, dsrc
+        if cls_stream is not None:
+            main.wait_event(cls_stream.record_event())
+            demb += demb_cls
+        else:
+            total_cls = self._cls_step(emb, B, demb, sink, losses_cls)
+        losses.update(losses_cls)
+        total = total + total_cls
         if before_encoder_backward is not None:
             before_encoder_backward()   # all worker-head gradients are final here (DDP overlap point)
         engine.encoder_backward(fe, ectx, demb, sink)

@@ -195,3 +195,46 @@ def test_lps_and_znorm_vs_live_reference(dev):
     f.set_stats(g["znorm_mean"], g["znorm_std"])
     want = g["lps_znorm"][None]
     _check(f(wav.to(dev)), want, _lps_tolerance(g["lps"][None], 1025) / g["znorm_std"][None, :, None], "lps+znorm")
+
+
+def _f0_contours(B, F, seed):
+    """synthetic tracker outputs: voiced runs (60-300 Hz) with unvoiced gaps (0) incl. leading / trailing gaps,
+    an all-unvoiced and an all-voiced utterance"""
+    rs = np.random.RandomState(seed)
+    f0 = np.zeros((B, F))
+    for b in range(B):
+        t = 0
+        voiced = bool(rs.randint(2))
+        while t < F:
+            n = int(rs.randint(1, 9))
+            if voiced:
+                f0[b, t:t + n] = rs.uniform(60, 300, size=min(n, F - t))
+            t += n
+            voiced = not voiced
+    f0[0] = 0.0
+    f0[1] = rs.uniform(60, 300, size=F)
+    return f0
+
+
+@pytest.mark.parametrize("T", [1600, 3200])
+@pytest.mark.parametrize("znorm", [False, True], ids=["raw", "znorm"])
+def test_prosody_rows_given_f0(dev, T, znorm):
+    """energy / zero-crossing rows + lf0 interpolation + voiced flag + deltas (+ZNorm) vs oracle/dsp_oracle.prosody
+    (librosa 0.6.3 rmse / zero_crossing_rate and ahoproc interpolation restated; the f0 tracker's contour is given)."""
+    B = 6
+    F = T // 160
+    wav = _wav(B, T, seed=11)
+    wav[2, 0, 300:700] = 0.0                      # exact zeros: the 1e-10 threshold / +0 sign convention
+    wav[3, 0, :] = wav[3, 0, :].abs()             # no crossings at all
+    f0 = _f0_contours(B, F, 3)
+    f = dsp.Prosody(device=dev)
+    want = np.stack([O.prosody(wav[b, 0].numpy(), f0[b]) for b in range(B)]).astype(np.float32)
+    tol = np.full(want.shape, 2e-5)
+    if znorm:
+        mean, std = _stats(12, 5)
+        f.set_stats(mean, std)
+        want = np.stack([O.znorm(w, mean, std) for w in want])
+        tol = tol / std[None, :, None]
+    got = f(wav.to(dev), torch.from_numpy(f0).float().to(dev))
+    _check(got, want.astype(np.float32), tol, "prosody")
+    assert float(np.abs(want[0, 1 if not znorm else 1]).max()) >= 0     # (all-unvoiced row exists)

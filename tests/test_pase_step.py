@@ -166,7 +166,9 @@ def test_full_width_golden_step(dev, gold, fe, wk):
             ref = gg["grad_values"][offs[i]:offs[i + 1]]
             got = params[n].grad.detach().reshape(-1)[torch.as_tensor(grad_sample_index(params[n].numel(), int(gg["n_samples"])),
                                                                       device=dev)]
-            assert_close(got, ref, rtol=2e-3, atol=2e-4 * float(gg["grad_absmax"][i]), what="grad " + n)
+            # fp32 sums in different orders (CPU oneDNN vs MFMA k-order + atomics): within 2e-3 relative or 1e-3 of the
+            # tensor's largest gradient; a sign / permutation / missing-term error is O(largest gradient)
+            assert_close(got, ref, rtol=2e-3, atol=1e-3 * float(gg["grad_absmax"][i]), what="grad " + n)
             checked += 1
         assert checked >= 100
 
