@@ -133,12 +133,42 @@ __device__ __forceinline__ float grad_post_act(const PaseActBwd& p, int s, int c
     return v;
 }
 
+// ---- E4 / E5 work decomposition -------------------------------------------------------------------
+// A unit of work is a SEGMENT: `seg_len` consecutive time steps of one (sequence, channel) row.  Long rows
+// (T >= 2048) are cut into segments of <= 8192 elements handled by a whole 256-thread block; short rows (the
+// 200 ... 1600-frame layers, 49 152 rows each) are handled one row per WAVE, four rows per block, so that no
+// barrier and no cross-wave reduction sits behind a 200-element loop.  Per-thread partial sums are fp32 over
+// <= 32 elements (4 independent chains, loads of all four in flight), widened to fp64 for the lane / wave /
+// global reduction.
+struct ActBwdGrid { int waves_per_seg, segs_per_row, seg_len; long nseg; };
+
+__device__ __forceinline__ void act_bwd_locate(const PaseActBwd& p, const ActBwdGrid& g, int& row, int& t0, int& t1,
+                                               int& lane_id, int& nlanes) {
+    if (g.waves_per_seg == 4) {                 // block per segment
+        const long seg = blockIdx.x;
+        row = (int)(seg / g.segs_per_row);
+        const int k = (int)(seg % g.segs_per_row);
+        t0 = k * g.seg_len;
+        t1 = min(p.T, t0 + g.seg_len);
+        lane_id = threadIdx.x;
+        nlanes = NT;
+    } else {                                    // wave per row
+        const long seg = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+        row = seg < g.nseg ? (int)seg : -1;
+        t0 = 0;
+        t1 = p.T;
+        lane_id = threadIdx.x & 63;
+        nlanes = 64;
+    }
+}
+
 // ---- E4: reduce pass.  sums[c] = { sum dz, sum dz*xhat, sum dA*z*[z<=0] } ------------------------
-__global__ void __launch_bounds__(NT) act_bwd_reduce_kernel(PaseActBwd p, int chunks) {
+__global__ void __launch_bounds__(NT) act_bwd_reduce_kernel(PaseActBwd p, ActBwdGrid g) {
     __shared__ double sh[NT / 64];
-    const int row = blockIdx.x / chunks;      // (s, c)
-    const int ch = blockIdx.x % chunks;
-    const int s = row / p.C, c = row % p.C;
+    int row, t0, t1, lid, nl;
+    act_bwd_locate(p, g, row, t0, t1, lid, nl);
+    const bool live = row >= 0;
+    const int s = live ? row / p.C : 0, c = live ? row % p.C : 0;
     const float a = p.scale ? p.scale[c] : 1.f, b = p.shift ? p.shift[c] : 0.f;
     const float al = p.alpha ? p.alpha[c] : 1.f;
     const float mean = p.mean ? p.mean[c] : 0.f, rstd = p.rstd ? p.rstd[c] : 1.f;
@@ -147,34 +177,50 @@ __global__ void __launch_bounds__(NT) act_bwd_reduce_kernel(PaseActBwd p, int ch
     // dy does not depend on the sums: written here, no apply pass (one read of y / dA less)
     float* drow = (p.has_bn != 1 && p.dy) ? p.dy + ((size_t)s * p.y_ctot + p.y_coff + c) * (size_t)p.T : nullptr;
     const float dmul = p.has_bn == 2 ? a : 1.f;
-    const int per = (p.T + chunks - 1) / chunks;
-    const int t0 = ch * per, t1 = min(p.T, t0 + per);
-    double s_dz = 0.0, s_dzx = 0.0, s_da = 0.0;
-    for (int t = t0 + threadIdx.x; t < t1; t += NT) {
-        const float yv = yrow[t];
-        const float z = yv * a + b;
-        const float dA = grad_post_act(p, s, c, t);
-        const float dz = z > 0.f ? dA : dA * al;
-        if (drow) drow[t] = dz * dmul;
-        const float xhat = (yv - mean) * rstd;
-        s_dz += (double)dz;
-        s_dzx += (double)(dz * xhat);
-        if (!(z > 0.f)) s_da += (double)(dA * z);
+    float f_dz[4] = {0.f, 0.f, 0.f, 0.f}, f_dzx[4] = {0.f, 0.f, 0.f, 0.f}, f_da[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        for (int tb = t0 + lid; tb < t1; tb += 4 * nl) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = tb + u * nl;
+                if (t < t1) {
+                    const float yv = yrow[t];
+                    const float z = yv * a + b;
+                    const float dA = grad_post_act(p, s, c, t);
+                    const float dz = z > 0.f ? dA : dA * al;
+                    if (drow) drow[t] = dz * dmul;
+                    const float xhat = (yv - mean) * rstd;
+                    f_dz[u] += dz;
+                    f_dzx[u] = fmaf(dz, xhat, f_dzx[u]);
+                    if (!(z > 0.f)) f_da[u] = fmaf(dA, z, f_da[u]);
+                }
+            }
+        }
     }
-    s_dz = block_sum_d(s_dz, sh);
-    s_dzx = block_sum_d(s_dzx, sh);
-    s_da = block_sum_d(s_da, sh);
-    if (threadIdx.x == 0) {
-        atomicAdd(p.sums + (size_t)c * 3 + 0, s_dz);
-        atomicAdd(p.sums + (size_t)c * 3 + 1, s_dzx);
-        atomicAdd(p.sums + (size_t)c * 3 + 2, s_da);
+    double s_dz = ((double)f_dz[0] + (double)f_dz[1]) + ((double)f_dz[2] + (double)f_dz[3]);
+    double s_dzx = ((double)f_dzx[0] + (double)f_dzx[1]) + ((double)f_dzx[2] + (double)f_dzx[3]);
+    double s_da = ((double)f_da[0] + (double)f_da[1]) + ((double)f_da[2] + (double)f_da[3]);
+    if (g.waves_per_seg == 4) {
+        s_dz = block_sum_d(s_dz, sh);
+        s_dzx = block_sum_d(s_dzx, sh);
+        s_da = block_sum_d(s_da, sh);
+        if (threadIdx.x != 0) return;
+    } else {
+        s_dz = pase_wave_sum64d(s_dz);
+        s_dzx = pase_wave_sum64d(s_dzx);
+        s_da = pase_wave_sum64d(s_da);
+        if ((threadIdx.x & 63) != 0 || !live) return;
     }
+    atomicAdd(p.sums + (size_t)c * 3 + 0, s_dz);
+    atomicAdd(p.sums + (size_t)c * 3 + 1, s_dzx);
+    atomicAdd(p.sums + (size_t)c * 3 + 2, s_da);
 }
 
 // ---- E5: apply pass.  dy = scale * (dz - mean(dz) - xhat * mean(dz*xhat))   (BN)  or  dy = dz ----
-__global__ void __launch_bounds__(NT) act_bwd_apply_kernel(PaseActBwd p, int chunks) {
-    const int row = blockIdx.x / chunks;
-    const int ch = blockIdx.x % chunks;
+__global__ void __launch_bounds__(NT) act_bwd_apply_kernel(PaseActBwd p, ActBwdGrid g) {
+    int row, t0, t1, lid, nl;
+    act_bwd_locate(p, g, row, t0, t1, lid, nl);
+    if (row < 0) return;
     const int s = row / p.C, c = row % p.C;
     const float a = p.scale ? p.scale[c] : 1.f, b = p.shift ? p.shift[c] : 0.f;
     const float al = p.alpha ? p.alpha[c] : 1.f;
@@ -187,21 +233,28 @@ __global__ void __launch_bounds__(NT) act_bwd_apply_kernel(PaseActBwd p, int chu
     }
     const float* yrow = p.y + ((size_t)s * p.y_ctot + p.y_coff + c) * (size_t)p.T;
     float* drow = p.dy + ((size_t)s * p.y_ctot + p.y_coff + c) * (size_t)p.T;
-    const int per = (p.T + chunks - 1) / chunks;
-    const int t0 = ch * per, t1 = min(p.T, t0 + per);
-    for (int t = t0 + threadIdx.x; t < t1; t += NT) {
-        const float yv = yrow[t];
-        const float z = yv * a + b;
-        const float dA = grad_post_act(p, s, c, t);
-        const float dz = z > 0.f ? dA : dA * al;
-        float out = dz;
-        if (p.has_bn == 1) {
-            const float xhat = (yv - mean) * rstd;
-            out = a * (dz - m1 - xhat * m2);
-        } else if (p.has_bn == 2) {
-            out = a * dz;
+    for (int tb = t0 + lid; tb < t1; tb += 4 * nl) {
+        float yv[4], dA[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = tb + u * nl;
+            yv[u] = t < t1 ? yrow[t] : 0.f;
+            dA[u] = t < t1 ? grad_post_act(p, s, c, t) : 0.f;
         }
-        drow[t] = out;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = tb + u * nl;
+            const float z = yv[u] * a + b;
+            const float dz = z > 0.f ? dA[u] : dA[u] * al;
+            float out = dz;
+            if (p.has_bn == 1) {
+                const float xhat = (yv[u] - mean) * rstd;
+                out = a * (dz - m1 - xhat * m2);
+            } else if (p.has_bn == 2) {
+                out = a * dz;
+            }
+            if (t < t1) drow[t] = out;
+        }
     }
 }
 
@@ -251,9 +304,25 @@ extern "C" int pase_bn_act_apply(const float* y, float* out, const float* scale,
     return 0;
 }
 
-static int act_bwd_chunks(int T) {
-    int chunks = (T + 4095) / 4096;
-    return chunks < 1 ? 1 : chunks;
+static ActBwdGrid act_bwd_grid(const PaseActBwd& p) {
+    ActBwdGrid g;
+    const long rows = (long)p.S * p.C;
+    if (p.T >= 2048) {
+        g.waves_per_seg = 4;
+        g.segs_per_row = (p.T + 8191) / 8192;
+        g.seg_len = (p.T + g.segs_per_row - 1) / g.segs_per_row;
+        g.nseg = rows * g.segs_per_row;
+    } else {
+        g.waves_per_seg = 1;
+        g.segs_per_row = 1;
+        g.seg_len = p.T;
+        g.nseg = rows;
+    }
+    return g;
+}
+
+static unsigned act_bwd_blocks(const ActBwdGrid& g) {
+    return (unsigned)(g.waves_per_seg == 4 ? g.nseg : (g.nseg + NT / 64 - 1) / (NT / 64));
 }
 
 extern "C" int pase_act_bwd_reduce(const PaseActBwd* d, void* stream) {
@@ -261,19 +330,21 @@ extern "C" int pase_act_bwd_reduce(const PaseActBwd* d, void* stream) {
     if (!p.sums || !p.y) return -2;
     const long rows = (long)p.S * p.C;
     if (rows <= 0 || p.T <= 0) return 0;
-    const int chunks = act_bwd_chunks(p.T);
-    PASE_LAUNCH(act_bwd_reduce_kernel, dim3((unsigned)(rows * chunks)), dim3(NT), (hipStream_t)stream, p, chunks);
+    const ActBwdGrid g = act_bwd_grid(p);
+    if (g.nseg >= 0x7fffffffL) return -8;
+    PASE_LAUNCH(act_bwd_reduce_kernel, dim3(act_bwd_blocks(g)), dim3(NT), (hipStream_t)stream, p, g);
     PASE_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int pase_act_bwd_apply(const PaseActBwd* d, void* stream) {
     const PaseActBwd p = *d;
-    if (!p.dy || !p.y || (p.has_bn && !p.sums)) return -2;
+    if (!p.dy || !p.y || (p.has_bn == 1 && !p.sums)) return -2;
     const long rows = (long)p.S * p.C;
     if (rows <= 0 || p.T <= 0) return 0;
-    const int chunks = act_bwd_chunks(p.T);
-    PASE_LAUNCH(act_bwd_apply_kernel, dim3((unsigned)(rows * chunks)), dim3(NT), (hipStream_t)stream, p, chunks);
+    const ActBwdGrid g = act_bwd_grid(p);
+    if (g.nseg >= 0x7fffffffL) return -8;
+    PASE_LAUNCH(act_bwd_apply_kernel, dim3(act_bwd_blocks(g)), dim3(NT), (hipStream_t)stream, p, g);
     PASE_CHECK_LAUNCH();
     return 0;
 }

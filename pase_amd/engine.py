@@ -47,7 +47,58 @@ def _new(shape, like, dtype=torch.float32):
     return torch.empty(shape, device=like.device, dtype=dtype)
 
 
+class ZeroArena:
+    """One buffer, ONE memset per step, for the few dozen small zero-initialised scratch tensors of a step (loss
+    accumulators, per-channel sums, split weight-gradient staging): the fused trainer calls begin_step(), every
+    `_zeros` below then hands out a view.  The layout repeats from step to step; a step that needs more than the
+    current capacity falls back to torch.zeros for the overflow and the arena is regrown at the next begin_step.
+    Views are only valid until the next begin_step()."""
+
+    LIMIT = 64 << 20      # larger requests keep their own allocation
+
+    def __init__(self):
+        self.buf = None
+        self.stream = None
+        self.used = 0
+        self.need = 0
+
+    def begin_step(self, device):
+        self.stream = torch.cuda.current_stream(device)
+        want = max(self.need, self.used)
+        if self.buf is None or self.buf.device != device or self.buf.numel() < want:
+            self.buf = torch.empty(max(want * 5 // 4, 1 << 20), dtype=torch.uint8, device=device)
+            self.buf.zero_()
+        elif self.used:
+            self.buf[:self.used].zero_()
+        self.used = 0
+        self.need = 0
+
+    def take(self, shape, dtype):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        if nbytes > self.LIMIT or nbytes == 0:
+            return None
+        off = (self.used + 255) // 256 * 256
+        self.need = max(self.need, off + nbytes)
+        if self.buf is None or off + nbytes > self.buf.numel():
+            self.need = off + nbytes
+            self.used = off + nbytes          # keep the layout (and the regrow size) consistent
+            return None
+        self.used = off + nbytes
+        return self.buf[off:off + nbytes].view(dtype).view(shape)
+
+
+_ARENA = None          # set by the fused trainer for the duration of a step
+
+
 def _zeros(shape, like, dtype=torch.float32):
+    if (_ARENA is not None and like.is_cuda and like.device == _ARENA.buf.device
+            and torch.cuda.current_stream(like.device) == _ARENA.stream):
+        t = _ARENA.take(tuple(shape), dtype)
+        if t is not None:
+            return t
     return torch.zeros(shape, device=like.device, dtype=dtype)
 
 
@@ -334,9 +385,12 @@ def encoder_forward(fe, x, training, need_ctx=True):
     return out, ctx
 
 
-def encoder_backward(fe, ctx, demb, sink, want_dx=False):
+def encoder_backward(fe, ctx, demb, sink, want_dx=False, on_ready=None):
     """Accumulates d(loss)/d(param) into `sink` given demb = d(loss)/d(emb); with want_dx also returns
-    d(loss)/d(input waveform) (S, num_inputs, T)."""
+    d(loss)/d(input waveform) (S, num_inputs, T).  on_ready(tag): called as soon as a group of parameter gradients
+    is final ON THE CURRENT STREAM -- "head" (W, dense-skip projections, QRNN), then each conv block index from the
+    last to the first -- so a data-parallel trainer can start that bucket's all-reduce under the rest of the
+    backward (reverse-order bucketing)."""
     demb = demb.contiguous()
     x = ctx.x
     S, F_ = x.shape[0], ctx.F
@@ -388,6 +442,8 @@ def encoder_backward(fe, ctx, demb, sink, want_dx=False):
         K.conv_gemm(dgates, None, dxl, wt=wt, S=S, Cin=3 * H, Tin=F_, M=cin, K=3 * H * 2, taps=2, Ncols=F_, Tout=F_,
                     stride=1, tapstep=1, padL=0, pad_mode=K.PAD_ZERO)
         dsrc, dsrc_ctot, dsrc_coff = dxl, cin, 0
+    if on_ready is not None:
+        on_ready("head")
     # ---- conv blocks, last to first -----------------------------------------------------------------
     dsrc_Tp, dsrc_padL, dsrc_mode = F_, 0, K.PAD_ZERO
     nb = len(fe.blocks)
@@ -424,6 +480,8 @@ def encoder_backward(fe, ctx, demb, sink, want_dx=False):
             dbias = sink.buf(blk.conv.bias) if rec["has_bn"] else None
             conv_wgrad(dy, inp, sink.buf(blk.conv.weight).view(C, -1), dbias, taps=taps, stride=blk.stride,
                        padL=rec["padL"], pad_mode=K.PAD_REFLECT)
+        if on_ready is not None:
+            on_ready(n)
         if n > 0 or want_dx:
             cin = inp.C
             w_nat = rec["filt"] if blk.sincnet else blk.conv.weight

@@ -165,7 +165,7 @@ class pase(Model):
     # (what trainer.train_ -> model.forward -> backprop_scheduler._base_scheduler do through
     # autograd in the reference: trainer.py:229-232, worker_scheduler.py:43-75)
     # ------------------------------------------------------------------------------------------
-    def loss_and_grads(self, batch, sink=None, device=None, before_encoder_backward=None):
+    def loss_and_grads(self, batch, sink=None, device=None, before_encoder_backward=None, on_encoder_grads=None):
         """Returns {worker: loss_weight*loss, 'total': sum} (0-dim float64 device tensors) and
         accumulates every parameter gradient into `sink` (default: param.grad)."""
         if sink is None:
@@ -236,6 +236,6 @@ class pase(Model):
         total = total + total_cls
         if before_encoder_backward is not None:
             before_encoder_backward()   # all worker-head gradients are final here (DDP overlap point)
-        engine.encoder_backward(fe, ectx, demb, sink)
+        engine.encoder_backward(fe, ectx, demb, sink, on_ready=on_encoder_grads)
         losses["total"] = total
         return losses

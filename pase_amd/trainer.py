@@ -64,14 +64,16 @@ class FusedAdam(object):
     `flat_p` and their .grad to views of `flat_g`; state_dict() uses torch.optim.Adam's layout so
     reference-style `weights_*.ckpt` files stay interchangeable."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_buffer=None):
         self.params = [p for p in params]
         if len(self.params) == 0:
             raise ValueError("FusedAdam: no parameters")
         dev = self.params[0].device
         n = sum(p.numel() for p in self.params)
         self.flat_p = torch.empty(n, device=dev)
-        self.flat_g = torch.zeros(n, device=dev)
+        # grad_buffer: this optimizer's slice of a gradient arena shared by all optimizers (zeroed once per step)
+        self.flat_g = torch.zeros(n, device=dev) if grad_buffer is None else grad_buffer
+        assert self.flat_g.numel() == n
         self.exp_avg = torch.zeros(n, device=dev)
         self.exp_avg_sq = torch.zeros(n, device=dev)
         off = 0
@@ -161,14 +163,29 @@ class trainer(object):
         lrdec = cfg.get("lrdec_step", 30)
         max_ckpts = cfg.get("max_ckpts", 5)
         self.savers = []
-        self.frontend_optim = FusedAdam(self.model.frontend.parameters(), lr=fe_lr)
+        # ONE gradient arena for the 13 logical optimizers (frontend last, so the worker part -- final before the
+        # encoder backward starts -- is one contiguous range): slices are 256-B aligned
+        mods = list(self.model.classification_workers) + list(self.model.regression_workers) + [self.model.frontend]
+        sizes = [sum(p.numel() for p in m.parameters()) for m in mods]
+        offs, tot = [], 0
+        for n_ in sizes:
+            offs.append(tot)
+            tot += (n_ + 63) // 64 * 64
+        pdev = next(self.model.parameters()).device
+        self.grad_arena = torch.zeros(tot, device=pdev)
+        self._worker_grads = self.grad_arena[:offs[-1]]       # 12 worker buffers: ONE collective (87 MB at PASE+)
+        self._frontend_grads = self.grad_arena[offs[-1]:]
+        self._zero_arena = None
+        gslice = {id(m): self.grad_arena[o:o + n_] for m, o, n_ in zip(mods, offs, sizes)}
+        self.frontend_optim = FusedAdam(self.model.frontend.parameters(), lr=fe_lr,
+                                        grad_buffer=gslice[id(self.model.frontend)])
         self.fe_scheduler = LR_Scheduler(lr_mode, lr_step=lrdec, optim_name="frontend", base_lr=fe_lr,
                                          num_epochs=self.epoch, iters_per_epoch=self.bpe)
         self.savers.append(Saver(self.model.frontend, self.save_path, max_ckpts=max_ckpts,
                                  optimizer=self.frontend_optim, prefix="PASE-"))
         self.cls_optim, self.cls_scheduler = {}, {}
         for worker in self.model.classification_workers:
-            self.cls_optim[worker.name] = FusedAdam(worker.parameters(), lr=min_lr)
+            self.cls_optim[worker.name] = FusedAdam(worker.parameters(), lr=min_lr, grad_buffer=gslice[id(worker)])
             self.cls_scheduler[worker.name] = LR_Scheduler(lr_mode, lr_step=lrdec, optim_name=worker.name,
                                                            base_lr=min_lr, num_epochs=self.epoch,
                                                            iters_per_epoch=self.bpe)
@@ -176,7 +193,7 @@ class trainer(object):
                                      optimizer=self.cls_optim[worker.name], prefix="M-{}-".format(worker.name)))
         self.regr_optim, self.regr_scheduler = {}, {}
         for worker in self.model.regression_workers:
-            self.regr_optim[worker.name] = FusedAdam(worker.parameters(), lr=min_lr)
+            self.regr_optim[worker.name] = FusedAdam(worker.parameters(), lr=min_lr, grad_buffer=gslice[id(worker)])
             self.regr_scheduler[worker.name] = LR_Scheduler(lr_mode, lr_step=lrdec, optim_name=worker.name,
                                                             base_lr=min_lr, num_epochs=self.epoch,
                                                             iters_per_epoch=self.bpe)
@@ -205,9 +222,9 @@ class trainer(object):
         for b in self.model.buffers():
             dist.broadcast(b, src=0)
 
-    def _allreduce(self, opts):
-        for opt in opts:
-            dist.all_reduce(opt.flat_g, op=dist.ReduceOp.SUM)
+    def _allreduce(self, buf):
+        if buf.numel():
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
 
     def use_device_targets(self, workers_cfg, hop=160, stats=None, device="cuda"):
         """Produce the LPS / FBanks / MFCC (+ZNorm) regression labels on the GPU from the clean chunk
@@ -234,45 +251,98 @@ class trainer(object):
         self.model.train()
         if self.device_targets is not None:
             batch = self._fill_targets(batch, device)
-        for opt in self.optimizers():
-            opt.zero_grad()
+        self.grad_arena.zero_()                 # every optimizer's flat gradient buffer: one memset
         sink = engine.GradSink(direct=True)
-        if self.world > 1:
-            losses = self._step_ddp(batch, sink, device)
-        else:
-            losses = self.model.loss_and_grads(batch, sink, device)
-            for opt in self.optimizers():
-                opt.step()
+        dev = self.grad_arena.device
+        if dev.type == "cuda":
+            if self._zero_arena is None:
+                self._zero_arena = engine.ZeroArena()
+            self._zero_arena.begin_step(dev)
+            engine._ARENA = self._zero_arena
+        try:
+            if self.world > 1:
+                losses = self._step_ddp(batch, sink, device)
+            else:
+                losses = self.model.loss_and_grads(batch, sink, device)
+                for opt in self.optimizers():
+                    opt.step()
+        finally:
+            engine._ARENA = None
         return losses
 
+    def _frontend_buckets(self):
+        """Reverse-order buckets of the frontend gradient buffer: {tag: [(begin, end), ...]} element ranges that are
+        final when engine.encoder_backward reports `tag` ("head" = W + dense skips + QRNN; then conv blocks from the
+        last to the first).  Small early blocks are merged into the bucket of block 0 (one collective for the tail)."""
+        if getattr(self, "_buckets", None) is not None:
+            return self._buckets
+        fe = self.model.frontend
+        opt = self.frontend_optim
+        where = {id(p): (off, off + k) for p, (off, k) in zip(opt.params, opt.offsets)}
+
+        def ranges(params):
+            r = sorted(where[id(p)] for p in params if id(p) in where)
+            out = []
+            for b, e in r:
+                if out and out[-1][1] == b:
+                    out[-1] = (out[-1][0], e)
+                else:
+                    out.append((b, e))
+            return out
+        nb = len(fe.blocks)
+        block_params = [list(fe.blocks[n].parameters()) for n in range(nb)]
+        in_blocks = set(id(p) for ps in block_params for p in ps)
+        head = [p for p in opt.params if id(p) not in in_blocks]
+        buckets = {"head": ranges(head)}
+        small, merged = 1 << 20, []           # blocks under 4 MB of gradients ride with block 0
+        for n in reversed(range(nb)):
+            ps = block_params[n]
+            if n > 0 and sum(p.numel() for p in ps) < small:
+                merged += ps
+                buckets[n] = []
+            elif n == 0:
+                buckets[0] = ranges(ps + merged)
+            else:
+                buckets[n] = ranges(ps)
+        self._buckets = buckets
+        return buckets
+
     def _step_ddp(self, batch, sink, device):
-        """Data-parallel step: per-rank batch, sum-all-reduce of the flat gradient buffers over
-        RCCL/xGMI (mean via grad_mul = 1/world in the Adam kernel).  The worker-head buffers
-        (87 MB of the 119 MB) are final before the encoder backward starts: their all-reduce runs
-        on a side stream underneath it."""
+        """Data-parallel step: per-rank batch, sum-all-reduce of the flat gradient arena over RCCL/xGMI (mean via
+        grad_mul = 1/world in the Adam kernel), bucketed in reverse-autograd order on a side stream:
+          * the 12 worker buffers (87 MB of the 119 MB, one contiguous range) are final before the encoder backward
+            starts: ONE collective underneath it;
+          * the frontend buffer goes out as its groups complete -- head (W / dense skips / QRNN), then conv blocks
+            7, 6, ... -- so only the last small bucket is exposed after the backward."""
         use_side = torch.cuda.is_available() and next(self.model.parameters()).is_cuda
         model = self.model
+        if use_side and self._side is None:
+            self._side = torch.cuda.Stream()
+        side = self._side
+        buckets = self._frontend_buckets()
+        fg = self._frontend_grads
+
+        def launch(bufs):
+            if not bufs:
+                return
+            if use_side:
+                side.wait_event(torch.cuda.current_stream().record_event())
+                with torch.cuda.stream(side):
+                    for b in bufs:
+                        self._allreduce(b)
+            else:                              # CPU (gloo tests): same buckets, issued in line
+                for b in bufs:
+                    self._allreduce(b)
+
+        losses = model.loss_and_grads(
+            batch, sink, device, before_encoder_backward=lambda: launch([self._worker_grads]),
+            on_encoder_grads=lambda tag: launch([fg[b:e] for b, e in buckets.get(tag, [])]))
         if use_side:
-            if self._side is None:
-                self._side = torch.cuda.Stream()
-            hook = self._make_overlap_hook()
-            losses = model.loss_and_grads(batch, sink, device, before_encoder_backward=hook)
-            self._allreduce([self.frontend_optim])
-            torch.cuda.current_stream().wait_stream(self._side)
-        else:
-            losses = model.loss_and_grads(batch, sink, device)
-            self._allreduce(self.optimizers())
+            torch.cuda.current_stream().wait_stream(side)
         inv = 1.0 / self.world
         for opt in self.optimizers():
             opt.step(grad_mul=inv)
         return losses
-
-    def _make_overlap_hook(self):
-        def hook():
-            self._side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self._side):
-                self._allreduce(self.worker_optimizers())
-        return hook
 
     def adjust_lr(self, bidx, epoch, losses=None):
         """trainer.py:245-254 (called every log_freq iterations in the reference)."""

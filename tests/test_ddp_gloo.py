@@ -159,3 +159,51 @@ def test_two_rank_step_on_gpu_side_stream_overlap():
     for n, p in tr.model.named_parameters():
         if not is_noise_grad(n):
             torch.testing.assert_close(p.detach().cpu(), r0["params"][n], rtol=0, atol=2e-5, msg=n)
+
+
+def _worker4(rank, world, port, outdir):
+    import random
+    import time
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HIPEMU_THREADS"] = "1"
+    from pase_amd import _lib, build
+    _lib.use_library(build.build_emu(), "cpu")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(1000 + rank)          # every rank starts from different weights: the broadcast must fix it
+    from pase_amd.trainer import trainer
+    tr = quiet(trainer, frontend_cfg=dict(MINI_FE), minions_cfg=with_losses(mini_workers()),
+               cfg=dict(fe_lr=1e-3, min_lr=5e-4, epoch=1, bpe=4, save_path=os.path.join(outdir, "ckpt")), lr_mode="poly")
+    assert tr.world == world and tr.rank == rank
+    rnd = random.Random(rank)
+    for step in range(2):
+        time.sleep(rnd.uniform(0.0, 0.4))   # uneven step timing: the bucketed collectives must still pair up
+        tr.train_step(_batch(300 + 10 * step + rank, B=1, T=1600))
+    tr.save_epoch(0, 2)                      # rank-0-only checkpoint + barrier
+    sd = {n: p.detach().clone() for n, p in tr.model.named_parameters()}
+    torch.save(sd, os.path.join(outdir, "rank%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_four_ranks_uneven_timing_stay_identical_and_rank0_checkpoints():
+    """world_size 4 over gloo with random per-rank delays before every step: the reverse-order bucketed all-reduces
+    (worker range, frontend head, conv blocks last-to-first) pair up across ranks, parameters stay bit-identical,
+    and only rank 0 writes the epoch checkpoint (one index entry per saver)."""
+    import json
+    port = 29500 + ((os.getpid() + 7) % 2000)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker4, args=(4, port, d), nprocs=4, join=True)
+        sds = [torch.load(os.path.join(d, "rank%d.pt" % r)) for r in range(4)]
+        for r in range(1, 4):
+            for n in sds[0]:
+                assert torch.equal(sds[0][n], sds[r][n]), "rank %d diverged on %s" % (r, n)
+        ck = os.path.join(d, "ckpt")
+        assert os.path.exists(os.path.join(ck, "FE_e0.ckpt"))
+        idx = [f for f in os.listdir(ck) if f.endswith("checkpoints")]
+        assert len(idx) == 6                 # frontend + 5 workers: one index each
+        for f in idx:
+            with open(os.path.join(ck, f)) as fh:
+                j = json.load(fh)
+            assert len(j["latest"]) == 1, (f, j)     # a second writer would have appended a duplicate

@@ -113,3 +113,33 @@ def test_saver_and_lr_scheduler(tmp_path):
     sch = LR_Scheduler("poly", "frontend", 1e-3, num_epochs=4, iters_per_epoch=100)
     lr = sch(Opt, 50, 1, 0.0)
     assert abs(lr - 1e-3 * (1 - 150 / 400) ** 0.9) < 1e-15 and Opt.param_groups[0]["lr"] == lr
+
+
+def test_ddp_frontend_buckets_partition_the_gradient_buffer():
+    """trainer._frontend_buckets: the reverse-order all-reduce buckets cover every element of the frontend gradient
+    buffer exactly once, the head bucket holds W / dense skips / QRNN, and block 0's bucket carries the merged small
+    blocks (no GPU, no process group needed)."""
+    import contextlib
+    import io
+    from pase_amd import _lib, build
+    from pase_amd.trainer import trainer
+    from util import MINI_FE, mini_workers, with_losses
+    _lib.use_library(build.build_emu(), "cpu")
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            tr = trainer(frontend_cfg=dict(MINI_FE), minions_cfg=with_losses(mini_workers()), cfg=dict(epoch=1, bpe=2))
+        bk = tr._frontend_buckets()
+        n = tr.frontend_optim.flat_g.numel()
+        cover = [0] * n
+        for tag, rs in bk.items():
+            for b, e in rs:
+                for i in range(b, e):
+                    cover[i] += 1
+        assert min(cover) == 1 and max(cover) == 1
+        assert set(bk) == {"head"} | set(range(len(tr.model.frontend.blocks)))
+        names = {id(p): k for k, p in tr.model.frontend.named_parameters()}
+        head_elems = sum(e - b for b, e in bk["head"])
+        want = sum(p.numel() for p in tr.frontend_optim.params if not names[id(p)].startswith("blocks."))
+        assert head_elems == want
+    finally:
+        _lib.use_library(None, "cuda")

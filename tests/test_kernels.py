@@ -200,10 +200,12 @@ def test_bn_act_pool(dev, d):
     assert_close(out[:, 1:1 + C], ref, rtol=1e-5, atol=1e-5)
 
 
-def test_act_backward_reflect_fold_and_pool_branch(dev):
-    """d/dy of sum(g1 * conv-input-padded(a)) + sum(g2 * meanpool(a)), a = PReLU(BN_train(y))."""
+@pytest.mark.parametrize("T", [24, 2052, 8200], ids=["wave-per-row", "block-per-row", "two-segments"])
+def test_act_backward_reflect_fold_and_pool_branch(dev, T):
+    """d/dy of sum(g1 * conv-input-padded(a)) + sum(g2 * meanpool(a)), a = PReLU(BN_train(y)); the three work
+    decompositions of the kernel (one wave per short row, one block per row, several segments per long row)."""
     torch.manual_seed(7)
-    S, C, T, pL, pR, d = 3, 4, 24, 4, 5, 4
+    S, C, pL, pR, d = (3, 4, 4, 5, 4) if T < 100 else (2, 3, 4, 5, 4)
     y = torch.randn(S, C, T, requires_grad=True)
     gamma = (torch.rand(C) + 0.5).requires_grad_(True)
     beta = torch.randn(C, requires_grad=True)
@@ -227,9 +229,10 @@ def test_act_backward_reflect_fold_and_pool_branch(dev):
     K.act_bwd_reduce(y.detach().to(dev), **kw)
     K.act_bwd_apply(y.detach().to(dev), **kw)
     assert_close(dy, y.grad, rtol=1e-4, atol=1e-5, what="dy")
-    assert_close(sums[:, 0], beta.grad, rtol=1e-4, atol=1e-5, what="dbeta")
-    assert_close(sums[:, 1], gamma.grad, rtol=1e-4, atol=1e-5, what="dgamma")
-    assert_close(sums[:, 2], al.grad, rtol=1e-4, atol=1e-5, what="dalpha")
+    big = 1e-5 * max(1.0, T / 100.0)       # sums over S*T terms of O(1)
+    assert_close(sums[:, 0], beta.grad, rtol=1e-4, atol=big, what="dbeta")
+    assert_close(sums[:, 1], gamma.grad, rtol=1e-4, atol=big, what="dgamma")
+    assert_close(sums[:, 2], al.grad, rtol=1e-4, atol=big, what="dalpha")
 
 
 def test_act_backward_without_batchnorm_is_single_pass(dev):
