@@ -276,7 +276,14 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
 
     int gc_n = g_begin / pl.n_gt, gt_n = g_begin - gc_n * pl.n_gt;   // (gc, gt) of the next stage to load
 
-    auto load_stage = [&]() __attribute__((always_inline)) {
+    // A stage's loads = stage_begin() (uniform bookkeeping: which channels / taps, base pointers) followed by
+    // NPIECE independent pieces (A slab passes, then X slots; the on-load parameters ride with the last X piece).
+    // load_stage() issues them back to back; the flat instantiation spreads them over the first half of the
+    // current stage's MFMA loop instead (see the k-loop).
+    constexpr int NPIECE = PA_MAX + NS;
+    int k0_st = 0, ci0s_st = 0;
+    const float* xb_st = p.x;
+    auto stage_begin = [&]() __attribute__((always_inline)) {
         const int ci0 = gc_n * pl.CB, kk0 = gt_n * pl.TB;
         const int TBe = min(pl.TB, p.taps - kk0);
         // a ragged last channel group is shifted back so it ends at Cin; rows below `lo` (channels the
@@ -290,37 +297,50 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
             slot_setup(kk0, TBe);
             x_allvalid = pase_wave_all(xmask == all_slots) != 0;
         }
-        // ---- straight-line issue: A slab rows k0 + RA*pass of the K-major pack (BM contiguous floats
-        // each; rows past K re-read row K-1 and are zeroed / ignored), then the X slots.  Only raw loads
-        // here (they stay in flight under the MFMAs of the current stage); the on-load affine / PReLU is
-        // applied in store_stage.
-        const int k0 = ci0s * p.taps + kk0 + ar;
-        const float* xb = p.x + (size_t)(p.x_coff + ci0s) * p.Tin;
-#pragma unroll
-        for (int ps = 0; ps < PA_MAX; ++ps) {
-            const unsigned row = (unsigned)min(k0 + RA * ps, p.K - 1);
-            areg[ps] = *reinterpret_cast<const F4*>(p.wt + (row * (unsigned)p.ldwt + a_col));
-        }
-#pragma unroll
-        for (int t = 0; t < NS; ++t) {
+        k0_st = ci0s * p.taps + kk0 + ar;
+        ci0s_st = ci0s;
+        xb_st = p.x + (size_t)(p.x_coff + ci0s) * p.Tin;
+    };
+    // ---- straight-line issue: A slab rows k0 + RA*pass of the K-major pack (BM contiguous floats
+    // each; rows past K re-read row K-1 and are zeroed / ignored), then the X slots.  Only raw loads
+    // here (they stay in flight under the MFMAs of the current stage); the on-load affine / PReLU is
+    // applied in store_stage.
+    auto load_piece = [&](auto piece_tag) __attribute__((always_inline)) {
+        constexpr int i = decltype(piece_tag)::value;
+        if constexpr (i < PA_MAX) {
+            const unsigned row = (unsigned)min(k0_st + RA * i, p.K - 1);
+            areg[i] = *reinterpret_cast<const F4*>(p.wt + (row * (unsigned)p.ldwt + a_col));
+        } else {
+            constexpr int t = i - PA_MAX;
             if (XV) {
-                const F4 v = *reinterpret_cast<const F4*>(xb + (unsigned)xoff[t]);
+                const F4 v = *reinterpret_cast<const F4*>(xb_st + (unsigned)xoff[t]);
                 xreg[4 * t + 0] = v.x; xreg[4 * t + 1] = v.y; xreg[4 * t + 2] = v.z; xreg[4 * t + 3] = v.w;
             } else {
-                xreg[t] = xb[(unsigned)xoff[t]];
+                xreg[t] = xb_st[(unsigned)xoff[t]];
             }
-        }
-        if (XFM != 0) {
+            if (t == NS - 1 && XFM != 0) {
 #pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                const int ch = min(ci0s + xrow + j * RPP, p.Cin - 1);
-                if (XFM != 1) {
-                    par_s[j] = sc_p[ch * aff_on];
-                    par_h[j] = sh_p[ch * aff_on];
+                for (int j = 0; j < NP; ++j) {
+                    const int ch = min(ci0s_st + xrow + j * RPP, p.Cin - 1);
+                    if (XFM != 1) {
+                        par_s[j] = sc_p[ch * aff_on];
+                        par_h[j] = sh_p[ch * aff_on];
+                    }
+                    par_a[j] = al_p[ch * alpha_on];
                 }
-                par_a[j] = al_p[ch * alpha_on];
             }
         }
+    };
+    auto load_pieces = [&](auto first_tag, auto count_tag) __attribute__((always_inline)) {
+        constexpr int F = decltype(first_tag)::value, N = decltype(count_tag)::value;
+        pase_static_for<N>([&](auto j) __attribute__((always_inline)) {
+            constexpr int i = F + decltype(j)::value;
+            if constexpr (i < NPIECE) load_piece(std::integral_constant<int, i>{});
+        });
+    };
+    auto load_stage = [&]() __attribute__((always_inline)) {
+        stage_begin();
+        load_pieces(std::integral_constant<int, 0>{}, std::integral_constant<int, NPIECE>{});
     };
     auto xform = [&](float v, float sc, float sh, float al) __attribute__((always_inline)) {
         v = fmaf(v, sc, sh);
@@ -385,7 +405,8 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
     for (int g = g_begin; g < g_end; ++g) {
         const int cur = (g - g_begin) & 1;
         PASE_TACC_BEGIN();
-        if (g + 1 < g_end) load_stage();   // global loads in flight under the MFMAs
+        const bool spread_loads = XV && kg == KG_T;               // uniform: flat full stage issues them inside the loop
+        if (g + 1 < g_end && !spread_loads) load_stage();   // global loads in flight under the MFMAs
         PASE_TACC(0);
         // K order inside a stage.  An MFMA step consumes two flat k values (fk = 0 / 1).  With two or more
         // channel rows per stage (CB is even then) the pair is (row 2p, tap j) / (row 2p+1, tap j); with a
@@ -393,6 +414,55 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
         // LDS offsets of a step are [per-lane constant] + [uniform scalar walk]: the walk is SALU only and
         // the per-step VALU work is the three address adds of the ds_reads -- index arithmetic in this
         // loop competes directly with MFMA issue (tools/mfma_probe: -15 % for a 10-instruction walk).
+        if (XV && kg == KG_T) {
+            // ---- flat 1x1, full 32-row stage: the K order is simply rows (2 ks + fk), so every LDS offset is an
+            // immediate and the 8 x (2 k-steps) loop is fully unrolled.  The NEXT stage's global loads are issued
+            // one or two at a time behind the MFMAs of the first half of this loop instead of in one burst before it:
+            // a single-round split-K launch (the K = 21 525 data-gradients) runs all its workgroups phase-locked, and
+            // 500 simultaneous 32 KB bursts queue at the L2 while the memory system idles during the MFMA phases.
+            constexpr int NIT = KG_T / 4;
+            constexpr int PER_IT = (NPIECE + NIT / 2 - 1) / (NIT / 2);
+            const float* aL = &As[cur][fk][wm * 64 + fr];
+            const float* x0L = &XsG[cur][4 + fk * BN + xc0];
+            const float* x1L = &XsG[cur][4 + fk * BN + xc1];
+            const bool has_next = g + 1 < g_end;
+            if (has_next) stage_begin();
+            float pa0 = aL[0], pa1 = aL[32], pb0 = x0L[0], pb1 = x1L[0], qa0, qa1, qb0, qb1;
+            pase_static_for<NIT>([&](auto it_tag) __attribute__((always_inline)) {
+                constexpr int it = decltype(it_tag)::value;
+                constexpr int k1 = 2 * it + 1, k2 = (2 * it + 2 < KG_T / 2) ? 2 * it + 2 : 2 * it + 1;
+                qa0 = aL[k1 * 2 * LDA]; qa1 = aL[k1 * 2 * LDA + 32]; qb0 = x0L[k1 * 2 * BN]; qb1 = x1L[k1 * 2 * BN];
+                PASE_SCHED_BARRIER();
+                acc[0][0] = pase_mfma_32x32x2(pa0, pb0, acc[0][0]);
+                acc[0][1] = pase_mfma_32x32x2(pa0, pb1, acc[0][1]);
+                acc[1][0] = pase_mfma_32x32x2(pa1, pb0, acc[1][0]);
+                acc[1][1] = pase_mfma_32x32x2(pa1, pb1, acc[1][1]);
+                PASE_SCHED_BARRIER();
+                pa0 = aL[k2 * 2 * LDA]; pa1 = aL[k2 * 2 * LDA + 32]; pb0 = x0L[k2 * 2 * BN]; pb1 = x1L[k2 * 2 * BN];
+                PASE_SCHED_BARRIER();
+                acc[0][0] = pase_mfma_32x32x2(qa0, qb0, acc[0][0]);
+                acc[0][1] = pase_mfma_32x32x2(qa0, qb1, acc[0][1]);
+                acc[1][0] = pase_mfma_32x32x2(qa1, qb0, acc[1][0]);
+                acc[1][1] = pase_mfma_32x32x2(qa1, qb1, acc[1][1]);
+                PASE_SCHED_BARRIER();
+                if constexpr (it < NIT / 2) {
+                    if (has_next) {
+                        load_pieces(std::integral_constant<int, it * PER_IT>{}, std::integral_constant<int, PER_IT>{});
+                        PASE_SCHED_BARRIER();
+                    }
+                }
+            });
+            PASE_TACC(1);
+            if (has_next) {
+                store_stage(cur ^ 1);
+                kg = kg_next;
+                tbe = tbe_next;
+            }
+            PASE_TACC(2);
+            __syncthreads();
+            PASE_TACC(3);
+            continue;
+        }
         const int ts = p.tapstep;
         const bool pair_rows = pl.CB > 1;                       // uniform
         const int nks = pair_rows ? (kg >> 1) : ((tbe + 1) >> 1);

@@ -96,3 +96,15 @@ __device__ __forceinline__ double pase_wave_sum64d(double v) {
     v += __shfl_xor(v, 32);
     return v;
 }
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{})
+#include <type_traits>
+#include <utility>
+template <int... Is, class F>
+__host__ __device__ __forceinline__ void pase_static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__host__ __device__ __forceinline__ void pase_static_for(F&& f) {
+    pase_static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
