@@ -158,10 +158,23 @@ typedef struct PaseActBwd {
     int dsrc_ctot, dsrc_coff, Tp, padL, pad_mode;
     int dpool_ctot, dpool_coff, pool_F, pool_d;
     float pool_inv;        /* 1 / pool_d                                                          */
-    int has_bn;            /* 0 none, 1 BatchNorm with batch statistics, 2 BatchNorm with frozen statistics */
+    int has_bn;            /* 0 none, 1 BatchNorm with batch statistics, 2 BatchNorm with frozen statistics;
+                              3 / 4: InstanceNorm / LayerNorm for pase_rownorm_act_bwd */
 } PaseActBwd;
 int pase_act_bwd_reduce(const PaseActBwd* desc, void* stream);
 int pase_act_bwd_apply(const PaseActBwd* desc, void* stream);
+
+/* Per-sample normalisations of the other norm_type values (pase/models/modules.py:77-109): nn.InstanceNorm1d
+ * ('inorm', 'affinorm', and WaveFe.norm_out when norm_type != 'bnorm', frontend.py:206-210; mode 0: statistics per
+ * (sequence, channel) over time) and nn.LayerNorm(C) on the transposed tensor ('lnorm'; mode 1: statistics per
+ * (sequence, time step) over channels).  Forward materialises out = PReLU(gamma * xhat + beta) (gamma / beta /
+ * alpha NULL = identity) and the group statistics mean_out / rstd_out ((S, C) in mode 0, (S, T) in mode 1; biased
+ * variance, eps inside the square root, like torch).  Backward: the PaseActBwd descriptor with has_bn = 3 (instance)
+ * or 4 (layer), scale / shift = gamma / beta, mean / rstd = the forward's group statistics; writes dy and accumulates
+ * sums[c] = {dbeta, dgamma, dalpha} in one launch. */
+int pase_rownorm_act_fwd(const float* y, float* out, const float* gamma, const float* beta, const float* alpha,
+                         float* mean_out, float* rstd_out, int S, int C, int T, float eps, int mode, void* stream);
+int pase_rownorm_act_bwd(const PaseActBwd* desc, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * QRNN (third-party salesforce/pytorch-qrnn; call sites pase/models/modules.py:48-53,

@@ -128,7 +128,9 @@ def encoder_forward(P, cfg, x, training=True, stats_out=None, taps=None):
     h = x
     skips = []
     nb = len(cfg["kwidths"])
-    bn = cfg["norm_type"] == "bnorm"
+    nt = cfg["norm_type"]
+    if nt not in ("bnorm", "lnorm", "inorm", "affinorm", None):
+        raise NotImplementedError(nt)
     for n in range(nb):
         k, st = cfg["kwidths"][n], cfg["strides"][n]
         pre = "blocks.%d." % n
@@ -141,8 +143,16 @@ def encoder_forward(P, cfg, x, training=True, stats_out=None, taps=None):
             h = F.conv1d(fe_pad(h, k, st), P[pre + "conv.weight"], P[pre + "conv.bias"], stride=st)
         if taps is not None:
             taps["conv%d" % n] = h
-        if bn:
+        # build_norm_layer / forward_norm (modules.py:77-109)
+        if nt == "bnorm":
             h = batch_norm(h, pre + "norm", P, training, stats_out)
+        elif nt == "lnorm":               # nn.LayerNorm(C) on the (B, T, C) transpose
+            h = F.layer_norm(h.transpose(1, 2), (h.shape[1],), P[pre + "norm.weight"], P[pre + "norm.bias"],
+                             1e-5).transpose(1, 2)
+        elif nt == "inorm":               # nn.InstanceNorm1d(C, affine=False)
+            h = F.instance_norm(h, eps=1e-5)
+        elif nt == "affinorm":
+            h = F.instance_norm(h, weight=P[pre + "norm.weight"], bias=P[pre + "norm.bias"], eps=1e-5)
         h = prelu(h, P[pre + "act.weight"])
         if cfg["denseskips"] and n + 1 < nb:
             skips.append(F.conv1d(h, P["denseskips.%d.weight" % n]))
@@ -160,8 +170,11 @@ def encoder_forward(P, cfg, x, training=True, stats_out=None, taps=None):
         y = y + s
     if taps is not None:
         taps["pre_norm"] = y
-    if cfg["norm_out"]:
-        y = batch_norm(y, "norm_out", P, training, stats_out, affine=False)
+    if cfg["norm_out"]:                   # frontend.py:206-210
+        if nt == "bnorm":
+            y = batch_norm(y, "norm_out", P, training, stats_out, affine=False)
+        else:
+            y = F.instance_norm(y, eps=1e-5)
     return y
 
 

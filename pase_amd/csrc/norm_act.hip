@@ -258,6 +258,191 @@ __global__ void __launch_bounds__(NT) act_bwd_apply_kernel(PaseActBwd p, ActBwdG
     }
 }
 
+// =====================================================================================================
+// Per-sample normalisations: nn.InstanceNorm1d (statistics per (sequence, channel) over time; norm_type 'inorm' /
+// 'affinorm', and WaveFe.norm_out when norm_type != 'bnorm', pase/models/frontend.py:206-210) and nn.LayerNorm(C)
+// applied on the transposed tensor (statistics per (sequence, time step) over channels; norm_type 'lnorm',
+// pase/models/modules.py:85-86,98-105).  Their scale / shift depend on the sample, so they cannot ride on the
+// consumer's per-channel on-load transform like BatchNorm: the activated tensor a = PReLU(gamma * xhat + beta) is
+// materialised once (consumers then load it untransformed) together with the group statistics for the backward.
+// Not on the benchmark path (PASE+.cfg is 'bnorm'): written for clarity, two passes over the group.
+// =====================================================================================================
+constexpr int LN_TT = 64;      // time steps per block in layer mode (lanes along time: coalesced rows)
+
+__device__ __forceinline__ float block_sum_f(float v, float* sh) {
+    v = pase_wave_sum64(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) t += sh[w];
+    return t;
+}
+
+// mode 0: instance (block = one (s, c) row);  mode 1: layer (block = LN_TT time steps of one sequence)
+__global__ void __launch_bounds__(NT) rownorm_act_fwd_kernel(const float* y, float* out, const float* gamma,
+                                                             const float* beta, const float* alpha, float* mean_out,
+                                                             float* rstd_out, int S, int C, int T, float eps, int mode) {
+    __shared__ float sh[NT / 64];
+    __shared__ float sm[LN_TT][NT / 64 + 1], sq[LN_TT][NT / 64 + 1];
+    __shared__ float s_mean[LN_TT], s_rstd[LN_TT];
+    if (mode == 0) {
+        const int row = blockIdx.x;
+        const int c = row % C;
+        const float* yr = y + (size_t)row * T;
+        float* orow = out + (size_t)row * T;
+        float a1 = 0.f;
+        for (int t = threadIdx.x; t < T; t += NT) a1 += yr[t];
+        const float mean = block_sum_f(a1, sh) / (float)T;
+        float a2 = 0.f;
+        for (int t = threadIdx.x; t < T; t += NT) { const float d = yr[t] - mean; a2 = fmaf(d, d, a2); }
+        const float var = block_sum_f(a2, sh) / (float)T;          // biased, like torch
+        const float rstd = 1.f / sqrtf(var + eps);
+        if (threadIdx.x == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        for (int t = threadIdx.x; t < T; t += NT) {
+            float v = (yr[t] - mean) * rstd * g + b;
+            if (alpha) v = v > 0.f ? v : v * alpha[c];
+            orow[t] = v;
+        }
+        return;
+    }
+    const int tiles = (T + LN_TT - 1) / LN_TT;
+    const int s = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * LN_TT;
+    const int tl = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const int t = t0 + tl;
+    const bool ok = t < T;
+    const float* yb = y + (size_t)s * C * T + t;
+    float a1 = 0.f;
+    for (int c = cg; c < C; c += NT / 64) a1 += ok ? yb[(size_t)c * T] : 0.f;
+    sm[tl][cg] = a1;
+    __syncthreads();
+    if (cg == 0) {
+        float m = 0.f;
+        for (int w = 0; w < NT / 64; ++w) m += sm[tl][w];
+        s_mean[tl] = m / (float)C;
+    }
+    __syncthreads();
+    const float mean = s_mean[tl];
+    float a2 = 0.f;
+    for (int c = cg; c < C; c += NT / 64) { const float d = ok ? yb[(size_t)c * T] - mean : 0.f; a2 = fmaf(d, d, a2); }
+    sq[tl][cg] = a2;
+    __syncthreads();
+    if (cg == 0) {
+        float v = 0.f;
+        for (int w = 0; w < NT / 64; ++w) v += sq[tl][w];
+        const float rstd = 1.f / sqrtf(v / (float)C + eps);
+        s_rstd[tl] = rstd;
+        if (ok) { mean_out[(size_t)s * T + t] = mean; rstd_out[(size_t)s * T + t] = rstd; }
+    }
+    __syncthreads();
+    const float rstd = s_rstd[tl];
+    float* ob = out + (size_t)s * C * T + t;
+    for (int c = cg; c < C; c += NT / 64) {
+        if (!ok) continue;
+        float v = (yb[(size_t)c * T] - mean) * rstd * (gamma ? gamma[c] : 1.f) + (beta ? beta[c] : 0.f);
+        if (alpha) v = v > 0.f ? v : v * alpha[c];
+        ob[(size_t)c * T] = v;
+    }
+}
+
+// Backward of a = PReLU(gamma * xhat + beta), xhat = (y - mean_g) * rstd_g over group g (p.has_bn: 3 = instance,
+// 4 = layer; p.scale / p.shift carry gamma / beta, p.mean / p.rstd the group statistics):
+//   dz = dA * prelu'(z);  dxh = dz * gamma;  dy = rstd_g * (dxh - mean_g(dxh) - xhat * mean_g(dxh * xhat))
+//   sums[c] += { sum dz (dbeta), sum dz * xhat (dgamma), sum dA * z * [z <= 0] (dalpha) }
+__global__ void __launch_bounds__(NT) rownorm_act_bwd_kernel(PaseActBwd p) {
+    __shared__ float sh[NT / 64];
+    __shared__ float r1[LN_TT][NT / 64 + 1], r2[LN_TT][NT / 64 + 1];
+    __shared__ float m1s[LN_TT], m2s[LN_TT];
+    if (p.has_bn == 3) {
+        const int row = blockIdx.x;
+        const int s = row / p.C, c = row % p.C;
+        const float g = p.scale ? p.scale[c] : 1.f, b = p.shift ? p.shift[c] : 0.f;
+        const float al = p.alpha ? p.alpha[c] : 1.f;
+        const float mean = p.mean[row], rstd = p.rstd[row];
+        const float* yr = p.y + ((size_t)s * p.y_ctot + p.y_coff + c) * (size_t)p.T;
+        float* dr = p.dy + ((size_t)s * p.y_ctot + p.y_coff + c) * (size_t)p.T;
+        float s1 = 0.f, s2 = 0.f, sa = 0.f;
+        for (int t = threadIdx.x; t < p.T; t += NT) {
+            const float xh = (yr[t] - mean) * rstd;
+            const float z = xh * g + b;
+            const float dA = grad_post_act(p, s, c, t);
+            const float dz = z > 0.f ? dA : dA * al;
+            s1 += dz;
+            s2 = fmaf(dz, xh, s2);
+            if (!(z > 0.f)) sa = fmaf(dA, z, sa);
+        }
+        s1 = block_sum_f(s1, sh);
+        s2 = block_sum_f(s2, sh);
+        sa = block_sum_f(sa, sh);
+        if (threadIdx.x == 0) {
+            atomicAdd(p.sums + (size_t)c * 3 + 0, (double)s1);
+            atomicAdd(p.sums + (size_t)c * 3 + 1, (double)s2);
+            atomicAdd(p.sums + (size_t)c * 3 + 2, (double)sa);
+        }
+        const float m1 = s1 * g / (float)p.T, m2 = s2 * g / (float)p.T;
+        for (int t = threadIdx.x; t < p.T; t += NT) {
+            const float xh = (yr[t] - mean) * rstd;
+            const float z = xh * g + b;
+            const float dA = grad_post_act(p, s, c, t);
+            const float dz = z > 0.f ? dA : dA * al;
+            dr[t] = rstd * (dz * g - m1 - xh * m2);
+        }
+        return;
+    }
+    const int tiles = (p.T + LN_TT - 1) / LN_TT;
+    const int s = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * LN_TT;
+    const int tl = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const int t = t0 + tl;
+    const bool ok = t < p.T;
+    const float mean = ok ? p.mean[(size_t)s * p.T + t] : 0.f, rstd = ok ? p.rstd[(size_t)s * p.T + t] : 0.f;
+    float a1 = 0.f, a2 = 0.f;
+    for (int c = cg; c < p.C; c += NT / 64) {
+        float dz = 0.f, xh = 0.f, da = 0.f;
+        if (ok) {
+            const float yv = p.y[((size_t)s * p.y_ctot + p.y_coff + c) * (size_t)p.T + t];
+            const float g = p.scale ? p.scale[c] : 1.f, b = p.shift ? p.shift[c] : 0.f;
+            xh = (yv - mean) * rstd;
+            const float z = xh * g + b;
+            const float dA = grad_post_act(p, s, c, t);
+            dz = z > 0.f ? dA : dA * (p.alpha ? p.alpha[c] : 1.f);
+            if (!(z > 0.f)) da = dA * z;
+            a1 = fmaf(dz, g, a1);
+            a2 = fmaf(dz * g, xh, a2);
+        }
+        // per-channel parameter gradients: reduce this wave's 64 time steps, one atomic per (block, channel)
+        const float q0 = pase_wave_sum64(dz), q1 = pase_wave_sum64(dz * xh), q2 = pase_wave_sum64(da);
+        if (tl == 0) {
+            atomicAdd(p.sums + (size_t)c * 3 + 0, (double)q0);
+            atomicAdd(p.sums + (size_t)c * 3 + 1, (double)q1);
+            atomicAdd(p.sums + (size_t)c * 3 + 2, (double)q2);
+        }
+    }
+    r1[tl][cg] = a1;
+    r2[tl][cg] = a2;
+    __syncthreads();
+    if (cg == 0) {
+        float u = 0.f, v = 0.f;
+        for (int w = 0; w < NT / 64; ++w) { u += r1[tl][w]; v += r2[tl][w]; }
+        m1s[tl] = u / (float)p.C;
+        m2s[tl] = v / (float)p.C;
+    }
+    __syncthreads();
+    const float m1 = m1s[tl], m2 = m2s[tl];
+    for (int c = cg; c < p.C; c += NT / 64) {
+        if (!ok) continue;
+        const size_t o = ((size_t)s * p.y_ctot + p.y_coff + c) * (size_t)p.T + t;
+        const float g = p.scale ? p.scale[c] : 1.f, b = p.shift ? p.shift[c] : 0.f;
+        const float xh = (p.y[o] - mean) * rstd;
+        const float z = xh * g + b;
+        const float dA = grad_post_act(p, s, c, t);
+        const float dz = z > 0.f ? dA : dA * (p.alpha ? p.alpha[c] : 1.f);
+        p.dy[o] = rstd * (dz * g - m1 - xh * m2);
+    }
+}
+
 }  // namespace
 
 extern "C" int pase_bn_finalize(const float* stat_part, int ntiles, int C, double count, const float* gamma,
@@ -345,6 +530,31 @@ extern "C" int pase_act_bwd_apply(const PaseActBwd* d, void* stream) {
     const ActBwdGrid g = act_bwd_grid(p);
     if (g.nseg >= 0x7fffffffL) return -8;
     PASE_LAUNCH(act_bwd_apply_kernel, dim3(act_bwd_blocks(g)), dim3(NT), (hipStream_t)stream, p, g);
+    PASE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pase_rownorm_act_fwd(const float* y, float* out, const float* gamma, const float* beta, const float* alpha,
+                                    float* mean_out, float* rstd_out, int S, int C, int T, float eps, int mode,
+                                    void* stream) {
+    if (S <= 0 || C <= 0 || T <= 0) return 0;
+    if (mode != 0 && mode != 1) return -2;
+    const long blocks = mode == 0 ? (long)S * C : (long)S * ((T + LN_TT - 1) / LN_TT);
+    if (blocks >= 0x7fffffffL) return -8;
+    PASE_LAUNCH(rownorm_act_fwd_kernel, dim3((unsigned)blocks), dim3(NT), (hipStream_t)stream, y, out, gamma, beta, alpha,
+                mean_out, rstd_out, S, C, T, eps, mode);
+    PASE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pase_rownorm_act_bwd(const PaseActBwd* d, void* stream) {
+    const PaseActBwd p = *d;
+    if (!p.sums || !p.y || !p.dy || !p.mean || !p.rstd) return -2;
+    if (p.has_bn != 3 && p.has_bn != 4) return -2;
+    if (p.S <= 0 || p.C <= 0 || p.T <= 0) return 0;
+    const long blocks = p.has_bn == 3 ? (long)p.S * p.C : (long)p.S * ((p.T + LN_TT - 1) / LN_TT);
+    if (blocks >= 0x7fffffffL) return -8;
+    PASE_LAUNCH(rownorm_act_bwd_kernel, dim3((unsigned)blocks), dim3(NT), (hipStream_t)stream, p);
     PASE_CHECK_LAUNCH();
     return 0;
 }

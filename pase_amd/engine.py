@@ -199,6 +199,49 @@ def bn_eval(norm):
     return scale.contiguous(), shift.contiguous(), norm.running_mean, rstd
 
 
+def norm_kind(norm):
+    """'bn' (statistics ride on the consumer's on-load transform), 'in' / 'ln' (per-sample statistics: the activated
+    tensor is materialised by pase_rownorm_act_fwd), None."""
+    import torch.nn as nn
+    if norm is None:
+        return None
+    if isinstance(norm, nn.BatchNorm1d):
+        return "bn"
+    if isinstance(norm, nn.InstanceNorm1d):
+        if norm.track_running_stats:
+            raise NotImplementedError("pase_amd: InstanceNorm1d(track_running_stats=True)")
+        return "in"
+    if isinstance(norm, nn.LayerNorm):
+        return "ln"
+    raise NotImplementedError("pase_amd: norm layer %r" % type(norm).__name__)
+
+
+def rownorm_fwd(y, norm, kind, alpha):
+    """a = PReLU(norm(y)) materialised, plus the per-group statistics for the backward."""
+    S, C, T = y.shape
+    out = _new((S, C, T), y)
+    n = S * C if kind == "in" else S * T
+    mean, rstd = _new((n,), y), _new((n,), y)
+    affine = norm.elementwise_affine if kind == "ln" else norm.affine
+    K.rownorm_act_fwd(y, out, norm.weight if affine else None, norm.bias if affine else None, alpha, mean, rstd,
+                      S=S, C_=C, T=T, eps=float(norm.eps), mode=K.NORM_INSTANCE if kind == "in" else K.NORM_LAYER)
+    return out, mean, rstd
+
+
+def rownorm_backward(y, norm, kind, alpha, mean, rstd, *, dsrc=None, dsrc_ctot=None, dsrc_coff=0, Tp=None, padL=0,
+                     pad_mode=K.PAD_ZERO, dpool=None, dpool_ctot=0, dpool_coff=0, pool_F=0, pool_d=1):
+    """Backward of a = PReLU(norm(y)) for the per-sample norms: (dy, sums (C,3) = {dbeta, dgamma, dalpha})."""
+    S, C, T = y.shape
+    sums = _zeros((C, 3), y, torch.float64)
+    dy = _new((S, C, T), y)
+    affine = norm.elementwise_affine if kind == "ln" else norm.affine
+    K.rownorm_act_bwd(y, S=S, C_=C, T=T, dsrc=dsrc, dsrc_ctot=dsrc_ctot, dsrc_coff=dsrc_coff, Tp=Tp, padL=padL,
+                      pad_mode=pad_mode, dpool=dpool, dpool_ctot=dpool_ctot, dpool_coff=dpool_coff, pool_F=pool_F,
+                      pool_d=pool_d, scale=norm.weight if affine else None, shift=norm.bias if affine else None,
+                      alpha=alpha, mean=mean, rstd=rstd, sums=sums, dy=dy, has_bn=3 if kind == "in" else 4)
+    return dy, sums
+
+
 def act_backward(y, *, C, T, S, has_bn, scale=None, shift=None, alpha=None, mean=None, rstd=None, dsrc=None,
                  dsrc_ctot=None, dsrc_coff=0, Tp=None, padL=0, pad_mode=K.PAD_ZERO, dpool=None, dpool_ctot=0,
                  dpool_coff=0, pool_F=0, pool_d=1, y_ctot=None, y_coff=0, dy_out=None):
@@ -303,7 +346,8 @@ def encoder_forward(fe, x, training, need_ctx=True):
         else:
             pL, pR = reflect_pads(k, st)
             w2d, bias, taps = blk.conv.weight.view(blk.fmaps, -1), blk.conv.bias, k
-        has_bn = blk.norm is not None
+        kind = norm_kind(getattr(blk, "norm", None))
+        has_bn = kind == "bn"
         y, stat = conv_fwd(cur, w2d, bias, Cout=blk.fmaps, taps=taps, stride=st, padL=pL, padR=pR,
                            pad_mode=K.PAD_REFLECT, want_stats=has_bn and training)
         if has_bn:
@@ -314,9 +358,15 @@ def encoder_forward(fe, x, training, need_ctx=True):
         else:
             scale = shift = mean = rstd = None
         rec.update(inp=cur, y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, padL=pL, padR=pR, taps=taps,
-                   has_bn=has_bn)
+                   has_bn=has_bn, kind=kind)
+        if kind in ("in", "ln"):
+            # per-sample statistics: materialise a = PReLU(norm(y)); consumers load it untransformed
+            amat, gmean, grstd = rownorm_fwd(y, blk.norm, kind, blk.act.weight)
+            rec.update(amat=amat, mean=gmean, rstd=grstd)
+            cur = Act(amat, C=blk.fmaps)
+        else:
+            cur = Act(y, C=blk.fmaps, scale=scale, shift=shift, alpha=blk.act.weight)
         ctx.blocks.append(rec)
-        cur = Act(y, C=blk.fmaps, scale=scale, shift=shift, alpha=blk.act.weight)
     F_ = cur.T
     ctx.F = F_
 
@@ -358,8 +408,12 @@ def encoder_forward(fe, x, training, need_ctx=True):
             rec = ctx.blocks[n]
             Tn = rec["y"].shape[2]
             d = Tn // F_
-            K.bn_act_pool(rec["y"], acat, rec["scale"], rec["shift"], blk.act.weight, S=S, C_=blk.fmaps, T=Tn,
-                          F=F_, d=d, o_ctot=ccat, o_coff=off)
+            if "amat" in rec:
+                K.bn_act_pool(rec["amat"], acat, None, None, None, S=S, C_=blk.fmaps, T=Tn, F=F_, d=d, o_ctot=ccat,
+                              o_coff=off)
+            else:
+                K.bn_act_pool(rec["y"], acat, rec["scale"], rec["shift"], blk.act.weight, S=S, C_=blk.fmaps, T=Tn,
+                              F=F_, d=d, o_ctot=ccat, o_coff=off)
             ctx.skip_off.append((off, d))
             off += blk.fmaps
         wcat = torch.cat([fe.W.weight.view(emb, -1)] + [p.weight.view(emb, -1) for p in fe.denseskips], dim=1)
@@ -368,9 +422,10 @@ def encoder_forward(fe, x, training, need_ctx=True):
         wcat = fe.W.weight.view(emb, -1)
         ain = rnn_in
     norm_out = fe.norm_out_mod
-    yemb, stat = conv_fwd(ain, wcat, fe.W.bias, Cout=emb, taps=1, want_stats=(norm_out is not None and training),
-                          Tout=F_)
-    if norm_out is not None:
+    yemb, stat = conv_fwd(ain, wcat, fe.W.bias, Cout=emb, taps=1,
+                          want_stats=(norm_kind(norm_out) == "bn" and training), Tout=F_)
+    ctx.out_kind = norm_kind(norm_out)
+    if ctx.out_kind == "bn":
         if training:
             scale, shift, mean, rstd = bn_train(stat, emb, S * F_, norm_out, x)
         else:
@@ -378,6 +433,9 @@ def encoder_forward(fe, x, training, need_ctx=True):
         out = _new((S, emb, F_), x)
         K.bn_act_apply(yemb, out, scale, shift, None, S=S, C_=emb, T=F_)
         ctx.out_bn = (scale, shift, mean, rstd)
+    elif ctx.out_kind is not None:          # InstanceNorm1d(emb) (frontend.py:209-210)
+        out, gmean, grstd = rownorm_fwd(yemb, norm_out, ctx.out_kind, None)
+        ctx.out_bn = (None, None, gmean, grstd)
     else:
         out = yemb
         ctx.out_bn = None
@@ -397,10 +455,17 @@ def encoder_backward(fe, ctx, demb, sink, want_dx=False, on_ready=None):
     emb = fe.W.out_channels
     bn_mode = 1 if ctx.training else 2     # eval-mode forward => frozen-statistics backward (dy = scale*dz)
     # ---- norm_out (BatchNorm1d affine=False) -----------------------------------------------------
-    if ctx.out_bn is not None:
+    if ctx.out_bn is not None and ctx.out_kind == "bn":
         scale, shift, mean, rstd = ctx.out_bn
         dyemb, _ = act_backward(ctx.yemb, C=emb, T=F_, S=S, has_bn=bn_mode, scale=scale, shift=shift, mean=mean,
                                 rstd=rstd, dsrc=demb)
+    elif ctx.out_bn is not None:
+        _, _, gmean, grstd = ctx.out_bn
+        norm_out = fe.norm_out_mod
+        dyemb, osums = rownorm_backward(ctx.yemb, norm_out, ctx.out_kind, None, gmean, grstd, dsrc=demb, dsrc_ctot=emb,
+                                        Tp=F_)
+        if norm_out.affine:
+            sink.add_cols(osums, 3, emb, [(norm_out.bias, 0), (norm_out.weight, 1)])
     else:
         dyemb = demb
     # ---- W + dense-skip projections: one wgrad + one dgrad over the concatenated channels --------
@@ -456,14 +521,23 @@ def encoder_backward(fe, ctx, demb, sink, want_dx=False, on_ready=None):
         if fe.denseskips_on and n < nb - 1:
             off, d = ctx.skip_off[n]
             kw = dict(dpool=dacat, dpool_ctot=ccat, dpool_coff=off, pool_F=F_, pool_d=d)
-        dy, sums = act_backward(y, C=C, T=Tn, S=S, has_bn=bn_mode if rec["has_bn"] else 0, scale=rec["scale"], shift=rec["shift"],
-                                alpha=blk.act.weight, mean=rec["mean"], rstd=rec["rstd"], dsrc=dsrc,
-                                dsrc_ctot=dsrc_ctot, dsrc_coff=dsrc_coff, Tp=dsrc_Tp, padL=dsrc_padL,
-                                pad_mode=dsrc_mode, **kw)
-        bn_aff = rec["has_bn"] and blk.norm.affine
-        no_bn_bias = (not rec["has_bn"]) and not blk.sincnet          # bias gradient = sum dz when no BatchNorm follows
-        sink.add_cols(sums, 3, C, [(blk.norm.bias if bn_aff else (blk.conv.bias if no_bn_bias else None), 0),
-                                   (blk.norm.weight if bn_aff else None, 1), (blk.act.weight, 2)])
+        kind = rec.get("kind")
+        if kind in ("in", "ln"):
+            dy, sums = rownorm_backward(y, blk.norm, kind, blk.act.weight, rec["mean"], rec["rstd"], dsrc=dsrc,
+                                        dsrc_ctot=dsrc_ctot, dsrc_coff=dsrc_coff, Tp=dsrc_Tp, padL=dsrc_padL,
+                                        pad_mode=dsrc_mode, **kw)
+            aff = blk.norm.elementwise_affine if kind == "ln" else blk.norm.affine
+            sink.add_cols(sums, 3, C, [(blk.norm.bias if aff else None, 0), (blk.norm.weight if aff else None, 1),
+                                       (blk.act.weight, 2)])
+        else:
+            dy, sums = act_backward(y, C=C, T=Tn, S=S, has_bn=bn_mode if rec["has_bn"] else 0, scale=rec["scale"],
+                                    shift=rec["shift"], alpha=blk.act.weight, mean=rec["mean"], rstd=rec["rstd"],
+                                    dsrc=dsrc, dsrc_ctot=dsrc_ctot, dsrc_coff=dsrc_coff, Tp=dsrc_Tp, padL=dsrc_padL,
+                                    pad_mode=dsrc_mode, **kw)
+            bn_aff = rec["has_bn"] and blk.norm.affine
+            no_bn_bias = (not rec["has_bn"]) and not blk.sincnet      # bias gradient = sum dz when no norm follows
+            sink.add_cols(sums, 3, C, [(blk.norm.bias if bn_aff else (blk.conv.bias if no_bn_bias else None), 0),
+                                       (blk.norm.weight if bn_aff else None, 1), (blk.act.weight, 2)])
         inp = rec["inp"]
         taps = rec["taps"]
         if blk.sincnet:
@@ -477,7 +551,7 @@ def encoder_backward(fe, ctx, demb, sink, want_dx=False, on_ready=None):
             sink.add(conv.low_hz_, dlow)
             sink.add(conv.band_hz_, dband)
         else:
-            dbias = sink.buf(blk.conv.bias) if rec["has_bn"] else None
+            dbias = sink.buf(blk.conv.bias) if (rec["has_bn"] or rec.get("kind") in ("in", "ln")) else None
             conv_wgrad(dy, inp, sink.buf(blk.conv.weight).view(C, -1), dbias, taps=taps, stride=blk.stride,
                        padL=rec["padL"], pad_mode=K.PAD_REFLECT)
         if on_ready is not None:

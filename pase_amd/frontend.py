@@ -103,10 +103,11 @@ class WaveFe(Model):
         self.emb_dim = emb_dim
         self.rnn_pool = rnn_pool
         self.quantizer = None
-        if norm_out:
-            if norm_type != "bnorm":
-                raise NotImplementedError("pase_amd WaveFe: norm_out with norm_type != bnorm")
-            self.norm_out = nn.BatchNorm1d(self.emb_dim, affine=False)
+        if norm_out:                      # frontend.py:206-210
+            if norm_type == "bnorm":
+                self.norm_out = nn.BatchNorm1d(self.emb_dim, affine=False)
+            else:
+                self.norm_out = nn.InstanceNorm1d(self.emb_dim)
         self.tanh_out = tanh_out
 
     @property

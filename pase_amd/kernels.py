@@ -224,6 +224,8 @@ _SIMPLE.update({
     "pase_bn_act_apply": [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp],
     "pase_act_bwd_reduce": [C.POINTER(PaseActBwd), _fp],
     "pase_act_bwd_apply": [C.POINTER(PaseActBwd), _fp],
+    "pase_rownorm_act_fwd": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _f, _i, _fp],
+    "pase_rownorm_act_bwd": [C.POINTER(PaseActBwd), _fp],
     "pase_qrnn_scan_fwd": [_fp, _fp, _fp, _i, _i, _i, _i, _i, _fp],
     "pase_qrnn_scan_bwd": [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp],
     "pase_head1_fwd": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _f, _fp],
@@ -334,6 +336,19 @@ def act_bwd_reduce(y, **kw):
 def act_bwd_apply(y, **kw):
     d = _act_bwd_desc(y, **kw)
     _check(_lib.lib().pase_act_bwd_apply(C.byref(d), _stream()), "pase_act_bwd_apply")
+
+
+NORM_INSTANCE, NORM_LAYER = 0, 1
+
+
+def rownorm_act_fwd(y, out, gamma, beta, alpha, mean_out, rstd_out, *, S, C_, T, eps, mode):
+    _check(_lib.lib().pase_rownorm_act_fwd(_ptr(y), _ptr(out), _ptr(gamma), _ptr(beta), _ptr(alpha), _ptr(mean_out),
+                                           _ptr(rstd_out), S, C_, T, eps, mode, _stream()), "pase_rownorm_act_fwd")
+
+
+def rownorm_act_bwd(y, **kw):
+    d = _act_bwd_desc(y, **kw)
+    _check(_lib.lib().pase_rownorm_act_bwd(C.byref(d), _stream()), "pase_rownorm_act_bwd")
 
 
 def qrnn_scan_fwd(gates, h_out, c_out, *, S, H, F, h_ctot, h_coff):

@@ -264,12 +264,20 @@ class FeBlock(NeuralBlock):
                                       pad_mode=pad_mode)
         else:
             self.conv = nn.Conv1d(num_inputs, fmaps, kwidth, stride, dilation=dilation)
+        # build_norm_layer (pase/models/modules.py:77-96); the spectral / weight-norm reparametrisations are not built
         if norm_type == "bnorm":
             self.norm = nn.BatchNorm1d(fmaps)
+        elif norm_type == "lnorm":
+            self.norm = nn.LayerNorm(fmaps)
+        elif norm_type == "inorm":
+            self.norm = nn.InstanceNorm1d(fmaps, affine=False)
+        elif norm_type == "affinorm":
+            self.norm = nn.InstanceNorm1d(fmaps, affine=True)
         elif norm_type is None:
             self.norm = None
         else:
-            raise NotImplementedError("pase_amd FeBlock: norm_type %r (PASE/PASE+ cfgs use bnorm)" % norm_type)
+            raise NotImplementedError("pase_amd FeBlock: norm_type %r (snorm / bsnorm / wnorm reparametrise the conv "
+                                      "weight; outside the PASE(+) cfgs)" % norm_type)
         self.act = nn.PReLU(fmaps, init=0)
 
 

@@ -158,3 +158,37 @@ def test_train_mode_input_gradient(dev):
     (O.encoder_forward(P, MINI_FE, x, True, {}) * g).sum().backward()
     (fe(xd) * g.to(dev)).sum().backward()
     assert_close(xd.grad, x.grad, rtol=1e-3, atol=1e-4 * max(1.0, float(x.grad.abs().max())), what="d/d waveform")
+
+
+@pytest.mark.parametrize("norm_type", ["lnorm", "inorm", "affinorm"])
+def test_per_sample_norm_types_forward_backward(dev, norm_type):
+    """norm_type 'lnorm' / 'inorm' / 'affinorm' (modules.py:77-109; norm_out becomes an InstanceNorm1d,
+    frontend.py:206-210): the 2xQRNN dense-skip encoder of BASELINE.json configs[4] at mini width, forward and
+    every parameter gradient vs the oracle (itself pinned to the live reference for these norm types)."""
+    cfg = dict(MINI_FE, rnn_layers=2, norm_type=norm_type)
+    fe = _build(cfg, dev, seed=8)
+    with torch.no_grad():
+        for n, p in fe.named_parameters():
+            if n.endswith("norm.weight"):
+                p.uniform_(0.5, 1.5)
+            elif n.endswith("norm.bias"):
+                p.normal_(0, 0.2)
+    P = oracle_params(fe)
+    x = torch.randn(4, 1, 3200) * 0.3
+    fe.train()
+    y = fe(x.to(dev))
+    yo = O.encoder_forward(P, cfg, x, True, {})
+    assert_close(y, yo, rtol=1e-4, atol=1e-4, what="forward")
+    g = torch.randn_like(yo)
+    (yo * g).sum().backward()
+    (y * g.to(dev)).sum().backward()
+    for n, p in fe.named_parameters():
+        ref = P[n].grad
+        # instance norms cancel the conv bias in front of them exactly like BatchNorm (round-off-only gradients);
+        # LayerNorm (statistics over channels) does not
+        if norm_type != "lnorm" and is_noise_grad(n):
+            continue
+        assert_close(p.grad, ref, rtol=1e-3, atol=1e-4 * max(1.0, float(ref.abs().max())), what=n)
+    fe.eval()                      # per-sample statistics: eval == train arithmetic
+    with torch.no_grad():
+        assert_close(fe(x.to(dev)), O.encoder_forward(P, cfg, x, False), rtol=1e-4, atol=1e-4, what="eval forward")

@@ -284,3 +284,30 @@ def test_gap_worker_vs_live_reference(dev):
         y, lab = w(torch.from_numpy(g["gap_x"]).to(dev), 1, device=dev)
     assert_close(y, g["gap_y"], rtol=1e-4, atol=1e-5, what="gap prediction")
     assert_close(lab, g["gap_label"], rtol=0, atol=0, what="gap label")
+
+
+def test_fused_step_config5_shaped_lnorm_2xqrnn(dev):
+    """BASELINE.json configs[4] shape at mini width: dense-skip encoder with norm_type='lnorm', two QRNN layers,
+    InstanceNorm norm_out + the workers: fused step losses and every gradient vs the oracle."""
+    from pase_amd.pase import pase
+    fe_cfg = dict(MINI_FE, rnn_layers=2, norm_type="lnorm")
+    seed_all(12)
+    m = quiet(pase, frontend_cfg=dict(fe_cfg), minions_cfg=with_losses(mini_workers()), cls_lst=["mi", "cmi"],
+              regr_lst=["cchunk", "lps", "prosody"])
+    randomize_affine(m)
+    m = m.to(dev)
+    P = oracle_params(m)
+    batch = _mini_batch(seed=13)
+    raw = mini_workers()
+    h, chunk, preds, labels = O.pase_forward(P, fe_cfg, raw, batch, True)
+    lo = O.pase_losses(raw, preds, labels)
+    lo["total"].backward()
+    m.train()
+    lf = m.loss_and_grads({k: v.to(dev) for k, v in batch.items()})
+    for k, v in lo.items():
+        assert abs(float(lf[k]) - float(v)) <= 1e-4 * max(1.0, abs(float(v))), (k, float(lf[k]), float(v))
+    for n, p in m.named_parameters():
+        if n == "frontend.W.bias":          # cancelled by the InstanceNorm norm_out
+            continue
+        ref = P[n].grad
+        assert_close(p.grad, ref, rtol=1e-3, atol=1e-4 * max(1e-2, float(ref.abs().max())), what=n)
