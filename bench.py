@@ -110,7 +110,9 @@ def cpu_targets_baseline(raw, T=32000):
     import numpy as np
     from oracle import dsp_oracle as D
     x = (0.1 * np.random.RandomState(0).standard_normal(T)).astype(np.float32)
-    fns = {"lps": D.lps, "fbank": D.fbanks, "gtn": D.gammatone, "mfcc": D.mfcc}
+    from oracle import swipe_oracle as SW
+    fns = {"lps": D.lps, "fbank": D.fbanks, "gtn": D.gammatone, "mfcc": D.mfcc,
+           "prosody": lambda x_, **kw_: D.prosody(x_, SW.swipe(x_), **kw_)}
     per = {}
     t_all = 0.0
     for w in raw["regr"]:
@@ -124,7 +126,7 @@ def cpu_targets_baseline(raw, T=32000):
         t_all += per[w["name"]]
     return {"value": round(1.0 / t_all, 3), "unit": "utterances/s", "cores": 1, "kind": "port",
             "seconds_per_utterance": per,
-            "sample": "oracle/dsp_oracle.py: LPS / FBANK / gammatone / MFCC (+ _long variants) of one %d-sample "
+            "sample": "oracle/dsp_oracle.py + swipe_oracle.py: LPS / FBANK / gammatone / MFCC (+ _long variants) / prosody of one %d-sample "
                       "utterance, single thread" % T}
 
 
@@ -271,13 +273,11 @@ def main():
             f_.set_stats(torch.zeros(D_), torch.ones(D_))
         prod = PR.DeviceBatchProducer(PR.DeviceChunker(pool, T, rng=rs), PR.DeviceReverb(irs, device=dev), 0.5,
                                       PR.DeviceAdditive(noises, device=dev), 0.5, tg, rng=rs)
-        extra = {k: v for k, v in batch.items() if k not in ("chunk", "chunk_ctxt", "chunk_rand", "cchunk")}
+        missing = [w["name"] for w in raw["regr"] if w["name"] not in tg.feats and w["name"] != "cchunk"]
+        assert not missing, missing          # every regression target (incl. prosody: SWIPE' f0) is produced on device
 
         def next_batch():
-            b = prod(B)
-            for k, v in extra.items():          # the prosody target (SWIPE' f0) is not produced on device
-                b.setdefault(k, v)
-            return b
+            return prod(B)
 
     def sync():
         if world > 1:
@@ -386,7 +386,7 @@ def main():
                        if args.producer else
                        "PASE+.cfg + workers+.cfg self-supervised train step (BASELINE.json configs[2])",
                        "batch_per_gpu": B, "global_batch": B * world, "chunk_samples": T,
-                       "targets": ("lps/lps_long/fbank/fbank_long/gtn/gtn_long/mfcc/mfcc_long computed on device; prosody N(0,1)"
+                       "targets": ("lps/lps_long/fbank/fbank_long/gtn/gtn_long/mfcc/mfcc_long/prosody all computed on device from the clean chunk"
                                    if args.producer else "given (N(0,1) tensors resident in HBM)"), "parallelism": "dp%d" % world,
                        "final_total_loss": round(total_loss, 5), "inputs": "resident in HBM (see `h2d` for the "
                        "host-buffer leg)", "collective_backend": backend},

@@ -30,7 +30,10 @@ enum { PASE_EPI_STORE = 0, PASE_EPI_MSE_CTX = 1 };
 enum { PASE_POST_NONE = 0,
        PASE_POST_POW = 1,     /* rows come in (re, im) pairs: out[row/2] = (re^2 + im^2) * post_scale            */
        PASE_POST_LOGPOW = 2,  /* out[row/2] = post_scale * ln(re^2 + im^2 + post_eps)                          */
-       PASE_POST_LOG = 3 };   /* out[row] = post_scale * ln(v == 0 ? post_eps : v)                             */
+       PASE_POST_LOG = 3,     /* out[row] = post_scale * ln(v == 0 ? post_eps : v)                             */
+       PASE_POST_MAG = 4,     /* pairs: out[row/2] = post_scale * sqrt(re^2 + im^2)   (SWIPE' magnitude spectra)  */
+       PASE_POST_RELU = 5,    /* out[row] = max(v, 0)                                                          */
+       PASE_POST_SQRTPOS = 6 };/* out[row] = sqrt(max(v, 0))          (SWIPE' loudness at the ERB frequencies)  */
 enum { PASE_LOSS_NONE = 0, PASE_LOSS_L1 = 1, PASE_LOSS_MSE = 2, PASE_LOSS_BCE_LOGITS = 3 };
 
 /* ------------------------------------------------------------------------------------------
@@ -256,10 +259,24 @@ int pase_power_to_db(const float* x, float* y, unsigned* umax_scratch, long per_
  * edge-padded frame / win (|x| <= 1e-10 counts as +0).  x (B, T), out (B, out_ctot, F). */
 int pase_zcr_rms(const float* x, float* out, int B, int T, int F, int hop, int win, int out_ctot, int out_coff,
                  void* stream);
-/* Prosody target, pitch rows (pase/transforms.py:948-961): f0 (B, F) in Hz with 0 on unvoiced frames ->
- * out[b, out_coff] = log(f0 + 1e-10) with unvoiced stretches interpolated (ahoproc_tools interpolation(lf0, -1)),
- * out[b, out_coff+1] = voiced flag; an all-unvoiced chunk gets log(f0_min) / 0. */
-int pase_lf0_interp(const float* f0, float* out, int B, int F, int out_ctot, int out_coff, float f0_min, void* stream);
+/* Prosody target, pitch rows (pase/transforms.py:948-961): f0 (B, Fin) in Hz with 0 on unvoiced frames ->
+ * out[b, out_coff] = log(f0 + 1e-10) with unvoiced stretches interpolated over the WHOLE contour (ahoproc_tools
+ * interpolation(lf0, -1)), then truncated to F <= Fin frames; out[b, out_coff+1] = voiced flag; a chunk without a
+ * voiced frame among the kept ones gets log(f0_min) / 0.  out (B, out_ctot, F). */
+int pase_lf0_interp(const float* f0, float* out, int B, int Fin, int F, int out_ctot, int out_coff, float f0_min,
+                    void* stream);
+/* SWIPE' f0 tracker (what pysptk.swipe computes for the Prosody target, pase/transforms.py:948-952), the two steps
+ * that are not pase_conv_gemm launches:
+ *   pase_swipe_accumulate: one window size's pitch strengths num / sqrt(den2) ((B, nj, nfr) each, 0 where den2 == 0),
+ *     interpolated linearly to the output frames (frame f sits at f * frames_per_out of that window's hops) and
+ *     added, times mu[c], into row cand[c] of S (B, NC, F) (caller-zeroed before the first window);
+ *   pase_swipe_pick: per output frame the strongest candidate (candidate c = 2^(log2_fmin + c * dlog2p) Hz), f0 = 0
+ *     when its strength is below st, else the maximum of the parabola through the three strengths around it on a
+ *     `polyv`-octave grid; strength (optional) receives the winning strength. */
+int pase_swipe_accumulate(const float* num, const float* den2, const float* mu, const int* cand, float* S, int B, int nj,
+                          int nfr, int NC, int F, float frames_per_out, void* stream);
+int pase_swipe_pick(const float* S, float* f0, float* strength, int B, int NC, int F, float log2_fmin, float dlog2p,
+                    float polyv, float st, void* stream);
 /* Framing prologue of LPS / FBanks / MFCC (transforms.py:465-466 torch.stft centre padding, :517
  * logfbank framing + pre-emphasis, :700 librosa stft): y (B, hop, Q) with
  * y[b][r][q] = xpad[q*hop + r], xpad = x padded by padL on the left (pad_mode PASE_PAD_REFLECT or

@@ -565,7 +565,8 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
     }
     const bool rows_full = m0 + wm * 64 + 64 <= p.M;   // uniform
 
-    if (p.epilogue == PASE_EPI_STORE && (p.post_op == PASE_POST_POW || p.post_op == PASE_POST_LOGPOW)) {
+    if (p.epilogue == PASE_EPI_STORE &&
+        (p.post_op == PASE_POST_POW || p.post_op == PASE_POST_LOGPOW || p.post_op == PASE_POST_MAG)) {
         // spectra: accumulator rows r, r+1 (same lane) are the (re, im) parts of one frequency bin
         int cbase[2];
         bool colok[2];
@@ -586,7 +587,8 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
                 for (int b = 0; b < 2; ++b) {
                     const float re = acc[a][b][r], im = acc[a][b][r + 1];
                     float v = re * re + im * im;
-                    v = (p.post_op == PASE_POST_LOGPOW) ? p.post_scale * logf(v + p.post_eps) : v * p.post_scale;
+                    v = (p.post_op == PASE_POST_LOGPOW) ? p.post_scale * logf(v + p.post_eps)
+                        : (p.post_op == PASE_POST_MAG ? p.post_scale * sqrtf(v) : v * p.post_scale);
                     if (colok[b]) p.y[(unsigned)(cbase[b] + rowoff)] = v;
                 }
             }
@@ -636,6 +638,8 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
                     for (int b = 0; b < 2; ++b) {
                         float v = acc[a][b][r] + bv;
                         if (!FAST && p.post_op == PASE_POST_LOG) v = p.post_scale * logf(v == 0.f ? p.post_eps : v);
+                        if (!FAST && p.post_op == PASE_POST_RELU) v = fmaxf(v, 0.f);
+                        if (!FAST && p.post_op == PASE_POST_SQRTPOS) v = sqrtf(fmaxf(v, 0.f));
                         const bool ok = FAST || (mok && colok[b] && (!pshuf || (unsigned)(posb[b] + ph) < (unsigned)p.Tout));
                         if (ok) {
                             float* dst = p.y + (unsigned)(cbase[b] + rowoff);
@@ -918,7 +922,8 @@ extern "C" int pase_conv_gemm(const PaseConvGemm* d, void* stream) {
     const HostPlan h = make_plan(p);
     if (h.pl.CB < 1) return -6;
     if (h.pl.splitk > 1 && (p.stat_part || p.epilogue != PASE_EPI_STORE || p.post_op != PASE_POST_NONE)) return -7;
-    if ((p.post_op == PASE_POST_POW || p.post_op == PASE_POST_LOGPOW) && (p.ps != 1 || p.stat_part || (p.M & 1))) return -9;
+    if ((p.post_op == PASE_POST_POW || p.post_op == PASE_POST_LOGPOW || p.post_op == PASE_POST_MAG) &&
+        (p.ps != 1 || p.stat_part || (p.M & 1))) return -9;
     // 32-bit element offsets in the loader and the epilogue
     const long LIM = 0x7fffffffL;
     if ((long)p.S * p.Ncols >= LIM) return -8;

@@ -100,39 +100,118 @@ __global__ void __launch_bounds__(NT) zcr_rms_kernel(const float* x, float* out,
 // linearly between their voiced neighbours, a leading stretch takes the first voiced value, a trailing one the
 // last voiced value; uv = 1 on voiced frames; an all-unvoiced chunk gets lf0 = log(f0_min), uv = 0.
 // One thread per utterance (F = 200 frames, sequential by nature).  out rows: out_coff = lf0, out_coff+1 = uv.
-__global__ void lf0_interp_kernel(const float* f0, float* out, int B, int F, int out_ctot, int out_coff, float f0_min) {
+__global__ void lf0_interp_kernel(const float* f0, float* out, int B, int Fin, int F, int out_ctot, int out_coff,
+                                  float f0_min) {
+    // Fin = frames of the tracker's contour (the interpolation runs over ALL of them, transforms.py:955), F <= Fin =
+    // frames kept (:956-957 truncate afterwards; :958-960 then test the truncated voiced flags)
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const float* f = f0 + (size_t)b * F;
+    const float* f = f0 + (size_t)b * Fin;
     float* lf = out + ((size_t)b * out_ctot + out_coff) * (size_t)F;
     float* uv = lf + F;
     const double us = -1.0;
     auto L = [&](int t) { return log((double)f[t] + 1e-10); };
-    for (int t = 0; t < F; ++t) { lf[t] = (float)L(t); uv[t] = 1.f; }
+    auto put = [&](int i, double v, float flag) { if (i < F) { lf[i] = (float)v; uv[i] = flag; } };
+    bool any_voiced = false;
+    for (int t = 0; t < Fin; ++t) { const double v = L(t); any_voiced = any_voiced || v > us; put(t, v, 1.f); }
     int tb0 = -1;              // tbound[0]
     double fb0 = 0.0;          // fbound[0]
     bool have_b0 = false;      // tbound != [None, None]
     double prev = L(0);
-    for (int t = 1; t < F; ++t) {
+    for (int t = 1; t < Fin; ++t) {
         const double cur = L(t);
         if (cur > us && prev <= us && !have_b0) {
             // leading unvoiced stretch: constant first voiced value
-            for (int i = 0; i < t; ++i) { lf[i] = (float)cur; uv[i] = 0.f; }
+            for (int i = 0; i < t; ++i) put(i, cur, 0.f);
         } else if (cur <= us && prev > us) {
             tb0 = t - 1; fb0 = prev; have_b0 = true;
         } else if (cur > us && prev <= us) {
             const double slope = (cur - fb0) / (double)(t - tb0);
-            for (int i = tb0; i < t; ++i) { lf[i] = (float)(fb0 + (double)(i - tb0) * slope); uv[i] = 0.f; }
+            for (int i = tb0; i < t; ++i) put(i, fb0 + (double)(i - tb0) * slope, 0.f);
             have_b0 = false; tb0 = -1;
         }
         prev = cur;
     }
-    if (have_b0) for (int i = tb0; i < F; ++i) { lf[i] = (float)fb0; uv[i] = 0.f; }
-    bool all_unv = true;
+    if (have_b0) for (int i = tb0; i < Fin; ++i) put(i, fb0, 0.f);
     float uvsum = 0.f;
-    for (int t = 0; t < F; ++t) { all_unv = all_unv && !((double)lf[t] > us); uvsum += uv[t]; }
-    if (all_unv) { for (int t = 0; t < F; ++t) uv[t] = 0.f; uvsum = 0.f; }
+    if (!any_voiced) for (int t = 0; t < F; ++t) uv[t] = 0.f;
+    for (int t = 0; t < F; ++t) uvsum += uv[t];
     if (uvsum == 0.f) for (int t = 0; t < F; ++t) lf[t] = logf(f0_min);
+}
+
+// ---- SWIPE' pitch tracker (the f0 contour behind the Prosody target, pase/transforms.py:948-952: pysptk.swipe) ----
+// The spectra, the ERB-scale loudness and the kernel inner products are pase_conv_gemm launches (pase_amd/dsp.py:
+// SwipeTracker); these two kernels do the rest.
+// (1) per window size: pitch strength S_i = (K . L) / sqrt(tail . L^2) at that window's own frame rate (0 when the
+//     loudness above the candidate's first bin is zero), interpolated linearly in time to the output frame times
+//     t = f * hop / fs and accumulated, weighted by mu[c], into the rows cand_index[c] of S (B, NC, F).
+__global__ void __launch_bounds__(NT) swipe_accumulate_kernel(const float* num, const float* den2, const float* mu,
+                                                              const int* cand, float* S, int B, int nj, int nfr, int NC,
+                                                              int F, float frames_per_out) {
+    const long total = (long)B * nj * F;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int f = (int)(i % F);
+        const int c = (int)((i / F) % nj);
+        const int b = (int)(i / ((long)F * nj));
+        const float pos = (float)f * frames_per_out;          // output time in units of this window's hop
+        int i0 = (int)floorf(pos);
+        float w = pos - (float)i0;
+        if (i0 >= nfr - 1) { i0 = nfr - 2; w = pos - (float)i0; }
+        const float* nr = num + ((size_t)b * nj + c) * (size_t)nfr;
+        const float* dr = den2 + ((size_t)b * nj + c) * (size_t)nfr;
+        const float d0 = dr[i0], d1 = dr[i0 + 1];
+        const float s0 = d0 > 0.f ? nr[i0] / sqrtf(d0) : 0.f;
+        const float s1 = d1 > 0.f ? nr[i0 + 1] / sqrtf(d1) : 0.f;
+        float v = s0 + w * (s1 - s0);
+        if (w > 1.f || pos < 0.f) v = 0.f;                    // outside the analysed span (interp1's NaN): no support
+        S[((size_t)b * NC + cand[c]) * (size_t)F + f] += mu[c] * v;
+    }
+}
+
+// (2) per output frame: strongest candidate, strength threshold, parabolic refinement on a 1/768-octave grid
+//     (swipep.m's polyfit through the three strengths around the maximum, in normalised period units).
+__global__ void __launch_bounds__(NT) swipe_pick_kernel(const float* S, float* f0, float* strength, int B, int NC, int F,
+                                                        float log2_fmin, float dlog2p, float polyv, float st) {
+    const long total = (long)B * F;
+    const long i = (long)blockIdx.x * NT + threadIdx.x;
+    if (i >= total) return;
+    const int f = (int)(i % F), b = (int)(i / F);
+    const float* col = S + (size_t)b * NC * (size_t)F + f;
+    int im = 0;
+    float sm = col[0];
+    for (int c = 1; c < NC; ++c) {
+        const float v = col[(size_t)c * F];
+        if (v > sm) { sm = v; im = c; }
+    }
+    double pitch = 0.0, sbest = (double)sm;
+    if (sm >= st) {
+        if (im == 0 || im == NC - 1) {
+            pitch = exp2((double)log2_fmin + (double)im * (double)dlog2p);
+        } else {
+            const double l0 = (double)log2_fmin + (double)(im - 1) * (double)dlog2p;
+            const double tc1 = exp2(-(l0 + (double)dlog2p));
+            double xs[3], ys[3];
+            for (int k = 0; k < 3; ++k) {
+                xs[k] = (exp2(-(l0 + k * (double)dlog2p)) / tc1 - 1.0) * 6.283185307179586;
+                ys[k] = (double)col[(size_t)(im - 1 + k) * F];
+            }
+            // interpolating parabola through the three points (what polyfit(.,.,2) returns for three samples)
+            const double d01 = xs[0] - xs[1], d02 = xs[0] - xs[2], d12 = xs[1] - xs[2];
+            const double a0 = ys[0] / (d01 * d02), a1 = -ys[1] / (d01 * d12), a2 = ys[2] / (d02 * d12);
+            const int ng = (int)floor(2.0 * (double)dlog2p / (double)polyv + 1e-9) + 1;
+            int kb = 0;
+            double vb = -1e300;
+            for (int k = 0; k < ng; ++k) {
+                const double x = (exp2(-(l0 + k * (double)polyv)) / tc1 - 1.0) * 6.283185307179586;
+                const double v = a0 * (x - xs[1]) * (x - xs[2]) + a1 * (x - xs[0]) * (x - xs[2]) + a2 * (x - xs[0]) * (x - xs[1]);
+                if (v > vb) { vb = v; kb = k; }
+            }
+            pitch = exp2(l0 + kb * (double)polyv);
+            sbest = vb;
+        }
+    }
+    f0[i] = (float)pitch;
+    if (strength) strength[i] = (float)sbest;
 }
 
 // Framing prologue shared by every spectral target: the waveform, padded (reflect / zero) by padL on the
@@ -230,12 +309,36 @@ extern "C" int pase_zcr_rms(const float* x, float* out, int B, int T, int F, int
     return 0;
 }
 
-extern "C" int pase_lf0_interp(const float* f0, float* out, int B, int F, int out_ctot, int out_coff, float f0_min,
-                               void* stream) {
+extern "C" int pase_lf0_interp(const float* f0, float* out, int B, int Fin, int F, int out_ctot, int out_coff,
+                               float f0_min, void* stream) {
     if (B <= 0 || F <= 0) return 0;
-    if (out_coff + 2 > out_ctot) return -2;
-    PASE_LAUNCH(lf0_interp_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), (hipStream_t)stream, f0, out, B, F, out_ctot,
-                out_coff, f0_min);
+    if (out_coff + 2 > out_ctot || Fin < F) return -2;
+    PASE_LAUNCH(lf0_interp_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), (hipStream_t)stream, f0, out, B, Fin, F,
+                out_ctot, out_coff, f0_min);
+    PASE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pase_swipe_accumulate(const float* num, const float* den2, const float* mu, const int* cand, float* S, int B,
+                                     int nj, int nfr, int NC, int F, float frames_per_out, void* stream) {
+    const long total = (long)B * nj * F;
+    if (total <= 0) return 0;
+    if (nfr < 2) return -2;
+    long blocks = (total + NT - 1) / NT;
+    if (blocks > 65535) blocks = 65535;
+    PASE_LAUNCH(swipe_accumulate_kernel, dim3((unsigned)blocks), dim3(NT), (hipStream_t)stream, num, den2, mu, cand, S, B,
+                nj, nfr, NC, F, frames_per_out);
+    PASE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pase_swipe_pick(const float* S, float* f0, float* strength, int B, int NC, int F, float log2_fmin,
+                               float dlog2p, float polyv, float st, void* stream) {
+    const long total = (long)B * F;
+    if (total <= 0) return 0;
+    if (NC < 1) return -2;
+    PASE_LAUNCH(swipe_pick_kernel, dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), (hipStream_t)stream, S, f0, strength,
+                B, NC, F, log2_fmin, dlog2p, polyv, st);
     PASE_CHECK_LAUNCH();
     return 0;
 }

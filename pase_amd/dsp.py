@@ -12,8 +12,8 @@ Third-party arithmetic the reference delegates to (not installed here; restated 
 algorithms, parity UNPINNED -- SURVEY.md section 8c): legacy torch.stft (rectangular window centred in
 n_fft, reflect centre padding) for LPS; python_speech_features 0.6 `logfbank` for FBanks; librosa 0.6.3
 `feature.mfcc` (periodic Hann, Slaney mel bank with area normalisation, power_to_db top_db=80, DCT-II
-ortho) and `feature.delta` (Savitzky-Golay width 9) for MFCC / deltas.  Gammatone (gtgram IIR bank) and
-Prosody (SWIPE' pitch) are not built.
+ortho) and `feature.delta` (Savitzky-Golay width 9) for MFCC / deltas; detly/gammatone `gtgram` for Gammatone;
+pysptk.swipe (SWIPE' f0), ahoproc_tools `interpolation` and librosa `rmse` / `zero_crossing_rate` for Prosody.
 """
 import math
 
@@ -292,6 +292,138 @@ class Gammatone(_Feature):
         return blocks
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# SWIPE' f0 tracker (A. Camacho 2007/2008; what pysptk.swipe -- SPTK's swipe.c -- computes for the Prosody target,
+# pase/transforms.py:948-952).  PARITY UNPINNED: the third-party tracker is not installed; the published algorithm
+# (swipep.m) with swipe.c's constants is implemented: 1/96-octave candidates, ERB-scale sqrt-magnitude loudness every
+# 0.1 ERB, Hann windows of the power-of-two sizes nearest 8 periods at 50 % overlap, prime-harmonic cosine kernels,
+# linear interpolation in time, lambda-weighted combination of window sizes, parabolic refinement on a 1/768-octave
+# grid, strength threshold 0.3, unvoiced frames reported as f0 = 0.
+# Device mapping: per window size the spectrogram is ONE DFT-basis pase_conv_gemm launch (Hann window folded into
+# the basis, |.| post-op), the natural-cubic-spline resampling to the ERB frequencies and the kernel / tail-energy
+# inner products are 1x1 pase_conv_gemm launches against host-built matrices; pase_swipe_accumulate / _pick finish.
+# ---------------------------------------------------------------------------------------------------------------
+def _primes_upto(n):
+    return [q for q in range(2, n + 1) if all(q % r for r in range(2, int(q ** 0.5) + 1))]
+
+
+def natural_spline_matrix(n, xq):
+    """(len(xq), n) matrix of natural-cubic-spline interpolation from the uniform grid 0..n-1 (in grid units) to the
+    query abscissae xq; rows of queries outside [0, n-1] are zero (interp1(..., 'spline', 0))."""
+    A = np.zeros((n, n))
+    Bm = np.zeros((n, n))
+    A[0, 0] = A[n - 1, n - 1] = 1.0                       # natural ends: second derivative 0
+    for i in range(1, n - 1):
+        A[i, i - 1], A[i, i], A[i, i + 1] = 1.0, 4.0, 1.0
+        Bm[i, i - 1], Bm[i, i], Bm[i, i + 1] = 6.0, -12.0, 6.0
+    M2 = np.linalg.solve(A, Bm)                           # second derivatives as a linear map of the samples
+    xq = np.asarray(xq, dtype=np.float64)
+    E = np.zeros((len(xq), n))
+    inside = (xq >= 0) & (xq <= n - 1)
+    i0 = np.clip(np.floor(xq).astype(int), 0, n - 2)
+    u = xq - i0                                           # in [0, 1]
+    eye = np.eye(n)
+    for r in np.where(inside)[0]:
+        i, t = i0[r], u[r]
+        a, b = 1.0 - t, t
+        E[r] = a * eye[i] + b * eye[i + 1] + ((a ** 3 - a) * M2[i] + (b ** 3 - b) * M2[i + 1]) / 6.0
+    return E
+
+
+class SwipeTracker(object):
+    """f0 = SwipeTracker(...)(wav): wav (B, 1, T) -> (B, T // hop + 1) Hz, 0 on unvoiced frames."""
+
+    DLOG2P, DERBS, POLYV = 1.0 / 96.0, 0.1, 1.0 / 12.0 / 64.0
+
+    def __init__(self, fs=16000, hop=160, f0_min=60.0, f0_max=300.0, threshold=0.3, device="cuda"):
+        self.fs, self.hop, self.fmin, self.fmax, self.st = fs, hop, float(f0_min), float(f0_max), float(threshold)
+        self.device = torch.device(device)
+        log2pc = np.arange(np.log2(self.fmin), np.log2(self.fmax), self.DLOG2P)
+        pc = 2.0 ** log2pc
+        self.NC = len(pc)
+        logws = np.round(np.log2(8.0 * fs / np.array([self.fmin, self.fmax]))).astype(int)
+        wss = 2 ** np.arange(logws[0], logws[1] - 1, -1)
+        pO = 8.0 * fs / wss
+        d = 1.0 + log2pc - np.log2(8.0 * fs / wss[0])
+        erb = lambda hz: 21.4 * np.log10(1.0 + hz / 229.0)
+        ferbs = (10.0 ** (np.arange(erb(pc.min() / 4.0), erb(fs / 2.0), self.DERBS) / 21.4) - 1.0) * 229.0
+        dev = self.device
+        self.windows = []
+        for i, w in enumerate(int(v) for v in wss):
+            ii = i + 1
+            dn = max(1, int(round(8.0 * 0.5 * fs / pO[i])))
+            if len(wss) == 1:
+                j, k = np.arange(len(pc)), np.array([], dtype=np.int64)
+            elif ii == len(wss):
+                j = np.where(d - ii > -1)[0]
+                k = np.where(d[j] - ii < 0)[0]
+            elif ii == 1:
+                j = np.where(d - ii < 1)[0]
+                k = np.where(d[j] - ii > 0)[0]
+            else:
+                j = np.where(np.abs(d - ii) < 1)[0]
+                k = np.arange(len(j))
+            ferbs = ferbs[int(np.argmax(ferbs > pc[j[0]] / 4.0)):]
+            mu = np.ones(len(j))
+            mu[k] = 1.0 - np.abs(d[j[k]] - ii)
+            E = natural_spline_matrix(w // 2 + 1, ferbs * w / float(fs))
+            Kmat = np.zeros((len(j), len(ferbs)))
+            tail = np.zeros((len(j), len(ferbs)))
+            start = 0
+            for r, p_ in enumerate(pc[j]):
+                start += int(np.argmax(ferbs[start:] > p_ / 4.0))
+                fj = ferbs[start:]
+                nh = int(np.fix(fj[-1] / p_ - 0.75))
+                if nh == 0:
+                    raise ValueError("SWIPE': candidate %.1f Hz has no harmonic below fs/2" % p_)
+                q = fj / p_
+                kk = np.zeros(len(fj))
+                for h in [1] + _primes_upto(nh):
+                    a = np.abs(q - h)
+                    pk = a < 0.25
+                    kk[pk] = np.cos(2.0 * np.pi * q[pk])
+                    v = (0.25 < a) & (a < 0.75)
+                    kk[v] += np.cos(2.0 * np.pi * q[v]) / 2.0
+                kk *= np.sqrt(1.0 / fj)
+                kk /= np.linalg.norm(kk[kk > 0])
+                Kmat[r, start:] = kk
+                tail[r, start:] = 1.0
+            n = np.arange(1, w + 1, dtype=np.float64)
+            hann = 0.5 * (1.0 - np.cos(2.0 * np.pi * n / (w + 1)))          # MATLAB hanning(w)
+            basis, taps = _hop_major(_dft_basis(w, w, 0, window=hann), dn)
+            t32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+            self.windows.append(dict(ws=w, dn=dn, taps=taps, basis=t32(basis), E=t32(E), K=t32(Kmat), tail=t32(tail),
+                                     mu=t32(mu), cand=torch.from_numpy(j.astype(np.int32)).to(dev), nj=len(j),
+                                     nerb=len(ferbs), bins=w // 2 + 1))
+
+    def __call__(self, wav, return_strength=False):
+        B, _, T = wav.shape
+        F = T // self.hop + 1                               # t = 0 : dt : len/fs
+        dev = wav.device
+        S = torch.zeros(B, self.NC, F, device=dev)
+        wav = wav.contiguous()
+
+        def gemm(x, wgt, M, Kd, nfr, post):
+            y = torch.empty(B, M, nfr, device=dev)
+            K.conv_gemm(x, wgt, y, S=B, Cin=Kd, Tin=nfr, M=M, K=Kd, taps=1, Ncols=nfr, Tout=nfr, post_op=post, splitk=1)
+            return y
+        for w in self.windows:
+            ws, dn = w["ws"], w["dn"]
+            nfr = (T + ws + dn - (ws - dn)) // dn
+            X = _spectrum(wav, w["basis"], w["taps"], dn, nfr, ws // 2, K.PAD_ZERO, 0.0, K.POST_MAG, 1.0)
+            L = gemm(X, w["E"], w["nerb"], w["bins"], nfr, K.POST_SQRTPOS)
+            L2 = gemm(X, w["E"], w["nerb"], w["bins"], nfr, K.POST_RELU)
+            num = gemm(L, w["K"], w["nj"], w["nerb"], nfr, K.POST_NONE)
+            den2 = gemm(L2, w["tail"], w["nj"], w["nerb"], nfr, K.POST_NONE)
+            K.swipe_accumulate(num, den2, w["mu"], w["cand"], S, B=B, nj=w["nj"], nfr=nfr, NC=self.NC, F=F,
+                               frames_per_out=float(self.hop) / float(dn))
+        f0 = torch.empty(B, F, device=dev)
+        strength = torch.empty(B, F, device=dev) if return_strength else None
+        K.swipe_pick(S, f0, strength, B=B, NC=self.NC, F=F, log2_fmin=float(np.log2(self.fmin)), dlog2p=self.DLOG2P,
+                     polyv=self.POLYV, st=self.st)
+        return (f0, strength) if return_strength else f0
+
+
 class Prosody(_Feature):
     """Prosody target (pase/transforms.py:919-999): rows [lf0, uv, energy, zcr] (+ deltas, ZNorm).  The energy and
     zero-crossing rows and the lf0 interpolation / voiced flag run on the device (pase_zcr_rms, pase_lf0_interp);
@@ -312,11 +444,11 @@ class Prosody(_Feature):
             if self.tracker is None:
                 raise ValueError("pase_amd Prosody: no f0 contour given and no device tracker attached")
             f0 = self.tracker(wav)
-        f0 = f0[:, :F].contiguous().float()
+        f0 = f0.contiguous().float()
         if f0.shape[1] < F:       # transforms.py:951-953: a short contour repeats its tail
             f0 = torch.cat((f0, f0[:, f0.shape[1] - (F - f0.shape[1]):]), 1).contiguous()
         base = torch.empty(B, 4, F, device=wav.device)
-        K.lf0_interp(f0, base, B=B, F=F, out_ctot=4, out_coff=0, f0_min=float(self.f0_min))
+        K.lf0_interp(f0, base, B=B, Fin=f0.shape[1], F=F, out_ctot=4, out_coff=0, f0_min=float(self.f0_min))
         K.zcr_rms(wav.contiguous(), base, B=B, T=T, F=F, hop=self.hop, win=self.win, out_ctot=4, out_coff=2)
         return self._finish(base, F, F)
 
@@ -339,8 +471,11 @@ class DeviceTargets(object):
                 f = MFCC(hop=hop, name=name, device=device, **kw)
             elif "gtn" in name:
                 f = Gammatone(hop=hop, name=name, device=device, **kw)
+            elif "prosody" in name:
+                f = Prosody(hop=hop, name=name, device=device, **kw)
+                f.tracker = SwipeTracker(fs=f.sr, hop=hop, f0_min=f.f0_min, f0_max=f.f0_max, device=device)
             else:
-                continue      # cchunk (the waveform itself), prosody: not produced here
+                continue      # cchunk: the waveform itself
             if stats is not None and name in stats:
                 f.set_stats(stats[name]["mean"], stats[name]["std"])
             self.feats[name] = f

@@ -11,7 +11,7 @@ from . import _lib
 
 PAD_ZERO, PAD_REFLECT = 0, 1
 EPI_STORE, EPI_MSE_CTX = 0, 1
-POST_NONE, POST_POW, POST_LOGPOW, POST_LOG = 0, 1, 2, 3
+POST_NONE, POST_POW, POST_LOGPOW, POST_LOG, POST_MAG, POST_RELU, POST_SQRTPOS = 0, 1, 2, 3, 4, 5, 6
 
 _fp = C.c_void_p
 
@@ -253,7 +253,9 @@ _SIMPLE.update({
     "pase_power_to_db": [_fp, _fp, _fp, _l, _i, _f, _f, _f, _fp],
     "pase_frame_prep": [_fp, _fp, _i, _i, _i, _i, _i, _i, _f, _fp],
     "pase_zcr_rms": [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp],
-    "pase_lf0_interp": [_fp, _fp, _i, _i, _i, _i, _f, _fp],
+    "pase_lf0_interp": [_fp, _fp, _i, _i, _i, _i, _i, _f, _fp],
+    "pase_swipe_accumulate": [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _fp],
+    "pase_swipe_pick": [_fp, _fp, _fp, _i, _i, _i, _f, _f, _f, _f, _fp],
 })
 
 LOSS_NONE, LOSS_L1, LOSS_MSE, LOSS_BCE = 0, 1, 2, 3
@@ -432,9 +434,19 @@ def zcr_rms(x, out, *, B, T, F, hop, win, out_ctot, out_coff):
     _check(_lib.lib().pase_zcr_rms(_ptr(x), _ptr(out), B, T, F, hop, win, out_ctot, out_coff, _stream()), "pase_zcr_rms")
 
 
-def lf0_interp(f0, out, *, B, F, out_ctot, out_coff, f0_min):
-    _check(_lib.lib().pase_lf0_interp(_ptr(f0), _ptr(out), B, F, out_ctot, out_coff, f0_min, _stream()),
+def lf0_interp(f0, out, *, B, Fin, F, out_ctot, out_coff, f0_min):
+    _check(_lib.lib().pase_lf0_interp(_ptr(f0), _ptr(out), B, Fin, F, out_ctot, out_coff, f0_min, _stream()),
            "pase_lf0_interp")
+
+
+def swipe_accumulate(num, den2, mu, cand, S, *, B, nj, nfr, NC, F, frames_per_out):
+    _check(_lib.lib().pase_swipe_accumulate(_ptr(num), _ptr(den2), _ptr(mu), _ptr(cand, torch.int32), _ptr(S), B, nj, nfr,
+                                            NC, F, frames_per_out, _stream()), "pase_swipe_accumulate")
+
+
+def swipe_pick(S, f0, strength, *, B, NC, F, log2_fmin, dlog2p, polyv, st):
+    _check(_lib.lib().pase_swipe_pick(_ptr(S), _ptr(f0), _ptr(strength), B, NC, F, log2_fmin, dlog2p, polyv, st,
+                                      _stream()), "pase_swipe_pick")
 
 
 def frame_prep(x, y, *, B, T, hop, Q, padL, pad_mode, preemph=0.0):
