@@ -37,7 +37,6 @@
 //   * a ragged last channel group is shifted back to end at Cin (its already-covered rows get zero
 //     weights), so the loader has no channel-validity branches.
 // Two shapes: <128,128> (waves 2x2) and <64,256> (waves 1x4) for the 64-row layers.
-#include <cstdlib>
 #include <type_traits>
 
 #include "hip_compat.h"
@@ -55,7 +54,6 @@ constexpr int NPAR = 4;       // on-load (scale, shift, alpha) triples prefetche
 constexpr int KG_FLAT = 32, XS_FLAT = 4096, NS_FLAT = 4;
 
 struct ConvPlan {
-    int stagger;   // kilocycles a workgroup that arrives as the odd one on its CU pauses before its k-loop (0 = off)
     int CB, TB, SPAN, SPANV, n_gc, n_gt, mode, tiles_per_seq, splitk;
     int tl;        // log2(threads per slab row)
     int pmajor;    // 0: slot t = sample c + t*TPR of row tid/TPR;  1 (flat 1x1): slot t = row t*RPP + tid/TPR
@@ -118,10 +116,6 @@ struct alignas(16) F4 { float x, y, z, w; };
 // (plain global memory, not constant address space: a pointer selected between it and a kernel argument
 // must stay a GLOBAL pointer -- a generic one turns the loads into flat_load and every wait into vmcnt(0))
 __device__ float g_ident[2] = {1.f, 0.f};
-
-// workgroup arrivals per compute unit (pase_cu_arrival): the parity decides which of two co-resident workgroups
-// starts its k-loop half a stage late
-__device__ unsigned g_cu_arrivals[2048];
 
 // NS = X slots per thread (the plan rounds its slot count up to 3 / 6 / 12), XV = float4 slots (flat 1x1).
 // Both are compile-time so that the per-stage loader is straight-line code: every load is issued
@@ -401,21 +395,11 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
     const int xc0 = (pl.mode != MODE_FLAT && j0c >= lenA) ? SA + (j0c - lenA) * xstep : j0c * xstep;
     const int xc1 = (pl.mode != MODE_FLAT && j1c >= lenA) ? SA + (j1c - lenA) * xstep : j1c * xstep;
 
-    // ---- anti-phase start.  Two workgroups share a CU (one wave each per SIMD).  Dispatched together, with identical
-    // stage lengths, they stay IN PHASE: both in their MFMA loops at once (sharing the matrix pipe at half rate each),
-    // then both in their store / barrier / load-issue phase with the pipe idle -- measured: two co-resident
-    // workgroups deliver only 1.08x the throughput of one.  The workgroup that arrives second on a CU therefore
-    // waits one MFMA phase before entering its loop; the offset persists (equal stage lengths), one workgroup's
-    // staging then runs under the other's MFMAs, and successors inherit the offset because the pair now finishes
-    // half a stage apart.
-    __shared__ unsigned s_arrival;
-    if (pl.stagger > 0 && tid == 0) s_arrival = pase_cu_arrival(g_cu_arrivals);
     load_stage();
     PASE_STAMP(1);
     store_stage(0);
     int kg = kg_next, tbe = tbe_next;
     __syncthreads();
-    if (pl.stagger > 0 && (s_arrival & 1u)) pase_pause_kilocycles(pl.stagger);
     PASE_STAMP(2);
     PASE_TACC_DECL;
     for (int g = g_begin; g < g_end; ++g) {
@@ -912,11 +896,6 @@ HostPlan make_plan(const PaseConvGemm& p) {
     }
     pl.splitk = splitk;
     h.blocks = tiles * splitk;
-    // one MFMA phase of a stage at the full pipe rate: (k per stage / 2) steps x 4 MFMAs x 64 cycles, in kilocycles
-    static const int stagger_pct = [] { const char* e = getenv("PASE_STAGGER"); return e ? atoi(e) : 100; }();
-    const int kstage = flat ? pl.CB : pl.CB * pl.TB;
-    pl.stagger = (int)((long)(kstage / 2) * 4 * 64 * stagger_pct / 100 / 1024);
-    if (G < 4) pl.stagger = 0;      // a handful of stages: the pause would not pay for itself
     return h;
 }
 

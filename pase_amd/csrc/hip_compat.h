@@ -14,9 +14,6 @@ __device__ __forceinline__ int pase_uniform(int v) { return v; }
 #define PASE_LAUNDER(x) ((void)0)
 #define PASE_SCHED_BARRIER() ((void)0)
 #define PASE_SGB(mask, n) ((void)0)
-// arrival parity of this workgroup on its compute unit / a timed pause: no-ops on the emulator
-__device__ __forceinline__ unsigned pase_cu_arrival(unsigned* counters) { (void)counters; return 0u; }
-__device__ __forceinline__ void pase_pause_kilocycles(int n) { (void)n; }
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -38,20 +35,6 @@ __device__ __forceinline__ int pase_uniform(int v) { return __builtin_amdgcn_rea
 #define PASE_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 // ask the scheduler for `n` instructions of class `mask` next (0x8 MFMA, 0x2 VALU, 0x4 SALU, 0x100 DS read)
 #define PASE_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-// Running count of workgroups that have started on THIS compute unit (counters: 2048 unsigned in global memory,
-// indexed by the hardware (XCC, SE, SH, CU) id).  Call from one thread.
-__device__ __forceinline__ unsigned pase_cu_arrival(unsigned* counters) {
-    unsigned hw, xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    const unsigned cu = (hw >> 8) & 0xFu, sh = (hw >> 12) & 0x1u, se = (hw >> 13) & 0x7u;
-    const unsigned key = (((xcc & 0xFu) * 8u + se) * 2u + sh) * 16u + cu;
-    return atomicAdd(counters + (key & 2047u), 1u);
-}
-// idle this wave for about n x 1024 shader cycles without occupying any execution pipe
-__device__ __forceinline__ void pase_pause_kilocycles(int n) {
-    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
-}
 #endif
 
 #ifdef PASE_HIPEMU
