@@ -36,6 +36,7 @@ constexpr int ZPT_SMALL = 9, ZPT_LARGE = 19;
 
 struct WgradPlan {
     int bias_rowsum;   // dbias from row sums of the G slab in column-tile 0 (no extra all-ones column tile)
+    int zshift;        // ZV: samples between the aligned load address and the span start (0..3)
     int gvec, flat, SPANW, chunks_per_seq, n_chunks, kt_per_split, n_row_tiles, n_col_tiles;
     unsigned span_magic, ncols_magic;
 };
@@ -45,14 +46,19 @@ __device__ __forceinline__ unsigned div_magic(unsigned e, unsigned magic) {
     return magic ? (unsigned)(((unsigned long long)e * magic) >> 32) : e;
 }
 
-template <int BM, int BN, int ZPT>
-__global__ void __launch_bounds__(NTHREADS, (ZPT <= ZPT_SMALL ? 2 : 1)) wgrad_gemm_kernel(PaseWgrad p, WgradPlan pl) {
-    constexpr int ZS_DATA = ZPT * NTHREADS;
+// ZV = 1: the spans are staged with 16-byte loads (ZPT = float4 slots per thread): every channel row of the slab is
+// SPANW rounded up to whole float4s, read from the 16-byte-aligned address `zshift` samples in front of the span.
+// That is the large-span case (the stride-10 block-1 layer: 14 channels x 330 samples per stage) at a quarter of the
+// load / LDS-store instructions and 14 fewer offset registers, which is what lets it run two workgroups per CU.
+template <int BM, int BN, int ZPT, int ZV = 0>
+__global__ void __launch_bounds__(NTHREADS, ((ZPT <= ZPT_SMALL || ZV) ? 2 : 1)) wgrad_gemm_kernel(PaseWgrad p, WgradPlan pl) {
+    constexpr int ZW = ZV ? 4 : 1;                     // floats per slot
+    constexpr int ZS_DATA = ZPT * NTHREADS * ZW;
     constexpr int ZS_TOTAL = ZS_DATA + ZS_ONES;
     constexpr int WAVES_N = BN / 64;
     constexpr int A_ROWS = BM / 8;
     __shared__ float As[2][BKQ][BM + 1];
-    __shared__ float Zs[2][ZS_TOTAL];
+    __shared__ __attribute__((aligned(16))) float Zs[2][ZS_TOTAL];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -86,7 +92,7 @@ __global__ void __launch_bounds__(NTHREADS, (ZPT <= ZPT_SMALL ? 2 : 1)) wgrad_ge
         const int j = j0 + wn * 64 + b * 32 + fr;
         if (j < Kw) {
             const int ci = j / p.taps, kk = j - ci * p.taps;
-            boff[b] = (ci - c_lo) * pl.SPANW + (p.tapstep > 0 ? kk : p.taps - 1 - kk);
+            boff[b] = (ci - c_lo) * pl.SPANW + (ZV ? pl.zshift : 0) + (p.tapstep > 0 ? kk : p.taps - 1 - kk);
         } else {
             boff[b] = ZS_DATA;      // ones (bias column when j == Kw, discarded otherwise)
         }
@@ -100,7 +106,7 @@ __global__ void __launch_bounds__(NTHREADS, (ZPT <= ZPT_SMALL ? 2 : 1)) wgrad_ge
     // rows (tid >> 5) + 8*i at time step tid & 31.  Rows past M re-read row M-1 (never stored).
     constexpr int GS = A_ROWS / 4;
     float areg[A_ROWS];
-    float zreg[ZPT];
+    float zreg[ZPT * ZW];
     const int k4 = (tid & 7) * 4;
     unsigned goff[GS];
     float g_al[GS];
@@ -116,14 +122,15 @@ __global__ void __launch_bounds__(NTHREADS, (ZPT <= ZPT_SMALL ? 2 : 1)) wgrad_ge
     const int ntot = p.S * p.Ncols;
     const int total = NC * pl.SPANW;
     unsigned zoff[ZPT];
-    constexpr bool PRE = ZPT <= ZPT_SMALL;       // on-load (scale, shift, alpha) per slot held in registers
+    constexpr bool PRE = ZPT <= ZPT_SMALL || ZV; // on-load (scale, shift, alpha) per slot held in registers
     constexpr int NPRE = PRE ? ZPT : 1;
     float z_sc[NPRE], z_sh[NPRE], z_al[NPRE];
     const bool has_aff = p.in_scale != nullptr, has_al = p.in_alpha != nullptr;
     const bool has_xf = has_aff || has_al;
 #pragma unroll
     for (int t = 0; t < ZPT; ++t) {
-        const int e = min(tid + NTHREADS * t, max(total - 1, 0));   // slots past the slab re-read its last element
+        // slot t = element (ZV: float4) e of the [NC][SPANW] slab; slots past the slab re-read its last element
+        const int e = min((tid + NTHREADS * t) * ZW, max(total - ZW, 0));
         const int cl = (int)div_magic((unsigned)e, pl.span_magic);
         zoff[t] = (unsigned)(cl * p.Tz + (e - cl * pl.SPANW));
         if (PRE) {
@@ -180,44 +187,56 @@ __global__ void __launch_bounds__(NTHREADS, (ZPT <= ZPT_SMALL ? 2 : 1)) wgrad_ge
         // ---- Z spans: NC rows of SPANW floats.  Two paths only: (fast) the whole span is real
         // data of one sequence -> unconditional loads off a uniform base; (slow) chunk at a
         // sequence edge / crossing sequences -> per-slot padding + sequence logic.
-        const int u0 = pl.flat ? q0 : q0 * p.stride - p.padL + (p.tapstep > 0 ? 0 : -(p.taps - 1));
+        // (ZV: the staged row starts zshift samples in front of the span, at a 16-byte-aligned address)
+        const int u0 = pl.flat ? q0 : q0 * p.stride - p.padL + (p.tapstep > 0 ? 0 : -(p.taps - 1)) - (ZV ? pl.zshift : 0);
         const bool fast = pl.flat ? (!straddle && (long)c * BKQ + pl.SPANW <= ntot) : (u0 >= 0 && u0 + pl.SPANW <= p.Tz);
         zfast_next = fast;
         if (fast) {
             const float* zb = p.z + ((size_t)s * p.z_ctot + p.z_coff + c_lo) * (size_t)p.Tz + u0;
 #pragma unroll
-            for (int t = 0; t < ZPT; ++t) zreg[t] = zb[zoff[t]];
+            for (int t = 0; t < ZPT; ++t) {
+                if (ZV) {
+                    const float4 v = *reinterpret_cast<const float4*>(zb + zoff[t]);
+                    zreg[4 * t + 0] = v.x; zreg[4 * t + 1] = v.y; zreg[4 * t + 2] = v.z; zreg[4 * t + 3] = v.w;
+                } else {
+                    zreg[t] = zb[zoff[t]];
+                }
+            }
         } else {
             zmask = 0u;
 #pragma unroll
             for (int t = 0; t < ZPT; ++t) {
-                const int e = tid + NTHREADS * t;
-                float v = 0.f;
-                if (e < total) {
-                    const int cl = (int)div_magic((unsigned)e, pl.span_magic);
-                    const int i = e - cl * pl.SPANW;
-                    int sz = s, u;
-                    bool ok;
-                    if (pl.flat) {
-                        const int n = c * BKQ + i;
-                        sz = (int)div_magic((unsigned)n, pl.ncols_magic);
-                        u = n - sz * p.Ncols;
-                        if (u < 0) { --sz; u += p.Ncols; }
-                        ok = n < ntot;
-                    } else {
-                        u = u0 + i;
-                        if (p.pad_mode == PASE_PAD_REFLECT) {
-                            if (u < 0) u = -u;
-                            if (u >= p.Tz) u = 2 * (p.Tz - 1) - u;
+                const int e0 = (tid + NTHREADS * t) * ZW;
+                const int cl = e0 < total ? (int)div_magic((unsigned)e0, pl.span_magic) : 0;
+#pragma unroll
+                for (int w = 0; w < ZW; ++w) {
+                    const int e = e0 + w;
+                    float v = 0.f;
+                    if (e < total) {
+                        const int i = e - cl * pl.SPANW;
+                        int sz = s, u;
+                        bool ok;
+                        if (pl.flat) {
+                            const int n = c * BKQ + i;
+                            sz = (int)div_magic((unsigned)n, pl.ncols_magic);
+                            u = n - sz * p.Ncols;
+                            if (u < 0) { --sz; u += p.Ncols; }
+                            ok = n < ntot;
+                        } else {
+                            u = u0 + i;
+                            if (p.pad_mode == PASE_PAD_REFLECT) {
+                                if (u < 0) u = -u;
+                                if (u >= p.Tz) u = 2 * (p.Tz - 1) - u;
+                            }
+                            ok = u >= 0 && u < p.Tz;
                         }
-                        ok = u >= 0 && u < p.Tz;
+                        if (ok) {
+                            v = p.z[((size_t)sz * p.z_ctot + p.z_coff + c_lo + cl) * (size_t)p.Tz + u];
+                            zmask |= 1u << (t * ZW + w);
+                        }
                     }
-                    if (ok) {
-                        v = p.z[((size_t)sz * p.z_ctot + p.z_coff + c_lo + cl) * (size_t)p.Tz + u];
-                        zmask |= 1u << t;
-                    }
+                    zreg[t * ZW + w] = v;
                 }
-                zreg[t] = v;
             }
         }
         gvec_next = pl.gvec && !straddle;
@@ -254,7 +273,9 @@ __global__ void __launch_bounds__(NTHREADS, (ZPT <= ZPT_SMALL ? 2 : 1)) wgrad_ge
 #pragma unroll
         for (int t = 0; t < ZPT; ++t) {
             if (part >= 0 && (t * NP) / ZPT != part) continue;
-            float v = zreg[t];
+            float v[ZW];
+#pragma unroll
+            for (int w = 0; w < ZW; ++w) v[w] = zreg[t * ZW + w];
             if (has_xf) {
                 float sc, sh, al;
                 if (PRE) {
@@ -266,12 +287,16 @@ __global__ void __launch_bounds__(NTHREADS, (ZPT <= ZPT_SMALL ? 2 : 1)) wgrad_ge
                     sh = has_aff ? p.in_shift[ci] : 0.f;
                     al = has_al ? p.in_alpha[ci] : 1.f;
                 }
-                v = fmaf(v, sc, sh);
-                v = v > 0.f ? v : v * al;
-                // padding / out-of-range samples are zeros of the ACTIVATED tensor
-                if (!zfast_next && !(zmask & (1u << t))) v = 0.f;
+#pragma unroll
+                for (int w = 0; w < ZW; ++w) {
+                    v[w] = fmaf(v[w], sc, sh);
+                    v[w] = v[w] > 0.f ? v[w] : v[w] * al;
+                    // padding / out-of-range samples are zeros of the ACTIVATED tensor
+                    if (!zfast_next && !(zmask & (1u << (t * ZW + w)))) v[w] = 0.f;
+                }
             }
-            Zs[buf][tid + NTHREADS * t] = v;
+            if (ZV) *reinterpret_cast<float4*>(&Zs[buf][(tid + NTHREADS * t) * 4]) = make_float4(v[0], v[ZW > 1 ? 1 : 0], v[ZW > 2 ? 2 : 0], v[ZW > 3 ? 3 : 0]);
+            else Zs[buf][tid + NTHREADS * t] = v[0];
         }
     };
 
@@ -563,9 +588,30 @@ extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
         if (max_nc > p.Cin) max_nc = p.Cin;
         return max_nc * pl.SPANW;
     };
-    if (narrow && need(256) > ZPT_LARGE * NTHREADS) narrow = false;
-    if (!narrow && need(128) > ZPT_LARGE * NTHREADS) return -6;
+    // 16-byte span staging for the large-span case: chunk starts are multiples of 32*stride samples, so the span start
+    // has a fixed residue mod 4; stage from the aligned address zshift samples earlier, rows padded to whole float4s
+    constexpr int ZV_SLOTS = 5;
+    const int SPANW_raw = pl.SPANW;
+    const int u0res = -p.padL - (p.tapstep > 0 ? 0 : p.taps - 1);
+    const int zshift = ((u0res % 4) + 4) % 4;
+    const int SPANW_zv = (SPANW_raw + zshift + 3) / 4 * 4;
+    const bool zv_ok = !pl.flat && ((BKQ * p.stride) % 4) == 0 && (p.Tz % 4) == 0 &&
+                       (((unsigned long long)(size_t)p.z) % 16) == 0;
+    auto need_zv = [&](int bn) {
+        long max_nc = (bn - 1) / p.taps + 2;
+        if (max_nc > p.Cin) max_nc = p.Cin;
+        return max_nc * SPANW_zv;
+    };
+    pl.zshift = 0;
+    bool use_zv = false;
+    if (narrow && need(256) > ZPT_LARGE * NTHREADS && !(zv_ok && need_zv(256) <= ZV_SLOTS * 4 * NTHREADS)) narrow = false;
+    if (!narrow && need(128) > ZPT_LARGE * NTHREADS && !(zv_ok && need_zv(128) <= ZV_SLOTS * 4 * NTHREADS)) return -6;
     const bool small = need(narrow ? 256 : 128) <= ZPT_SMALL * NTHREADS;
+    if (!small && zv_ok && need_zv(narrow ? 256 : 128) <= ZV_SLOTS * 4 * NTHREADS) {
+        use_zv = true;
+        pl.zshift = zshift;
+        pl.SPANW = SPANW_zv;
+    }
     const int BMv = narrow ? 64 : 128, BNv = narrow ? 256 : 128;
     if ((BKQ - 1) * (pl.flat ? 1 : p.stride) + 1 > ZS_ONES) return -6;
     pl.bias_rowsum = (p.dbias && (flat_fast || ((p.Cin * p.taps) % BNv) == 0)) ? 1 : 0;
@@ -607,7 +653,9 @@ extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
         PASE_CHECK_LAUNCH();
         return 0;
     }
-    if (narrow && small)       PASE_LAUNCH((wgrad_gemm_kernel<64, 256, ZPT_SMALL>), grid, block, st, p, pl);
+    if (use_zv && narrow)      PASE_LAUNCH((wgrad_gemm_kernel<64, 256, 5, 1>), grid, block, st, p, pl);
+    else if (use_zv)           PASE_LAUNCH((wgrad_gemm_kernel<128, 128, 5, 1>), grid, block, st, p, pl);
+    else if (narrow && small)  PASE_LAUNCH((wgrad_gemm_kernel<64, 256, ZPT_SMALL>), grid, block, st, p, pl);
     else if (narrow)           PASE_LAUNCH((wgrad_gemm_kernel<64, 256, ZPT_LARGE>), grid, block, st, p, pl);
     else if (small)            PASE_LAUNCH((wgrad_gemm_kernel<128, 128, ZPT_SMALL>), grid, block, st, p, pl);
     else                       PASE_LAUNCH((wgrad_gemm_kernel<128, 128, ZPT_LARGE>), grid, block, st, p, pl);

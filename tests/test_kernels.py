@@ -285,3 +285,29 @@ def test_head1_forward_backward(dev, loss_name, lt):
     assert_close(s3[:, 1], al.grad, rtol=1e-4, atol=1e-6)
     assert_close(s3[:, 2], z.grad.sum((0, 2)), rtol=1e-4, atol=1e-6)
     assert_close(sums[C * 3:], b.grad, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("Cout", [40, 70], ids=["narrow-64x256", "wide-128x128"])
+def test_wgrad_large_span_float4_staging(dev, Cout):
+    """The stride-10 / 20-tap block-1 geometry (pase/models/modules.py:1058-1071 pads (9, 10)): 14 channels x 330
+    samples per stage do not fit the scalar small-span slab -> the 16-byte staged instantiation (aligned loads 3
+    samples in front of the span, rows padded to whole float4s), incl. the reflect-padded first / last chunks."""
+    torch.manual_seed(3)
+    S, Cin, k, st, T = 2, 16, 20, 10, 1280
+    x = torch.randn(S, Cin, T)
+    sc, sh, al = torch.rand(Cin) + 0.5, torch.randn(Cin) * 0.1, torch.rand(Cin) * 0.5
+    w = torch.randn(Cout, Cin, k, requires_grad=True)
+    b = torch.zeros(Cout, requires_grad=True)
+    xin = x * sc[None, :, None] + sh[None, :, None]
+    xin = torch.where(xin > 0, xin, xin * al[None, :, None])
+    y = F.conv1d(F.pad(xin, (9, 10), mode="reflect"), w, b, stride=st)
+    assert y.shape[2] == T // st
+    g = torch.randn_like(y)
+    (y * g).sum().backward()
+    dw = torch.zeros(Cout, Cin * k, device=dev)
+    db = torch.zeros(Cout, device=dev)
+    K.wgrad_gemm(g.to(dev), x.to(dev), dw, S=S, M=Cout, Tg=y.shape[2], Ncols=y.shape[2], Cin=Cin, Tz=T, taps=k,
+                 dbias=db, in_scale=sc.to(dev), in_shift=sh.to(dev), in_alpha=al.to(dev), stride=st, padL=9,
+                 pad_mode=K.PAD_REFLECT)
+    assert_close(dw.view(Cout, Cin, k), w.grad, rtol=1e-4, atol=2e-3, what="dW")
+    assert_close(db, b.grad, rtol=1e-4, atol=2e-3, what="db")
