@@ -616,11 +616,15 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
                 // the block's 16 bias values first (independent loads; see mse_rows on why not inside the store loop)
                 float bvs[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = rbase + a * 32 + (r & 3) + 8 * (r >> 2);
-                    int co = m;
-                    if (pshuf) co = m - (int)div_magic((unsigned)m, pl.cout_magic) * p.Cout_store;
-                    bvs[r] = (biasp && (FAST || m < p.M)) ? biasp[co] : 0.f;
+                for (int r = 0; r < 16; ++r) bvs[r] = 0.f;
+                if (biasp) {   // uniform (data-gradients carry no bias: no index arithmetic for them)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = rbase + a * 32 + (r & 3) + 8 * (r >> 2);
+                        int co = m;
+                        if (pshuf) co = m - (int)div_magic((unsigned)m, pl.cout_magic) * p.Cout_store;
+                        if (FAST || m < p.M) bvs[r] = biasp[co];
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {

@@ -9,7 +9,11 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 G = os.path.join(ROOT, "gpurun_out")
-out = {}
+sys.path.insert(0, ROOT)
+from pase_amd import build as _B  # noqa: E402
+# the digest of the kernel sources these profiles were taken of: bench.py reports `roofline.traffic` from this file
+# only while it matches the library that is loaded
+out = {"tag": tag, "lib_digest": _B.hip_digest()}
 
 
 def short(n):
@@ -27,7 +31,9 @@ def last_step(rows):
 
 def counters(path):
     agg = defaultdict(lambda: defaultdict(float))
-    f = os.path.join(G, path, "r_counter_collection.csv")
+    f = os.path.join(G, path + "_" + tag, "r_counter_collection.csv")
+    if not os.path.exists(f):
+        f = os.path.join(G, path, "r_counter_collection.csv")
     if not os.path.exists(f):
         return None
     rows = list(csv.DictReader(open(f)))
@@ -43,7 +49,7 @@ def counters(path):
 
 # --- kernel time per family for one step
 kt = None
-for cand in ("prof4", "prof3", "prof2"):
+for cand in ("prof_" + tag, "prof4", "prof3", "prof2"):
     f = os.path.join(G, cand, "r1_kernel_trace.csv")
     if os.path.exists(f):
         kt = f
