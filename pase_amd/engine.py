@@ -637,7 +637,7 @@ def worker_forward(layers, out_conv, a: Act, *, loss=None, want_pred=True):
         ltype = LOSS_TYPES[loss["name"]]
         r = loss.get("r")
         gscale = float(loss.get("weight", 1.0)) / ctx.numel
-        ctx.loss_acc = _zeros((1,), cur.t, torch.float64)
+        ctx.loss_acc = loss["acc"] if loss.get("acc") is not None else _zeros((1,), cur.t, torch.float64)
         ctx.dpred = _new((B, nout, T), cur.t)
     if nout == 1 and cur.scale is None and cur.coff == 0 and cur.ctot == cur.C:
         # single-output head: streaming kernel with the loss fused
@@ -736,7 +736,7 @@ def worker_backward(layers, out_conv, ctx, dpred, sink, need_dinput=True):
     return dsrc if need_dinput else None
 
 
-def mlp_group_step(workers, a: Act, targets, sink):
+def mlp_group_step(workers, a: Act, targets, sink, accs=None):
     """Forward + loss + backward of several one-hidden-layer MLP regression workers that read the
     SAME input (the chunk embedding): their first layers run as ONE stacked GEMM (9 x (256->256) ->
     one 2304-row launch instead of nine 100-workgroup launches), their input gradient as ONE dgrad,
@@ -762,7 +762,7 @@ def mlp_group_step(workers, a: Act, targets, sink):
         cur = Act(z_all, C=h, coff=off, alpha=blk.act.weight)
         numel = B * nout * F_
         gscale = float(w.loss_weight) / numel
-        acc = _zeros((1,), x, torch.float64)
+        acc = accs[w.name] if accs is not None else _zeros((1,), x, torch.float64)
         dpred = _new((B, nout, F_), x)
         tgt = targets[w.name].contiguous()
         w2d = oc.weight.view(nout, -1)

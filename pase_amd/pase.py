@@ -12,6 +12,38 @@ from .minions import cls_worker_maker, make_samples, minion_maker
 from .modules import Model
 
 
+class _LossBook(object):
+    """Per-step loss bookkeeping of the fused schedule: ONE float64 vector holds every worker's loss sum (each fused
+    loss kernel accumulates into its slot), finalize() applies loss_weight / numel and adds the total."""
+    _scale_cache = {}
+
+    def __init__(self, names, like):
+        self.names = list(names)
+        self.index = {n: i for i, n in enumerate(self.names)}
+        self.acc = engine._zeros((len(self.names),), like, torch.float64)
+        self.scales = [0.0] * len(self.names)
+
+    def slot(self, name):
+        i = self.index[name]
+        return self.acc[i:i + 1]
+
+    def scale(self, name, s):
+        self.scales[self.index[name]] = float(s)
+
+    def finalize(self):
+        key = (tuple(self.scales), str(self.acc.device))
+        sc = self._scale_cache.get(key)
+        if sc is None:                       # constant per model / batch shape: uploaded once
+            sc = torch.tensor(self.scales, dtype=torch.float64, device=self.acc.device)
+            if len(self._scale_cache) > 64:
+                self._scale_cache.clear()
+            self._scale_cache[key] = sc
+        vec = self.acc * sc
+        losses = {n: vec[i] for i, n in enumerate(self.names)}
+        losses["total"] = vec.sum()
+        return losses
+
+
 class pase(Model):
     def __init__(self, frontend=None, frontend_cfg=None, minions_cfg=None, cls_lst=["mi", "cmi", "spc"],
                  regr_lst=["chunk", "lps", "mfcc", "prosody"], pretrained_ckpt=None, name="adversarial"):
@@ -69,12 +101,11 @@ class pase(Model):
             labels[worker.name] = label
         return h, chunk, preds, labels
 
-    def _cls_step(self, emb, B, demb, sink, losses):
+    def _cls_step(self, emb, B, demb, sink, book):
         """Forward + loss + backward of the contrastive / classification workers (pase.py:345-354); their
-        gradient w.r.t. the embeddings is accumulated into `demb`.  Returns their summed weighted loss."""
+        gradient w.r.t. the embeddings is accumulated into `demb`, their loss sums into `book`."""
         E, F_ = emb.shape[1], emb.shape[2]
         chunk = emb[:B]
-        total = torch.zeros((), dtype=torch.float64, device=emb.device)
         h = (emb[:B], emb[B:2 * B], emb[2 * B:3 * B])
         for worker in self.classification_workers:
             mn = worker.minion
@@ -90,16 +121,15 @@ class pase(Model):
                                    torch.zeros(nb // 2, 1, 1, device=emb.device)), dim=0)
                 wctx = engine.worker_forward(list(mn.blocks), mn.W, Act(xin, C=xin.shape[1]),
                                              loss=dict(name=loss.loss_name, r=loss.r, target=label,
-                                                       weight=worker.loss_weight), want_pred=False)
+                                                       weight=worker.loss_weight, acc=book.slot(worker.name)),
+                                             want_pred=False)
                 dsrc = engine.worker_backward(list(mn.blocks), mn.W, wctx, wctx.dpred, sink)
                 dx = dsrc.dense(xin.shape[1], 1)[:, :, 0]
                 pos, neg = dx[:B], dx[B:]
                 demb[:B, :, t] += pos[:, :E] + neg[:, :E]
                 demb[:B, :, ft:ft + N] += pos[:, E:].reshape(B, E, N)
                 demb[:B, :, pt - N:pt] += neg[:, E:].reshape(B, E, N)
-                l = wctx.loss_acc[0] * (worker.loss_weight / wctx.numel)
-                losses[worker.name] = l
-                total = total + l
+                book.scale(worker.name, worker.loss_weight / wctx.numel)
                 del wctx, dsrc
                 continue
             if worker.name == "gap":
@@ -109,16 +139,15 @@ class pase(Model):
                 label = mn.labels(aidx, bidx, F_, emb.device)
                 wctx = engine.worker_forward(list(mn.blocks), mn.W, Act(xin, C=xin.shape[1]),
                                              loss=dict(name=loss.loss_name, r=loss.r, target=label,
-                                                       weight=worker.loss_weight), want_pred=False)
+                                                       weight=worker.loss_weight, acc=book.slot(worker.name)),
+                                             want_pred=False)
                 dsrc = engine.worker_backward(list(mn.blocks), mn.W, wctx, wctx.dpred, sink)
                 dx = dsrc.dense(xin.shape[1], 1)[:, :, 0]
                 ar = torch.arange(B, device=emb.device)
                 dv = demb[:B]          # (i, :, a_i) is unique per item; a_i == b_i is handled by the two statements
                 dv[ar, :, torch.as_tensor(aidx, device=emb.device)] += dx[:, :E]
                 dv[ar, :, torch.as_tensor(bidx, device=emb.device)] += dx[:, E:]
-                l = wctx.loss_acc[0] * (worker.loss_weight / wctx.numel)
-                losses[worker.name] = l
-                total = total + l
+                book.scale(worker.name, worker.loss_weight / wctx.numel)
                 del wctx, dsrc
                 continue
             x_pos, x_neg = make_samples(h, worker.augment)
@@ -136,7 +165,8 @@ class pase(Model):
                                torch.zeros(nb // 2, 1, Tw, device=emb.device)), dim=0)
             wctx = engine.worker_forward(list(mn.blocks), mn.W, Act(win, C=2 * E),
                                          loss=dict(name=loss.loss_name, r=loss.r, target=label,
-                                                   weight=worker.loss_weight), want_pred=False)
+                                                   weight=worker.loss_weight, acc=book.slot(worker.name)),
+                                         want_pred=False)
             dsrc = engine.worker_backward(list(mn.blocks), mn.W, wctx, wctx.dpred, sink)
             dx = dsrc.dense(2 * E, Tw)
             if worker.time_mean:
@@ -154,11 +184,8 @@ class pase(Model):
                 demb[:B] += pos[:, :E] + neg[:, :E]
                 demb[B:2 * B] += pos[:, E:]
                 demb[2 * B:] += neg[:, E:]
-            l = wctx.loss_acc[0] * (worker.loss_weight / wctx.numel)
-            losses[worker.name] = l
-            total = total + l
+            book.scale(worker.name, worker.loss_weight / wctx.numel)
             del wctx, dsrc
-        return total
 
     # ------------------------------------------------------------------------------------------
     # fused training schedule: forward + all losses + backward in one hand-scheduled pass
@@ -181,61 +208,55 @@ class pase(Model):
         B = batch["chunk"].shape[0]
         E, F_ = emb.shape[1], emb.shape[2]
         demb = torch.zeros_like(emb)
-        losses = {}
-        total = torch.zeros((), dtype=torch.float64, device=emb.device)
         chunk = emb[:B]
+        from .minions import MLPMinion
+        group = [w for w in self.regression_workers
+                 if isinstance(w, MLPMinion) and len(w.blocks) == 1 and w.blocks[0].context == 1
+                 and w.W.kernel_size[0] == 1 and w.W.out_channels > 1]
+        if len(group) <= 1:
+            group = []
+        # one float64 slot per worker for its loss sum (one zero-fill, one scale, one reduction per step instead of a
+        # fill + multiply + add per worker), reported in the order regression-group, other regression, contrastive
+        others = [w for w in self.regression_workers if not any(w is g for g in group)]
+        book = _LossBook([w.name for w in group] + [w.name for w in others] +
+                         [w.name for w in self.classification_workers], emb)
         # The contrastive workers are a few dozen 50-100-workgroup launches: they run on a side HIP stream underneath
         # the regression workers (own gradient buffer, merged after the join) instead of serialising behind them.
         side = engine.side_streams(emb, 4)
         cls_stream = side[3] if (side and engine.K.GEMM_TIMER is None and len(self.classification_workers) > 0) else None
-        losses_cls = {}
         if cls_stream is not None:
             main = torch.cuda.current_stream()
             cls_stream.wait_event(main.record_event())
             with torch.cuda.stream(cls_stream):
                 demb_cls = torch.zeros_like(emb)
-                total_cls = self._cls_step(emb, B, demb_cls, sink, losses_cls)
+                self._cls_step(emb, B, demb_cls, sink, book)
         # one-hidden-layer MLP workers share their input: run their first layers stacked
-        from .minions import MLPMinion
-        group = [w for w in self.regression_workers
-                 if isinstance(w, MLPMinion) and len(w.blocks) == 1 and w.blocks[0].context == 1
-                 and w.W.kernel_size[0] == 1 and w.W.out_channels > 1]
-        if len(group) > 1:
+        if group:
             tg = {w.name: (batch[w.name].to(device) if device is not None else batch[w.name]) for w in group}
-            res, dx = engine.mlp_group_step(group, Act(chunk, C=E), tg, sink)
+            res, dx = engine.mlp_group_step(group, Act(chunk, C=E), tg, sink, accs={w.name: book.slot(w.name) for w in group})
             demb[:B] += dx
             for w in group:
-                acc, numel = res[w.name]
-                l = acc[0] * (w.loss_weight / numel)
-                losses[w.name] = l
-                total = total + l
-        else:
-            group = []
-        for worker in self.regression_workers:
-            if any(worker is g for g in group):
-                continue
+                book.scale(w.name, w.loss_weight / res[w.name][1])
+        for worker in others:
             loss = worker.loss
             tgt = batch[worker.name]
             if device is not None:
                 tgt = tgt.to(device)
             wctx = engine.worker_forward(list(worker.blocks), worker.W, Act(chunk, C=E),
                                          loss=dict(name=loss.loss_name, r=loss.r, target=tgt,
-                                                   weight=worker.loss_weight), want_pred=False)
+                                                   weight=worker.loss_weight, acc=book.slot(worker.name)),
+                                         want_pred=False)
             dsrc = engine.worker_backward(list(worker.blocks), worker.W, wctx, wctx.dpred, sink)
             demb[:B] += dsrc.dense(E, F_)
-            l = wctx.loss_acc[0] * (worker.loss_weight / wctx.numel)
-            losses[worker.name] = l
-            total = total + l
+            book.scale(worker.name, worker.loss_weight / wctx.numel)
             del wctx, dsrc
         if cls_stream is not None:
             main.wait_event(cls_stream.record_event())
             demb += demb_cls
         else:
-            total_cls = self._cls_step(emb, B, demb, sink, losses_cls)
-        losses.update(losses_cls)
-        total = total + total_cls
+            self._cls_step(emb, B, demb, sink, book)
+        losses = book.finalize()
         if before_encoder_backward is not None:
             before_encoder_backward()   # all worker-head gradients are final here (DDP overlap point)
         engine.encoder_backward(fe, ectx, demb, sink, on_ready=on_encoder_grads)
-        losses["total"] = total
         return losses
