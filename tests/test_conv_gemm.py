@@ -209,3 +209,76 @@ def test_auto_splitk_with_pixel_shuffle_and_direct_kmajor_weight(dev):
     dx = torch.zeros(2, 8, 20, device=dev)
     K.conv_gemm(g.to(dev), None, dx, wt=wt, S=2, Cin=12, Tin=20, M=8, K=12, taps=1, Ncols=20, Tout=20, splitk=1)
     torch.testing.assert_close(dx.cpu(), torch.einsum("ro,srt->sot", W, g), rtol=2e-5, atol=2e-5)
+
+
+# ---- producer / consumer flat 1x1 variant (gemm_flat_ws.hip): M > 64, Ncols % 4 == 0 ---------------------------
+def _ws_inputs(S, Cin, Cout, T, seed=0):
+    torch.manual_seed(seed)
+    x = torch.randn(S, Cin, T)
+    w = torch.randn(Cout, Cin) * 0.2
+    b = torch.randn(Cout)
+    return x, w, b
+
+
+@pytest.mark.parametrize("xf", ["none", "alpha", "affine"])
+@pytest.mark.parametrize("S,Cin,Cout,T", [(3, 70, 130, 40), (5, 33, 260, 100), (2, 256, 140, 200)])
+def test_flat_ws_store_bias_stats(dev, xf, S, Cin, Cout, T):
+    """ragged M (two / three row tiles), ragged K (Cin % 32 != 0), column tiles crossing sequences, the three on-load
+    transform specialisations, BatchNorm partial sums"""
+    x, w, b = _ws_inputs(S, Cin, Cout, T)
+    sc, sh, al = torch.rand(Cin) + 0.5, torch.randn(Cin) * 0.1, torch.rand(Cin) * 0.5
+    xin = x
+    kw = {}
+    if xf == "affine":
+        xin = x * sc[None, :, None] + sh[None, :, None]
+        kw.update(in_scale=sc.to(dev), in_shift=sh.to(dev))
+    if xf in ("alpha", "affine"):
+        xin = torch.where(xin > 0, xin, xin * al[None, :, None])
+        kw.update(in_alpha=al.to(dev))
+    ref = F.conv1d(xin, w[:, :, None], b)
+    y = torch.zeros(S, Cout, T, device=dev)
+    nt = K.stat_tiles(M=Cout, S=S, Ncols=T, Cin=Cin, taps=1)
+    stat = torch.zeros(nt, Cout, 2, device=dev)
+    K.conv_gemm(x.to(dev), w.to(dev), y, S=S, Cin=Cin, Tin=T, M=Cout, K=Cin, taps=1, Ncols=T, Tout=T, bias=b.to(dev),
+                stat_part=stat, **kw)
+    torch.testing.assert_close(y.cpu(), ref, **_tol(dev))
+    st = stat.cpu().double().sum(0)
+    torch.testing.assert_close(st[:, 0], ref.double().sum((0, 2)), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(st[:, 1], (ref.double() ** 2).sum((0, 2)), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("splitk", [1, 4, 0])
+def test_flat_ws_long_reduction_splitk(dev, splitk):
+    S, Cin, Cout, T = 2, 1500, 130, 64
+    x, w, b = _ws_inputs(S, Cin, Cout, T, seed=1)
+    ref = F.conv1d(x, w[:, :, None], b)
+    y = torch.full((S, Cout, T), 3.0, device=dev)            # conv_gemm zero-fills it when the plan splits
+    K.conv_gemm(x.to(dev), w.to(dev), y, S=S, Cin=Cin, Tin=T, M=Cout, K=Cin, taps=1, Ncols=T, Tout=T, bias=b.to(dev),
+                splitk=splitk)
+    torch.testing.assert_close(y.cpu(), ref, rtol=1e-4, atol=1e-4)
+
+
+def test_flat_ws_mse_context_epilogue_wide(dev):
+    """the worker-head shape: rows m = d*r + j against the r-context of the label, M over several row tiles"""
+    torch.manual_seed(2)
+    B, Cin, D, r, Fr = 3, 40, 37, 7, 20
+    M = D * r
+    h = torch.randn(B, Cin, Fr)
+    al = torch.rand(Cin) * 0.5
+    w = torch.randn(M, Cin) * 0.2
+    b = torch.randn(M)
+    lab = torch.randn(B, D, Fr)
+    hin = torch.where(h > 0, h, h * al[None, :, None])
+    pred = F.conv1d(hin, w[:, :, None], b)
+    pl = F.pad(lab, (r // 2, r // 2))
+    tgt = torch.stack([pl[:, :, j:j + Fr] for j in range(r)], 2).reshape(B, M, Fr)      # channel d*r + j
+    gs = 0.37
+    y = torch.zeros(B, M, Fr, device=dev)
+    g = torch.zeros(B, M, Fr, device=dev)
+    acc = torch.zeros(1, dtype=torch.float64, device=dev)
+    K.conv_gemm(h.to(dev), w.to(dev), y, S=B, Cin=Cin, Tin=Fr, M=M, K=Cin, taps=1, Ncols=Fr, Tout=Fr, bias=b.to(dev),
+                in_alpha=al.to(dev), epilogue=K.EPI_MSE_CTX, label=lab.to(dev), grad_out=g, loss_acc=acc,
+                grad_scale=gs, r_ctx=r, label_D=D)
+    torch.testing.assert_close(y.cpu(), pred, **_tol(dev))
+    torch.testing.assert_close(g.cpu(), (pred - tgt) * gs, rtol=1e-4, atol=1e-5)
+    assert abs(float(acc) - float(((pred - tgt).double() ** 2).sum())) < 1e-3 * float(((pred - tgt) ** 2).sum())
