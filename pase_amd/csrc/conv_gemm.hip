@@ -823,7 +823,8 @@ HostPlan make_plan(const PaseConvGemm& p) {
     ConvPlan& pl = h.pl;
     // flat (1x1 as a plain GEMM over the flattened (s, q) columns) needs float4 slots: 4 consecutive columns
     // stay inside one sequence and are 16-B aligned.  Other 1x1 shapes run as a one-tap convolution.
-    const bool flat = (p.taps == 1 && p.stride == 1 && p.padL == 0 && p.tapstep == 1) && (p.Ncols % 4) == 0 &&
+    // (a single tap has no direction: the 1x1 data-gradients arrive with tapstep = -1 like every transposed conv)
+    const bool flat = (p.taps == 1 && p.stride == 1 && p.padL == 0) && (p.Ncols % 4) == 0 &&
                       (p.Tin % 4) == 0 && (((unsigned long long)(size_t)p.x) % 16) == 0;
     pl.mode = flat ? MODE_FLAT : (p.Ncols >= h.BN ? MODE_SEG : MODE_PERSEQ);
     pl.xvec = flat ? 1 : 0;

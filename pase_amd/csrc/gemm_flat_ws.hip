@@ -335,7 +335,7 @@ unsigned magic_of(int d) {
 // Returns -100 when the launch is outside what this variant covers (the caller then uses the generic kernel).
 extern "C" int pase_gemm_flat_ws(const PaseConvGemm* d, int splitk, void* stream) {
     const PaseConvGemm p = *d;
-    if (p.taps != 1 || p.stride != 1 || p.padL != 0 || p.tapstep != 1 || p.ps != 1 || p.poff != 0) return -100;
+    if (p.taps != 1 || p.stride != 1 || p.padL != 0 || p.ps != 1 || p.poff != 0) return -100;
     if ((p.Ncols % 4) || (p.Tin % 4) || (((unsigned long long)(size_t)p.x) % 16) || p.Ncols != p.Tin) return -100;
     if (p.post_op == PASE_POST_POW || p.post_op == PASE_POST_LOGPOW || p.post_op == PASE_POST_MAG) return -100;
     if (p.epilogue == PASE_EPI_STORE && p.Tout != p.Ncols) return -100;
