@@ -917,8 +917,6 @@ extern "C" int pase_pack_wt(const float* w, float* wt, int M, int K, int Cin, in
     return 0;
 }
 
-extern "C" int pase_gemm_flat_ws(const PaseConvGemm* d, int splitk, void* stream);   // gemm_flat_ws.hip
-
 extern "C" int pase_conv_gemm(const PaseConvGemm* d, void* stream) {
     const PaseConvGemm p = *d;
     if (p.M <= 0 || p.K <= 0 || p.S <= 0 || p.Ncols <= 0) return 0;
@@ -943,13 +941,6 @@ extern "C" int pase_conv_gemm(const PaseConvGemm* d, void* stream) {
     if (p.ps != 1 && (long)p.M * p.Cout_store >= 0xffffffffL) return -8;      // exact magic division
     if (p.epilogue == PASE_EPI_MSE_CTX && (long)p.M * p.r_ctx >= 0xffffffffL) return -8;
     hipStream_t st = (hipStream_t)stream;
-    // flat 1x1 with 128-row tiles: the producer / consumer variant (gemm_flat_ws.hip); PASE_FLAT_WS=0 keeps the
-    // single-role kernel below (A/B switch for the benchmarks; both pass the same tests)
-    static const bool flat_ws = [] { const char* e = getenv("PASE_FLAT_WS"); return !e || atoi(e) != 0; }();
-    if (flat_ws && h.pl.xvec && !h.narrow) {
-        const int rc = pase_gemm_flat_ws(&p, h.pl.splitk, stream);
-        if (rc != -100) return rc;
-    }
     const dim3 grid((unsigned)h.blocks), block(NTHREADS);
 #define PASE_CONV_LAUNCH(BM_, BN_)                                                                       \
     do {                                                                                                 \

@@ -211,7 +211,7 @@ def test_auto_splitk_with_pixel_shuffle_and_direct_kmajor_weight(dev):
     torch.testing.assert_close(dx.cpu(), torch.einsum("ro,srt->sot", W, g), rtol=2e-5, atol=2e-5)
 
 
-# ---- producer / consumer flat 1x1 variant (gemm_flat_ws.hip): M > 64, Ncols % 4 == 0 ---------------------------
+# ---- flat 1x1 path at 128-row tiles: M > 64, Ncols % 4 == 0 --------------------------------------------------
 def _ws_inputs(S, Cin, Cout, T, seed=0):
     torch.manual_seed(seed)
     x = torch.randn(S, Cin, T)

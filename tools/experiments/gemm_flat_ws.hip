@@ -1,3 +1,7 @@
+// NOT BUILT.  Experiment kept for the record: producer / consumer persistent variant of the flat 1x1 GEMM.
+// Measured equal to the single-role flat kernel on long reductions (116 vs 115 TFLOP/s, K = 21 525) and 3-17 % slower on
+// the K = 256 heads; it was therefore not adopted.  It was wired into pase_conv_gemm behind PASE_FLAT_WS and passed the
+// flat-path tests of tests/test_conv_gemm.py on the emulator and on the GPU.
 // gemm_flat_ws.hip -- producer / consumer ("wave-specialised") variant of the flat 1x1 path of pase_conv_gemm.
 //
 //   Y[s, m, q] = bias[m] + sum_k wt[k, m] * act(X[s, k, q])          (taps = 1, stride = 1, no padding)
