@@ -79,10 +79,6 @@ typedef struct PaseConvGemm {
     int splitk;            /* 1: none; >1: split the reduction, partial tiles atomically added into a
                               caller-zeroed y (EPI_STORE without stat_part only); 0: library decides --
                               query pase_conv_gemm_splitk() and zero y when it returns > 1        */
-    int ps_minor;          /* pixel-shuffle row order (ps > 1): 0 rows = (phase, channel): row = phase*Cout_store + co;
-                              1 rows = (channel, phase): row = co*ps + phase (pase_pack_dgrad_t phase_minor = 1).
-                              With the phases of a channel on adjacent rows a tile owns whole output runs of ps*128
-                              consecutive samples per channel and stores them coalesced through LDS.         */
 } PaseConvGemm;
 
 int pase_conv_gemm(const PaseConvGemm* desc, void* stream);
@@ -233,7 +229,7 @@ int pase_pack_dgrad(const float* src, float* dst, int R, int O, int k, int st, l
 /* same pack written K-major for pase_conv_gemm's `wt` operand: dst ((R*ceil(k/st)), ldt),
  * dst[(red*taps_p + j)*ldt + (p*O + o)]; ldt % 4 == 0, ldt >= st*O, pad columns zero-filled */
 int pase_pack_dgrad_t(const float* src, float* dst, int R, int O, int k, int st, long s_red, long s_out,
-                      long s_k, int ldt, int phase_minor, void* stream);
+                      long s_k, int ldt, void* stream);
 
 /* torch.optim.Adam (defaults; WorkerScheduler/trainer.py:91,111,134) over flat buffers; lr and step
  * are device scalars so a captured hipGraph stays valid.  grad_mul pre-scales g (1/world_size). */

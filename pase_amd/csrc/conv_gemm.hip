@@ -55,8 +55,6 @@ constexpr int NPAR = 4;       // on-load (scale, shift, alpha) triples prefetche
 constexpr int KG_FLAT = 32, XS_FLAT = 4096, NS_FLAT = 4;
 
 struct ConvPlan {
-    int RH;        // rows of each 64-row half of a tile that carry output rows (64; floor(64/ps)*ps with ps_minor rows)
-    unsigned ps_magic;        // ceil(2^32 / ps)
     int CB, TB, SPAN, SPANV, n_gc, n_gt, mode, tiles_per_seq, splitk;
     int tl;        // log2(threads per slab row)
     int pmajor;    // 0: slot t = sample c + t*TPR of row tid/TPR;  1 (flat 1x1): slot t = row t*RPP + tid/TPR
@@ -159,16 +157,14 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
 
     // ---- tile decode -----------------------------------------------------------------------
     const int ntot = p.S * p.Ncols;
-    // rows per tile: BM, or with (channel, phase)-ordered pixel-shuffle rows 2 * RH (whole channels per 64-row half)
-    const int rows_tile = (BM == 128) ? 2 * pl.RH : BM;
-    const int n_row_tiles = (p.M + rows_tile - 1) / rows_tile;
+    const int n_row_tiles = (p.M + BM - 1) / BM;
     const int n_col_tiles = (pl.mode == MODE_PERSEQ) ? p.S * pl.tiles_per_seq : (ntot + BN - 1) / BN;
     const int ntiles = n_row_tiles * n_col_tiles;
     const int split = blockIdx.x / ntiles;
     const int tile = xcd_swizzle(blockIdx.x % ntiles, ntiles);
     const int mt = tile % n_row_tiles;
     const int nt = tile / n_row_tiles;
-    const int m0 = mt * rows_tile;
+    const int m0 = mt * BM;
     // segment A = first sequence touched (s0, columns qA .. qA+lenA-1), segment B = the next one
     int s0, qA, lenA, lenB, n0 = 0;
     if (pl.mode == MODE_PERSEQ) {
@@ -199,8 +195,7 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
     // A: thread -> (slab row ar + RA*pass, 4 tile columns from acl) of the K-major pack
     const int ar = tid / TA;
     const int acl = (tid % TA) * 4;
-    // tile column acl of the A slab -> packed column (the second 64-row half starts RH rows after the first)
-    const unsigned a_col = (unsigned)min(m0 + (BM == 128 && acl >= 64 ? acl - 64 + pl.RH : acl), p.ldwt - 4);
+    const unsigned a_col = (unsigned)min(m0 + acl, p.ldwt - 4);
     F4 areg[PA_MAX];
     // X: thread -> slab row `xrow` (+ t*RPP when pmajor), samples xc + t*TPR (q-major)
     constexpr int NXR = XV ? 4 * NS : NS;      // staged floats per thread
@@ -550,10 +545,7 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
     // D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  All offsets are 32-bit element
     // offsets off a uniform base (host-checked), rows advance by compile-time constants.
     PASE_STAMP(3);
-    // (with (channel, phase)-ordered rows the second 64-row half of the tile starts RH output rows after the first,
-    //  and only the first RH rows of each half carry output)
-    const int rbase = m0 + wm * (BM == 128 ? pl.RH : 64) + 4 * (lane >> 5);
-    const int lrow0 = 4 * (lane >> 5);            // local row of accumulator register 0 within the wave's half
+    const int rbase = m0 + wm * 64 + 4 * (lane >> 5);
     int cs[2], cq[2];
     bool cok[2];
 #pragma unroll
@@ -572,7 +564,7 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
             cq[b] = jj < lenA ? qA + jj : jj - lenA;
         }
     }
-    const bool rows_full = pl.RH == 64 && m0 + wm * 64 + 64 <= p.M;   // uniform
+    const bool rows_full = m0 + wm * 64 + 64 <= p.M;   // uniform
 
     if (p.epilogue == PASE_EPI_STORE &&
         (p.post_op == PASE_POST_POW || p.post_op == PASE_POST_LOGPOW || p.post_op == PASE_POST_MAG)) {
@@ -631,24 +623,18 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
                     for (int r = 0; r < 16; ++r) {
                         const int m = rbase + a * 32 + (r & 3) + 8 * (r >> 2);
                         int co = m;
-                        if (pshuf) co = p.ps_minor ? (int)div_magic((unsigned)m, pl.ps_magic)
-                                                   : m - (int)div_magic((unsigned)m, pl.cout_magic) * p.Cout_store;
-                        if (FAST || m < p.M) bvs[r] = biasp[min(co, p.Cout_store - 1)];
+                        if (pshuf) co = m - (int)div_magic((unsigned)m, pl.cout_magic) * p.Cout_store;
+                        if (FAST || m < p.M) bvs[r] = biasp[co];
                     }
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = rbase + a * 32 + (r & 3) + 8 * (r >> 2);
-                    const bool mok = FAST || (m < p.M && lrow0 + a * 32 + (r & 3) + 8 * (r >> 2) < pl.RH);
+                    const bool mok = FAST || m < p.M;
                     int ph = 0, co = m;
                     if (pshuf) {   // uniform
-                        if (p.ps_minor) {
-                            co = (int)div_magic((unsigned)m, pl.ps_magic);
-                            ph = m - co * p.ps;
-                        } else {
-                            ph = (int)div_magic((unsigned)m, pl.cout_magic);
-                            co = m - ph * p.Cout_store;
-                        }
+                        ph = (int)div_magic((unsigned)m, pl.cout_magic);
+                        co = m - ph * p.Cout_store;
                     }
                     const float bv = bvs[r];
                     const int rowoff = co * p.Tout + ph;
@@ -681,59 +667,7 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
             }
         };
         const bool fast = rows_full && p.post_op == PASE_POST_NONE && pase_wave_all(interior) != 0;
-        if (BM == 128 && !XV && pshuf && p.ps_minor && pl.splitk == 1 && p.post_op == PASE_POST_NONE && !p.stat_part) {
-            // ---- coalesced pixel-shuffle store.  Rows are (channel, phase): a 64-row half of the tile holds RH / ps
-            // WHOLE channels, i.e. for each of them the ps * 128 consecutive output samples of this column tile.
-            // Written straight from the accumulator layout every store instruction scatters 4-byte pieces ps * 4 bytes
-            // apart (32-64 cache lines per instruction: 16 k line writes per tile); staged through LDS (the dead
-            // weight slab) the 256 threads write each channel's run with consecutive lanes on consecutive addresses.
-            float* T = &As[0][0][0];
-            const int LDT = BN + (p.ps >= 8 ? 4 : (p.ps >= 4 ? 8 : 16));     // conflict-free (phase, column) reads
-            static_assert(sizeof(float) * 64 * (BN + 16) <= sizeof(As) || BM != 128 || XV, "staging tile");
-            const int run = BN * p.ps;                                       // samples per channel in this tile
-            for (int hh = 0; hh < 2; ++hh) {
-                __syncthreads();
-                if (wm == hh) {
-#pragma unroll
-                    for (int a = 0; a < 2; ++a) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int rl = lrow0 + a * 32 + (r & 3) + 8 * (r >> 2);
-                            const int m = m0 + hh * pl.RH + rl;
-                            float bv = 0.f;
-                            if (biasp && rl < pl.RH && m < p.M) bv = biasp[div_magic((unsigned)m, pl.ps_magic)];
-#pragma unroll
-                            for (int b = 0; b < 2; ++b) T[rl * LDT + wn * 64 + b * 32 + fr] = acc[a][b][r] + bv;
-                        }
-                    }
-                }
-                __syncthreads();
-                const int co0 = (int)div_magic((unsigned)(m0 + hh * pl.RH), pl.ps_magic);
-                const int nelem = pl.RH * BN;
-                for (int i = tid; i < nelem; i += NTHREADS) {
-                    const int cl = i / run;
-                    const int rem = i - cl * run;
-                    const int col = (int)div_magic((unsigned)rem, pl.ps_magic);
-                    const int ph = rem - col * p.ps;
-                    const int co = co0 + cl;
-                    if (co < p.Cout_store && col < ncols_valid) {
-                        int s_, q_;
-                        if (pl.mode == MODE_FLAT) {
-                            const unsigned n = (unsigned)(n0 + col);
-                            s_ = (int)div_magic(n, pl.ncols_magic);
-                            q_ = (int)n - s_ * p.Ncols;
-                            if (q_ < 0) { --s_; q_ += p.Ncols; }
-                        } else {
-                            s_ = col < lenA ? s0 : s0 + 1;
-                            q_ = col < lenA ? qA + col : col - lenA;
-                        }
-                        const int pos = q_ * p.ps + ph + p.poff;
-                        if ((unsigned)pos < (unsigned)p.Tout)
-                            p.y[(unsigned)((s_ * p.y_ctot + p.y_coff + co) * p.Tout + pos)] = T[(cl * p.ps + ph) * LDT + col];
-                    }
-                }
-            }
-        } else if (pl.splitk > 1) {
+        if (pl.splitk > 1) {
             if (fast) store_rows(std::true_type{}, std::true_type{});
             else store_rows(std::false_type{}, std::true_type{});
         } else {
@@ -928,8 +862,6 @@ HostPlan make_plan(const PaseConvGemm& p) {
         pl.nslots = pl.nslots <= 3 ? 3 : (pl.nslots <= 6 ? 6 : 12);   // kernel instantiations: 3 / 6 / 12 slots
         pl.SPAN = pl.nslots << pl.tl;
     }
-    pl.RH = (!h.narrow && p.ps > 1 && p.ps_minor) ? (64 / p.ps) * p.ps : 64;
-    pl.ps_magic = magic_of(p.ps);
     pl.n_gc = pl.CB ? (p.Cin + pl.CB - 1) / pl.CB : 0;
     pl.n_gt = (p.taps + pl.TB - 1) / pl.TB;
     const int RA = NTHREADS / (BM / 4);
@@ -940,8 +872,7 @@ HostPlan make_plan(const PaseConvGemm& p) {
     pl.rctx_magic = magic_of(p.r_ctx);
     const long ntot = (long)p.S * p.Ncols;
     h.n_col_tiles = (pl.mode == MODE_PERSEQ) ? p.S * pl.tiles_per_seq : (int)((ntot + h.BN - 1) / h.BN);
-    const int rows_tile = h.narrow ? BM : 2 * pl.RH;
-    const long tiles = (long)((p.M + rows_tile - 1) / rows_tile) * h.n_col_tiles;
+    const long tiles = (long)((p.M + BM - 1) / BM) * h.n_col_tiles;
     int splitk = 1;
     const int G = pl.n_gc * pl.n_gt;
     if (p.splitk > 1) splitk = p.splitk;

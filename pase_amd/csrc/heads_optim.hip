@@ -251,10 +251,8 @@ __global__ void __launch_bounds__(NT) pack_dgrad_kernel(const float* src, float*
 
 // K-major variant for pase_conv_gemm's `wt` operand: dst[(red*taps_p + j)*ldt + (p*O + o)] = src[red, o, p + st*j];
 // consecutive threads walk the (p, o) index, so writes are coalesced; pad columns up to ldt are zero-filled.
-// phase_minor: column m = o*st + p (the phases of an output channel adjacent) instead of p*O + o.
 __global__ void __launch_bounds__(NT) pack_dgrad_t_kernel(const float* src, float* dst, int R, int O, int k, int st,
-                                                          int taps_p, long s_red, long s_out, long s_k, int ldt,
-                                                          int phase_minor) {
+                                                          int taps_p, long s_red, long s_out, long s_k, int ldt) {
     const long total = (long)R * taps_p * ldt;
     const int M = st * O;
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
@@ -264,9 +262,7 @@ __global__ void __launch_bounds__(NT) pack_dgrad_t_kernel(const float* src, floa
         const int red = (int)(kr / taps_p);
         float v = 0.f;
         if (m < M) {
-            int ph, o;
-            if (phase_minor) { o = m / st; ph = m - o * st; }
-            else { ph = m / O; o = m - ph * O; }
+            const int ph = m / O, o = m - ph * O;
             const int kk = ph + st * j;
             if (kk < k) v = src[red * s_red + o * s_out + kk * s_k];
         }
@@ -389,13 +385,13 @@ extern "C" int pase_pack_dgrad(const float* src, float* dst, int R, int O, int k
 }
 
 extern "C" int pase_pack_dgrad_t(const float* src, float* dst, int R, int O, int k, int st, long s_red, long s_out,
-                                 long s_k, int ldt, int phase_minor, void* stream) {
+                                 long s_k, int ldt, void* stream) {
     const int taps_p = (k + st - 1) / st;
     if (ldt < st * O || (ldt & 3)) return -4;
     const long total = (long)R * taps_p * ldt;
     if (total <= 0) return 0;
     PASE_LAUNCH(pack_dgrad_t_kernel, dim3(grid_for(total)), dim3(NT), (hipStream_t)stream, src, dst, R, O, k, st,
-                taps_p, s_red, s_out, s_k, ldt, phase_minor);
+                taps_p, s_red, s_out, s_k, ldt);
     PASE_CHECK_LAUNCH();
     return 0;
 }

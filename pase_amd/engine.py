@@ -137,14 +137,12 @@ def conv_dgrad(dy, w_nat, *, R, O, k, stride, Tin, padL, padR, s_red, s_out, s_k
     dXpad[s,o,u] = sum_{red,kk} W[red,o,kk] * dy[s,red,(u-kk)/stride]  (phase decomposition)."""
     S, _, Tg = dy.shape
     taps_p = -(-k // stride)
-    # strided: rows ordered (channel, phase) so that a tile stores whole runs of consecutive output samples
-    pm = stride > 1
-    wt = K.pack_dgrad_t(w_nat, R=R, O=O, k=k, st=stride, s_red=s_red, s_out=s_out, s_k=s_k, phase_minor=pm)
+    wt = K.pack_dgrad_t(w_nat, R=R, O=O, k=k, st=stride, s_red=s_red, s_out=s_out, s_k=s_k)
     Tp = Tin + padL + padR
     Ncols = -(-Tp // stride)
     dx = _new((S, O, Tp), dy)
     K.conv_gemm(dy, None, dx, wt=wt, S=S, Cin=R, Tin=Tg, M=stride * O, K=R * taps_p, taps=taps_p, Ncols=Ncols, Tout=Tp,
-                stride=1, tapstep=-1, padL=0, pad_mode=K.PAD_ZERO, Cout_store=O, ps=stride, poff=0, ps_minor=pm)
+                stride=1, tapstep=-1, padL=0, pad_mode=K.PAD_ZERO, Cout_store=O, ps=stride, poff=0)
     return dx
 
 
@@ -164,14 +162,13 @@ def deconv_fwd(a: Act, w_nat, bias, *, Cout, k, stride):
     S, Tin = a.S, a.T
     pad = max(0, (stride - k) // -2)
     taps_p = -(-k // stride)
-    pm = stride > 1
-    wt = K.pack_dgrad_t(w_nat, R=a.C, O=Cout, k=k, st=stride, s_red=Cout * k, s_out=k, s_k=1, phase_minor=pm)
+    wt = K.pack_dgrad_t(w_nat, R=a.C, O=Cout, k=k, st=stride, s_red=Cout * k, s_out=k, s_k=1)
     Tout = (Tin - 1) * stride - 2 * pad + k
     y = _new((S, Cout, Tout), a.t)
     K.conv_gemm(a.t, None, y, wt=wt, S=S, Cin=a.C, Tin=Tin, M=stride * Cout, K=a.C * taps_p, taps=taps_p,
                 Ncols=Tin + taps_p - 1, Tout=Tout, bias=bias, in_scale=a.scale, in_shift=a.shift, in_alpha=a.alpha,
                 x_ctot=a.ctot, x_coff=a.coff, stride=1, tapstep=-1, padL=0, pad_mode=K.PAD_ZERO, Cout_store=Cout,
-                ps=stride, poff=-pad, ps_minor=pm)
+                ps=stride, poff=-pad)
     return y
 
 

@@ -31,7 +31,7 @@ class PaseConvGemm(C.Structure):
         ("poff", C.c_int), ("Tout", C.c_int),
         ("epilogue", C.c_int), ("r_ctx", C.c_int), ("label_D", C.c_int),
         ("tile_hint", C.c_int), ("post_op", C.c_int), ("post_scale", C.c_float), ("post_eps", C.c_float),
-        ("splitk", C.c_int), ("ps_minor", C.c_int),
+        ("splitk", C.c_int),
     ]
 
 
@@ -87,8 +87,7 @@ def _conv_desc(x, w, y, *, S, Cin, Tin, M, K, taps, Ncols, Tout, ldw=None, bias=
                x_ctot=None, x_coff=0, tap_major=0, stride=1, tapstep=1, padL=0, pad_mode=PAD_ZERO,
                y_ctot=None, y_coff=0, Cout_store=None, ps=1, poff=0,
                epilogue=EPI_STORE, label=None, grad_out=None, loss_acc=None, grad_scale=0.0,
-               r_ctx=0, label_D=0, tile_hint=0, splitk=0, post_op=0, post_scale=1.0, post_eps=0.0, wt=None,
-               ps_minor=0):
+               r_ctx=0, label_D=0, tile_hint=0, splitk=0, post_op=0, post_scale=1.0, post_eps=0.0, wt=None):
     d = PaseConvGemm()
     if wt is not None:
         d.wt, d.ldwt = _ptr(wt), wt.shape[1]
@@ -110,7 +109,6 @@ def _conv_desc(x, w, y, *, S, Cin, Tin, M, K, taps, Ncols, Tout, ldw=None, bias=
     d.epilogue, d.r_ctx, d.label_D = epilogue, r_ctx, label_D
     d.tile_hint = tile_hint
     d.splitk = splitk
-    d.ps_minor = int(ps_minor)
     return d
 
 
@@ -236,7 +234,7 @@ _SIMPLE.update({
     "pase_sinc_filters": [_fp, _fp, _fp, _fp, _fp, _i, _i, _f, _f, _f, _fp],
     "pase_sinc_filters_bwd": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _f, _f, _f, _fp],
     "pase_pack_dgrad": [_fp, _fp, _i, _i, _i, _i, _l, _l, _l, _fp],
-    "pase_pack_dgrad_t": [_fp, _fp, _i, _i, _i, _i, _l, _l, _l, _i, _i, _fp],
+    "pase_pack_dgrad_t": [_fp, _fp, _i, _i, _i, _i, _l, _l, _l, _i, _fp],
     "pase_chunk_gather": [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _fp],
     "pase_peak_scale": [_fp, _fp, _i, _i, _fp],
     "pase_reverb": [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp],
@@ -398,7 +396,7 @@ def pack_dgrad(src, dst, *, R, O, k, st, s_red, s_out, s_k):
            "pase_pack_dgrad")
 
 
-def pack_dgrad_t(src, *, R, O, k, st, s_red, s_out, s_k, phase_minor=False):
+def pack_dgrad_t(src, *, R, O, k, st, s_red, s_out, s_k):
     """K-major data-gradient / transposed-conv weight pack, ready to be conv_gemm's wt= operand.
     A 1x1 weight stored (R, O) row-major already IS that pack: it is returned as is when aligned."""
     taps_p = -(-k // st)
@@ -407,8 +405,7 @@ def pack_dgrad_t(src, *, R, O, k, st, s_red, s_out, s_k, phase_minor=False):
         return src.view(R, O)
     ldt = (st * O + 3) // 4 * 4
     dst = torch.empty(R * taps_p, ldt, device=src.device, dtype=torch.float32)
-    _check(_lib.lib().pase_pack_dgrad_t(_ptr(src), _ptr(dst), R, O, k, st, s_red, s_out, s_k, ldt, int(phase_minor),
-                                        _stream()),
+    _check(_lib.lib().pase_pack_dgrad_t(_ptr(src), _ptr(dst), R, O, k, st, s_red, s_out, s_k, ldt, _stream()),
            "pase_pack_dgrad_t")
     return dst
 

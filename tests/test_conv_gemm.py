@@ -282,45 +282,3 @@ def test_flat_ws_mse_context_epilogue_wide(dev):
     torch.testing.assert_close(y.cpu(), pred, **_tol(dev))
     torch.testing.assert_close(g.cpu(), (pred - tgt) * gs, rtol=1e-4, atol=1e-5)
     assert abs(float(acc) - float(((pred - tgt).double() ** 2).sum())) < 1e-3 * float(((pred - tgt) ** 2).sum())
-
-
-@pytest.mark.parametrize("Cin,Cout,k,stride,T,S", [
-    (5, 70, 30, 10, 7, 2),       # one ragged column tile per sequence
-    (6, 40, 30, 10, 200, 3),     # 400 rows: RH = 60 (6 channels per half), column tiles straddling sequences
-    (8, 64, 30, 4, 150, 3),      # ps 4: 16 channels per half, odd deconv padding (13)
-    (6, 5, 30, 4, 10, 2),        # narrow tile (20 rows): direct store with (channel, phase) row decode
-])
-def test_conv_transpose_phase_minor_coalesced_store(dev, Cin, Cout, k, stride, T, S):
-    """ConvTranspose1d through the engine's deconv_fwd: rows ordered (channel, phase) by pase_pack_dgrad_t, whole
-    output runs per channel staged through LDS and stored coalesced (wide tiles) / decoded directly (narrow)."""
-    from pase_amd import engine
-    from pase_amd.engine import Act
-    torch.manual_seed(4)
-    x = torch.randn(S, Cin, T)
-    w = torch.randn(Cin, Cout, k) * 0.2
-    b = torch.randn(Cout)
-    al = torch.rand(Cin) * 0.5
-    pad = max(0, (stride - k) // -2)
-    xin = torch.where(x > 0, x, x * al[None, :, None])
-    ref = F.conv_transpose1d(xin, w, b, stride=stride, padding=pad)
-    y = engine.deconv_fwd(Act(x.to(dev), C=Cin, alpha=al.to(dev)), w.to(dev), b.to(dev), Cout=Cout, k=k, stride=stride)
-    assert tuple(y.shape) == tuple(ref.shape)
-    torch.testing.assert_close(y.cpu(), ref, **_tol(dev))
-
-
-@pytest.mark.parametrize("Cin,Cout,k,stride,T", [(64, 20, 20, 10, 640), (24, 70, 11, 2, 300), (12, 16, 30, 4, 64)])
-def test_strided_dgrad_phase_minor(dev, Cin, Cout, k, stride, T):
-    """data-gradient of a strided reflect-padded conv (engine.conv_dgrad) in padded coordinates vs autograd: the
-    block-1 geometry (k 20, stride 10, 64 input channels -> 640 rows), a stride-2 layer and a narrow one."""
-    from pase_amd import engine
-    torch.manual_seed(5)
-    S = 2
-    pL, pR = engine.reflect_pads(k, stride)
-    xp = torch.randn(S, Cin, T + pL + pR, requires_grad=True)          # the PADDED input: gradient w.r.t. it
-    w = torch.randn(Cout, Cin, k) * 0.2
-    yref = F.conv1d(xp, w, stride=stride)
-    g = torch.randn_like(yref)
-    (yref * g).sum().backward()
-    dx = engine.conv_dgrad(g.to(dev), w.to(dev), R=Cout, O=Cin, k=k, stride=stride, Tin=T, padL=pL, padR=pR,
-                           s_red=Cin * k, s_out=k, s_k=1)
-    torch.testing.assert_close(dx.cpu(), xp.grad, rtol=1e-4, atol=1e-4)
