@@ -94,8 +94,9 @@ _ARENA = None          # set by the fused trainer for the duration of a step
 
 
 def _zeros(shape, like, dtype=torch.float32):
-    if (_ARENA is not None and like.is_cuda and like.device == _ARENA.buf.device
-            and torch.cuda.current_stream(like.device) == _ARENA.stream):
+    # (side streams fork from the step's main stream after begin_step's memset and join before the next one, so arena
+    #  views are safe on them too)
+    if _ARENA is not None and like.is_cuda and like.device == _ARENA.buf.device:
         t = _ARENA.take(tuple(shape), dtype)
         if t is not None:
             return t
@@ -172,6 +173,9 @@ def deconv_fwd(a: Act, w_nat, bias, *, Cout, k, stride):
     return y
 
 
+_NBT = None      # BatchNorm counters touched by the encoder forward in flight (one multi-tensor increment)
+
+
 def bn_train(stat, C, count, norm, like):
     """Batch-statistics BatchNorm1d: returns (scale, shift, mean, rstd); updates running stats."""
     scale, shift, mean, rstd = (_new((C,), like) for _ in range(4))
@@ -184,7 +188,10 @@ def bn_train(stat, C, count, norm, like):
     K.bn_finalize(stat, C, count, gamma, beta, norm.eps, mom, norm.running_mean, norm.running_var, scale, shift,
                   mean, rstd)
     if norm.num_batches_tracked is not None:
-        norm.num_batches_tracked.add_(1)
+        if _NBT is not None:
+            _NBT.append(norm.num_batches_tracked)      # committed together at the end of encoder_forward
+        else:
+            norm.num_batches_tracked.add_(1)
     return scale, shift, mean, rstd
 
 
@@ -299,6 +306,15 @@ class GradSink:
     def add(self, p, value):
         self.buf(p).add_(value.reshape(p.shape))
 
+    def add_many(self, pairs):
+        """param.grad += value for several (param, value) pairs in ONE multi-tensor launch."""
+        dst = [self.buf(p) for p, _ in pairs]
+        src = [v.reshape(p.shape) for p, v in pairs]
+        if len(dst) == 1:
+            dst[0].add_(src[0])
+        elif dst:
+            torch._foreach_add_(dst, src)
+
     def get(self, p):
         return self.store.get(p)
 
@@ -320,6 +336,17 @@ def encoder_forward(fe, x, training, need_ctx=True):
     assert x.dim() == 3 and x.shape[1] == fe.num_inputs, x.shape
     x = x.contiguous()
     S = x.shape[0]
+    global _NBT
+    _NBT = []
+    try:
+        return _encoder_forward(fe, x, training, S)
+    finally:
+        if _NBT:
+            torch._foreach_add_(_NBT, 1)
+        _NBT = None
+
+
+def _encoder_forward(fe, x, training, S):
     ctx = EncoderCtx()
     ctx.x = x
     ctx.training = bool(training)
@@ -474,13 +501,14 @@ def encoder_backward(fe, ctx, demb, sink, want_dx=False, on_ready=None):
     dwcat = _zeros((emb, ccat), x)
     conv_wgrad(dyemb, ain, dwcat, sink.buf(fe.W.bias), taps=1)
     cw = fe.W.in_channels
-    sink.add(fe.W.weight, dwcat[:, :cw].contiguous())
+    pairs = [(fe.W.weight, dwcat[:, :cw])]
     if fe.denseskips_on:
         off = cw
         for p in fe.denseskips:
             c = p.weight.shape[1]
-            sink.add(p.weight, dwcat[:, off:off + c].contiguous())
+            pairs.append((p.weight, dwcat[:, off:off + c]))
             off += c
+    sink.add_many(pairs)
     dacat = conv_dgrad(dyemb, ctx.wcat, R=emb, O=ccat, k=1, stride=1, Tin=F_, padL=0, padR=0, s_red=ccat, s_out=1,
                        s_k=1)  # (S, ccat, F)
     # gradient w.r.t. the last block's activation
@@ -810,7 +838,6 @@ def mlp_group_step(workers, a: Act, targets, sink, accs=None):
     # stacked first layer: one wgrad, one dgrad
     dw1 = _zeros((htot, cin), x)
     conv_wgrad(dz_all, a, dw1, None, taps=1)
-    for w, h, off in zip(workers, hs, offs):
-        sink.add(w.blocks[0].W.weight, dw1[off:off + h])
+    sink.add_many([(w.blocks[0].W.weight, dw1[off:off + h]) for w, h, off in zip(workers, hs, offs)])
     dx = conv_dgrad(dz_all, w1cat, R=htot, O=cin, k=1, stride=1, Tin=F_, padL=0, padR=0, s_red=cin, s_out=1, s_k=1)
     return out, dx

@@ -95,12 +95,13 @@ class FusedAdam(object):
     def zero_grad(self, set_to_none=False):
         self.flat_g.zero_()
 
-    def step(self, grad_mul=1.0):
+    def step(self, grad_mul=1.0, tick=True):
         lr = float(self.param_groups[0]["lr"])
         if lr != self._lr_host:
             self.lr_t.fill_(lr)
             self._lr_host = lr
-        K.step_tick(self.step_t)
+        if tick:                       # (the trainer advances all 13 step counters in one multi-tensor launch)
+            K.step_tick(self.step_t)
         K.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.lr_t, self.step_t,
                     beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, grad_mul=grad_mul)
 
@@ -264,8 +265,7 @@ class trainer(object):
                 losses = self._step_ddp(batch, sink, device)
             else:
                 losses = self.model.loss_and_grads(batch, sink, device)
-                for opt in self.optimizers():
-                    opt.step()
+                self._step_all(1.0)
         finally:
             engine._ARENA = None
         return losses
@@ -339,10 +339,14 @@ class trainer(object):
             on_encoder_grads=lambda tag: launch([fg[b:e] for b, e in buckets.get(tag, [])]))
         if use_side:
             torch.cuda.current_stream().wait_stream(side)
-        inv = 1.0 / self.world
-        for opt in self.optimizers():
-            opt.step(grad_mul=inv)
+        self._step_all(1.0 / self.world)
         return losses
+
+    def _step_all(self, grad_mul):
+        opts = self.optimizers()
+        torch._foreach_add_([o.step_t for o in opts], 1)
+        for opt in opts:
+            opt.step(grad_mul=grad_mul, tick=False)
 
     def adjust_lr(self, bidx, epoch, losses=None):
         """trainer.py:245-254 (called every log_freq iterations in the reference)."""
