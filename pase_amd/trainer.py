@@ -392,14 +392,31 @@ class trainer(object):
     def train_(self, dataloader, valid_dataloader=None, device=None):
         """Epoch loop of trainer.py:200-278 without the tqdm / tensorboard / aux-supervisor side
         channels (out of scope)."""
+        state = {"it": iter(dataloader)}
+
+        def host_batch():
+            try:
+                return next(state["it"])
+            except StopIteration:
+                state["it"] = iter(dataloader)
+                return next(state["it"])
+
+        first = host_batch()
+        dev = torch.device(device) if device is not None else next(self.model.parameters()).device
+        feeder = None
+        if dev.type == "cuda" and any(torch.is_tensor(v) and not v.is_cuda for v in first.values()):
+            # host-side dataloader: copies run on a copy stream one step ahead (pinned ring, double-buffered slots)
+            from .producer import PinnedBatchFeeder
+            pending = [first]
+            feeder = PinnedBatchFeeder(lambda: pending.pop() if pending else host_batch(), dev)
         for e in range(self.epoch_beg, self.epoch):
-            iterator = iter(dataloader)
             for bidx in range(1, self.bpe + 1):
-                try:
-                    batch = next(iterator)
-                except StopIteration:
-                    iterator = iter(dataloader)
-                    batch = next(iterator)
+                if feeder is not None:
+                    batch = feeder.next()
+                elif first is not None:
+                    batch, first = first, None
+                else:
+                    batch = host_batch()
                 losses = self.train_step(batch, device)
                 if bidx % self.log_freq == 0 or bidx >= self.bpe:
                     lrs = self.adjust_lr(bidx, e, losses)

@@ -311,3 +311,24 @@ def test_fused_step_config5_shaped_lnorm_2xqrnn(dev):
             continue
         ref = P[n].grad
         assert_close(p.grad, ref, rtol=1e-3, atol=1e-4 * max(1e-2, float(ref.abs().max())), what=n)
+
+
+def test_trainer_epoch_loop_checkpoints_and_resume(dev, tmp_path):
+    """trainer.train_ (trainer.py:200-278): epoch loop over a host-side loader (on the GPU the batches travel through
+    the pinned feeder), poly LR at the log points, FE_e{e}.ckpt + Saver checkpoints per epoch, resume_training."""
+    from pase_amd.trainer import trainer
+    seed_all(3)
+    cfg = dict(fe_lr=1e-3, min_lr=5e-4, epoch=2, bpe=2, log_freq=1, save_path=str(tmp_path / "ck"))
+    tr = quiet(trainer, frontend_cfg=dict(MINI_FE), minions_cfg=with_losses(mini_workers()), cfg=cfg, lr_mode="poly",
+               device=dev)
+    loader = [_mini_batch(seed=20 + i) for i in range(3)]          # shorter than epoch * bpe: the iterator restarts
+    w0 = tr.model.frontend.W.weight.detach().clone()
+    quiet(tr.train_, loader, device=dev)
+    assert not torch.equal(w0, tr.model.frontend.W.weight.detach())
+    assert os.path.exists(os.path.join(cfg["save_path"], "FE_e1.ckpt"))
+    assert int(tr.frontend_optim.step_t.item()) == 4
+    tr2 = quiet(trainer, frontend_cfg=dict(MINI_FE), minions_cfg=with_losses(mini_workers()), cfg=cfg, lr_mode="poly",
+                device=dev)
+    assert quiet(tr2.resume_training, dev) and tr2.epoch_beg == 2
+    for (n, p), (_, q) in zip(tr.model.named_parameters(), tr2.model.named_parameters()):
+        assert torch.equal(p.detach().cpu(), q.detach().cpu()), n

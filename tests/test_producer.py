@@ -238,3 +238,32 @@ def test_live_reference_dictcollater_layout(dev):
         assert tuple(batch[k].shape) == g["collate_" + k].shape
     # (the reference collates `overlap` as (B, 1, F); the label is consumed as (B, F) by the overlap worker's loss here)
     assert tuple(batch["overlap"].shape) == (3, g["collate_overlap"].shape[2])
+
+
+@pytest.mark.gpu
+def test_pinned_batch_feeder_delivers_every_batch_intact():
+    """Host -> HBM leg (the asynchronous form of the reference's `.to(device)`, modules.py:16-31 / pase.py:338): 12
+    distinct host batches (pinned and pageable sources mixed) through the double-buffered copy stream, each consumed by
+    a kernel on the compute stream while the next copy is in flight; every delivered batch must equal its source."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    src = []
+    for i in range(12):
+        b = {"chunk": torch.randn(8, 1, 32000, generator=g), "lps": torch.randn(8, 3075, 200, generator=g)}
+        if i % 2 == 0:
+            b = {k: v.pin_memory() for k, v in b.items()}
+        src.append(b)
+    it = iter(src)
+    feeder = P.PinnedBatchFeeder(lambda: next(it, src[-1]), dev, depth=2)
+    sums = []
+    for i in range(11):
+        d = feeder.next()
+        # some work on the compute stream that reads the slot while the following copy runs
+        sums.append((d["chunk"].double().sum() + d["lps"].double().sum()).clone())
+        y = d["lps"] @ d["lps"].transpose(1, 2)          # keep the compute stream busy
+        del y
+    torch.cuda.synchronize()
+    for i, s in enumerate(sums):
+        want = src[i]["chunk"].double().sum() + src[i]["lps"].double().sum()
+        assert abs(float(s) - float(want)) <= 1e-6 * abs(float(want)) + 1e-6, i
+    assert feeder.bytes_per_batch == 8 * 32000 * 4 + 8 * 3075 * 200 * 4
