@@ -417,12 +417,17 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
         // loop competes directly with MFMA issue (tools/mfma_probe: -15 % for a 10-instruction walk).
         if (XV && kg == KG_T) {
             // ---- flat 1x1, full 32-row stage: the K order is simply rows (2 ks + fk), so every LDS offset is an
-            // immediate and the 8 x (2 k-steps) loop is fully unrolled.  The NEXT stage's global loads are issued
-            // one or two at a time behind the MFMAs of the first half of this loop instead of in one burst before it:
-            // a single-round split-K launch (the K = 21 525 data-gradients) runs all its workgroups phase-locked, and
-            // 500 simultaneous 32 KB bursts queue at the L2 while the memory system idles during the MFMA phases.
+            // immediate and the 8 x (2 k-steps) loop is fully unrolled (no address VALU, static waitcnt pattern).
             constexpr int NIT = KG_T / 4;
-            constexpr int PER_IT = (NPIECE + NIT / 2 - 1) / (NIT / 2);
+            // the whole next stage is issued behind the first iteration's MFMAs (measured, tools/ab_flat_burst.py:
+            // spreading the eight loads over the first half of the loop instead is 3-10 % SLOWER: 97 vs 108 TFLOP/s on
+            // K = 21 525, 99 vs 104 on the K = 256 heads; -DPASE_FLAT_SPREAD rebuilds that variant)
+#ifdef PASE_FLAT_SPREAD
+            constexpr int SPREAD_ITS = NIT / 2;
+#else
+            constexpr int SPREAD_ITS = 1;
+#endif
+            constexpr int PER_IT = (NPIECE + SPREAD_ITS - 1) / SPREAD_ITS;
             const float* aL = &As[cur][fk][wm * 64 + fr];
             const float* x0L = &XsG[cur][4 + fk * BN + xc0];
             const float* x1L = &XsG[cur][4 + fk * BN + xc1];
@@ -446,7 +451,7 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
                 acc[1][0] = pase_mfma_32x32x2(qa1, qb0, acc[1][0]);
                 acc[1][1] = pase_mfma_32x32x2(qa1, qb1, acc[1][1]);
                 PASE_SCHED_BARRIER();
-                if constexpr (it < NIT / 2) {
+                if constexpr (it < SPREAD_ITS) {
                     if (has_next) {
                         load_pieces(std::integral_constant<int, it * PER_IT>{}, std::integral_constant<int, PER_IT>{});
                         PASE_SCHED_BARRIER();
