@@ -406,7 +406,11 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
     for (int g = g_begin; g < g_end; ++g) {
         const int cur = (g - g_begin) & 1;
         PASE_TACC_BEGIN();
+#ifndef PASE_FLAT_GENERIC
         const bool spread_loads = XV && kg == KG_T;               // uniform: flat full stage issues them inside the loop
+#else
+        const bool spread_loads = false;
+#endif
         if (g + 1 < g_end && !spread_loads) load_stage();   // global loads in flight under the MFMAs
         PASE_TACC(0);
         // K order inside a stage.  An MFMA step consumes two flat k values (fk = 0 / 1).  With two or more
@@ -415,13 +419,14 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
         // LDS offsets of a step are [per-lane constant] + [uniform scalar walk]: the walk is SALU only and
         // the per-step VALU work is the three address adds of the ds_reads -- index arithmetic in this
         // loop competes directly with MFMA issue (tools/mfma_probe: -15 % for a 10-instruction walk).
+#ifndef PASE_FLAT_GENERIC      // (-DPASE_FLAT_GENERIC: A/B build that keeps the flat path on the generic stage loop below)
         if (XV && kg == KG_T) {
             // ---- flat 1x1, full 32-row stage: the K order is simply rows (2 ks + fk), so every LDS offset is an
             // immediate and the 8 x (2 k-steps) loop is fully unrolled (no address VALU, static waitcnt pattern).
             constexpr int NIT = KG_T / 4;
-            // the whole next stage is issued behind the first iteration's MFMAs (measured, tools/ab_flat_burst.py:
-            // spreading the eight loads over the first half of the loop instead is 3-10 % SLOWER: 97 vs 108 TFLOP/s on
-            // K = 21 525, 99 vs 104 on the K = 256 heads; -DPASE_FLAT_SPREAD rebuilds that variant)
+            // the whole next stage is issued behind the first iteration's MFMAs.  tools/ab_flat_loads.py (A/B builds
+            // -DPASE_FLAT_SPREAD: the eight loads spread over the first half of the loop; -DPASE_FLAT_GENERIC: the
+            // generic stage loop below): no measurable difference between the three (104-105 TFLOP/s on K = 21 525).
 #ifdef PASE_FLAT_SPREAD
             constexpr int SPREAD_ITS = NIT / 2;
 #else
@@ -469,6 +474,7 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
             PASE_TACC(3);
             continue;
         }
+#endif
         const int ts = p.tapstep;
         const bool pair_rows = pl.CB > 1;                       // uniform
         const int nks = pair_rows ? (kg >> 1) : ((tbe + 1) >> 1);

@@ -9,12 +9,14 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 SO = os.path.join(ROOT, "tools", "_trace", "libpase_flat_spread.so")
+SO_GEN = os.path.join(ROOT, "tools", "_trace", "libpase_flat_generic.so")
 if sys.argv[1:] == ["build"]:
     from pase_amd import build as B
     os.makedirs(os.path.dirname(SO), exist_ok=True)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                           "-DPASE_FLAT_SPREAD", "-I", B.INCLUDE, "-I", B.CSRC, "-Wno-unused-result", "-o", SO] + B._sources())
-    print(SO)
+    for so, d in ((SO, "-DPASE_FLAT_SPREAD"), (SO_GEN, "-DPASE_FLAT_GENERIC")):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                               d, "-I", B.INCLUDE, "-I", B.CSRC, "-Wno-unused-result", "-o", so] + B._sources())
+        print(so)
     sys.exit(0)
 import torch  # noqa: E402
 from pase_amd import _lib  # noqa: E402
@@ -45,7 +47,11 @@ def run(tag):
         print("%-8s %-20s %.3f ms  %.1f TFLOP/s" % (tag, name, ms, 2.0 * S * T * M * Kd / ms / 1e9), flush=True)
 
 
+# (the first library timed in a process runs ~8 % slower than the following ones whatever it is -- clocks / first touch:
+#  one untimed pass first, then two interleaved rounds)
 _lib.use_library(None, "cuda")
-run("burst")
-_lib.use_library(SO, "cuda")
-run("spread")
+run("warm-up")
+for _ in range(2):
+    for tag, so in (("burst", None), ("spread", SO), ("generic", SO_GEN)):
+        _lib.use_library(so, "cuda")
+        run(tag)
