@@ -125,11 +125,6 @@ def conv_fwd(a: Act, w2d, bias, *, Cout, taps, stride=1, padL=0, padR=0, pad_mod
         Tout = (Tin + padL + padR - taps) // stride + 1
     y = out if out is not None else _new((S, Cout, Tout), a.t)
     stat = None
-    if fuse is not None and K.conv_gemm_would_split(
-            a.t, y, S=S, Cin=a.C, Tin=Tin, M=Cout, K=a.C * taps, taps=taps, Ncols=Tout, Tout=Tout, x_ctot=a.ctot,
-            x_coff=a.coff, stride=stride, tapstep=tapstep, padL=padL, pad_mode=pad_mode, y_ctot=y.shape[1],
-            Cout_store=Cout) > 1:
-        fuse = None      # the launch wants split-K (few tiles, long reduction): a non-linear epilogue cannot be split
     if want_stats or fuse is not None:
         stat = _new((K.stat_tiles(M=Cout, S=S, Ncols=Tout, Cin=a.C, taps=taps, stride=stride, padL=padL,
                                   tapstep=tapstep), Cout, 2), a.t)

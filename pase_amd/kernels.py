@@ -172,13 +172,6 @@ def pack_wt(w, *, M, K, Cin, taps, ldw=None, tap_major=0):
     return wt
 
 
-def conv_gemm_would_split(x, y, **kw):
-    """split-K factor pase_conv_gemm's plan would pick for this launch (1 = none)."""
-    d = _conv_desc(x, None, y, **kw)          # only the shape fields and the alignment of x matter to the plan
-    d.ldwt = (d.M + 3) // 4 * 4
-    return _lib.lib().pase_conv_gemm_splitk(C.byref(d))
-
-
 def conv_gemm(x, w, y, **kw):
     """see include/pase_amd.h PaseConvGemm.  With splitk > 1 the output is zero-filled here first.
     The kernel reads the K-major pack of the weight: pass it as wt= (e.g. straight from pack_dgrad, or a
