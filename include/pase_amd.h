@@ -66,14 +66,6 @@ typedef struct PaseConvGemm {
     const float* label;    /* EPI_MSE_CTX: (S, label_D, Ncols) target                             */
     float* grad_out;       /* EPI_MSE_CTX: (S, M, Ncols) d(loss)/d(pred) = (pred-tgt)*grad_scale, or NULL */
     double* loss_acc;      /* EPI_MSE_CTX: += sum (pred-tgt)^2  (caller zeroes)                   */
-    const float* fuse_z;   /* EPI_STORE, fused PReLU backward: the launch computes a data-gradient dA w.r.t. the
-                              ACTIVATION a = PReLU(z) of the layer below; with fuse_z = that layer's raw output z
-                              (S, M, Tout; same layout as y) and fuse_alpha = its slopes (M) the epilogue stores
-                              dz = dA * prelu'(z) instead, and stat_part receives per tile and row
-                              (sum dz, sum dA * z * [z <= 0]) = the bias and slope gradients of that layer
-                              (pase_stat_commit adds them up).  Needs ps == 1, splitk == 1, y_coff == 0,
-                              y_ctot == M, no post-op.  NULL = plain store.                              */
-    const float* fuse_alpha;
     float grad_scale;
     int S, Cin, Tin, x_ctot, x_coff;
     int M, K, ldw, ldwt, taps, tap_major;
@@ -232,9 +224,6 @@ int pase_sinc_filters_bwd(const float* low_hz_, const float* band_hz_, const flo
  * AccumulateGrad does for those parameters in the reference) */
 int pase_commit_cols(const double* sums, int ld, int C, float* g0, int c0, float* g1, int c1, float* g2, int c2,
                      void* stream);
-/* g0[c] += sum_t stat_part[t, c, 0], g1[c] += sum_t stat_part[t, c, 1] (either may be NULL): folds the per-tile
- * partials of a pase_conv_gemm launch with fuse_z into the bias / PReLU-slope gradient buffers. */
-int pase_stat_commit(const float* stat_part, int ntiles, int C, float* g0, float* g1, void* stream);
 int pase_pack_dgrad(const float* src, float* dst, int R, int O, int k, int st, long s_red, long s_out, long s_k,
                     void* stream);
 /* same pack written K-major for pase_conv_gemm's `wt` operand: dst ((R*ceil(k/st)), ldt),

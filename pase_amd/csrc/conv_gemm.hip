@@ -638,19 +638,6 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
                         if (FAST || m < p.M) bvs[r] = biasp[co];
                     }
                 }
-                // fused PReLU backward (fuse_z): the block's 32 z values first, like the bias (loads ahead of the stores)
-                float zv[16][2];
-                if (p.fuse_z) {   // uniform
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = rbase + a * 32 + (r & 3) + 8 * (r >> 2);
-#pragma unroll
-                        for (int b = 0; b < 2; ++b) {
-                            zv[r][b] = 1.f;
-                            if (FAST || (m < p.M && colok[b])) zv[r][b] = p.fuse_z[(unsigned)(cbase[b] + m * p.Tout)];
-                        }
-                    }
-                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = rbase + a * 32 + (r & 3) + 8 * (r >> 2);
@@ -662,7 +649,6 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
                     }
                     const float bv = bvs[r];
                     const int rowoff = co * p.Tout + ph;
-                    const float fal = (p.fuse_z && mok) ? p.fuse_alpha[m] : 1.f;
                     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
@@ -673,19 +659,10 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
                         const bool ok = FAST || (mok && colok[b] && (!pshuf || (unsigned)(posb[b] + ph) < (unsigned)p.Tout));
                         if (ok) {
                             float* dst = p.y + (unsigned)(cbase[b] + rowoff);
-                            if (p.fuse_z) {   // v is dA: store dz = dA * prelu'(z); partials = (sum dz, sum dA z [z <= 0])
-                                const float zr = zv[r][b];
-                                const bool pos = zr > 0.f;
-                                const float dz = pos ? v : v * fal;
-                                *dst = dz;
-                                s1 += dz;
-                                if (!pos) s2 = fmaf(v, zr, s2);
-                            } else {
-                                if (ATOMIC) atomicAdd(dst, v);
-                                else *dst = v;
-                                s1 += v;
-                                s2 += v * v;
-                            }
+                            if (ATOMIC) atomicAdd(dst, v);
+                            else *dst = v;
+                            s1 += v;
+                            s2 += v * v;
                         }
                     }
                     if (!ATOMIC && p.stat_part) {   // uniform branch
@@ -962,9 +939,6 @@ extern "C" int pase_conv_gemm(const PaseConvGemm* d, void* stream) {
     const HostPlan h = make_plan(p);
     if (h.pl.CB < 1) return -6;
     if (h.pl.splitk > 1 && (p.stat_part || p.epilogue != PASE_EPI_STORE || p.post_op != PASE_POST_NONE)) return -7;
-    if (p.fuse_z && (!p.fuse_alpha || !p.stat_part || p.epilogue != PASE_EPI_STORE || p.post_op != PASE_POST_NONE ||
-                     p.ps != 1 || p.poff != 0 || p.y_coff != 0 || p.y_ctot != p.M || p.Cout_store != p.M ||
-                     p.Tout != p.Ncols)) return -11;
     if ((p.post_op == PASE_POST_POW || p.post_op == PASE_POST_LOGPOW || p.post_op == PASE_POST_MAG) &&
         (p.ps != 1 || p.stat_part || (p.M & 1))) return -9;
     // 32-bit element offsets in the loader and the epilogue

@@ -282,30 +282,6 @@ __global__ void __launch_bounds__(NT) commit_cols_kernel(const double* sums, int
     if (g2) g2[c] += (float)row[c2];
 }
 
-// Fold the per-tile partials of a fused-PReLU-backward conv_gemm launch: g0[c] += sum_t part[t, c, 0] (bias gradient
-// = sum dz), g1[c] += sum_t part[t, c, 1] (slope gradient).  One block per channel, fp64 accumulation.
-__global__ void __launch_bounds__(NT) stat_commit_kernel(const float* part, int ntiles, int C, float* g0, float* g1) {
-    __shared__ double sh0[NT / 64], sh1[NT / 64];
-    const int c = blockIdx.x;
-    double a0 = 0.0, a1 = 0.0;
-    for (int t = threadIdx.x; t < ntiles; t += NT) {
-        const float* q = part + ((size_t)t * C + c) * 2;
-        a0 += (double)q[0];
-        a1 += (double)q[1];
-    }
-    a0 = pase_wave_sum64d(a0);
-    a1 = pase_wave_sum64d(a1);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { sh0[wave] = a0; sh1[wave] = a1; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t0 = 0.0, t1 = 0.0;
-        for (int w = 0; w < NT / 64; ++w) { t0 += sh0[w]; t1 += sh1[w]; }
-        if (g0) g0[c] += (float)t0;
-        if (g1) g1[c] += (float)t1;
-    }
-}
-
 // ---- Adam (torch.optim.Adam defaults; WorkerScheduler/trainer.py:91,111,134) ----------------------
 // One launch per logical optimizer over its flat parameter / gradient / moment buffers.  `step` and
 // `lr` live in device memory so a captured hipGraph replays correctly as they change.
@@ -425,13 +401,6 @@ extern "C" int pase_commit_cols(const double* sums, int ld, int C, float* g0, in
     if (C <= 0) return 0;
     PASE_LAUNCH(commit_cols_kernel, dim3((unsigned)((C + NT - 1) / NT)), dim3(NT), (hipStream_t)stream, sums, ld, C, g0,
                 c0, g1, c1, g2, c2);
-    PASE_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int pase_stat_commit(const float* stat_part, int ntiles, int C, float* g0, float* g1, void* stream) {
-    if (C <= 0 || ntiles <= 0) return 0;
-    PASE_LAUNCH(stat_commit_kernel, dim3((unsigned)C), dim3(NT), (hipStream_t)stream, stat_part, ntiles, C, g0, g1);
     PASE_CHECK_LAUNCH();
     return 0;
 }

@@ -116,40 +116,27 @@ def reflect_pads(k, stride):
 
 
 def conv_fwd(a: Act, w2d, bias, *, Cout, taps, stride=1, padL=0, padR=0, pad_mode=K.PAD_ZERO, want_stats=False,
-             tap_major=0, tapstep=1, out=None, out_coff=0, Tout=None, fuse=None):
-    """y[s,co,t] = b + sum w[co,(ci,kk)] * a~[s,ci,t*stride + kk*tapstep - padL].
-    fuse = (z, alpha): the result is a data-gradient w.r.t. PReLU(z); store dz = y * prelu'(z) instead and return the
-    per-tile (sum dz, sum y z [z <= 0]) partials as `stat` (PaseConvGemm.fuse_z)."""
+             tap_major=0, tapstep=1, out=None, out_coff=0, Tout=None):
+    """y[s,co,t] = b + sum w[co,(ci,kk)] * a~[s,ci,t*stride + kk*tapstep - padL]."""
     S, Tin = a.S, a.T
     if Tout is None:
         Tout = (Tin + padL + padR - taps) // stride + 1
     y = out if out is not None else _new((S, Cout, Tout), a.t)
     stat = None
-    if want_stats or fuse is not None:
+    if want_stats:
         stat = _new((K.stat_tiles(M=Cout, S=S, Ncols=Tout, Cin=a.C, taps=taps, stride=stride, padL=padL,
                                   tapstep=tapstep), Cout, 2), a.t)
     K.conv_gemm(a.t, w2d, y, S=S, Cin=a.C, Tin=Tin, M=Cout, K=a.C * taps, taps=taps, Ncols=Tout, Tout=Tout,
                 ldw=w2d.shape[1], bias=bias, in_scale=a.scale, in_shift=a.shift, in_alpha=a.alpha, stat_part=stat,
                 x_ctot=a.ctot, x_coff=a.coff, tap_major=tap_major, stride=stride, tapstep=tapstep, padL=padL,
-                pad_mode=pad_mode, y_ctot=y.shape[1], y_coff=out_coff, Cout_store=Cout,
-                fuse_z=None if fuse is None else fuse[0], fuse_alpha=None if fuse is None else fuse[1])
+                pad_mode=pad_mode, y_ctot=y.shape[1], y_coff=out_coff, Cout_store=Cout)
     return y, stat
 
 
-def conv_dgrad(dy, w_nat, *, R, O, k, stride, Tin, padL, padR, s_red, s_out, s_k, fuse=None):
+def conv_dgrad(dy, w_nat, *, R, O, k, stride, Tin, padL, padR, s_red, s_out, s_k):
     """Data-gradient of a (strided) conv in *padded* coordinates: (S, O, Tin+padL+padR).
-    dXpad[s,o,u] = sum_{red,kk} W[red,o,kk] * dy[s,red,(u-kk)/stride]  (phase decomposition).
-    fuse = (z, alpha) (1x1, unpadded only): returns (dz, stat) like conv_fwd(fuse=...)."""
+    dXpad[s,o,u] = sum_{red,kk} W[red,o,kk] * dy[s,red,(u-kk)/stride]  (phase decomposition)."""
     S, _, Tg = dy.shape
-    if fuse is not None:
-        assert k == 1 and stride == 1 and padL == 0 and padR == 0
-        wt = K.pack_dgrad_t(w_nat, R=R, O=O, k=1, st=1, s_red=s_red, s_out=s_out, s_k=s_k)
-        dx = _new((S, O, Tin), dy)
-        stat = _new((K.stat_tiles(M=O, S=S, Ncols=Tin, Cin=R, taps=1), O, 2), dy)
-        K.conv_gemm(dy, None, dx, wt=wt, S=S, Cin=R, Tin=Tg, M=O, K=R, taps=1, Ncols=Tin, Tout=Tin, stride=1,
-                    tapstep=-1, padL=0, pad_mode=K.PAD_ZERO, Cout_store=O, ps=1, poff=0, stat_part=stat,
-                    fuse_z=fuse[0], fuse_alpha=fuse[1])
-        return dx, stat
     taps_p = -(-k // stride)
     wt = K.pack_dgrad_t(w_nat, R=R, O=O, k=k, st=stride, s_red=s_red, s_out=s_out, s_k=s_k)
     Tp = Tin + padL + padR
@@ -737,10 +724,7 @@ def worker_backward(layers, out_conv, ctx, dpred, sink, need_dinput=True):
         dsrc = GradSrc(conv_dgrad(dpred, out_conv.weight, R=nout, O=cur.C, k=1, stride=1, Tin=T, padL=0, padR=0,
                                   s_red=cur.C, s_out=1, s_k=1), ctot=cur.C, Tp=T)
         have_dz = False
-    recs = ctx.recs
-    committed = False          # the PReLU-slope / bias gradients of the current layer came out of a fused epilogue
-    for ri in reversed(range(len(recs))):
-        kind, blk, inp, z = recs[ri]
+    for kind, blk, inp, z in reversed(ctx.recs):
         C, Tz = z.shape[1], z.shape[2]
         if not have_dz:
             dz, sums = act_backward(z, C=C, T=Tz, S=B, has_bn=False, alpha=blk.act.weight, dsrc=dsrc.t,
@@ -748,18 +732,8 @@ def worker_backward(layers, out_conv, ctx, dpred, sink, need_dinput=True):
                                     pad_mode=dsrc.pad_mode)
             psums, pcols = sums, (2, 0)
         have_dz = False
-        if not committed:
-            # PReLU slope gradient + the bias gradient (= sum dz) of this layer's conv, one launch
-            sink.add_cols(psums, 3, C, [(blk.act.weight, pcols[0]),
-                                        ((blk.deconv if kind == "deconv" else blk.W).bias, pcols[1])])
-        committed = False
-        # The data-gradient this layer hands down is the gradient w.r.t. PReLU(z_below) of the layer below.  When that
-        # layer is a plain PReLU layer on an unpadded grid, the producing conv_gemm applies prelu'(z_below) in its
-        # epilogue and emits the slope / bias partials: no separate pass over the (up to 131 M-element) tensor.
-        below = recs[ri - 1] if ri > 0 else None
-        fuse = None
-        if below is not None and inp.t is below[3] and inp.scale is None and inp.coff == 0 and inp.ctot == inp.C:
-            fuse = (below[3], below[1].act.weight)
+        # PReLU slope gradient + the bias gradient (= sum dz) of this layer's conv, one launch
+        sink.add_cols(psums, 3, C, [(blk.act.weight, pcols[0]), ((blk.deconv if kind == "deconv" else blk.W).bias, pcols[1])])
         if kind == "deconv":
             dc = blk.deconv
             k, st = blk.kwidth, blk.stride
@@ -773,30 +747,18 @@ def worker_backward(layers, out_conv, ctx, dpred, sink, need_dinput=True):
                          pad_mode=K.PAD_ZERO, g_alpha=inp.alpha)
             last = blk is layers[0]
             if need_dinput or not last:
-                din, stat = conv_fwd(Act(dz, C=C), dc.weight.view(cin, -1), None, Cout=cin, taps=k, stride=st, padL=pad,
-                                     padR=pad, pad_mode=K.PAD_ZERO, Tout=inp.T, fuse=fuse)
+                din, _ = conv_fwd(Act(dz, C=C), dc.weight.view(cin, -1), None, Cout=cin, taps=k, stride=st, padL=pad,
+                                  padR=pad, pad_mode=K.PAD_ZERO, Tout=inp.T)
                 dsrc = GradSrc(din, ctot=cin, Tp=inp.T)
         else:
             k = blk.context
             cin = inp.C
             conv_wgrad(dz, inp, sink.buf(blk.W.weight).view(C, -1), None, taps=k, padL=k // 2, pad_mode=K.PAD_ZERO)
             last = blk is layers[0]
-            stat = None
             if need_dinput or not last:
-                if fuse is not None and k == 1:
-                    din, stat = conv_dgrad(dz, blk.W.weight, R=C, O=cin, k=1, stride=1, Tin=inp.T, padL=0, padR=0,
-                                           s_red=cin, s_out=1, s_k=1, fuse=fuse)
-                    dsrc = GradSrc(din, ctot=cin, Tp=inp.T)
-                else:
-                    fuse = None
-                    din = conv_dgrad(dz, blk.W.weight, R=C, O=cin, k=k, stride=1, Tin=inp.T, padL=k // 2, padR=k // 2,
-                                     s_red=cin * k, s_out=k, s_k=1)
-                    dsrc = GradSrc(din, ctot=cin, Tp=din.shape[2], padL=k // 2)
-        if fuse is not None and stat is not None and (need_dinput or not last):
-            bl_kind, bl_blk = below[0], below[1]
-            K.stat_commit(stat, cin, sink.buf((bl_blk.deconv if bl_kind == "deconv" else bl_blk.W).bias),
-                          sink.buf(bl_blk.act.weight))
-            dz, have_dz, committed = din, True, True
+                din = conv_dgrad(dz, blk.W.weight, R=C, O=cin, k=k, stride=1, Tin=inp.T, padL=k // 2, padR=k // 2,
+                                 s_red=cin * k, s_out=k, s_k=1)
+                dsrc = GradSrc(din, ctot=cin, Tp=din.shape[2], padL=k // 2)
     if len(ctx.recs) == 0 and ctx.head1:
         raise NotImplementedError("1-output worker without hidden layers")
     return dsrc if need_dinput else None

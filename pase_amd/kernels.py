@@ -21,7 +21,6 @@ class PaseConvGemm(C.Structure):
         ("x", _fp), ("w", _fp), ("wt", _fp), ("y", _fp), ("bias", _fp),
         ("in_scale", _fp), ("in_shift", _fp), ("in_alpha", _fp),
         ("stat_part", _fp), ("label", _fp), ("grad_out", _fp), ("loss_acc", _fp),
-        ("fuse_z", _fp), ("fuse_alpha", _fp),
         ("grad_scale", C.c_float),
         ("S", C.c_int), ("Cin", C.c_int), ("Tin", C.c_int), ("x_ctot", C.c_int), ("x_coff", C.c_int),
         ("M", C.c_int), ("K", C.c_int), ("ldw", C.c_int), ("ldwt", C.c_int), ("taps", C.c_int),
@@ -88,8 +87,7 @@ def _conv_desc(x, w, y, *, S, Cin, Tin, M, K, taps, Ncols, Tout, ldw=None, bias=
                x_ctot=None, x_coff=0, tap_major=0, stride=1, tapstep=1, padL=0, pad_mode=PAD_ZERO,
                y_ctot=None, y_coff=0, Cout_store=None, ps=1, poff=0,
                epilogue=EPI_STORE, label=None, grad_out=None, loss_acc=None, grad_scale=0.0,
-               r_ctx=0, label_D=0, tile_hint=0, splitk=0, post_op=0, post_scale=1.0, post_eps=0.0, wt=None,
-               fuse_z=None, fuse_alpha=None):
+               r_ctx=0, label_D=0, tile_hint=0, splitk=0, post_op=0, post_scale=1.0, post_eps=0.0, wt=None):
     d = PaseConvGemm()
     if wt is not None:
         d.wt, d.ldwt = _ptr(wt), wt.shape[1]
@@ -98,7 +96,6 @@ def _conv_desc(x, w, y, *, S, Cin, Tin, M, K, taps, Ncols, Tout, ldw=None, bias=
     d.in_scale, d.in_shift, d.in_alpha = _ptr(in_scale), _ptr(in_shift), _ptr(in_alpha)
     d.stat_part, d.label, d.grad_out = _ptr(stat_part), _ptr(label), _ptr(grad_out)
     d.loss_acc = _ptr(loss_acc, torch.float64)
-    d.fuse_z, d.fuse_alpha = _ptr(fuse_z), _ptr(fuse_alpha)
     d.grad_scale = grad_scale
     d.S, d.Cin, d.Tin = S, Cin, Tin
     d.x_ctot = Cin if x_ctot is None else x_ctot
@@ -249,7 +246,6 @@ _SIMPLE.update({
     "pase_gammatone_blocks": [_fp, _fp, _fp, _i, _i, _i, _i, _fp],
     "pase_gammatone_frames": [_fp, _fp, _i, _i, _i, _i, _i, _i, _f, _fp],
     "pase_commit_cols": [_fp, _i, _i, _fp, _i, _fp, _i, _fp, _i, _fp],
-    "pase_stat_commit": [_fp, _i, _i, _fp, _fp, _fp],
     "pase_pack_wt": [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp],
     "pase_adam_step": [_fp, _fp, _fp, _fp, _l, _fp, _fp, _f, _f, _f, _f, _fp],
     "pase_step_tick": [_fp, _fp],
@@ -412,12 +408,6 @@ def pack_dgrad_t(src, *, R, O, k, st, s_red, s_out, s_k):
     _check(_lib.lib().pase_pack_dgrad_t(_ptr(src), _ptr(dst), R, O, k, st, s_red, s_out, s_k, ldt, _stream()),
            "pase_pack_dgrad_t")
     return dst
-
-
-def stat_commit(stat_part, C_, g0, g1):
-    """g0[c] += sum_t stat_part[t, c, 0]; g1[c] += sum_t stat_part[t, c, 1]"""
-    _check(_lib.lib().pase_stat_commit(_ptr(stat_part), stat_part.shape[0], C_, _ptr(g0), _ptr(g1), _stream()),
-           "pase_stat_commit")
 
 
 def adam_step(p, g, m, v, lr, step, *, beta1=0.9, beta2=0.999, eps=1e-8, grad_mul=1.0):

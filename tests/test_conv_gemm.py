@@ -282,34 +282,3 @@ def test_flat_ws_mse_context_epilogue_wide(dev):
     torch.testing.assert_close(y.cpu(), pred, **_tol(dev))
     torch.testing.assert_close(g.cpu(), (pred - tgt) * gs, rtol=1e-4, atol=1e-5)
     assert abs(float(acc) - float(((pred - tgt).double() ** 2).sum())) < 1e-3 * float(((pred - tgt) ** 2).sum())
-
-
-@pytest.mark.parametrize("k,stride,Cin,Cout,T", [(1, 1, 24, 70, 64), (30, 4, 6, 130, 40), (11, 1, 5, 40, 300)])
-def test_fused_prelu_backward_epilogue(dev, k, stride, Cin, Cout, T):
-    """fuse_z: the conv output is a gradient dA w.r.t. PReLU(z); the epilogue stores dz = dA * prelu'(z) and emits per
-    tile the partial sums of dz (bias gradient of the layer below) and dA * z * [z <= 0] (its slope gradient), which
-    pase_stat_commit folds into the gradient buffers (engine.worker_backward: decoder / MLP hidden layers)."""
-    from pase_amd import engine
-    from pase_amd.engine import Act
-    torch.manual_seed(6)
-    S = 3
-    x = torch.randn(S, Cin, T)
-    w = torch.randn(Cout, Cin, k) * 0.2
-    pad = k // 2 if stride == 1 else 13
-    dA = F.conv1d(F.pad(x, (pad, pad)), w, stride=stride)
-    Tout = dA.shape[2]
-    z = torch.randn(S, Cout, Tout)
-    z[0, :, :3] = 0.0                                   # z == 0 takes the slope branch, like torch's prelu backward
-    al = torch.rand(Cout) * 0.5
-    dz_ref = torch.where(z > 0, dA, dA * al[None, :, None])
-    dalpha_ref = (dA * z * (z <= 0)).sum((0, 2))
-    dbias_ref = dz_ref.sum((0, 2))
-    dz, stat = engine.conv_fwd(Act(x.to(dev), C=Cin), w.reshape(Cout, -1).contiguous().to(dev), None, Cout=Cout, taps=k,
-                               stride=stride, padL=pad, padR=pad, pad_mode=K.PAD_ZERO, Tout=Tout,
-                               fuse=(z.to(dev), al.to(dev)))
-    torch.testing.assert_close(dz.cpu(), dz_ref, **_tol(dev))
-    g0 = torch.full((Cout,), 2.0, device=dev)
-    g1 = torch.full((Cout,), -1.0, device=dev)
-    K.stat_commit(stat, Cout, g0, g1)
-    torch.testing.assert_close(g0.cpu() - 2.0, dbias_ref, rtol=1e-4, atol=1e-3)
-    torch.testing.assert_close(g1.cpu() + 1.0, dalpha_ref, rtol=1e-4, atol=1e-3)
