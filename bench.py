@@ -211,6 +211,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=32000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the second timed leg (batch handed over as host buffers)")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the step in a hipGraph (trainer.capture_step) and time the replays (N=1 only)")
     ap.add_argument("--torch-gpu-baseline", action="store_true",
                     help="also time the torch-op restatement of the reference step on this GPU (stock PyTorch-ROCm "
                          "kernels) and report it as `torch_rocm_baseline`")
@@ -284,6 +286,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.graph and world == 1 and not args.producer:
+        tr.capture_step(batch)
     for _ in range(args.warmup):
         losses = tr.train_step(next_batch())
     sync()
@@ -342,7 +346,7 @@ def main():
     K.GEMM_TIMER = K.GemmTimer()
     extra = 2
     for _ in range(extra):
-        tr.train_step(batch)
+        tr._eager_step(batch)          # (eager even when the timed steps were graph replays: per-launch events)
     fams = K.GEMM_TIMER.summary()
     K.GEMM_TIMER = None
     traffic = None
@@ -389,7 +393,8 @@ def main():
                        "targets": ("lps/lps_long/fbank/fbank_long/gtn/gtn_long/mfcc/mfcc_long/prosody all computed on device from the clean chunk"
                                    if args.producer else "given (N(0,1) tensors resident in HBM)"), "parallelism": "dp%d" % world,
                        "final_total_loss": round(total_loss, 5), "inputs": "resident in HBM (see `h2d` for the "
-                       "host-buffer leg)", "collective_backend": backend},
+                       "host-buffer leg)", "collective_backend": backend,
+                       "hipgraph": bool(getattr(tr, "_graph", None) is not None)},
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (all launches of one step)",
                          "achieved": round(cg_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(cg_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,

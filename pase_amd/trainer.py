@@ -95,11 +95,15 @@ class FusedAdam(object):
     def zero_grad(self, set_to_none=False):
         self.flat_g.zero_()
 
-    def step(self, grad_mul=1.0, tick=True):
+    def sync_lr(self):
+        """host-side learning rate -> the device scalar the Adam kernel reads (outside any captured graph)"""
         lr = float(self.param_groups[0]["lr"])
         if lr != self._lr_host:
             self.lr_t.fill_(lr)
             self._lr_host = lr
+
+    def step(self, grad_mul=1.0, tick=True):
+        self.sync_lr()
         if tick:                       # (the trainer advances all 13 step counters in one multi-tensor launch)
             K.step_tick(self.step_t)
         K.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.lr_t, self.step_t,
@@ -246,9 +250,45 @@ class trainer(object):
             batch[n] = self.device_targets.feats[n](clean.contiguous().float())
         return batch
 
+    def capture_step(self, example_batch):
+        """Capture one training step (forward, losses, backward, 13 Adam updates: ~260 kernel launches on four
+        streams) in a hipGraph for batches shaped like `example_batch` (device tensors).  train_step then copies the
+        batch into the graph's static input buffers and replays: one graph launch per step instead of ~260 kernel
+        launches from Python.  The learning rates and step counters are device scalars, so the captured graph stays
+        valid as they change.  Single-GPU only (the data-parallel step issues its collectives eagerly)."""
+        if self.world > 1:
+            raise NotImplementedError("pase_amd trainer: hipGraph capture of the data-parallel step")
+        dev = self.grad_arena.device
+        self._graph = None
+        self._static = {k: v.detach().clone() for k, v in example_batch.items() if torch.is_tensor(v)}
+        cur = torch.cuda.current_stream(dev)
+        warm = torch.cuda.Stream(device=dev)
+        warm.wait_stream(cur)
+        with torch.cuda.stream(warm):               # allocator / arena / caches reach their steady state
+            for _ in range(2):
+                self._eager_step(self._static, None)
+        cur.wait_stream(warm)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._static_losses = self._eager_step(self._static, None)
+        self._graph = graph
+        return graph
+
     def train_step(self, batch, device=None):
         """_base_scheduler (worker_scheduler.py:43-75): zero grads, total = sum w*loss, backward,
         every optimizer steps.  Returns the loss dict (device scalars; no host sync)."""
+        if getattr(self, "_graph", None) is not None and all(
+                k in batch and batch[k].shape == v.shape for k, v in self._static.items()):
+            for opt in self.optimizers():
+                opt.sync_lr()
+            for k, v in self._static.items():
+                v.copy_(batch[k], non_blocking=True)
+            self._graph.replay()
+            return dict(self._static_losses)
+        return self._eager_step(batch, device)
+
+    def _eager_step(self, batch, device=None):
         self.model.train()
         if self.device_targets is not None:
             batch = self._fill_targets(batch, device)

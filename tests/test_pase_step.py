@@ -332,3 +332,39 @@ def test_trainer_epoch_loop_checkpoints_and_resume(dev, tmp_path):
     assert quiet(tr2.resume_training, dev) and tr2.epoch_beg == 2
     for (n, p), (_, q) in zip(tr.model.named_parameters(), tr2.model.named_parameters()):
         assert torch.equal(p.detach().cpu(), q.detach().cpu()), n
+
+
+@pytest.mark.gpu
+def test_captured_step_matches_eager_steps():
+    """trainer.capture_step: the hipGraph replay of the fused step (side streams, arenas, multi-tensor commits, Adam
+    with device-scalar lr / step) tracks an identical trainer stepping eagerly, over steps with changing batches and a
+    learning-rate change between them."""
+    from pase_amd.trainer import trainer
+    dev = torch.device("cuda:0")
+
+    def make():
+        seed_all(0)
+        return quiet(trainer, frontend_cfg=dict(MINI_FE), minions_cfg=with_losses(mini_workers()),
+                     cfg=dict(fe_lr=1e-3, min_lr=5e-4, epoch=2, bpe=10), lr_mode="poly", device=dev)
+    a, b = make(), make()
+    ex = {k: v.to(dev) for k, v in _mini_batch(seed=30).items()}
+    snap = {k: v.clone() for k, v in b.model.state_dict().items()}
+    b.capture_step(ex)
+    # capture runs warm-up steps: put model / optimizer state back to the common start
+    with torch.no_grad():
+        for k, v in b.model.state_dict().items():
+            v.copy_(snap[k])
+    for opt in b.optimizers():
+        opt.exp_avg.zero_(); opt.exp_avg_sq.zero_(); opt.step_t.zero_()
+    for step in range(4):
+        batch = {k: v.to(dev) for k, v in _mini_batch(seed=40 + step).items()}
+        if step == 2:
+            a.adjust_lr(5, 0)
+            b.adjust_lr(5, 0)
+        la = a.train_step(batch)
+        lb = b.train_step(batch)
+        assert abs(float(la["total"]) - float(lb["total"])) <= 1e-5 * abs(float(la["total"])), step
+    for (n, p), (_, q) in zip(a.model.named_parameters(), b.model.named_parameters()):
+        if not is_noise_grad(n):
+            assert_close(q, p, rtol=0, atol=2e-5, what=n)
+    assert int(b.frontend_optim.step_t.item()) == 4
