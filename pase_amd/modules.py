@@ -84,10 +84,13 @@ class Saver(object):
         ckpts = self._index()
         latest = ckpts["latest"]
         if len(latest) > 0 and self.max_ckpts is not None and len(latest) > self.max_ckpts:
-            todel = latest.pop(0)
-            fn = os.path.join(self.save_path, "weights_" + todel)
-            if os.path.exists(fn):
+            # modules.py:181-191: the oldest entry leaves the index only when its file could be removed
+            fn = os.path.join(self.save_path, "weights_" + latest[0])
+            try:
                 os.remove(fn)
+                latest = latest[1:]
+            except FileNotFoundError:
+                print("ERROR: ckpt is not there?")
         latest.append(model_path)
         ckpts["latest"] = latest
         ckpts["current"] = model_path
