@@ -79,6 +79,13 @@ typedef struct PaseConvGemm {
     int splitk;            /* 1: none; >1: split the reduction, partial tiles atomically added into a
                               caller-zeroed y (EPI_STORE without stat_part only); 0: library decides --
                               query pase_conv_gemm_splitk() and zero y when it returns > 1        */
+    const void* wx6;       /* NULL: contraction on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32).  Else: the
+                              split-bf16 pack of A written by pase_pack_x6() for THIS descriptor
+                              (pase_conv_gemm_x6_bytes() > 0): every fp32 operand is the exact sum of three
+                              truncated bf16 pieces hi + mid + lo and a product is evaluated as
+                              hh + hm + mh + hl + lh + mm on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
+                              (dropped terms <= 3 * 2^-24 |a b|: the error of an fp32 fma chain).  wt is then
+                              only the source of the pack.                                        */
 } PaseConvGemm;
 
 int pase_conv_gemm(const PaseConvGemm* desc, void* stream);
@@ -91,6 +98,13 @@ int pase_pack_wt(const float* w, float* wt, int M, int K, int Cin, int taps, int
 int pase_conv_gemm_stat_tiles(const PaseConvGemm* desc);
 /* the split-K factor the launch will actually use (after clamping) */
 int pase_conv_gemm_splitk(const PaseConvGemm* desc);
+/* bytes of the split-bf16 pack the launch described by desc (wx6 ignored) would read; 0 = this shape only runs on
+ * the fp32 matrix pipe */
+long pase_conv_gemm_x6_bytes(const PaseConvGemm* desc);
+/* desc->wx6 (pase_conv_gemm_x6_bytes(desc) bytes, 16-B aligned) <- desc->wt split into three bf16 planes in the
+ * fragment order of the launch desc describes (tile, stage and tap padding are functions of the descriptor: pack and
+ * launch must see the same one).  Like pase_pack_wt it runs once per weight use. */
+int pase_pack_x6(const PaseConvGemm* desc, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * pase_wgrad_gemm -- weight (+bias) gradient contraction, split-K with fp32 atomics.

@@ -53,6 +53,9 @@ constexpr int NPAR = 4;       // on-load (scale, shift, alpha) triples prefetche
 // flat 1x1 instantiation (float4 slots): 32 k per stage x BN columns = 4096 staged floats and a 32-row weight
 // slab -- more columns of X per stage than the span layout needs, fewer rows of A, same LDS footprint
 constexpr int KG_FLAT = 32, XS_FLAT = 4096, NS_FLAT = 4;
+// split-bf16 ("x6") instantiation: a stage is up to X6_STEPS MFMA steps of 16 k; its weight slab is the three bf16
+// planes in fragment order, 16-byte chunks [step][k-group][plane][tile row], single-buffered (36 KB for 128 rows)
+constexpr int X6_STEPS = 3;
 
 struct ConvPlan {
     int CB, TB, SPAN, SPANV, n_gc, n_gt, mode, tiles_per_seq, splitk;
@@ -64,6 +67,9 @@ struct ConvPlan {
     unsigned ncols_magic;     // ceil(2^32 / Ncols)
     unsigned cout_magic;      // ceil(2^32 / Cout_store)
     unsigned rctx_magic;      // ceil(2^32 / r_ctx)
+    // x6: a 16-deep MFMA step = xR channel rows x xTq taps (xR * xTq = 16; lane half fk takes rows fk, fk+2, ...);
+    // a stage = (CB / xR) row groups x xTS tap blocks = xSteps steps; TB is the tap count padded to xTS * xTq
+    int x6, xR, xTq, xTS, xSteps;
 };
 // column-tile modes
 //   MODE_FLAT  : 1x1, stride 1, no padding: columns are the flattened (s, q) index, a row of the
@@ -127,7 +133,10 @@ __device__ float g_ident[2] = {1.f, 0.f};
 // XFM (flat instantiation only; -1 = decided at run time): the row-major float4 slots of the flat 1x1 path carry one
 // (scale, shift, alpha) triple PER SLOT, i.e. 12 extra loads per stage next to the 8 operand loads -- specialised away
 // when the launch has no on-load transform (0: every data-gradient) or only a PReLU slope (1: the worker heads).
-template <int BM, int BN, int NS, int XV, int OCC = 2, int XFM = -1>
+// X6: the contraction runs on v_mfma_f32_32x32x16_bf16 with both operands split into three bf16 pieces (see
+// PaseConvGemm::wx6).  The weight slab arrives pre-split (pase_pack_x6); the activation spans are staged exactly as in
+// the fp32 instantiation and each wave splits its B fragment when it reads it.
+template <int BM, int BN, int NS, int XV, int OCC = 2, int XFM = -1, int X6 = 0>
 __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p, ConvPlan pl) {
     constexpr int WAVES_N = BN / 64;
     static_assert((BM / 64) * WAVES_N == 4, "4 waves");
@@ -137,13 +146,19 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
     constexpr int XS_T = XV ? XS_FLAT : (OCC == 3 ? NS * NTHREADS : XSMAX);
     constexpr int PA_MAX = (KG_T + RA - 1) / RA;      // 6 / 3 (4 / 2 flat)
     constexpr int LDA = BM + 4;
-    __shared__ __attribute__((aligned(16))) float As[2][KG_T][LDA];
+    constexpr int AX_CHUNKS = 3 * X6_STEPS * 2 * BM;              // x6: 16-byte chunks of one stage's weight slab
+    constexpr int NCH = AX_CHUNKS / NTHREADS;                     // ... per thread (9)
+    static_assert(!X6 || (AX_CHUNKS % NTHREADS == 0 && !XV), "x6 slab");
+    constexpr int A_BYTES = X6 ? AX_CHUNKS * 16 : 2 * KG_T * LDA * (int)sizeof(float);
+    __shared__ __attribute__((aligned(16))) unsigned char As_raw[A_BYTES];
+    float (*As)[KG_T][LDA] = reinterpret_cast<float (*)[KG_T][LDA]>(As_raw);
+    u32x4* AsX = reinterpret_cast<u32x4*>(As_raw);
     // 4 guard floats (zero) in front of each X buffer: the one zero-weight tap a reversed-tap single-row stage
     // with an odd tap count reads at span offset -1 must be finite
     __shared__ __attribute__((aligned(16))) float XsG[2][XS_T + 4];
     // epilogue scratch (BN partial sums / loss partials) reuses the weight slab: it is dead after the last stage
-    float (*red)[BM][2] = reinterpret_cast<float (*)[BM][2]>(&As[0][0][0]);
-    static_assert(sizeof(float) * WAVES_N * BM * 2 <= sizeof(As), "epilogue scratch");
+    float (*red)[BM][2] = reinterpret_cast<float (*)[BM][2]>(As_raw);
+    static_assert(sizeof(float) * WAVES_N * BM * 2 <= sizeof(As_raw), "epilogue scratch");
 
     PASE_STAMP(0);
     const int tid = threadIdx.x;
@@ -196,7 +211,11 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
     const int ar = tid / TA;
     const int acl = (tid % TA) * 4;
     const unsigned a_col = (unsigned)min(m0 + acl, p.ldwt - 4);
-    F4 areg[PA_MAX];
+    constexpr int PA_N = X6 ? NCH : PA_MAX;      // A pieces per stage
+    F4 areg[X6 ? 1 : PA_MAX];
+    u32x4 aregx[X6 ? NCH : 1];
+    const int ax_nch = 3 * pl.xSteps * 2 * BM;   // x6: chunks of this launch's stages
+    const u32x4* ax_st = nullptr;
     // X: thread -> slab row `xrow` (+ t*RPP when pmajor), samples xc + t*TPR (q-major)
     constexpr int NXR = XV ? 4 * NS : NS;      // staged floats per thread
     static_assert(NXR * NTHREADS <= XS_T, "slab");
@@ -281,7 +300,7 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
     // NPIECE independent pieces (A slab passes, then X slots; the on-load parameters ride with the last X piece).
     // load_stage() issues them back to back; the flat instantiation spreads them over the first half of the
     // current stage's MFMA loop instead (see the k-loop).
-    constexpr int NPIECE = PA_MAX + NS;
+    constexpr int NPIECE = PA_N + NS;
     int k0_st = 0, ci0s_st = 0;
     const float* xb_st = p.x;
     auto stage_begin = [&]() __attribute__((always_inline)) {
@@ -293,6 +312,7 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
         lo_next = (ci0 - ci0s) * pl.TB;
         kg_next = slots_invariant ? pl.CB * pl.TB : TBe;
         tbe_next = TBe;
+        if (X6) ax_st = reinterpret_cast<const u32x4*>(p.wx6) + (size_t)(mt * pl.n_gc + gc_n) * (unsigned)ax_nch;
         if (++gt_n == pl.n_gt) { gt_n = 0; ++gc_n; }
         if (!slots_invariant) {
             slot_setup(kk0, TBe);
@@ -308,11 +328,15 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
     // applied in store_stage.
     auto load_piece = [&](auto piece_tag) __attribute__((always_inline)) {
         constexpr int i = decltype(piece_tag)::value;
-        if constexpr (i < PA_MAX) {
-            const unsigned row = (unsigned)min(k0_st + RA * i, p.K - 1);
-            areg[i] = *reinterpret_cast<const F4*>(p.wt + (row * (unsigned)p.ldwt + a_col));
+        if constexpr (i < PA_N) {
+            if constexpr (X6) {
+                aregx[i] = ax_st[min(tid + NTHREADS * i, ax_nch - 1)];
+            } else {
+                const unsigned row = (unsigned)min(k0_st + RA * i, p.K - 1);
+                areg[i] = *reinterpret_cast<const F4*>(p.wt + (row * (unsigned)p.ldwt + a_col));
+            }
         } else {
-            constexpr int t = i - PA_MAX;
+            constexpr int t = i - PA_N;
             if (XV) {
                 const F4 v = *reinterpret_cast<const F4*>(xb_st + (unsigned)xoff[t]);
                 xreg[4 * t + 0] = v.x; xreg[4 * t + 1] = v.y; xreg[4 * t + 2] = v.z; xreg[4 * t + 3] = v.w;
@@ -349,13 +373,20 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
     };
     auto store_stage = [&](int buf) __attribute__((always_inline)) {
         // ---- A
-        const bool a_zero = lo_next > 0 || (kg_next & 3) != 0;   // uniform
+        if constexpr (X6) {
+            // pre-split chunks, already in LDS order (ragged channel groups / padded taps are zero in the pack)
 #pragma unroll
-        for (int ps = 0; ps < PA_MAX; ++ps) {
-            F4 v = areg[ps];
-            const int kl = ar + RA * ps;
-            if (a_zero && (kl < lo_next || kl >= kg_next)) v = F4{0.f, 0.f, 0.f, 0.f};
-            if (PA_MAX * RA == KG_T || kl < KG_T) *reinterpret_cast<F4*>(&As[buf][kl][acl]) = v;
+            for (int i = 0; i < NCH; ++i)
+                if (i < 3 || tid + NTHREADS * i < ax_nch) AsX[tid + NTHREADS * i] = aregx[i];
+        } else {
+            const bool a_zero = lo_next > 0 || (kg_next & 3) != 0;   // uniform
+#pragma unroll
+            for (int ps = 0; ps < PA_MAX; ++ps) {
+                F4 v = areg[ps];
+                const int kl = ar + RA * ps;
+                if (a_zero && (kl < lo_next || kl >= kg_next)) v = F4{0.f, 0.f, 0.f, 0.f};
+                if (PA_MAX * RA == KG_T || kl < KG_T) *reinterpret_cast<F4*>(&As[buf][kl][acl]) = v;
+            }
         }
         // ---- X
         float* xs = &XsG[buf][4 + xs_tbase];
@@ -475,6 +506,59 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
             continue;
         }
 #endif
+        if constexpr (X6) {
+            // ---- split-bf16 stage.  Step st = (row group rg, tap block tb): lane half fk holds rows
+            // rg*xR + fk + 2*(e / xTq), taps tb*xTq + e % xTq (e = 0..7) of its column -- the order pase_pack_x6 wrote
+            // the weight fragments in.  LDS offsets = [per-lane constant] + [uniform]; the B fragment is split into
+            // its three bf16 pieces here (2 x (8 ds_read_b32 + 44 VALU) per 24 MFMAs).
+            const int ts = p.tapstep;
+            const int lt = pl.xTq == 8 ? 3 : (pl.xTq == 4 ? 2 : (pl.xTq == 2 ? 1 : 0));
+            const int tap0 = ts > 0 ? 0 : pl.TB - 1;
+            const float* x0L = &XsG[cur][4 + fk * pl.SPAN + tap0 + xc0];
+            const float* x1L = &XsG[cur][4 + fk * pl.SPAN + tap0 + xc1];
+            const u32x4* aL = &AsX[fk * 3 * BM + wm * 64 + fr];
+            int oe[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) oe[e] = 2 * (e >> lt) * pl.SPAN + ts * (e & (pl.xTq - 1));
+            const int n_rg = pl.xSteps / pl.xTS;
+            int st = 0;
+            for (int rg = 0; rg < n_rg; ++rg) {
+                for (int tb = 0; tb < pl.xTS; ++tb, ++st) {
+                    const int sb = rg * pl.xR * pl.SPAN + ts * (tb << lt);
+                    float xv0[8], xv1[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        xv0[e] = x0L[sb + oe[e]];
+                        xv1[e] = x1L[sb + oe[e]];
+                    }
+                    u32x4 fa[3][2], fb0[3], fb1[3];
+#pragma unroll
+                    for (int pz = 0; pz < 3; ++pz) {
+                        fa[pz][0] = aL[(st * 6 + pz) * BM];
+                        fa[pz][1] = aL[(st * 6 + pz) * BM + 32];
+                    }
+                    pase_split_bf16x3(xv0, fb0);
+                    pase_split_bf16x3(xv1, fb1);
+                    // hh + hm + mh + hl + lh + mm, smallest terms first (plane 0 = hi, 1 = mid, 2 = lo)
+                    constexpr int PZA[6] = {1, 0, 2, 0, 1, 0}, PZB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+                    for (int pi = 0; pi < 6; ++pi) {
+                        acc[0][0] = pase_mfma_bf16_32x32x16(fa[PZA[pi]][0], fb0[PZB[pi]], acc[0][0]);
+                        acc[0][1] = pase_mfma_bf16_32x32x16(fa[PZA[pi]][0], fb1[PZB[pi]], acc[0][1]);
+                        acc[1][0] = pase_mfma_bf16_32x32x16(fa[PZA[pi]][1], fb0[PZB[pi]], acc[1][0]);
+                        acc[1][1] = pase_mfma_bf16_32x32x16(fa[PZA[pi]][1], fb1[PZB[pi]], acc[1][1]);
+                    }
+                }
+            }
+            PASE_TACC(1);
+            // the weight slab is single-buffered: everyone is done reading it before the next one lands
+            __syncthreads();
+            if (g + 1 < g_end) store_stage(cur ^ 1);
+            PASE_TACC(2);
+            __syncthreads();
+            PASE_TACC(3);
+            continue;
+        }
         const int ts = p.tapstep;
         const bool pair_rows = pl.CB > 1;                       // uniform
         const int nks = pair_rows ? (kg >> 1) : ((tbe + 1) >> 1);
@@ -815,19 +899,82 @@ __global__ void __launch_bounds__(256) pack_wt_kernel(const float* w, float* wt,
     }
 }
 
+// wt (K-major fp32, k = ci * taps + tap) -> the three bf16 planes of the x6 weight slab, 16-byte chunks
+// [row tile][stage g][step][k-group fk][plane][tile row]; element e of a chunk = (row rg*R + fk + 2*(e / Tq),
+// tap tb*Tq + e % Tq) of step (rg, tb).  Zero for taps past the real count, for the rows of a ragged last channel
+// group that the previous stage already covered, and for tile rows past M.
+__global__ void pack_x6_kernel(const float* __restrict__ wt, u32x4* __restrict__ out, int M, int ldwt, int Cin,
+                               int taps, int CB, int R, int lt, int tsn, int steps, int n_gc, long total) {
+    constexpr int BM = 128;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int ml = (int)(idx % BM);
+        const int fk = (int)((idx / BM) % 2);
+        const int st = (int)((idx / (2 * BM)) % steps);
+        const int g = (int)((idx / (2L * BM * steps)) % n_gc);
+        const int rt = (int)(idx / (2L * BM * steps * n_gc));
+        const int rg = st / tsn, tb = st - rg * tsn;
+        const int ci0 = g * CB, ci0s = min(ci0, Cin - CB), lo = ci0 - ci0s;
+        const int m = rt * BM + ml;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int row = rg * R + fk + 2 * (e >> lt);
+            const int tap = (tb << lt) + (e & ((1 << lt) - 1));
+            v[e] = (row >= lo && tap < taps && m < M) ? wt[((size_t)(ci0s + row) * taps + tap) * ldwt + m] : 0.f;
+        }
+        u32x4 o[3];
+        pase_split_bf16x3(v, o);
+        u32x4* dst = out + ((((size_t)rt * n_gc + g) * steps + st) * 2 + fk) * 3 * BM + ml;
+#pragma unroll
+        for (int pz = 0; pz < 3; ++pz) dst[pz * BM] = o[pz];
+    }
+}
+
 struct HostPlan {
     ConvPlan pl;
     int BN, narrow;
     long blocks;
     int n_col_tiles;
+    long x6_chunks;     // 16-byte chunks of the split-bf16 pack (0: fp32 plan)
 };
+
+// Split-bf16 stage shape for a span-mode launch on the 128 x 128 tile, or false.  Candidates: (R rows x Tq taps) per
+// 16-deep step with R * Tq = 16; the taps are padded to a multiple of Tq (zero weights) and a stage holds as many
+// row groups as fit X6_STEPS steps.  Score = useful fraction of the padded taps x a penalty for short stages.
+bool plan_x6(const PaseConvGemm& p, int BN, ConvPlan& pl) {
+    double best = 0.0;
+    for (int R = 2; R <= 16; R *= 2) {
+        const int Tq = 16 / R;
+        const int TBp = (p.taps + Tq - 1) / Tq * Tq, tsn = TBp / Tq;
+        if (tsn > X6_STEPS) continue;
+        for (int rg = X6_STEPS / tsn; rg >= 1; --rg) {
+            const int CB = R * rg;
+            if (CB > p.Cin) continue;
+            const int SPANV = (BN - 1) * p.stride + (pl.mode == MODE_SEG ? 2 : 1) * TBp;
+            int tl = 8;
+            while ((NTHREADS >> tl) < CB) --tl;
+            const int nslots = (SPANV + 1 + (1 << tl) - 1) >> tl;
+            if (nslots > XPT) continue;
+            const int steps = rg * tsn;
+            const double eff = (double)p.taps / TBp * (steps == 3 ? 1.0 : (steps == 2 ? 0.93 : 0.8));
+            if (eff > best) {
+                best = eff;
+                pl.CB = CB; pl.TB = TBp; pl.SPANV = SPANV; pl.tl = tl; pl.nslots = nslots;
+                pl.xR = R; pl.xTq = Tq; pl.xTS = tsn; pl.xSteps = steps;
+            }
+            break;
+        }
+    }
+    return best >= 0.85;
+}
 
 unsigned magic_of(int d) {
     return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned long long)d);
 }
 
-HostPlan make_plan(const PaseConvGemm& p) {
+HostPlan make_plan(const PaseConvGemm& p, bool want_x6) {
     HostPlan h;
+    h.x6_chunks = 0;
     h.narrow = (p.tile_hint == 64) || (p.tile_hint == 0 && p.M <= 64);
     const int BM = h.narrow ? 64 : 128;
     h.BN = h.narrow ? 256 : 128;
@@ -840,7 +987,12 @@ HostPlan make_plan(const PaseConvGemm& p) {
     pl.mode = flat ? MODE_FLAT : (p.Ncols >= h.BN ? MODE_SEG : MODE_PERSEQ);
     pl.xvec = flat ? 1 : 0;
     pl.pmajor = pl.xvec;
-    if (flat) {
+    pl.x6 = pl.xR = pl.xTq = pl.xTS = pl.xSteps = 0;
+    if (want_x6 && !flat && !h.narrow && p.taps <= 24 && plan_x6(p, h.BN, pl)) {
+        pl.x6 = 1;
+        pl.nslots = pl.nslots <= 3 ? 3 : (pl.nslots <= 6 ? 6 : 12);
+        pl.SPAN = pl.nslots << pl.tl;
+    } else if (flat) {
         pl.TB = 1;
         pl.SPANV = pl.SPAN = h.BN;
         pl.CB = XS_FLAT / h.BN;
@@ -875,6 +1027,7 @@ HostPlan make_plan(const PaseConvGemm& p) {
     }
     pl.n_gc = pl.CB ? (p.Cin + pl.CB - 1) / pl.CB : 0;
     pl.n_gt = (p.taps + pl.TB - 1) / pl.TB;
+    if (pl.x6) h.x6_chunks = (long)((p.M + BM - 1) / BM) * pl.n_gc * pl.xSteps * 2 * 3 * BM;
     const int RA = NTHREADS / (BM / 4);
     pl.PA = (pl.CB * pl.TB + RA - 1) / RA;
     pl.tiles_per_seq = (p.Ncols + h.BN - 1) / h.BN;
@@ -897,7 +1050,7 @@ HostPlan make_plan(const PaseConvGemm& p) {
         double best = 1e30;
         const int max_split = G / 6 < 1 ? 1 : G / 6;
         // workgroup slots: 2 per CU, 3 for the small-footprint instantiation (see PASE_CONV_LAUNCH)
-        const long slots = (!h.narrow && !pl.xvec && pl.nslots == 3 && pl.CB * pl.TB <= 44) ? 768 : 512;
+        const long slots = (!h.narrow && !pl.xvec && !pl.x6 && pl.nslots == 3 && pl.CB * pl.TB <= 44) ? 768 : 512;
         for (int sk = 1; sk <= max_split && sk <= 64; ++sk) {
             const long W = tiles * sk;
             const long full = W / slots, tail = W % slots;
@@ -936,8 +1089,9 @@ extern "C" int pase_conv_gemm(const PaseConvGemm* d, void* stream) {
     if (p.epilogue == PASE_EPI_MSE_CTX && (!p.label || !p.loss_acc || p.r_ctx < 1)) return -2;
     if (p.pad_mode == PASE_PAD_REFLECT && (p.padL >= p.Tin)) return -3;
     if (p.tapstep != 1 && p.tapstep != -1) return -5;
-    const HostPlan h = make_plan(p);
+    const HostPlan h = make_plan(p, p.wx6 != nullptr);
     if (h.pl.CB < 1) return -6;
+    if (p.wx6 && (!h.pl.x6 || (((unsigned long long)(size_t)p.wx6) % 16) != 0)) return -11;
     if (h.pl.splitk > 1 && (p.stat_part || p.epilogue != PASE_EPI_STORE || p.post_op != PASE_POST_NONE)) return -7;
     if ((p.post_op == PASE_POST_POW || p.post_op == PASE_POST_LOGPOW || p.post_op == PASE_POST_MAG) &&
         (p.ps != 1 || p.stat_part || (p.M & 1))) return -9;
@@ -966,7 +1120,15 @@ extern "C" int pase_conv_gemm(const PaseConvGemm* d, void* stream) {
         else if (h.pl.nslots == 6) PASE_LAUNCH((conv_gemm_kernel<BM_, BN_, 6, 0>), grid, block, st, p, h.pl);  \
         else PASE_LAUNCH((conv_gemm_kernel<BM_, BN_, 12, 0>), grid, block, st, p, h.pl);                 \
     } while (0)
-    if (h.narrow) PASE_CONV_LAUNCH(64, 256);
+    if (h.pl.x6) {
+        // the kernel sees the convolution with its taps padded to the plan's multiple (zero weights in the pack)
+        PaseConvGemm q = p;
+        q.taps = h.pl.TB;
+        q.K = p.Cin * h.pl.TB;
+        if (h.pl.nslots == 3) PASE_LAUNCH((conv_gemm_kernel<128, 128, 3, 0, 2, -1, 1>), grid, block, st, q, h.pl);
+        else if (h.pl.nslots == 6) PASE_LAUNCH((conv_gemm_kernel<128, 128, 6, 0, 2, -1, 1>), grid, block, st, q, h.pl);
+        else PASE_LAUNCH((conv_gemm_kernel<128, 128, 12, 0, 2, -1, 1>), grid, block, st, q, h.pl);
+    } else if (h.narrow) PASE_CONV_LAUNCH(64, 256);
     else PASE_CONV_LAUNCH(128, 128);
 #undef PASE_CONV_LAUNCH
     PASE_CHECK_LAUNCH();
@@ -974,9 +1136,33 @@ extern "C" int pase_conv_gemm(const PaseConvGemm* d, void* stream) {
 }
 
 extern "C" int pase_conv_gemm_stat_tiles(const PaseConvGemm* d) {
-    return make_plan(*d).n_col_tiles;
+    return make_plan(*d, d->wx6 != nullptr).n_col_tiles;
 }
 
 extern "C" int pase_conv_gemm_splitk(const PaseConvGemm* d) {
-    return make_plan(*d).pl.splitk;
+    return make_plan(*d, d->wx6 != nullptr).pl.splitk;
+}
+
+extern "C" long pase_conv_gemm_x6_bytes(const PaseConvGemm* d) {
+    if (d->M <= 0 || d->K <= 0 || d->S <= 0 || d->Ncols <= 0 || d->K != d->Cin * d->taps) return 0;
+    if (d->tapstep != 1 && d->tapstep != -1) return 0;
+    const HostPlan h = make_plan(*d, true);
+    return h.pl.CB >= 1 ? h.x6_chunks * 16 : 0;
+}
+
+extern "C" int pase_pack_x6(const PaseConvGemm* d, void* stream) {
+    const PaseConvGemm p = *d;
+    if (!p.wx6 || !p.wt || (((unsigned long long)(size_t)p.wx6) % 16) != 0) return -10;
+    if (p.K != p.Cin * p.taps || p.ldwt < p.M) return -4;
+    const HostPlan h = make_plan(p, true);
+    if (!h.pl.x6 || h.pl.CB < 1) return -11;
+    const ConvPlan& pl = h.pl;
+    const int lt = pl.xTq == 8 ? 3 : (pl.xTq == 4 ? 2 : (pl.xTq == 2 ? 1 : 0));
+    const long total = h.x6_chunks / 3;
+    const long nb = (total + 255) / 256;
+    PASE_LAUNCH(pack_x6_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), (hipStream_t)stream, p.wt,
+                reinterpret_cast<u32x4*>(const_cast<void*>(p.wx6)), p.M, p.ldwt, p.Cin, p.taps, pl.CB, pl.xR, lt, pl.xTS,
+                pl.xSteps, pl.n_gc, total);
+    PASE_CHECK_LAUNCH();
+    return 0;
 }

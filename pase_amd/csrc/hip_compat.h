@@ -10,6 +10,12 @@
 __device__ __forceinline__ f32x16 pase_mfma_32x32x2(float a, float b, f32x16 c) {
     return emu_mfma_32x32x2(a, b, c);
 }
+__device__ __forceinline__ f32x16 pase_mfma_bf16_32x32x16(u32x4 a, u32x4 b, f32x16 c) {
+    return emu_mfma_bf16_32x32x16(a, b, c);
+}
+__device__ __forceinline__ unsigned pase_pack_hi16(unsigned lo_src, unsigned hi_src) {
+    return (lo_src >> 16) | (hi_src & 0xffff0000u);
+}
 __device__ __forceinline__ int pase_uniform(int v) { return v; }
 #define PASE_LAUNDER(x) ((void)0)
 #define PASE_SCHED_BARRIER() ((void)0)
@@ -25,6 +31,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // D: col=l&31, row=(reg&3)+8*(reg>>2)+4*(l>>5).
 __device__ __forceinline__ f32x16 pase_mfma_32x32x2(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// v_mfma_f32_32x32x16_bf16 (8 passes, 16x the fp32 MFMA rate): A[i=l&31][k=8*(l>>5)+e], B[k=8*(l>>5)+e][j=l&31],
+// e = the lane's eight bf16 (low half of dword 0 first); D layout as above.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 pase_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 pase_mfma_bf16_32x32x16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pase_bf16x8, a),
+                                                   __builtin_bit_cast(pase_bf16x8, b), c, 0, 0, 0);
+}
+// {lo_src[31:16], hi_src[31:16]} -> one dword of two bf16 (v_perm_b32)
+__device__ __forceinline__ unsigned pase_pack_hi16(unsigned lo_src, unsigned hi_src) {
+    return __builtin_amdgcn_perm(hi_src, lo_src, 0x07060302u);
 }
 // value known to be identical across the wave (e.g. threadIdx.x / 64): make it an SGPR so branches
 // on it are scalar (cdna_hip_programming.md T20: threadIdx-derived values are divergent to hipcc)
@@ -72,6 +90,25 @@ __device__ __forceinline__ float pase_half_sum_lane31(float v) {
         hipError_t e__ = hipGetLastError();      \
         if (e__ != hipSuccess) return (int)e__;  \
     } while (0)
+
+// x = hi + mid + lo with three truncated bf16 pieces (8 + 8 + 8 mantissa bits: exact for normal x);
+// eight values -> three fragments of eight bf16 each (element e of a fragment = piece of x[e])
+__device__ __forceinline__ void pase_split_bf16x3(const float (&x)[8], u32x4 (&out)[3]) {
+    float r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = x[i];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        unsigned b[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            b[i] = __float_as_uint(r[i]) & 0xffff0000u;
+            r[i] -= __uint_as_float(b[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[s][i] = pase_pack_hi16(b[2 * i], b[2 * i + 1]);
+    }
+}
 
 __device__ __forceinline__ float pase_wave_sum32(float v) {
     // sum over the 32 lanes that share (lane>>5); result valid in every lane of the half-wave

@@ -4,6 +4,7 @@ Tensors are torch tensors used purely as device buffers (data_ptr + the current 
 every wrapper checks dtype / contiguity / device and raises on a non-zero return code.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -32,6 +33,7 @@ class PaseConvGemm(C.Structure):
         ("epilogue", C.c_int), ("r_ctx", C.c_int), ("label_D", C.c_int),
         ("tile_hint", C.c_int), ("post_op", C.c_int), ("post_scale", C.c_float), ("post_eps", C.c_float),
         ("splitk", C.c_int),
+        ("wx6", C.c_void_p),
     ]
 
 
@@ -42,6 +44,10 @@ def declare(l):
     l.pase_conv_gemm_stat_tiles.restype = C.c_int
     l.pase_conv_gemm_splitk.argtypes = [C.POINTER(PaseConvGemm)]
     l.pase_conv_gemm_splitk.restype = C.c_int
+    l.pase_conv_gemm_x6_bytes.argtypes = [C.POINTER(PaseConvGemm)]
+    l.pase_conv_gemm_x6_bytes.restype = C.c_long
+    l.pase_pack_x6.argtypes = [C.POINTER(PaseConvGemm), C.c_void_p]
+    l.pase_pack_x6.restype = C.c_int
     l.pase_abi_sizeof.argtypes = [C.c_int]
     l.pase_abi_sizeof.restype = C.c_int
     if l.pase_abi_sizeof(0) != C.sizeof(PaseConvGemm):
@@ -169,6 +175,10 @@ def pack_wt(w, *, M, K, Cin, taps, ldw=None, tap_major=0):
     return wt
 
 
+# PASE_X6=0 keeps every contraction on the fp32 matrix pipe (A/B measurements, tools/)
+X6 = os.environ.get("PASE_X6", "1") != "0"
+
+
 def conv_gemm(x, w, y, **kw):
     """see include/pase_amd.h PaseConvGemm.  With splitk > 1 the output is zero-filled here first.
     The kernel reads the K-major pack of the weight: pass it as wt= (e.g. straight from pack_dgrad, or a
@@ -177,6 +187,14 @@ def conv_gemm(x, w, y, **kw):
         kw["wt"] = pack_wt(w, M=kw["M"], K=kw["K"], Cin=kw["Cin"], taps=kw["taps"], ldw=kw.get("ldw"),
                            tap_major=kw.get("tap_major", 0))
     d = _conv_desc(x, w, y, **kw)
+    if X6:
+        # contraction on the bf16 matrix pipe with both operands split into three bf16 pieces (fp32-grade result,
+        # see PaseConvGemm::wx6) for the launch shapes the library has a split-bf16 plan for
+        nbytes = _lib.lib().pase_conv_gemm_x6_bytes(C.byref(d))
+        if nbytes > 0:
+            wx6 = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            d.wx6 = wx6.data_ptr()
+            _check(_lib.lib().pase_pack_x6(C.byref(d), _stream()), "pase_pack_x6")
     if d.splitk != 1:
         if _lib.lib().pase_conv_gemm_splitk(C.byref(d)) > 1:
             y.zero_()

@@ -74,6 +74,7 @@ inline void __syncthreads() { hipemu::sync_block(); }
 // ---------------------------------------------------------------- vector types
 typedef float f32x16 __attribute__((vector_size(64)));
 typedef float f32x4 __attribute__((vector_size(16)));
+typedef uint32_t u32x4 __attribute__((vector_size(16)));
 struct float4 { float x, y, z, w; };
 struct float2 { float x, y; };
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
@@ -133,6 +134,42 @@ inline f32x16 emu_mfma_32x32x2(float a, float b, f32x16 c) {
         c[r] = acc;
     }
     hipemu::sync_wave();
+    return c;
+}
+
+// v_mfma_f32_32x32x16_bf16: lane l holds A[l&31][8*(l>>5)+e] and B[8*(l>>5)+e][l&31], e = 0..7 (bf16, low half of
+// dword 0 first).  The 16 products of an output element are summed exactly (double) and added to c once.
+inline f32x16 emu_mfma_bf16_32x32x16(u32x4 a, u32x4 b, f32x16 c) {
+    uint64_t* ba = hipemu::wave_buf(0);
+    uint64_t* bb = hipemu::wave_buf(1);
+    const int l = hipemu::cur->lane;
+    uint32_t la[64][4], lb[64][4];
+    for (int h = 0; h < 2; ++h) {
+        ba[l] = (uint64_t)a[2 * h] | ((uint64_t)a[2 * h + 1] << 32);
+        bb[l] = (uint64_t)b[2 * h] | ((uint64_t)b[2 * h + 1] << 32);
+        hipemu::sync_wave();
+        for (int j = 0; j < 64; ++j) {
+            la[j][2 * h] = (uint32_t)ba[j];
+            la[j][2 * h + 1] = (uint32_t)(ba[j] >> 32);
+            lb[j][2 * h] = (uint32_t)bb[j];
+            lb[j][2 * h + 1] = (uint32_t)(bb[j] >> 32);
+        }
+        hipemu::sync_wave();
+    }
+    auto bf = [](const uint32_t (&v)[4], int e) {
+        const uint32_t bits = ((v[e >> 1] >> (16 * (e & 1))) & 0xffffu) << 16;
+        float f;
+        memcpy(&f, &bits, 4);
+        return (double)f;
+    };
+    const int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        double acc = 0.0;
+        for (int kg = 0; kg < 2; ++kg)
+            for (int e = 0; e < 8; ++e) acc += bf(la[row + 32 * kg], e) * bf(lb[col + 32 * kg], e);
+        c[r] = (float)((double)c[r] + acc);
+    }
     return c;
 }
 

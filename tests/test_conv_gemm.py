@@ -20,6 +20,10 @@ def _tol(dev):
     (8, 70, 11, 1, 200, 3),     # column tiles straddle sequences (two spans per tile), float4 weight loads
     (8, 70, 11, 2, 410, 3),     # same, strided, T_out = 205
     (4, 8, 20, 10, 3000, 2),    # narrow 64x256 tile straddling sequences, stride 10
+    (14, 70, 6, 1, 300, 2),     # 128-row tile, 6 taps: 6-channel stage (36 rows) of the 3-workgroup 6-slot instantiation
+    (10, 130, 8, 1, 200, 3),    # 8 taps: 4-channel stage (32 rows) of the 3-workgroup 3-slot instantiation
+    (3, 70, 30, 10, 2900, 2),   # 30 taps stride 10, 128-row tile: single-channel stage, 6 slots, 3 workgroups / CU
+    (6, 70, 11, 2, 700, 2),     # 11 taps stride 2: 2-channel stage (22 rows), 3 slots
 ])
 def test_conv_fwd_reflect(dev, Cin, Cout, k, stride, T, S):
     torch.manual_seed(0)
