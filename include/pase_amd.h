@@ -126,6 +126,8 @@ typedef struct PaseWgrad {
     int S, M, Tg, g_ctot, g_coff, Ncols;
     int Cin, Tz, z_ctot, z_coff, taps, tap_major, stride, tapstep, padL, pad_mode, ldw;
     int splitk;            /* 0 = auto                                                            */
+    int x6;                /* 0: fp32 matrix pipe.  1: split-bf16 contraction where the library has an instantiation
+                              for the shape (see PaseConvGemm::wx6; both operands are split on the fly, no pack) */
 } PaseWgrad;
 int pase_wgrad_gemm(const PaseWgrad* desc, void* stream);
 

@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
     constexpr int LDA = BM + 4;
     constexpr int AX_CHUNKS = 3 * X6_STEPS * 2 * BM;              // x6: 16-byte chunks of one stage's weight slab
     constexpr int NCH = AX_CHUNKS / NTHREADS;                     // ... per thread (9)
-    static_assert(!X6 || (AX_CHUNKS % NTHREADS == 0 && !XV), "x6 slab");
+    static_assert(!X6 || AX_CHUNKS % NTHREADS == 0, "x6 slab");
     constexpr int A_BYTES = X6 ? AX_CHUNKS * 16 : 2 * KG_T * LDA * (int)sizeof(float);
     __shared__ __attribute__((aligned(16))) unsigned char As_raw[A_BYTES];
     float (*As)[KG_T][LDA] = reinterpret_cast<float (*)[KG_T][LDA]>(As_raw);
@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
         const int cur = (g - g_begin) & 1;
         PASE_TACC_BEGIN();
 #ifndef PASE_FLAT_GENERIC
-        const bool spread_loads = XV && kg == KG_T;               // uniform: flat full stage issues them inside the loop
+        const bool spread_loads = !X6 && XV && kg == KG_T;        // uniform: flat full stage issues them inside the loop
 #else
         const bool spread_loads = false;
 #endif
@@ -450,6 +450,59 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
         // LDS offsets of a step are [per-lane constant] + [uniform scalar walk]: the walk is SALU only and
         // the per-step VALU work is the three address adds of the ds_reads -- index arithmetic in this
         // loop competes directly with MFMA issue (tools/mfma_probe: -15 % for a 10-instruction walk).
+        if constexpr (X6) {
+            // ---- split-bf16 stage.  Step st = (row group rg, tap block tb): lane half fk holds rows
+            // rg*xR + fk + 2*(e / xTq), taps tb*xTq + e % xTq (e = 0..7) of its column -- the order pase_pack_x6 wrote
+            // the weight fragments in.  LDS offsets = [per-lane constant] + [uniform]; the B fragment is split into
+            // its three bf16 pieces here (2 x (8 ds_read_b32 + 44 VALU) per 24 MFMAs).
+            const int ts = p.tapstep;
+            const int lt = pl.xTq == 8 ? 3 : (pl.xTq == 4 ? 2 : (pl.xTq == 2 ? 1 : 0));
+            const int tap0 = ts > 0 ? 0 : pl.TB - 1;
+            const float* x0L = &XsG[cur][4 + fk * pl.SPAN + tap0 + xc0];
+            const float* x1L = &XsG[cur][4 + fk * pl.SPAN + tap0 + xc1];
+            const u32x4* aL = &AsX[fk * 3 * BM + wm * 64 + fr];
+            int oe[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) oe[e] = 2 * (e >> lt) * pl.SPAN + ts * (e & (pl.xTq - 1));
+            const int n_rg = pl.xSteps / pl.xTS;
+            int st = 0;
+            for (int rg = 0; rg < n_rg; ++rg) {
+                for (int tb = 0; tb < pl.xTS; ++tb, ++st) {
+                    const int sb = rg * pl.xR * pl.SPAN + ts * (tb << lt);
+                    float xv0[8], xv1[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        xv0[e] = x0L[sb + oe[e]];
+                        xv1[e] = x1L[sb + oe[e]];
+                    }
+                    u32x4 fa[3][2], fb0[3], fb1[3];
+#pragma unroll
+                    for (int pz = 0; pz < 3; ++pz) {
+                        fa[pz][0] = aL[(st * 6 + pz) * BM];
+                        fa[pz][1] = aL[(st * 6 + pz) * BM + 32];
+                    }
+                    pase_split_bf16x3(xv0, fb0);
+                    pase_split_bf16x3(xv1, fb1);
+                    // hh + hm + mh + hl + lh + mm, smallest terms first (plane 0 = hi, 1 = mid, 2 = lo)
+                    constexpr int PZA[6] = {1, 0, 2, 0, 1, 0}, PZB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+                    for (int pi = 0; pi < 6; ++pi) {
+                        acc[0][0] = pase_mfma_bf16_32x32x16(fa[PZA[pi]][0], fb0[PZB[pi]], acc[0][0]);
+                        acc[0][1] = pase_mfma_bf16_32x32x16(fa[PZA[pi]][0], fb1[PZB[pi]], acc[0][1]);
+                        acc[1][0] = pase_mfma_bf16_32x32x16(fa[PZA[pi]][1], fb0[PZB[pi]], acc[1][0]);
+                        acc[1][1] = pase_mfma_bf16_32x32x16(fa[PZA[pi]][1], fb1[PZB[pi]], acc[1][1]);
+                    }
+                }
+            }
+            PASE_TACC(1);
+            // the weight slab is single-buffered: everyone is done reading it before the next one lands
+            __syncthreads();
+            if (g + 1 < g_end) store_stage(cur ^ 1);
+            PASE_TACC(2);
+            __syncthreads();
+            PASE_TACC(3);
+            continue;
+        }
 #ifndef PASE_FLAT_GENERIC      // (-DPASE_FLAT_GENERIC: A/B build that keeps the flat path on the generic stage loop below)
         if (XV && kg == KG_T) {
             // ---- flat 1x1, full 32-row stage: the K order is simply rows (2 ks + fk), so every LDS offset is an
@@ -506,59 +559,6 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
             continue;
         }
 #endif
-        if constexpr (X6) {
-            // ---- split-bf16 stage.  Step st = (row group rg, tap block tb): lane half fk holds rows
-            // rg*xR + fk + 2*(e / xTq), taps tb*xTq + e % xTq (e = 0..7) of its column -- the order pase_pack_x6 wrote
-            // the weight fragments in.  LDS offsets = [per-lane constant] + [uniform]; the B fragment is split into
-            // its three bf16 pieces here (2 x (8 ds_read_b32 + 44 VALU) per 24 MFMAs).
-            const int ts = p.tapstep;
-            const int lt = pl.xTq == 8 ? 3 : (pl.xTq == 4 ? 2 : (pl.xTq == 2 ? 1 : 0));
-            const int tap0 = ts > 0 ? 0 : pl.TB - 1;
-            const float* x0L = &XsG[cur][4 + fk * pl.SPAN + tap0 + xc0];
-            const float* x1L = &XsG[cur][4 + fk * pl.SPAN + tap0 + xc1];
-            const u32x4* aL = &AsX[fk * 3 * BM + wm * 64 + fr];
-            int oe[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) oe[e] = 2 * (e >> lt) * pl.SPAN + ts * (e & (pl.xTq - 1));
-            const int n_rg = pl.xSteps / pl.xTS;
-            int st = 0;
-            for (int rg = 0; rg < n_rg; ++rg) {
-                for (int tb = 0; tb < pl.xTS; ++tb, ++st) {
-                    const int sb = rg * pl.xR * pl.SPAN + ts * (tb << lt);
-                    float xv0[8], xv1[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        xv0[e] = x0L[sb + oe[e]];
-                        xv1[e] = x1L[sb + oe[e]];
-                    }
-                    u32x4 fa[3][2], fb0[3], fb1[3];
-#pragma unroll
-                    for (int pz = 0; pz < 3; ++pz) {
-                        fa[pz][0] = aL[(st * 6 + pz) * BM];
-                        fa[pz][1] = aL[(st * 6 + pz) * BM + 32];
-                    }
-                    pase_split_bf16x3(xv0, fb0);
-                    pase_split_bf16x3(xv1, fb1);
-                    // hh + hm + mh + hl + lh + mm, smallest terms first (plane 0 = hi, 1 = mid, 2 = lo)
-                    constexpr int PZA[6] = {1, 0, 2, 0, 1, 0}, PZB[6] = {1, 2, 0, 1, 0, 0};
-#pragma unroll
-                    for (int pi = 0; pi < 6; ++pi) {
-                        acc[0][0] = pase_mfma_bf16_32x32x16(fa[PZA[pi]][0], fb0[PZB[pi]], acc[0][0]);
-                        acc[0][1] = pase_mfma_bf16_32x32x16(fa[PZA[pi]][0], fb1[PZB[pi]], acc[0][1]);
-                        acc[1][0] = pase_mfma_bf16_32x32x16(fa[PZA[pi]][1], fb0[PZB[pi]], acc[1][0]);
-                        acc[1][1] = pase_mfma_bf16_32x32x16(fa[PZA[pi]][1], fb1[PZB[pi]], acc[1][1]);
-                    }
-                }
-            }
-            PASE_TACC(1);
-            // the weight slab is single-buffered: everyone is done reading it before the next one lands
-            __syncthreads();
-            if (g + 1 < g_end) store_stage(cur ^ 1);
-            PASE_TACC(2);
-            __syncthreads();
-            PASE_TACC(3);
-            continue;
-        }
         const int ts = p.tapstep;
         const bool pair_rows = pl.CB > 1;                       // uniform
         const int nks = pair_rows ? (kg >> 1) : ((tbe + 1) >> 1);
@@ -993,12 +993,21 @@ HostPlan make_plan(const PaseConvGemm& p, bool want_x6) {
         pl.nslots = pl.nslots <= 3 ? 3 : (pl.nslots <= 6 ? 6 : 12);
         pl.SPAN = pl.nslots << pl.tl;
     } else if (flat) {
+        if (want_x6 && !h.narrow && p.Cin >= 16) {
+            // flat 1x1 on the bf16 pipe: a 16-deep step = 16 channel rows (lane half fk takes rows fk, fk + 2, ...)
+            pl.x6 = 1;
+            pl.xR = 16; pl.xTq = 1; pl.xTS = 1;
+        }
         pl.TB = 1;
         pl.SPANV = pl.SPAN = h.BN;
         pl.CB = XS_FLAT / h.BN;
         if (pl.CB > KG_FLAT) pl.CB = KG_FLAT;
         if (pl.CB > p.Cin) pl.CB = p.Cin;
         if (pl.CB > 1) pl.CB &= ~1;
+        if (pl.x6) {
+            pl.CB &= ~15;
+            pl.xSteps = pl.CB / 16;
+        }
         const int TPR = h.BN / 4;
         pl.tl = 0;
         while ((1 << pl.tl) < TPR) ++pl.tl;
@@ -1125,7 +1134,8 @@ extern "C" int pase_conv_gemm(const PaseConvGemm* d, void* stream) {
         PaseConvGemm q = p;
         q.taps = h.pl.TB;
         q.K = p.Cin * h.pl.TB;
-        if (h.pl.nslots == 3) PASE_LAUNCH((conv_gemm_kernel<128, 128, 3, 0, 2, -1, 1>), grid, block, st, q, h.pl);
+        if (h.pl.xvec) PASE_LAUNCH((conv_gemm_kernel<128, 128, NS_FLAT, 1, 2, -1, 1>), grid, block, st, q, h.pl);
+        else if (h.pl.nslots == 3) PASE_LAUNCH((conv_gemm_kernel<128, 128, 3, 0, 2, -1, 1>), grid, block, st, q, h.pl);
         else if (h.pl.nslots == 6) PASE_LAUNCH((conv_gemm_kernel<128, 128, 6, 0, 2, -1, 1>), grid, block, st, q, h.pl);
         else PASE_LAUNCH((conv_gemm_kernel<128, 128, 12, 0, 2, -1, 1>), grid, block, st, q, h.pl);
     } else if (h.narrow) PASE_CONV_LAUNCH(64, 256);

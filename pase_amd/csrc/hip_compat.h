@@ -110,6 +110,24 @@ __device__ __forceinline__ void pase_split_bf16x3(const float (&x)[8], u32x4 (&o
     }
 }
 
+// four values -> three pieces x two dwords (half a fragment)
+__device__ __forceinline__ void pase_split_bf16x3_quad(const float (&x)[4], unsigned (&out)[3][2]) {
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = x[i];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        unsigned b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            b[i] = __float_as_uint(r[i]) & 0xffff0000u;
+            r[i] -= __uint_as_float(b[i]);
+        }
+        out[s][0] = pase_pack_hi16(b[0], b[1]);
+        out[s][1] = pase_pack_hi16(b[2], b[3]);
+    }
+}
+
 __device__ __forceinline__ float pase_wave_sum32(float v) {
     // sum over the 32 lanes that share (lane>>5); result valid in every lane of the half-wave
     v += __shfl_xor(v, 1);

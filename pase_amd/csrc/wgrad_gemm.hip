@@ -50,14 +50,22 @@ __device__ __forceinline__ unsigned div_magic(unsigned e, unsigned magic) {
 // SPANW rounded up to whole float4s, read from the 16-byte-aligned address `zshift` samples in front of the span.
 // That is the large-span case (the stride-10 block-1 layer: 14 channels x 330 samples per stage) at a quarter of the
 // load / LDS-store instructions and 14 fewer offset registers, which is what lets it run two workgroups per CU.
-template <int BM, int BN, int ZPT, int ZV = 0>
+// X6 = 1: split-bf16 contraction (PaseWgrad::x6): a stage is two 16-deep v_mfma_f32_32x32x16_bf16 steps over its 32 time
+// steps.  The G slab is split into its three bf16 pieces when it is staged (LDS image [8 time steps][plane][row][8 bf16]:
+// one ds_read_b128 per A fragment); the spans stay fp32 in LDS and each wave splits its B fragment (the lane's 8
+// consecutive time steps of its (channel, tap) column) when it reads it.
+template <int BM, int BN, int ZPT, int ZV = 0, int X6 = 0>
 __global__ void __launch_bounds__(NTHREADS, ((ZPT <= ZPT_SMALL || ZV) ? 2 : 1)) wgrad_gemm_kernel(PaseWgrad p, WgradPlan pl) {
     constexpr int ZW = ZV ? 4 : 1;                     // floats per slot
     constexpr int ZS_DATA = ZPT * NTHREADS * ZW;
     constexpr int ZS_TOTAL = ZS_DATA + ZS_ONES;
     constexpr int WAVES_N = BN / 64;
     constexpr int A_ROWS = BM / 8;
-    __shared__ float As[2][BKQ][BM + 1];
+    constexpr int AX_BUF = (BKQ / 8) * 3 * BM;         // x6: 16-byte chunks per buffer
+    constexpr int A_BYTES = X6 ? 2 * AX_BUF * 16 : 2 * BKQ * (BM + 1) * (int)sizeof(float);
+    __shared__ __attribute__((aligned(16))) unsigned char As_raw[A_BYTES];
+    float (*As)[BKQ][BM + 1] = reinterpret_cast<float (*)[BKQ][BM + 1]>(As_raw);
+    u32x4* AsX = reinterpret_cast<u32x4*>(As_raw);
     __shared__ __attribute__((aligned(16))) float Zs[2][ZS_TOTAL];
 
     const int tid = threadIdx.x;
@@ -156,7 +164,7 @@ __global__ void __launch_bounds__(NTHREADS, ((ZPT <= ZPT_SMALL || ZV) ? 2 : 1)) 
         // a flat chunk that crosses a sequence boundary takes the per-element path
         const bool straddle = pl.flat && (q0 + pl.SPANW > p.Ncols);
         // ---- G slab.  Raw prefetch only.
-        if (pl.gvec && !straddle) {
+        if (X6 || (pl.gvec && !straddle)) {   // (x6 launches are float4-staged by construction: host-checked)
             // Ncols % 4 == 0: a float4 is all-valid or all-out; out-of-range ones re-read the row's last
             // valid float4 and are zeroed in store_piece
             gkeep_next = q0 + k4 < p.Ncols;
@@ -245,19 +253,42 @@ __global__ void __launch_bounds__(NTHREADS, ((ZPT <= ZPT_SMALL || ZV) ? 2 : 1)) 
     // current stage (a wave that has just issued four 64-cycle MFMAs has ~200 idle issue cycles):
     // piece q handles element e of an N-element list when e*NP/N == q.  part < 0 stores everything.
     constexpr int NP = 6;
+    const bool do_rowsum = pl.bias_rowsum && p.dbias && ct == 0;
+    // x6: the bias row sums are accumulated by the staging threads (the LDS image holds split pieces)
+    float rs_v[X6 ? GS : 1];
+#pragma unroll
+    for (int i = 0; i < (X6 ? GS : 1); ++i) rs_v[i] = 0.f;
     auto store_piece = [&](int buf, int part) __attribute__((always_inline)) {
         // on-load transforms (g_alpha on G, affine/PReLU on Z) are applied here
-        if (gvec_next) {
+        if (X6 || gvec_next) {
             const float keep = gkeep_next ? 1.f : 0.f;
 #pragma unroll
             for (int i = 0; i < GS; ++i) {
                 if (part >= 0 && (i * NP) / GS != part) continue;
                 const int r = (tid >> 3) + 32 * i;
+                if constexpr (X6) {
+                    float gv[4];
 #pragma unroll
-                for (int cidx = 0; cidx < 4; ++cidx) {
-                    float gv = areg[4 * i + cidx];
-                    if (has_ga) gv = gv > 0.f ? gv : gv * g_al[i];
-                    As[buf][k4 + cidx][r] = gv * keep;
+                    for (int cidx = 0; cidx < 4; ++cidx) {
+                        gv[cidx] = areg[4 * i + cidx];
+                        if (has_ga) gv[cidx] = gv[cidx] > 0.f ? gv[cidx] : gv[cidx] * g_al[i];
+                        gv[cidx] *= keep;
+                    }
+                    if (do_rowsum) rs_v[i] += (gv[0] + gv[1]) + (gv[2] + gv[3]);
+                    unsigned o[3][2];
+                    pase_split_bf16x3_quad(gv, o);
+                    // time steps k4 .. k4+3 = half (tid & 1) of k-group (tid & 7) >> 1
+                    unsigned char* dst = reinterpret_cast<unsigned char*>(&AsX[(buf * (BKQ / 8) + ((tid & 7) >> 1)) * 3 * BM + r]) + (tid & 1) * 8;
+#pragma unroll
+                    for (int pz = 0; pz < 3; ++pz)
+                        *reinterpret_cast<uint2*>(dst + pz * BM * 16) = make_uint2(o[pz][0], o[pz][1]);
+                } else {
+#pragma unroll
+                    for (int cidx = 0; cidx < 4; ++cidx) {
+                        float gv = areg[4 * i + cidx];
+                        if (has_ga) gv = gv > 0.f ? gv : gv * g_al[i];
+                        As[buf][k4 + cidx][r] = gv * keep;
+                    }
                 }
             }
         } else {
@@ -267,7 +298,9 @@ __global__ void __launch_bounds__(NTHREADS, ((ZPT <= ZPT_SMALL || ZV) ? 2 : 1)) 
                 const int r = (tid >> 5) + 8 * i;
                 float gv = areg[i];
                 if (has_ga && m0 + r < p.M) gv = gv > 0.f ? gv : gv * p.g_alpha[m0 + r];
-                As[buf][tid & 31][r] = gv;
+                if constexpr (!X6) {
+                    As[buf][tid & 31][r] = gv;
+                }
             }
         }
 #pragma unroll
@@ -311,7 +344,6 @@ __global__ void __launch_bounds__(NTHREADS, ((ZPT <= ZPT_SMALL || ZV) ? 2 : 1)) 
     const bool row_ok0 = m0 + wm * 64 < p.M, row_ok1 = m0 + wm * 64 + 32 < p.M;
     const bool col_ok0 = j0 + wn * 64 < Nw, col_ok1 = j0 + wn * 64 + 32 < Nw;
     const bool full_tile = row_ok0 && row_ok1 && col_ok0 && col_ok1;
-    const bool do_rowsum = pl.bias_rowsum && p.dbias && ct == 0;
     float rowsum = 0.f;
 
     load_stage(c_begin);
@@ -320,6 +352,43 @@ __global__ void __launch_bounds__(NTHREADS, ((ZPT <= ZPT_SMALL || ZV) ? 2 : 1)) 
     for (int c = c_begin; c < c_end; ++c) {
         const int cur = (c - c_begin) & 1;
         if (c + 1 < c_end) load_stage(c + 1);
+        if constexpr (X6) {
+            const bool has_next = c + 1 < c_end;
+            const u32x4* aL = &AsX[(cur * (BKQ / 8) + fk) * 3 * BM + wm * 64 + fr];
+            const float* z0_ = &Zs[cur][boff[0] + 8 * fk * zstep];
+            const float* z1_ = &Zs[cur][boff[1] + 8 * fk * zstep];
+#pragma unroll
+            for (int st = 0; st < BKQ / 16; ++st) {
+                float xv0[8], xv1[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    xv0[e] = z0_[(16 * st + e) * zstep];
+                    xv1[e] = z1_[(16 * st + e) * zstep];
+                }
+                u32x4 fa[3][2], fb0[3], fb1[3];
+#pragma unroll
+                for (int pz = 0; pz < 3; ++pz) {
+                    fa[pz][0] = aL[(st * 2 * 3 + pz) * BM];
+                    fa[pz][1] = aL[(st * 2 * 3 + pz) * BM + 32];
+                }
+                pase_split_bf16x3(xv0, fb0);
+                pase_split_bf16x3(xv1, fb1);
+                constexpr int PZA[6] = {1, 0, 2, 0, 1, 0}, PZB[6] = {1, 2, 0, 1, 0, 0};   // smallest terms first
+#pragma unroll
+                for (int pi = 0; pi < 6; ++pi) {
+                    acc[0][0] = pase_mfma_bf16_32x32x16(fa[PZA[pi]][0], fb0[PZB[pi]], acc[0][0]);
+                    acc[0][1] = pase_mfma_bf16_32x32x16(fa[PZA[pi]][0], fb1[PZB[pi]], acc[0][1]);
+                    acc[1][0] = pase_mfma_bf16_32x32x16(fa[PZA[pi]][1], fb0[PZB[pi]], acc[1][0]);
+                    acc[1][1] = pase_mfma_bf16_32x32x16(fa[PZA[pi]][1], fb1[PZB[pi]], acc[1][1]);
+                }
+                PASE_SCHED_BARRIER();     // keep one step's fragments live at a time
+                if (has_next) {
+#pragma unroll
+                    for (int q = 0; q < NP / 2; ++q) store_piece(cur ^ 1, st * (NP / 2) + q);
+                }
+                PASE_SCHED_BARRIER();
+            }
+        } else
         // software-pipelined operand fetch (ping-pong registers, schedule pinned): the ds_reads of step
         // ks+1 are in flight under the four MFMAs of step ks.  MFMAs are unconditional (see conv_gemm.hip).
         {
@@ -361,13 +430,25 @@ __global__ void __launch_bounds__(NTHREADS, ((ZPT <= ZPT_SMALL || ZV) ? 2 : 1)) 
                 }
             }
         }
-        if (do_rowsum && tid < BM) {
+        if (!X6 && do_rowsum && tid < BM) {
 #pragma unroll 8
             for (int kq = 0; kq < BKQ; ++kq) rowsum += As[cur][kq][tid];
         }
         __syncthreads();
     }
-    if (do_rowsum && tid < BM && m0 + tid < p.M) atomicAdd(p.dbias + m0 + tid, rowsum);
+    if (!X6 && do_rowsum && tid < BM && m0 + tid < p.M) atomicAdd(p.dbias + m0 + tid, rowsum);
+    if (X6 && do_rowsum) {
+        // staging-thread partials: 8 lanes share a row
+#pragma unroll
+        for (int i = 0; i < (X6 ? GS : 0); ++i) {
+            float v = rs_v[i];
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 4);
+            const int m = m0 + (tid >> 3) + 32 * i;
+            if ((tid & 7) == 0 && m < p.M && v != 0.f) atomicAdd(p.dbias + m, v);
+        }
+    }
 
     const int rbase = 4 * (lane >> 5);
 #pragma unroll
@@ -561,6 +642,181 @@ __global__ void __launch_bounds__(NTHREADS, 2) wgrad_flat_kernel(PaseWgrad p, Wg
     }
 }
 
+// ---- the same 1x1 contraction on the bf16 matrix pipe (PaseWgrad::x6): both operands are contiguous along the
+// reduction, so BOTH are split into their three bf16 pieces by the staging threads (a float4 = half a fragment:
+// one ds_write_b64 per piece) and the MFMA loop is 12 ds_read_b128 + 24 v_mfma_f32_32x32x16_bf16 per 16-deep stage,
+// no VALU.  LDS image per operand and buffer: [2 k-groups][3 planes][128 rows][8 bf16] = 12 KB.
+constexpr int BKX = 16;                 // reduction positions per stage of the split-bf16 1x1 kernel
+
+template <int BM, int BN>
+__global__ void __launch_bounds__(NTHREADS, 2) wgrad_flat_x6_kernel(PaseWgrad p, WgradPlan pl) {
+    constexpr int WAVES_N = BN / 64;
+    constexpr int TPR = BKX / 4;             // threads per row (one float4 each)
+    constexpr int RPP = NTHREADS / TPR;      // rows per pass (64)
+    constexpr int GS = BM / RPP, ZSL = BN / RPP;
+    constexpr int A_BUF = (BKX / 8) * 3 * BM, Z_BUF = (BKX / 8) * 3 * BN;   // 16-byte chunks per buffer
+    __shared__ __attribute__((aligned(16))) u32x4 AsX[2 * A_BUF];
+    __shared__ __attribute__((aligned(16))) u32x4 ZsX[2 * Z_BUF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = pase_uniform(tid >> 6);
+    const int wm = wave / WAVES_N;
+    const int wn = wave % WAVES_N;
+    const int fr = lane & 31;
+    const int fk = lane >> 5;
+
+    const int tiles = pl.n_row_tiles * pl.n_col_tiles;
+    const int tile = blockIdx.x % tiles;
+    const int split = blockIdx.x / tiles;
+    const int mt = tile % pl.n_row_tiles;
+    const int ct = tile / pl.n_row_tiles;
+    const int m0 = mt * BM;
+    const int j0 = ct * BN;
+    const int Kw = p.Cin;
+    const int c_begin = split * pl.kt_per_split;
+    const int c_end = min(pl.n_chunks, c_begin + pl.kt_per_split);
+    if (c_begin >= c_end) return;
+    const int ntot = p.S * p.Ncols;
+
+    // thread -> rows r0 + 64*i, time steps k4 .. k4+3 of the chunk = half (tid & 1) of k-group (tid & 3) >> 1
+    const int k4 = (tid % TPR) * 4;
+    const int r0 = tid / TPR;
+    unsigned goff[GS], zoff[ZSL];
+    float g_al[GS], z_sc[ZSL], z_sh[ZSL], z_al[ZSL];
+    const bool has_ga = p.g_alpha != nullptr;
+    const bool has_aff = p.in_scale != nullptr, has_al = p.in_alpha != nullptr;
+#pragma unroll
+    for (int i = 0; i < GS; ++i) {
+        const int m = min(m0 + r0 + RPP * i, p.M - 1);          // rows past M re-read row M-1 (never stored)
+        goff[i] = (unsigned)((p.g_coff + m) * p.Tg);
+        g_al[i] = has_ga ? p.g_alpha[m] : 1.f;
+    }
+#pragma unroll
+    for (int i = 0; i < ZSL; ++i) {
+        const int j = min(j0 + r0 + RPP * i, Kw - 1);
+        zoff[i] = (unsigned)((p.z_coff + j) * p.Tz);
+        z_sc[i] = has_aff ? p.in_scale[j] : 1.f;
+        z_sh[i] = has_aff ? p.in_shift[j] : 0.f;
+        z_al[i] = has_al ? p.in_alpha[j] : 1.f;
+    }
+    WF4 areg[GS], zreg[ZSL];
+    bool valid_next = true;
+    const bool do_rowsum = p.dbias && ct == 0;
+    float rs[GS];
+#pragma unroll
+    for (int i = 0; i < GS; ++i) rs[i] = 0.f;
+
+    auto load_stage = [&](int c) __attribute__((always_inline)) {
+        const int n = c * BKX + k4;                              // 4 consecutive n share a sequence (Ncols % 4 == 0)
+        valid_next = n < ntot;
+        const unsigned nn = (unsigned)min(n, ntot - 4);
+        int s = (int)div_magic(nn, pl.ncols_magic);
+        int q = (int)nn - s * p.Ncols;
+        if (q < 0) { --s; q += p.Ncols; }
+        const float* gb = p.g + (unsigned)(s * p.g_ctot * p.Tg + q);
+        const float* zb = p.z + (unsigned)(s * p.z_ctot * p.Tz + q);
+#pragma unroll
+        for (int i = 0; i < GS; ++i) areg[i] = *reinterpret_cast<const WF4*>(gb + goff[i]);
+#pragma unroll
+        for (int i = 0; i < ZSL; ++i) zreg[i] = *reinterpret_cast<const WF4*>(zb + zoff[i]);
+    };
+    auto prelu = [&](float v, float al) __attribute__((always_inline)) { return v > 0.f ? v : v * al; };
+    const int sub = ((tid % TPR) >> 1) * 3;                      // k-group of this thread's float4, in planes
+    const int halfb = (tid & 1) * 8;
+    auto store_stage = [&](int buf) __attribute__((always_inline)) {
+        const float keep = valid_next ? 1.f : 0.f;               // chunk tail beyond S*Ncols contributes zero
+#pragma unroll
+        for (int i = 0; i < GS; ++i) {
+            const int r = r0 + RPP * i;
+            float v[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (has_ga ? prelu(v[e], g_al[i]) : v[e]) * keep;
+            if (do_rowsum) rs[i] += (v[0] + v[1]) + (v[2] + v[3]);
+            unsigned o[3][2];
+            pase_split_bf16x3_quad(v, o);
+            unsigned char* dst = reinterpret_cast<unsigned char*>(&AsX[buf * A_BUF + sub * BM + r]) + halfb;
+#pragma unroll
+            for (int pz = 0; pz < 3; ++pz) *reinterpret_cast<uint2*>(dst + pz * BM * 16) = make_uint2(o[pz][0], o[pz][1]);
+        }
+#pragma unroll
+        for (int i = 0; i < ZSL; ++i) {
+            const int r = r0 + RPP * i;
+            float v[4] = {zreg[i].x, zreg[i].y, zreg[i].z, zreg[i].w};
+            if (has_aff || has_al) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = prelu(fmaf(v[e], z_sc[i], z_sh[i]), z_al[i]);
+            }
+            unsigned o[3][2];
+            pase_split_bf16x3_quad(v, o);
+            unsigned char* dst = reinterpret_cast<unsigned char*>(&ZsX[buf * Z_BUF + sub * BN + r]) + halfb;
+#pragma unroll
+            for (int pz = 0; pz < 3; ++pz) *reinterpret_cast<uint2*>(dst + pz * BN * 16) = make_uint2(o[pz][0], o[pz][1]);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    load_stage(c_begin);
+    store_stage(0);
+    __syncthreads();
+    for (int c = c_begin; c < c_end; ++c) {
+        const int cur = (c - c_begin) & 1;
+        const bool has_next = c + 1 < c_end;
+        if (has_next) load_stage(c + 1);
+        const u32x4* aL = &AsX[cur * A_BUF + fk * 3 * BM + wm * 64 + fr];
+        const u32x4* zL = &ZsX[cur * Z_BUF + fk * 3 * BN + wn * 64 + fr];
+        u32x4 fa[3][2], fb[3][2];
+#pragma unroll
+        for (int pz = 0; pz < 3; ++pz) {
+            fa[pz][0] = aL[pz * BM];
+            fa[pz][1] = aL[pz * BM + 32];
+            fb[pz][0] = zL[pz * BN];
+            fb[pz][1] = zL[pz * BN + 32];
+        }
+        constexpr int PZA[6] = {1, 0, 2, 0, 1, 0}, PZB[6] = {1, 2, 0, 1, 0, 0};   // smallest terms first
+#pragma unroll
+        for (int pi = 0; pi < 6; ++pi) {
+            acc[0][0] = pase_mfma_bf16_32x32x16(fa[PZA[pi]][0], fb[PZB[pi]][0], acc[0][0]);
+            acc[0][1] = pase_mfma_bf16_32x32x16(fa[PZA[pi]][0], fb[PZB[pi]][1], acc[0][1]);
+            acc[1][0] = pase_mfma_bf16_32x32x16(fa[PZA[pi]][1], fb[PZB[pi]][0], acc[1][0]);
+            acc[1][1] = pase_mfma_bf16_32x32x16(fa[PZA[pi]][1], fb[PZB[pi]][1], acc[1][1]);
+        }
+        if (has_next) store_stage(cur ^ 1);
+        __syncthreads();
+    }
+    if (do_rowsum) {
+#pragma unroll
+        for (int i = 0; i < GS; ++i) {
+            float v = rs[i];
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            const int m = m0 + r0 + RPP * i;
+            if ((tid % TPR) == 0 && m < p.M) atomicAdd(p.dbias + m, v);
+        }
+    }
+
+    const int rbase = m0 + wm * 64 + 4 * (lane >> 5);
+    const int jb = j0 + wn * 64 + fr;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = rbase + a * 32 + (r & 3) + 8 * (r >> 2);
+            if (m >= p.M) continue;
+            const unsigned rowoff = (unsigned)(m * p.ldw);
+            if (jb < Kw) atomicAdd(p.dw + (rowoff + (unsigned)jb), acc[a][0][r]);
+            if (jb + 32 < Kw) atomicAdd(p.dw + (rowoff + (unsigned)(jb + 32)), acc[a][1][r]);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
@@ -604,6 +860,11 @@ extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
     };
     pl.zshift = 0;
     bool use_zv = false;
+    // split-bf16 launches take the 64 x 256 tile whenever its span slab fits: half the split G slab (24 KB) and
+    // measurably faster than 128 x 128 on every PASE+ layer (127-158 vs 111-141 TFLOP/s fp32-equivalent)
+    const bool x6_can = p.x6 && !pl.flat && (p.Tg % 4) == 0 && (p.Ncols % 4) == 0 &&
+                        (((unsigned long long)(size_t)p.g) % 16) == 0 && (long)p.S * p.g_ctot * (long)p.Tg < 0x7fffffffL;
+    if (x6_can && (need(256) <= ZPT_SMALL * NTHREADS || (zv_ok && need_zv(256) <= ZV_SLOTS * 4 * NTHREADS))) narrow = true;
     if (narrow && need(256) > ZPT_LARGE * NTHREADS && !(zv_ok && need_zv(256) <= ZV_SLOTS * 4 * NTHREADS)) narrow = false;
     if (!narrow && need(128) > ZPT_LARGE * NTHREADS && !(zv_ok && need_zv(128) <= ZV_SLOTS * 4 * NTHREADS)) return -6;
     const bool small = need(narrow ? 256 : 128) <= ZPT_SMALL * NTHREADS;
@@ -620,7 +881,9 @@ extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
     pl.n_col_tiles = (Nw + BNv - 1) / BNv;
     const long kred = (long)p.S * p.Ncols;
     pl.chunks_per_seq = (p.Ncols + BKQ - 1) / BKQ;
-    pl.n_chunks = pl.flat ? (int)((kred + BKQ - 1) / BKQ) : p.S * pl.chunks_per_seq;
+    const bool flat_x6 = flat_fast && p.x6;
+    const int bkq = flat_x6 ? BKX : BKQ;                 // reduction positions per stage
+    pl.n_chunks = pl.flat ? (int)((kred + bkq - 1) / bkq) : p.S * pl.chunks_per_seq;
     pl.span_magic = (unsigned)((0x100000000ULL + pl.SPANW - 1) / (unsigned long long)pl.SPANW);
     pl.ncols_magic = (unsigned)((0x100000000ULL + p.Ncols - 1) / (unsigned long long)p.Ncols);
     pl.gvec = ((p.Tg % 4) == 0 && (p.Ncols % 4) == 0 && (((unsigned long long)(size_t)p.g) % 16) == 0 &&
@@ -632,10 +895,11 @@ extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
         // of 512; a nearly empty last round costs as much as a half-full one (measured: a lone workgroup on
         // a CU runs 1.85x faster than two co-resident ones).  Pick the split that minimises
         // rounds x (reduction share + atomic tile flush) per workgroup.
-        const int max_split = (pl.n_chunks + 3) / 4;      // at least 4 stages (256 MFMAs/wave) per split
+        const int min_stages = 4 * BKQ / bkq;             // at least 128 reduction positions per split
+        const int max_split = (pl.n_chunks + min_stages - 1) / min_stages;
         double best = 1e30;
         splitk = 1;
-        const double flush = 3.0 / (double)pl.n_chunks;   // atomic tile flush ~ 3 stages of work
+        const double flush = 3.0 * (BKQ / bkq) / (double)pl.n_chunks;   // atomic tile flush ~ 3 (32-deep) stages of work
         for (int sk = 1; sk <= max_split && sk <= 2048; ++sk) {
             const long W = (long)tiles * sk;
             const long full = W / 512, tail = W % 512;
@@ -648,8 +912,26 @@ extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
     pl.kt_per_split = (pl.n_chunks + splitk - 1) / splitk;
     splitk = (pl.n_chunks + pl.kt_per_split - 1) / pl.kt_per_split;
     const dim3 grid((unsigned)(tiles * splitk)), block(NTHREADS);
+    if (flat_x6) {
+        PASE_LAUNCH((wgrad_flat_x6_kernel<128, 128>), grid, block, st, p, pl);
+        PASE_CHECK_LAUNCH();
+        return 0;
+    }
     if (flat_fast) {
         PASE_LAUNCH((wgrad_flat_kernel<128, 128>), grid, block, st, p, pl);
+        PASE_CHECK_LAUNCH();
+        return 0;
+    }
+    // split-bf16 instantiations (LDS: 48 / 24 KB of split G slab + the span slab must leave two workgroups per CU)
+    const bool x6 = p.x6 && pl.gvec && !pl.flat;
+    if (x6 && use_zv && narrow) {
+        PASE_LAUNCH((wgrad_gemm_kernel<64, 256, 5, 1, 1>), grid, block, st, p, pl);
+        PASE_CHECK_LAUNCH();
+        return 0;
+    }
+    if (x6 && !use_zv && small) {
+        if (narrow) PASE_LAUNCH((wgrad_gemm_kernel<64, 256, ZPT_SMALL, 0, 1>), grid, block, st, p, pl);
+        else PASE_LAUNCH((wgrad_gemm_kernel<128, 128, ZPT_SMALL, 0, 1>), grid, block, st, p, pl);
         PASE_CHECK_LAUNCH();
         return 0;
     }

@@ -217,7 +217,7 @@ class PaseWgrad(C.Structure):
         ("Ncols", C.c_int),
         ("Cin", C.c_int), ("Tz", C.c_int), ("z_ctot", C.c_int), ("z_coff", C.c_int), ("taps", C.c_int),
         ("tap_major", C.c_int), ("stride", C.c_int), ("tapstep", C.c_int), ("padL", C.c_int),
-        ("pad_mode", C.c_int), ("ldw", C.c_int), ("splitk", C.c_int),
+        ("pad_mode", C.c_int), ("ldw", C.c_int), ("splitk", C.c_int), ("x6", C.c_int),
     ]
 
 
@@ -302,6 +302,7 @@ def wgrad_gemm(g, z, dw, *, S, M, Tg, Ncols, Cin, Tz, taps, ldw=None, dbias=None
     d.taps, d.tap_major, d.stride, d.tapstep, d.padL, d.pad_mode = taps, tap_major, stride, tapstep, padL, pad_mode
     d.ldw = Cin * taps if ldw is None else ldw
     d.splitk = splitk
+    d.x6 = 1 if X6 else 0
     ev0 = GEMM_TIMER.start() if GEMM_TIMER is not None else None
     _check(_lib.lib().pase_wgrad_gemm(C.byref(d), _stream()), "pase_wgrad_gemm")
     if ev0 is not None:
