@@ -53,9 +53,9 @@ constexpr int NPAR = 4;       // on-load (scale, shift, alpha) triples prefetche
 // flat 1x1 instantiation (float4 slots): 32 k per stage x BN columns = 4096 staged floats and a 32-row weight
 // slab -- more columns of X per stage than the span layout needs, fewer rows of A, same LDS footprint
 constexpr int KG_FLAT = 32, XS_FLAT = 4096, NS_FLAT = 4;
-// split-bf16 ("x6") instantiation: a stage is up to X6_STEPS MFMA steps of 16 k; its weight slab is the three bf16
+// split-bf16 ("x6") instantiations: a stage is up to X6 (template value: 3, or 4 for the 30-tap layers) MFMA steps of 16 k; its weight slab is the three bf16
 // planes in fragment order, 16-byte chunks [step][k-group][plane][tile row], single-buffered (36 KB for 128 rows)
-constexpr int X6_STEPS = 3;
+constexpr int X6_STEPS = 3, X6_STEPS_LONG = 4;
 
 struct ConvPlan {
     int CB, TB, SPAN, SPANV, n_gc, n_gt, mode, tiles_per_seq, splitk;
@@ -146,8 +146,8 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
     constexpr int XS_T = XV ? XS_FLAT : (OCC == 3 ? NS * NTHREADS : XSMAX);
     constexpr int PA_MAX = (KG_T + RA - 1) / RA;      // 6 / 3 (4 / 2 flat)
     constexpr int LDA = BM + 4;
-    constexpr int AX_CHUNKS = 3 * X6_STEPS * 2 * BM;              // x6: 16-byte chunks of one stage's weight slab
-    constexpr int NCH = AX_CHUNKS / NTHREADS;                     // ... per thread (9)
+    constexpr int AX_CHUNKS = 3 * (X6 ? X6 : 1) * 2 * BM;          // x6: 16-byte chunks of one stage's weight slab
+    constexpr int NCH = AX_CHUNKS / NTHREADS;                     // ... per thread (9 / 12)
     static_assert(!X6 || AX_CHUNKS % NTHREADS == 0, "x6 slab");
     constexpr int A_BYTES = X6 ? AX_CHUNKS * 16 : 2 * KG_T * LDA * (int)sizeof(float);
     __shared__ __attribute__((aligned(16))) unsigned char As_raw[A_BYTES];
@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
             // pre-split chunks, already in LDS order (ragged channel groups / padded taps are zero in the pack)
 #pragma unroll
             for (int i = 0; i < NCH; ++i)
-                if (i < 3 || tid + NTHREADS * i < ax_nch) AsX[tid + NTHREADS * i] = aregx[i];
+                if (tid + NTHREADS * i < ax_nch) AsX[tid + NTHREADS * i] = aregx[i];
         } else {
             const bool a_zero = lo_next > 0 || (kg_next & 3) != 0;   // uniform
 #pragma unroll
@@ -941,13 +941,13 @@ struct HostPlan {
 // Split-bf16 stage shape for a span-mode launch on the 128 x 128 tile, or false.  Candidates: (R rows x Tq taps) per
 // 16-deep step with R * Tq = 16; the taps are padded to a multiple of Tq (zero weights) and a stage holds as many
 // row groups as fit X6_STEPS steps.  Score = useful fraction of the padded taps x a penalty for short stages.
-bool plan_x6(const PaseConvGemm& p, int BN, ConvPlan& pl) {
+bool plan_x6(const PaseConvGemm& p, int BN, ConvPlan& pl, int max_steps) {
     double best = 0.0;
     for (int R = 2; R <= 16; R *= 2) {
         const int Tq = 16 / R;
         const int TBp = (p.taps + Tq - 1) / Tq * Tq, tsn = TBp / Tq;
-        if (tsn > X6_STEPS) continue;
-        for (int rg = X6_STEPS / tsn; rg >= 1; --rg) {
+        if (tsn > max_steps) continue;
+        for (int rg = max_steps / tsn; rg >= 1; --rg) {
             const int CB = R * rg;
             if (CB > p.Cin) continue;
             const int SPANV = (BN - 1) * p.stride + (pl.mode == MODE_SEG ? 2 : 1) * TBp;
@@ -956,7 +956,7 @@ bool plan_x6(const PaseConvGemm& p, int BN, ConvPlan& pl) {
             const int nslots = (SPANV + 1 + (1 << tl) - 1) >> tl;
             if (nslots > XPT) continue;
             const int steps = rg * tsn;
-            const double eff = (double)p.taps / TBp * (steps == 3 ? 1.0 : (steps == 2 ? 0.93 : 0.8));
+            const double eff = (double)p.taps / TBp * (steps >= 3 ? 1.0 : (steps == 2 ? 0.93 : 0.8));
             if (eff > best) {
                 best = eff;
                 pl.CB = CB; pl.TB = TBp; pl.SPANV = SPANV; pl.tl = tl; pl.nslots = nslots;
@@ -988,9 +988,12 @@ HostPlan make_plan(const PaseConvGemm& p, bool want_x6) {
     pl.xvec = flat ? 1 : 0;
     pl.pmajor = pl.xvec;
     pl.x6 = pl.xR = pl.xTq = pl.xTS = pl.xSteps = 0;
-    if (want_x6 && !flat && !h.narrow && p.taps <= 24 && plan_x6(p, h.BN, pl)) {
+    // (the 4-step slab costs 12 KB of LDS and 12 VGPRs more: only where 3 steps cannot hold the padded taps)
+    if (want_x6 && !flat && !h.narrow && p.taps <= 32 &&
+        (plan_x6(p, h.BN, pl, X6_STEPS) || plan_x6(p, h.BN, pl, X6_STEPS_LONG))) {
         pl.x6 = 1;
         pl.nslots = pl.nslots <= 3 ? 3 : (pl.nslots <= 6 ? 6 : 12);
+        if (pl.xSteps > X6_STEPS && pl.nslots < 6) pl.nslots = 6;      // the 4-step instantiations are 6 / 12 slots
         pl.SPAN = pl.nslots << pl.tl;
     } else if (flat) {
         if (want_x6 && !h.narrow && p.Cin >= 16) {
@@ -1134,10 +1137,13 @@ extern "C" int pase_conv_gemm(const PaseConvGemm* d, void* stream) {
         PaseConvGemm q = p;
         q.taps = h.pl.TB;
         q.K = p.Cin * h.pl.TB;
-        if (h.pl.xvec) PASE_LAUNCH((conv_gemm_kernel<128, 128, NS_FLAT, 1, 2, -1, 1>), grid, block, st, q, h.pl);
-        else if (h.pl.nslots == 3) PASE_LAUNCH((conv_gemm_kernel<128, 128, 3, 0, 2, -1, 1>), grid, block, st, q, h.pl);
-        else if (h.pl.nslots == 6) PASE_LAUNCH((conv_gemm_kernel<128, 128, 6, 0, 2, -1, 1>), grid, block, st, q, h.pl);
-        else PASE_LAUNCH((conv_gemm_kernel<128, 128, 12, 0, 2, -1, 1>), grid, block, st, q, h.pl);
+        if (h.pl.xvec) PASE_LAUNCH((conv_gemm_kernel<128, 128, NS_FLAT, 1, 2, -1, 3>), grid, block, st, q, h.pl);
+        else if (h.pl.xSteps > X6_STEPS && h.pl.nslots <= 6)
+            PASE_LAUNCH((conv_gemm_kernel<128, 128, 6, 0, 2, -1, 4>), grid, block, st, q, h.pl);
+        else if (h.pl.xSteps > X6_STEPS) PASE_LAUNCH((conv_gemm_kernel<128, 128, 12, 0, 2, -1, 4>), grid, block, st, q, h.pl);
+        else if (h.pl.nslots == 3) PASE_LAUNCH((conv_gemm_kernel<128, 128, 3, 0, 2, -1, 3>), grid, block, st, q, h.pl);
+        else if (h.pl.nslots == 6) PASE_LAUNCH((conv_gemm_kernel<128, 128, 6, 0, 2, -1, 3>), grid, block, st, q, h.pl);
+        else PASE_LAUNCH((conv_gemm_kernel<128, 128, 12, 0, 2, -1, 3>), grid, block, st, q, h.pl);
     } else if (h.narrow) PASE_CONV_LAUNCH(64, 256);
     else PASE_CONV_LAUNCH(128, 128);
 #undef PASE_CONV_LAUNCH
