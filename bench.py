@@ -26,6 +26,8 @@ sys.path.insert(0, ROOT)
 
 GFLOP_PER_UTT_TRAIN = 122.0      # SURVEY.md 8(d) / BASELINE.md section 3: canonical algorithmic FLOPs
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
+X6_MFMA_PER_PRODUCT = 6          # split-bf16 contraction: hh + hm + mh + hl + lh + mm per fp32 product
 
 
 def load_cfgs():
@@ -378,12 +380,22 @@ def main():
         wg = fams.get("wgrad_gemm", dict(launches=1, flops=0.0, ms=1.0))
         cg_tf = cg["flops"] / cg["ms"] / 1e9
         wg_tf = wg["flops"] / wg["ms"] / 1e9
+        # the contractions run as 6 bf16 MFMAs per fp32 product (PaseConvGemm::wx6 / PaseWgrad::x6; fp32-grade result):
+        # the pipe's ceiling in ALGORITHMIC (fp32-equivalent) FLOP/s is the dense bf16 peak / 6.  PASE_X6=0 puts them
+        # back on the fp32 matrix pipe (157.3 TFLOP/s).
+        x6 = bool(K.X6)
+        peak = PEAK_BF16_MFMA_TFLOPS / X6_MFMA_PER_PRODUCT if x6 else PEAK_F32_MFMA_TFLOPS
+        peak_note = ("peak = dense bf16 MFMA peak (2500) / 6 MFMAs per fp32 product = 416.7 fp32-equivalent TFLOP/s; "
+                     "the fp32 matrix pipe (v_mfma_f32_32x32x2_f32) peaks at 157.3") if x6 else \
+                    "peak = v_mfma_f32_32x32x2_f32 dense peak"
         out = {
             "metric": "utterances/sec (PASE+ bs32 32k-sample chunks; encoder-frames/sec = 600 x)",
             "value": round(utt_s, 3), "unit": "utterances/s",
             "encoder_frames_per_s": round(utt_s * 3 * (T // 160), 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": ("f32 (contractions: each fp32 operand = 3 exact bf16 pieces, 6 bf16 MFMAs per product, fp32 accumulate; "
+                      "measured error = that of an fp32 fma chain)") if x6 else "f32", "data": "synthetic",
             "config": {"workload": ("PASE+.cfg + workers+.cfg train step with the batch produced on device each step: crops "
                                     "of a resident pool, Reverb(24000-tap synthetic IRs, p=0.5) + additive noise (p=0.5), "
                                     "LPS/FBANK/gammatone/MFCC targets from the clean chunk (BASELINE.json configs[3] shape)")
@@ -396,8 +408,9 @@ def main():
                        "host-buffer leg)", "collective_backend": backend,
                        "hipgraph": bool(getattr(tr, "_graph", None) is not None)},
             "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (all launches of one step)",
-                         "achieved": round(cg_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(cg_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "achieved": round(cg_tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                         "frac": round(cg_tf / peak, 4), "frac_of_fp32_mfma_peak": round(cg_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                         "peak_note": peak_note, "traffic": traffic,
                          "traffic_unit": "GB per launch (PMC FETCH_SIZE x2 + WRITE_SIZE); null when no PMC profile of "
                                          "exactly this build exists", "traffic_source": traffic_src,
                          "launches_per_step": cg["launches"] // extra,
@@ -406,12 +419,13 @@ def main():
                          "note": "sum of the launches' executed contraction FLOPs (2*S*Ncols*M*K from each "
                                  "descriptor) / sum of HIP-event durations on the launch stream"},
             "roofline_wgrad": {"bound": "mfma", "kernel": "wgrad_gemm_kernel", "achieved": round(wg_tf, 2),
-                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(wg_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                               "peak": round(peak, 1), "unit": "TFLOP/s",
+                               "frac": round(wg_tf / peak, 4),
                                "launches_per_step": wg["launches"] // extra,
                                "avg_launch_ms": round(wg["ms"] / wg["launches"], 4)},
-            "roofline_step": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                              "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+            "roofline_step": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
+                              "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                              "frac_of_fp32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                               "note": "canonical algorithmic FLOPs (122.0 GFLOP per utterance, SURVEY 8d: minimal "
                                       "algorithm, dense skips pooled first) x utterances/s per GPU"},
         }

@@ -286,3 +286,46 @@ def test_flat_ws_mse_context_epilogue_wide(dev):
     torch.testing.assert_close(y.cpu(), pred, **_tol(dev))
     torch.testing.assert_close(g.cpu(), (pred - tgt) * gs, rtol=1e-4, atol=1e-5)
     assert abs(float(acc) - float(((pred - tgt).double() ** 2).sum())) < 1e-3 * float(((pred - tgt) ** 2).sum())
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,T,S", [
+    (64, 130, 11, 1, 300, 3),     # 4 rows x 4 taps per step (11 -> 12 taps), 3-slot spans
+    (64, 130, 11, 2, 600, 2),     # stride 2: 6-slot spans
+    (48, 70, 6, 1, 300, 2),       # 8 rows x 2 taps
+    (40, 70, 8, 1, 200, 2),       # 2 rows x 8 taps
+    (64, 70, 3, 1, 300, 2),       # 16 rows x 1 tap
+    (20, 70, 30, 10, 2900, 2),    # 30 taps: 4-step stages
+    (96, 130, 1, 1, 200, 3),      # flat 1x1
+])
+def test_split_bf16_is_fp32_grade(dev, Cin, Cout, k, stride, T, S):
+    """The split-bf16 contraction (PaseConvGemm::wx6: hi+mid+lo pieces, 6 bf16 MFMAs per product) against an fp64
+    reference: its error must be that of the fp32 matrix pipe on the same launch (not bf16-grade)."""
+    import ctypes as C
+    from pase_amd import _lib
+    torch.manual_seed(3)
+    x = torch.randn(S, Cin, T)
+    w = torch.randn(Cout, Cin, k) * 0.2
+    if k > 1:
+        P = (k // 2 - 1, k // 2) if (stride > 1 or k % 2 == 0) else (k // 2, k // 2)
+        xp = F.pad(x.double(), P, mode="reflect")
+    else:
+        P, xp = (0, 0), x.double()
+    ref = F.conv1d(xp, w.double(), None, stride=stride)
+    Tout = ref.shape[2]
+    kw = dict(S=S, Cin=Cin, Tin=T, M=Cout, K=Cin * k, taps=k, Ncols=Tout, Tout=Tout, stride=stride, padL=P[0],
+              pad_mode=K.PAD_REFLECT if k > 1 else K.PAD_ZERO, splitk=1)
+    w2 = w.reshape(Cout, -1).contiguous().to(dev)
+    d = K._conv_desc(x.to(dev), w2, torch.empty(S, Cout, Tout, device=dev), wt=K.pack_wt(w2, M=Cout, K=Cin * k, Cin=Cin, taps=k), **kw)
+    assert _lib.lib().pase_conv_gemm_x6_bytes(C.byref(d)) > 0, "shape expected to have a split-bf16 plan"
+    err = {}
+    saved = K.X6
+    try:
+        for mode in (True, False):
+            K.X6 = mode
+            y = torch.zeros(S, Cout, Tout, device=dev)
+            K.conv_gemm(x.to(dev), w2, y, **kw)
+            err[mode] = ((y.cpu().double() - ref).norm() / ref.norm()).item()
+    finally:
+        K.X6 = saved
+    assert err[True] < 5e-7, err
+    assert err[True] < 2.0 * err[False] + 1e-8, err

@@ -311,3 +311,35 @@ def test_wgrad_large_span_float4_staging(dev, Cout):
                  pad_mode=K.PAD_REFLECT)
     assert_close(dw.view(Cout, Cin, k), w.grad, rtol=1e-4, atol=2e-3, what="dW")
     assert_close(db, b.grad, rtol=1e-4, atol=2e-3, what="db")
+
+
+@pytest.mark.parametrize("Cin,Cout,k,st,T,S", [(32, 130, 11, 1, 400, 2), (32, 70, 11, 2, 400, 3), (128, 130, 1, 1, 200, 3),
+                                               (8, 40, 20, 10, 3000, 2)])
+def test_wgrad_split_bf16_is_fp32_grade(dev, Cin, Cout, k, st, T, S):
+    """PaseWgrad::x6 (both operands split into three bf16 pieces on the fly) vs an fp64 reference: fp32-grade error,
+    compared with the fp32-pipe launch of the same call."""
+    torch.manual_seed(5)
+    x = torch.randn(S, Cin, T)
+    P = (0, 0) if k == 1 else ((k // 2 - 1, k // 2) if (st > 1 or k % 2 == 0) else (k // 2, k // 2))
+    w = torch.randn(Cout, Cin, k, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    xp = F.pad(x.double(), P, mode="reflect") if k > 1 else x.double()
+    y = F.conv1d(xp, w, b, stride=st)
+    g = torch.randn(y.shape)
+    (y * g.double()).sum().backward()
+    err = {}
+    saved = K.X6
+    try:
+        for mode in (True, False):
+            K.X6 = mode
+            dw = torch.zeros(Cout, Cin * k, device=dev)
+            db = torch.zeros(Cout, device=dev)
+            K.wgrad_gemm(g.to(dev), x.to(dev), dw, S=S, M=Cout, Tg=y.shape[2], Ncols=y.shape[2], Cin=Cin, Tz=T, taps=k,
+                         dbias=db, stride=st, padL=P[0], pad_mode=K.PAD_REFLECT if k > 1 else K.PAD_ZERO)
+            e_w = ((dw.cpu().double().view_as(w.grad) - w.grad).norm() / w.grad.norm()).item()
+            e_b = ((db.cpu().double() - b.grad).norm() / b.grad.norm()).item()
+            err[mode] = (e_w, e_b)
+    finally:
+        K.X6 = saved
+    assert err[True][0] < 1e-6 and err[True][1] < 1e-6, err
+    assert err[True][0] < 2.0 * err[False][0] + 1e-8, err

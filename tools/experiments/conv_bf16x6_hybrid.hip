@@ -160,7 +160,14 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const u32x4* __restrict
                 float xv[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) xv[i] = x0[(2 * (i >> 2)) * SPANP + j * 32 + 4 * b + (i & 3)];
+#ifdef EXP_NOSPLIT      // timing probe (wrong results): no VALU between the LDS reads and the MFMAs
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bb[j][sp][i] = __float_as_uint(xv[(i + sp) & 7]) ^ __float_as_uint(xv[4 + ((i + sp) & 3)]);
+#else
                 split8(xv, bb[j]);
+#endif
             }
             constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};   // smallest terms first
 #pragma unroll
