@@ -146,6 +146,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const u32x4* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+#ifndef EXP_PIPE
     auto compute = [&](int cur) {
         const float* x0 = &Xs[cur][fk * SPANP + wn * 64 + fr];
 #pragma unroll
@@ -181,15 +182,67 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const u32x4* __restrict
                             acc[i][j], 0, 0, 0);
         }
     };
+#else
+    // EXP_PIPE: software pipeline inside a stage -- while the 24 MFMAs of step b run, the B fragments of step b + 1
+    // are read and split into a second register set (one MFMA : EXP_PIPE VALU : 1 DS, pinned with sched_group_barrier)
+    auto compute = [&](int cur) {
+        const float* x0 = &Xs[cur][fk * SPANP + wn * 64 + fr];
+        u32x4 bb[2][2][3];     // [set][col tile][plane]
+        auto read_split = [&](int b, int set) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float xv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xv[i] = x0[(2 * (i >> 2)) * SPANP + j * 32 + 4 * b + (i & 3)];
+                split8(xv, bb[set][j]);
+            }
+        };
+        read_split(0, 0);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int set = b & 1;
+            u32x4 a[3][2];
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[sp][i] = As[cur][sp][(b * 2 + fk) * BM + wm * 64 + i * 32 + fr];
+            if (b + 1 < NB) read_split(b + 1, set ^ 1);
+            constexpr int PA[6] = {2, 1, 1, 0, 0, 0}, PB[6] = {0, 1, 0, 2, 1, 0};
+#pragma unroll
+            for (int pi = 0; pi < 6; ++pi)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, a[PA[pi]][i]), __builtin_bit_cast(bf16x8, bb[set][j][PB[pi]]),
+                            acc[i][j], 0, 0, 0);
+            if (b + 1 < NB) {
+#pragma unroll
+                for (int q = 0; q < 24; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, EXP_PIPE, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+        }
+    };
+#endif
 
     gload(0);
     stash(0);
     __syncthreads();
     for (int cg = 0; cg + 1 < ncg; ++cg) {
+#ifndef EXP_NOLOAD       // timing probes (wrong results): EXP_NOLOAD = no staging of the next stage; EXP_NOBARRIER
         gload(cg + 1);
+#endif
         compute(cg & 1);
+#ifndef EXP_NOLOAD
         stash((cg & 1) ^ 1);
+#endif
+#ifndef EXP_NOBARRIER
         __syncthreads();
+#endif
     }
     compute((ncg - 1) & 1);
 #pragma unroll
