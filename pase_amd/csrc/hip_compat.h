@@ -98,7 +98,7 @@ __device__ __forceinline__ void pase_split_bf16x3(const float (&x)[8], u32x4 (&o
 #pragma unroll
     for (int i = 0; i < 8; ++i) r[i] = x[i];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < 2; ++s) {
         unsigned b[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -108,6 +108,9 @@ __device__ __forceinline__ void pase_split_bf16x3(const float (&x)[8], u32x4 (&o
 #pragma unroll
         for (int i = 0; i < 4; ++i) out[s][i] = pase_pack_hi16(b[2 * i], b[2 * i + 1]);
     }
+    // last piece: the pack takes the upper halves of the remainders as they are
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[2][i] = pase_pack_hi16(__float_as_uint(r[2 * i]), __float_as_uint(r[2 * i + 1]));
 }
 
 // four values -> three pieces x two dwords (half a fragment)
@@ -116,7 +119,7 @@ __device__ __forceinline__ void pase_split_bf16x3_quad(const float (&x)[4], unsi
 #pragma unroll
     for (int i = 0; i < 4; ++i) r[i] = x[i];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < 2; ++s) {
         unsigned b[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -126,6 +129,8 @@ __device__ __forceinline__ void pase_split_bf16x3_quad(const float (&x)[4], unsi
         out[s][0] = pase_pack_hi16(b[0], b[1]);
         out[s][1] = pase_pack_hi16(b[2], b[3]);
     }
+    out[2][0] = pase_pack_hi16(__float_as_uint(r[0]), __float_as_uint(r[1]));
+    out[2][1] = pase_pack_hi16(__float_as_uint(r[2]), __float_as_uint(r[3]));
 }
 
 __device__ __forceinline__ float pase_wave_sum32(float v) {

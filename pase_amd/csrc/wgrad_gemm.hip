@@ -902,7 +902,9 @@ extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
         const double flush = 3.0 * (BKQ / bkq) / (double)pl.n_chunks;   // atomic tile flush ~ 3 (32-deep) stages of work
         for (int sk = 1; sk <= max_split && sk <= 2048; ++sk) {
             const long W = (long)tiles * sk;
-            const long full = W / 512, tail = W % 512;
+            // (the split-bf16 1x1 kernel fits three workgroups per CU: 168 VGPRs, 48 KB of LDS)
+            const long slots = flat_x6 ? 768 : 512;
+            const long full = W / slots, tail = W % slots;
             const double tc = tail == 0 ? 0.0 : (tail <= 256 ? 0.55 : 1.0);
             const double est = ((double)full + tc) * (1.0 / sk + flush);   // rounds x (work + flush) per workgroup
             if (est < best - 1e-12) { best = est; splitk = sk; }
