@@ -277,8 +277,10 @@ __global__ void __launch_bounds__(NTHREADS, ((ZPT <= ZPT_SMALL || ZV) ? 2 : 1)) 
                     if (do_rowsum) rs_v[i] += (gv[0] + gv[1]) + (gv[2] + gv[3]);
                     unsigned o[3][2];
                     pase_split_bf16x3_quad(gv, o);
-                    // time steps k4 .. k4+3 = half (tid & 1) of k-group (tid & 7) >> 1
-                    unsigned char* dst = reinterpret_cast<unsigned char*>(&AsX[(buf * (BKQ / 8) + ((tid & 7) >> 1)) * 3 * BM + r]) + (tid & 1) * 8;
+                    // time steps k4 .. k4+3 = half (tid & 1) of k-group (tid & 7) >> 1.  Row index XOR 2 * k-group: the four
+                    // k-groups of one row (4 x 6 KB apart = one bank) land in four different 16-byte slots
+                    const int kgs = (tid & 7) >> 1;
+                    unsigned char* dst = reinterpret_cast<unsigned char*>(&AsX[(buf * (BKQ / 8) + kgs) * 3 * BM + (r ^ (2 * kgs))]) + (tid & 1) * 8;
 #pragma unroll
                     for (int pz = 0; pz < 3; ++pz)
                         *reinterpret_cast<uint2*>(dst + pz * BM * 16) = make_uint2(o[pz][0], o[pz][1]);
@@ -354,7 +356,7 @@ __global__ void __launch_bounds__(NTHREADS, ((ZPT <= ZPT_SMALL || ZV) ? 2 : 1)) 
         if (c + 1 < c_end) load_stage(c + 1);
         if constexpr (X6) {
             const bool has_next = c + 1 < c_end;
-            const u32x4* aL = &AsX[(cur * (BKQ / 8) + fk) * 3 * BM + wm * 64 + fr];
+            const u32x4* aB = &AsX[(cur * (BKQ / 8) + fk) * 3 * BM + wm * 64];
             const float* z0_ = &Zs[cur][boff[0] + 8 * fk * zstep];
             const float* z1_ = &Zs[cur][boff[1] + 8 * fk * zstep];
 #pragma unroll
@@ -366,6 +368,7 @@ __global__ void __launch_bounds__(NTHREADS, ((ZPT <= ZPT_SMALL || ZV) ? 2 : 1)) 
                     xv1[e] = z1_[(16 * st + e) * zstep];
                 }
                 u32x4 fa[3][2], fb0[3], fb1[3];
+                const u32x4* aL = aB + (fr ^ (2 * (2 * st + fk)));      // (row swizzle of the staging stores)
 #pragma unroll
                 for (int pz = 0; pz < 3; ++pz) {
                     fa[pz][0] = aL[(st * 2 * 3 + pz) * BM];
@@ -722,7 +725,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) wgrad_flat_x6_kernel(PaseWgrad p,
         for (int i = 0; i < ZSL; ++i) zreg[i] = *reinterpret_cast<const WF4*>(zb + zoff[i]);
     };
     auto prelu = [&](float v, float al) __attribute__((always_inline)) { return v > 0.f ? v : v * al; };
-    const int sub = ((tid % TPR) >> 1) * 3;                      // k-group of this thread's float4, in planes
+    const int kgs = (tid % TPR) >> 1;                            // k-group of this thread's float4
+    const int sub = kgs * 3;                                     // ... in planes
+    const int rsw = 4 * kgs;                                     // row XOR: the two k-groups of a row are one bank apart
     const int halfb = (tid & 1) * 8;
     auto store_stage = [&](int buf) __attribute__((always_inline)) {
         const float keep = valid_next ? 1.f : 0.f;               // chunk tail beyond S*Ncols contributes zero
@@ -735,7 +740,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) wgrad_flat_x6_kernel(PaseWgrad p,
             if (do_rowsum) rs[i] += (v[0] + v[1]) + (v[2] + v[3]);
             unsigned o[3][2];
             pase_split_bf16x3_quad(v, o);
-            unsigned char* dst = reinterpret_cast<unsigned char*>(&AsX[buf * A_BUF + sub * BM + r]) + halfb;
+            unsigned char* dst = reinterpret_cast<unsigned char*>(&AsX[buf * A_BUF + sub * BM + (r ^ rsw)]) + halfb;
 #pragma unroll
             for (int pz = 0; pz < 3; ++pz) *reinterpret_cast<uint2*>(dst + pz * BM * 16) = make_uint2(o[pz][0], o[pz][1]);
         }
@@ -749,7 +754,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) wgrad_flat_x6_kernel(PaseWgrad p,
             }
             unsigned o[3][2];
             pase_split_bf16x3_quad(v, o);
-            unsigned char* dst = reinterpret_cast<unsigned char*>(&ZsX[buf * Z_BUF + sub * BN + r]) + halfb;
+            unsigned char* dst = reinterpret_cast<unsigned char*>(&ZsX[buf * Z_BUF + sub * BN + (r ^ rsw)]) + halfb;
 #pragma unroll
             for (int pz = 0; pz < 3; ++pz) *reinterpret_cast<uint2*>(dst + pz * BN * 16) = make_uint2(o[pz][0], o[pz][1]);
         }
@@ -770,8 +775,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) wgrad_flat_x6_kernel(PaseWgrad p,
         const int cur = (c - c_begin) & 1;
         const bool has_next = c + 1 < c_end;
         if (has_next) load_stage(c + 1);
-        const u32x4* aL = &AsX[cur * A_BUF + fk * 3 * BM + wm * 64 + fr];
-        const u32x4* zL = &ZsX[cur * Z_BUF + fk * 3 * BN + wn * 64 + fr];
+        const u32x4* aL = &AsX[cur * A_BUF + fk * 3 * BM + wm * 64 + (fr ^ (4 * fk))];
+        const u32x4* zL = &ZsX[cur * Z_BUF + fk * 3 * BN + wn * 64 + (fr ^ (4 * fk))];
         u32x4 fa[3][2], fb[3][2];
 #pragma unroll
         for (int pz = 0; pz < 3; ++pz) {
