@@ -98,6 +98,11 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const u32x4* __restrict
                                                          float* __restrict__ Y, int M, int Cin, int S, int Tout) {
     __shared__ __attribute__((aligned(16))) u32x4 As[2][3][CHUNKS];
     __shared__ __attribute__((aligned(16))) float Xs[2][768];     // CB x SPANP = 576 used; every thread stores 3 slots
+#ifdef EXP_ONEWG      // occupancy probe: pad the workgroup's LDS so that only one fits a CU
+    __shared__ float lds_pad[18000];
+    if (threadIdx.x == 0 && M < 0) lds_pad[Cin] = 1.f;
+    if (M < -1) Y[0] = lds_pad[S];
+#endif
     const int Tin = Tout + TAPS - 1;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave & 1, wn = wave >> 1, fr = lane & 31, fk = lane >> 5;
@@ -145,8 +150,40 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const u32x4* __restrict
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#ifdef EXP_AGPR      // pin the accumulators to AGPRs: the function then "may need AGPRs" and MFMAs are selected in AGPR form
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" : "+a"(acc[i][j]));
+#endif
 
-#ifndef EXP_PIPE
+#if defined(EXP_NOLDS)
+    // EXP_NOLDS: MFMA issue ceiling of this register configuration -- fragments read once, 72 MFMAs per "stage"
+    u32x4 ka[3][2], kb[2][3];
+#pragma unroll
+    for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ka[sp][i] = As[0][sp][fk * BM + wm * 64 + i * 32 + fr];
+            kb[i][sp] = As[0][sp][(2 + fk) * BM + wn * 64 + i * 32 + fr];
+        }
+    auto compute = [&](int cur) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+            for (int pi = 0; pi < 6; ++pi)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, ka[PA[pi]][i]), __builtin_bit_cast(bf16x8, kb[j][PB[pi]]),
+                            acc[i][j], 0, 0, 0);
+        }
+        asm volatile("" ::: "memory");
+    };
+#elif !defined(EXP_PIPE) && !defined(EXP_PREF)
     auto compute = [&](int cur) {
         const float* x0 = &Xs[cur][fk * SPANP + wn * 64 + fr];
 #pragma unroll
@@ -180,6 +217,50 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const u32x4* __restrict
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                             __builtin_bit_cast(bf16x8, a[PA[pi]][i]), __builtin_bit_cast(bf16x8, bb[j][PB[pi]]),
                             acc[i][j], 0, 0, 0);
+        }
+    };
+#elif defined(EXP_PREF)
+    // EXP_PREF: the fragment reads of step b + 1 (six A fragments, sixteen raw B values) are issued before step b's
+    // MFMAs and consumed after them (their LDS latency hides under the MFMAs); EXP_PREF=2 also interleaves the split
+    auto compute = [&](int cur) {
+        const float* x0 = &Xs[cur][fk * SPANP + wn * 64 + fr];
+        u32x4 a[2][3][2];
+        float xv[2][2][8];
+        auto reads = [&](int b, int set) __attribute__((always_inline)) {
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[set][sp][i] = As[cur][sp][(b * 2 + fk) * BM + wm * 64 + i * 32 + fr];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) xv[set][j][i] = x0[(2 * (i >> 2)) * SPANP + j * 32 + 4 * b + (i & 3)];
+        };
+        u32x4 bb[2][3];
+        reads(0, 0);
+        split8(xv[0][0], bb[0]);
+        split8(xv[0][1], bb[1]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int set = b & 1;
+            if (b + 1 < NB) reads(b + 1, set ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+            for (int pi = 0; pi < 6; ++pi)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, a[set][PA[pi]][i]), __builtin_bit_cast(bf16x8, bb[j][PB[pi]]),
+                            acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (b + 1 < NB) {
+                split8(xv[set ^ 1][0], bb[0]);
+                split8(xv[set ^ 1][1], bb[1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 #else
