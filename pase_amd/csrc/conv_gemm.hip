@@ -69,7 +69,9 @@ struct ConvPlan {
     unsigned rctx_magic;      // ceil(2^32 / r_ctx)
     // x6: a 16-deep MFMA step = xR channel rows x xTq taps (xR * xTq = 16; lane half fk takes rows fk, fk+2, ...);
     // a stage = (CB / xR) row groups x xTS tap blocks = xSteps steps; TB is the tap count padded to xTS * xTq
-    int x6, xR, xTq, xTS, xSteps;
+    // xR == 1 (long filters on few channels, e.g. the 251-tap Sinc FIR on one): a step = 16 taps of ONE row (lane half fk
+    // takes taps 8 fk .. 8 fk + 7), a stage = up to xSteps steps of one tap group (TB = 16 xSteps), xTaps = padded tap count
+    int x6, xR, xTq, xTS, xSteps, xTaps;
 };
 // column-tile modes
 //   MODE_FLAT  : 1x1, stride 1, no padding: columns are the flattened (s, q) index, a row of the
@@ -147,8 +149,7 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
     constexpr int PA_MAX = (KG_T + RA - 1) / RA;      // 6 / 3 (4 / 2 flat)
     constexpr int LDA = BM + 4;
     constexpr int AX_CHUNKS = 3 * (X6 ? X6 : 1) * 2 * BM;          // x6: 16-byte chunks of one stage's weight slab
-    constexpr int NCH = AX_CHUNKS / NTHREADS;                     // ... per thread (9 / 12)
-    static_assert(!X6 || AX_CHUNKS % NTHREADS == 0, "x6 slab");
+    constexpr int NCH = (AX_CHUNKS + NTHREADS - 1) / NTHREADS;    // ... per thread (9 / 12; 5 for the 64-row tile)
     constexpr int A_BYTES = X6 ? AX_CHUNKS * 16 : 2 * KG_T * LDA * (int)sizeof(float);
     __shared__ __attribute__((aligned(16))) unsigned char As_raw[A_BYTES];
     float (*As)[KG_T][LDA] = reinterpret_cast<float (*)[KG_T][LDA]>(As_raw);
@@ -312,7 +313,8 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
         lo_next = (ci0 - ci0s) * pl.TB;
         kg_next = slots_invariant ? pl.CB * pl.TB : TBe;
         tbe_next = TBe;
-        if (X6) ax_st = reinterpret_cast<const u32x4*>(p.wx6) + (size_t)(mt * pl.n_gc + gc_n) * (unsigned)ax_nch;
+        if (X6) ax_st = reinterpret_cast<const u32x4*>(p.wx6) +
+                        (size_t)((mt * pl.n_gc + gc_n) * pl.n_gt + gt_n) * (unsigned)ax_nch;
         if (++gt_n == pl.n_gt) { gt_n = 0; ++gc_n; }
         if (!slots_invariant) {
             slot_setup(kk0, TBe);
@@ -456,18 +458,21 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
             // the weight fragments in.  LDS offsets = [per-lane constant] + [uniform]; the B fragment is split into
             // its three bf16 pieces here (2 x (8 ds_read_b32 + 44 VALU) per 24 MFMAs).
             const int ts = p.tapstep;
-            const int lt = pl.xTq == 8 ? 3 : (pl.xTq == 4 ? 2 : (pl.xTq == 2 ? 1 : 0));
+            const bool one_row = pl.xR == 1;                        // uniform
+            const int lt = one_row ? 4 : (pl.xTq == 8 ? 3 : (pl.xTq == 4 ? 2 : (pl.xTq == 2 ? 1 : 0)));
             const int tap0 = ts > 0 ? 0 : pl.TB - 1;
-            const float* x0L = &XsG[cur][4 + fk * pl.SPAN + tap0 + xc0];
-            const float* x1L = &XsG[cur][4 + fk * pl.SPAN + tap0 + xc1];
+            const int fkoff = one_row ? 8 * ts : pl.SPAN;
+            const float* x0L = &XsG[cur][4 + fk * fkoff + tap0 + xc0];
+            const float* x1L = &XsG[cur][4 + fk * fkoff + tap0 + xc1];
             const u32x4* aL = &AsX[fk * 3 * BM + wm * 64 + fr];
             int oe[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) oe[e] = 2 * (e >> lt) * pl.SPAN + ts * (e & (pl.xTq - 1));
-            const int n_rg = pl.xSteps / pl.xTS;
+            for (int e = 0; e < 8; ++e) oe[e] = one_row ? ts * e : 2 * (e >> lt) * pl.SPAN + ts * (e & (pl.xTq - 1));
+            const int n_rg = one_row ? 1 : pl.xSteps / pl.xTS;
+            const int n_tb = one_row ? (tbe >> 4) : pl.xTS;         // (a tap group's last stage may hold fewer steps)
             int st = 0;
             for (int rg = 0; rg < n_rg; ++rg) {
-                for (int tb = 0; tb < pl.xTS; ++tb, ++st) {
+                for (int tb = 0; tb < n_tb; ++tb, ++st) {
                     const int sb = rg * pl.xR * pl.SPAN + ts * (tb << lt);
                     float xv0[8], xv1[8];
 #pragma unroll
@@ -497,7 +502,10 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
             PASE_TACC(1);
             // the weight slab is single-buffered: everyone is done reading it before the next one lands
             __syncthreads();
-            if (g + 1 < g_end) store_stage(cur ^ 1);
+            if (g + 1 < g_end) {
+                store_stage(cur ^ 1);
+                tbe = tbe_next;
+            }
             PASE_TACC(2);
             __syncthreads();
             PASE_TACC(3);
@@ -904,27 +912,35 @@ __global__ void __launch_bounds__(256) pack_wt_kernel(const float* w, float* wt,
 // tap tb*Tq + e % Tq) of step (rg, tb).  Zero for taps past the real count, for the rows of a ragged last channel
 // group that the previous stage already covered, and for tile rows past M.
 __global__ void pack_x6_kernel(const float* __restrict__ wt, u32x4* __restrict__ out, int M, int ldwt, int Cin,
-                               int taps, int CB, int R, int lt, int tsn, int steps, int n_gc, long total) {
-    constexpr int BM = 128;
+                               int taps, int CB, int R, int lt, int tsn, int steps, int n_gc, int n_gt, int TB, long total,
+                               int BM) {
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int ml = (int)(idx % BM);
         const int fk = (int)((idx / BM) % 2);
         const int st = (int)((idx / (2 * BM)) % steps);
-        const int g = (int)((idx / (2L * BM * steps)) % n_gc);
-        const int rt = (int)(idx / (2L * BM * steps * n_gc));
+        const long gi = idx / (2L * BM * steps);
+        const int g = (int)(gi % ((long)n_gc * n_gt));           // stage = (channel group gc, tap group gt)
+        const int rt = (int)(gi / ((long)n_gc * n_gt));
+        const int gc = g / n_gt, gt = g - gc * n_gt;
         const int rg = st / tsn, tb = st - rg * tsn;
-        const int ci0 = g * CB, ci0s = min(ci0, Cin - CB), lo = ci0 - ci0s;
+        const int ci0 = gc * CB, ci0s = n_gt == 1 ? min(ci0, Cin - CB) : ci0, lo = ci0 - ci0s;
         const int m = rt * BM + ml;
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int row = rg * R + fk + 2 * (e >> lt);
-            const int tap = (tb << lt) + (e & ((1 << lt) - 1));
+            int row, tap;
+            if (R == 1) {                      // one row, 16 taps per step
+                row = 0;
+                tap = gt * TB + 16 * st + 8 * fk + e;
+            } else {
+                row = rg * R + fk + 2 * (e >> lt);
+                tap = (tb << lt) + (e & ((1 << lt) - 1));
+            }
             v[e] = (row >= lo && tap < taps && m < M) ? wt[((size_t)(ci0s + row) * taps + tap) * ldwt + m] : 0.f;
         }
         u32x4 o[3];
         pase_split_bf16x3(v, o);
-        u32x4* dst = out + ((((size_t)rt * n_gc + g) * steps + st) * 2 + fk) * 3 * BM + ml;
+        u32x4* dst = out + ((((size_t)rt * n_gc * n_gt + g) * steps + st) * 2 + fk) * 3 * BM + ml;
 #pragma unroll
         for (int pz = 0; pz < 3; ++pz) dst[pz * BM] = o[pz];
     }
@@ -965,6 +981,21 @@ bool plan_x6(const PaseConvGemm& p, int BN, ConvPlan& pl, int max_steps) {
             break;
         }
     }
+    // one row, 16 taps per step, tap groups of max_steps steps (long filters on too few channels for the patterns above;
+    // forward taps only)
+    if (p.tapstep == 1 && p.taps >= 32) {
+        const int taps_p = (p.taps + 15) / 16 * 16;
+        const int steps = taps_p / 16 < max_steps ? taps_p / 16 : max_steps;
+        const int TB = 16 * steps;
+        const int SPANV = (BN - 1) * p.stride + (pl.mode == MODE_SEG ? 2 : 1) * TB;
+        const int nslots = (SPANV + 1 + NTHREADS - 1) / NTHREADS;
+        const double eff = (double)p.taps / taps_p * (steps >= 3 ? 1.0 : (steps == 2 ? 0.93 : 0.8));
+        if (nslots <= XPT && eff > best) {
+            best = eff;
+            pl.CB = 1; pl.TB = TB; pl.SPANV = SPANV; pl.tl = 8; pl.nslots = nslots;
+            pl.xR = 1; pl.xTq = 16; pl.xTS = steps; pl.xSteps = steps; pl.xTaps = taps_p;
+        }
+    }
     return best >= 0.85;
 }
 
@@ -987,10 +1018,12 @@ HostPlan make_plan(const PaseConvGemm& p, bool want_x6) {
     pl.mode = flat ? MODE_FLAT : (p.Ncols >= h.BN ? MODE_SEG : MODE_PERSEQ);
     pl.xvec = flat ? 1 : 0;
     pl.pmajor = pl.xvec;
-    pl.x6 = pl.xR = pl.xTq = pl.xTS = pl.xSteps = 0;
-    // (the 4-step slab costs 12 KB of LDS and 12 VGPRs more: only where 3 steps cannot hold the padded taps)
-    if (want_x6 && !flat && !h.narrow && p.taps <= 32 &&
-        (plan_x6(p, h.BN, pl, X6_STEPS) || plan_x6(p, h.BN, pl, X6_STEPS_LONG))) {
+    pl.x6 = pl.xR = pl.xTq = pl.xTS = pl.xSteps = pl.xTaps = 0;
+    // (the 4-step slab costs 12 KB of LDS and 12 VGPRs more: only where 3 steps cannot hold the padded taps;
+    //  64-row tiles have a split-bf16 instantiation for the one-row plan only -- the Sinc FIR)
+    if (want_x6 && !flat &&
+        (plan_x6(p, h.BN, pl, X6_STEPS) || (!h.narrow && plan_x6(p, h.BN, pl, X6_STEPS_LONG))) &&
+        (!h.narrow || (pl.xR == 1 && pl.nslots <= 3))) {
         pl.x6 = 1;
         pl.nslots = pl.nslots <= 3 ? 3 : (pl.nslots <= 6 ? 6 : 12);
         if (pl.xSteps > X6_STEPS && pl.nslots < 6) pl.nslots = 6;      // the 4-step instantiations are 6 / 12 slots
@@ -1039,7 +1072,7 @@ HostPlan make_plan(const PaseConvGemm& p, bool want_x6) {
     }
     pl.n_gc = pl.CB ? (p.Cin + pl.CB - 1) / pl.CB : 0;
     pl.n_gt = (p.taps + pl.TB - 1) / pl.TB;
-    if (pl.x6) h.x6_chunks = (long)((p.M + BM - 1) / BM) * pl.n_gc * pl.xSteps * 2 * 3 * BM;
+    if (pl.x6) h.x6_chunks = (long)((p.M + BM - 1) / BM) * pl.n_gc * pl.n_gt * pl.xSteps * 2 * 3 * BM;
     const int RA = NTHREADS / (BM / 4);
     pl.PA = (pl.CB * pl.TB + RA - 1) / RA;
     pl.tiles_per_seq = (p.Ncols + h.BN - 1) / h.BN;
@@ -1135,9 +1168,10 @@ extern "C" int pase_conv_gemm(const PaseConvGemm* d, void* stream) {
     if (h.pl.x6) {
         // the kernel sees the convolution with its taps padded to the plan's multiple (zero weights in the pack)
         PaseConvGemm q = p;
-        q.taps = h.pl.TB;
-        q.K = p.Cin * h.pl.TB;
-        if (h.pl.xvec) PASE_LAUNCH((conv_gemm_kernel<128, 128, NS_FLAT, 1, 2, -1, 3>), grid, block, st, q, h.pl);
+        q.taps = h.pl.xR == 1 ? h.pl.xTaps : h.pl.TB;
+        q.K = p.Cin * q.taps;
+        if (h.narrow) PASE_LAUNCH((conv_gemm_kernel<64, 256, 3, 0, 2, -1, 3>), grid, block, st, q, h.pl);
+        else if (h.pl.xvec) PASE_LAUNCH((conv_gemm_kernel<128, 128, NS_FLAT, 1, 2, -1, 3>), grid, block, st, q, h.pl);
         else if (h.pl.xSteps > X6_STEPS && h.pl.nslots <= 6)
             PASE_LAUNCH((conv_gemm_kernel<128, 128, 6, 0, 2, -1, 4>), grid, block, st, q, h.pl);
         else if (h.pl.xSteps > X6_STEPS) PASE_LAUNCH((conv_gemm_kernel<128, 128, 12, 0, 2, -1, 4>), grid, block, st, q, h.pl);
@@ -1178,7 +1212,7 @@ extern "C" int pase_pack_x6(const PaseConvGemm* d, void* stream) {
     const long nb = (total + 255) / 256;
     PASE_LAUNCH(pack_x6_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), (hipStream_t)stream, p.wt,
                 reinterpret_cast<u32x4*>(const_cast<void*>(p.wx6)), p.M, p.ldwt, p.Cin, p.taps, pl.CB, pl.xR, lt, pl.xTS,
-                pl.xSteps, pl.n_gc, total);
+                pl.xSteps, pl.n_gc, pl.n_gt, pl.TB, total, h.narrow ? 64 : 128);
     PASE_CHECK_LAUNCH();
     return 0;
 }

@@ -296,6 +296,8 @@ def test_flat_ws_mse_context_epilogue_wide(dev):
     (64, 70, 3, 1, 300, 2),       # 16 rows x 1 tap
     (20, 70, 30, 10, 2900, 2),    # 30 taps: 4-step stages
     (96, 130, 1, 1, 200, 3),      # flat 1x1
+    (1, 40, 251, 1, 700, 2),      # Sinc FIR shape: one row, 16 taps per step, six tap groups, 64-row tile
+    (1, 70, 46, 1, 400, 2),       # one-row plan on the 128-row tile (a single 48-tap group)
 ])
 def test_split_bf16_is_fp32_grade(dev, Cin, Cout, k, stride, T, S):
     """The split-bf16 contraction (PaseConvGemm::wx6: hi+mid+lo pieces, 6 bf16 MFMAs per product) against an fp64
