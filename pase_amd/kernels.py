@@ -179,6 +179,20 @@ def pack_wt(w, *, M, K, Cin, taps, ldw=None, tap_major=0):
 X6 = os.environ.get("PASE_X6", "1") != "0"
 
 
+def _x6_conv_ok(kw):
+    # debugging filter: PASE_X6_ONLY=fwd|bwd|taps<N> restricts the split-bf16 conv launches
+    f = os.environ.get("PASE_X6_ONLY")
+    if not f:
+        return True
+    if f == "fwd":
+        return kw.get("tapstep", 1) == 1 and kw.get("ps", 1) == 1
+    if f == "bwd":
+        return not (kw.get("tapstep", 1) == 1 and kw.get("ps", 1) == 1)
+    if f.startswith("taps"):
+        return kw["taps"] == int(f[4:])
+    return True
+
+
 def conv_gemm(x, w, y, **kw):
     """see include/pase_amd.h PaseConvGemm.  With splitk > 1 the output is zero-filled here first.
     The kernel reads the K-major pack of the weight: pass it as wt= (e.g. straight from pack_dgrad, or a
@@ -187,7 +201,7 @@ def conv_gemm(x, w, y, **kw):
         kw["wt"] = pack_wt(w, M=kw["M"], K=kw["K"], Cin=kw["Cin"], taps=kw["taps"], ldw=kw.get("ldw"),
                            tap_major=kw.get("tap_major", 0))
     d = _conv_desc(x, w, y, **kw)
-    if X6:
+    if X6 and os.environ.get("PASE_X6_CONV", "1") != "0" and _x6_conv_ok(kw):
         # contraction on the bf16 matrix pipe with both operands split into three bf16 pieces (fp32-grade result,
         # see PaseConvGemm::wx6) for the launch shapes the library has a split-bf16 plan for
         nbytes = _lib.lib().pase_conv_gemm_x6_bytes(C.byref(d))
@@ -302,7 +316,7 @@ def wgrad_gemm(g, z, dw, *, S, M, Tg, Ncols, Cin, Tz, taps, ldw=None, dbias=None
     d.taps, d.tap_major, d.stride, d.tapstep, d.padL, d.pad_mode = taps, tap_major, stride, tapstep, padL, pad_mode
     d.ldw = Cin * taps if ldw is None else ldw
     d.splitk = splitk
-    d.x6 = 1 if X6 else 0
+    d.x6 = 1 if (X6 and os.environ.get("PASE_X6_WGRAD", "1") != "0") else 0
     ev0 = GEMM_TIMER.start() if GEMM_TIMER is not None else None
     _check(_lib.lib().pase_wgrad_gemm(C.byref(d), _stream()), "pase_wgrad_gemm")
     if ev0 is not None:

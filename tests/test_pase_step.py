@@ -160,16 +160,47 @@ def test_full_width_golden_step(dev, gold, fe, wk):
         gg = np.load(gfile)
         offs = gg["grad_offsets"]
         checked = 0
+        worst = (0.0, 0.0, "")
+        stats = []
         for i, n in enumerate(str(s) for s in gg["grad_names"]):
             if is_noise_grad(n):
                 continue
             ref = gg["grad_values"][offs[i]:offs[i + 1]]
             got = params[n].grad.detach().reshape(-1)[torch.as_tensor(grad_sample_index(params[n].numel(), int(gg["n_samples"])),
                                                                       device=dev)]
-            # fp32 sums in different orders (CPU oneDNN vs MFMA k-order + atomics): within 2e-3 relative or 1e-3 of the
-            # tensor's largest gradient; a sign / permutation / missing-term error is O(largest gradient)
-            assert_close(got, ref, rtol=2e-3, atol=1e-3 * float(gg["grad_absmax"][i]), what="grad " + n)
+            # With every contraction on the exact-fp32 matrix pipe (PASE_X6=0) the check is the tight one: every sampled
+            # element within 2e-3 relative or 1e-3 of the tensor's largest gradient (measured worst relative L2 2.6e-4, 3e-6
+            # on the SincNet vectors) -- the k-ordered fp32 MFMA chain reproduces the CPU reference's first layer bit for
+            # bit.  The split-bf16 contraction is fp32-GRADE (each output 1e-7 from fp64: tests/test_conv_gemm.py::
+            # test_split_bf16_is_fp32_grade; the Sinc layer with its real filters 1.8e-7 per channel against 2.9e-7 for the
+            # fp32 chain) but not bit-compatible with that reference, so the comparison becomes one between two fp32
+            # implementations with different summation orders, like tests/test_bench_config.py (bs32 against torch-ROCm:
+            # worst tensor 2.7e-3 relative L2 with the split contraction, 2.6e-3 on the fp32 pipe).  On this 2-utterance
+            # golden step the measured worst is 5.4e-3 relative L2 / 2.5 % of the largest gradient on a BatchNorm bias
+            # (one scalar per channel summed over positions of alternating sign), 4.0e-3 / 1.7 % on a weight tensor,
+            # 3.0e-3 on the SincNet vectors; moving ONLY the Sinc FIR to the split pipe accounts for 2.9e-3 of it (a 1e-7
+            # change of the first layer's output).  Bounds: 5 % of the largest gradient per element, relative L2 1e-2
+            # (weights) / 2e-2 (per-channel reductions, SincNet vectors); a sign / permutation / missing-term error is O(1).
+            refd = torch.as_tensor(ref).double()
+            gotd = got.cpu().double()
+            gmax = float(gg["grad_absmax"][i])
+            err = float((gotd - refd).abs().max())
+            rel2 = float((gotd - refd).norm() / refd.norm().clamp_min(1e-30))
+            per_channel = n.endswith(("norm.weight", "norm.bias", "act.weight", ".bias", "low_hz_", "band_hz_"))
+            from pase_amd import kernels as K
+            tight = not K.X6
+            ok = (err <= 1e-3 * gmax + 2e-3 * float(refd.abs().max())) if tight else \
+                 (err <= 5e-2 * gmax + 1e-9 and rel2 <= (2e-2 if per_channel else 1e-2))
+            stats.append((rel2, err / max(gmax, 1e-30), n))
+            assert ok or os.environ.get("PASE_GOLDEN_CALIB"), "grad %s: max|err| %.3e of max|g| %.3e, relL2 %.3e" % (n, err, gmax, rel2)
+            worst = max(worst, (rel2, err / max(gmax, 1e-30), n))
             checked += 1
+        print("worst element-wise gradient agreement (relL2, max|err|/max|g|, name):", worst)
+        if os.environ.get("PASE_GOLDEN_CALIB"):
+            for st_ in sorted(stats, reverse=True)[:10]:
+                print("   relL2 %.3e  max|err|/max|g| %.3e  %s" % st_)
+            for st_ in sorted(stats, key=lambda t: -t[1])[:6]:
+                print("   (by element) relL2 %.3e  max|err|/max|g| %.3e  %s" % st_)
         assert checked >= 100
 
 
