@@ -331,3 +331,30 @@ def test_split_bf16_is_fp32_grade(dev, Cin, Cout, k, stride, T, S):
         K.X6 = saved
     assert err[True] < 5e-7, err
     assert err[True] < 2.0 * err[False] + 1e-8, err
+
+
+def test_split_bf16_api_contract(dev):
+    """pase_conv_gemm_x6_bytes / pase_pack_x6 / PaseConvGemm::wx6: shapes without a split-bf16 plan report 0 bytes, a pack
+    pointer on such a launch is refused (-11) instead of being ignored, and the pack size follows the documented layout."""
+    import ctypes as C
+    from pase_amd import _lib
+    lib = _lib.lib()
+    S, Cin, Cout, T = 2, 3, 8, 300                       # 64-row tile, 20 taps x stride 10: no plan
+    x = torch.randn(S, Cin, T, device=dev)
+    w = torch.randn(Cout, Cin * 20, device=dev)
+    y = torch.zeros(S, Cout, 29, device=dev)
+    kw = dict(S=S, Cin=Cin, Tin=T, M=Cout, K=Cin * 20, taps=20, Ncols=29, Tout=29, stride=10, padL=0, splitk=1)
+    d = K._conv_desc(x, w, y, wt=K.pack_wt(w, M=Cout, K=Cin * 20, Cin=Cin, taps=20), **kw)
+    assert lib.pase_conv_gemm_x6_bytes(C.byref(d)) == 0
+    junk = torch.zeros(4096, dtype=torch.uint8, device=dev)
+    d.wx6 = junk.data_ptr()
+    assert lib.pase_pack_x6(C.byref(d), None) == -11
+    assert lib.pase_conv_gemm(C.byref(d), None) == -11
+    # 11 taps, 128-row tile: 4 rows x 4 taps per step, 3 steps per stage, ceil(Cin / 4) stages, 2 k-groups x 3 planes x 128 rows
+    Cin, Cout, T = 10, 70, 300
+    x = torch.randn(S, Cin, T, device=dev)
+    w = torch.randn(Cout, Cin * 11, device=dev)
+    y = torch.zeros(S, Cout, T, device=dev)
+    kw = dict(S=S, Cin=Cin, Tin=T, M=Cout, K=Cin * 11, taps=11, Ncols=T, Tout=T, stride=1, padL=5, pad_mode=K.PAD_REFLECT, splitk=1)
+    d = K._conv_desc(x, w, y, wt=K.pack_wt(w, M=Cout, K=Cin * 11, Cin=Cin, taps=11), **kw)
+    assert lib.pase_conv_gemm_x6_bytes(C.byref(d)) == 1 * 3 * 3 * 2 * 3 * 128 * 16
