@@ -72,6 +72,11 @@ struct ConvPlan {
     // xR == 1 (long filters on few channels, e.g. the 251-tap Sinc FIR on one): a step = 16 taps of ONE row (lane half fk
     // takes taps 8 fk .. 8 fk + 7), a stage = up to xSteps steps of one tap group (TB = 16 xSteps), xTaps = padded tap count
     int x6, xR, xTq, xTS, xSteps, xTaps;
+    // x6 pixel-shuffle launches: tile rows are re-ordered (channel, phase) by pase_pack_x6 (m = co * ps + phase), so the four
+    // consecutive rows a lane holds per register quad are consecutive OUTPUT samples: one 16-byte store instead of four
+    // 4-byte stores 40 bytes apart (the ps = 10 layers were bound by partial-line write transactions)
+    int xPerm;
+    unsigned ps_magic;        // ceil(2^32 / ps)
 };
 // column-tile modes
 //   MODE_FLAT  : 1x1, stride 1, no padding: columns are the flattened (s, q) index, a row of the
@@ -726,8 +731,45 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
                     for (int r = 0; r < 16; ++r) {
                         const int m = rbase + a * 32 + (r & 3) + 8 * (r >> 2);
                         int co = m;
-                        if (pshuf) co = m - (int)div_magic((unsigned)m, pl.cout_magic) * p.Cout_store;
+                        if (pshuf) co = (X6 && pl.xPerm) ? (int)div_magic((unsigned)m, pl.ps_magic)
+                                                         : m - (int)div_magic((unsigned)m, pl.cout_magic) * p.Cout_store;
                         if (FAST || m < p.M) bvs[r] = biasp[co];
+                    }
+                }
+                if constexpr (X6 != 0 && FAST && !ATOMIC) {
+                    if (pl.xPerm) {   // uniform: (channel, phase)-ordered rows -> runs of consecutive output samples
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const int m4 = rbase + a * 32 + 8 * g4;               // rows m4 .. m4 + 3 (m4 % 4 == 0)
+                            const int co0 = (int)div_magic((unsigned)m4, pl.ps_magic);
+                            const int ph0 = m4 - co0 * p.ps;
+                            const int n1 = min(4, p.ps - ph0);                   // samples left in channel co0
+#pragma unroll
+                            for (int b = 0; b < 2; ++b) {
+                                float v[4];
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) v[i] = acc[a][b][4 * g4 + i] + bvs[4 * g4 + i];
+                                float* d0 = p.y + (unsigned)(cbase[b] + co0 * p.Tout + ph0);
+                                if (n1 == 4) {
+                                    pase_store_run4(d0, v);
+                                } else {          // the quad straddles two channels: n1 samples, then 4 - n1 of co0 + 1
+                                    float* d1 = p.y + (unsigned)(cbase[b] + (co0 + 1) * p.Tout);
+                                    if (n1 == 2) {
+                                        pase_store_run2(d0, v[0], v[1]);
+                                        pase_store_run2(d1, v[2], v[3]);
+                                    } else if (n1 == 1) {
+                                        d0[0] = v[0];
+                                        pase_store_run2(d1, v[1], v[2]);
+                                        d1[2] = v[3];
+                                    } else {
+                                        pase_store_run2(d0, v[0], v[1]);
+                                        d0[2] = v[2];
+                                        d1[0] = v[3];
+                                    }
+                                }
+                            }
+                        }
+                        continue;
                     }
                 }
 #pragma unroll
@@ -736,8 +778,13 @@ __global__ void __launch_bounds__(NTHREADS, OCC) conv_gemm_kernel(PaseConvGemm p
                     const bool mok = FAST || m < p.M;
                     int ph = 0, co = m;
                     if (pshuf) {   // uniform
-                        ph = (int)div_magic((unsigned)m, pl.cout_magic);
-                        co = m - ph * p.Cout_store;
+                        if (X6 && pl.xPerm) {
+                            co = (int)div_magic((unsigned)m, pl.ps_magic);
+                            ph = m - co * p.ps;
+                        } else {
+                            ph = (int)div_magic((unsigned)m, pl.cout_magic);
+                            co = m - ph * p.Cout_store;
+                        }
                     }
                     const float bv = bvs[r];
                     const int rowoff = co * p.Tout + ph;
@@ -913,7 +960,7 @@ __global__ void __launch_bounds__(256) pack_wt_kernel(const float* w, float* wt,
 // group that the previous stage already covered, and for tile rows past M.
 __global__ void pack_x6_kernel(const float* __restrict__ wt, u32x4* __restrict__ out, int M, int ldwt, int Cin,
                                int taps, int CB, int R, int lt, int tsn, int steps, int n_gc, int n_gt, int TB, long total,
-                               int BM) {
+                               int BM, int perm_ps, int perm_cout) {
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int ml = (int)(idx % BM);
         const int fk = (int)((idx / BM) % 2);
@@ -925,6 +972,9 @@ __global__ void pack_x6_kernel(const float* __restrict__ wt, u32x4* __restrict__
         const int rg = st / tsn, tb = st - rg * tsn;
         const int ci0 = gc * CB, ci0s = n_gt == 1 ? min(ci0, Cin - CB) : ci0, lo = ci0 - ci0s;
         const int m = rt * BM + ml;
+        // (channel, phase) row order of the pixel-shuffle launches: tile row m = co * ps + phase reads source column
+        // phase * Cout + co of the (phase, channel)-ordered pack
+        const int msrc = perm_ps > 1 ? (m % perm_ps) * perm_cout + m / perm_ps : m;
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -936,7 +986,7 @@ __global__ void pack_x6_kernel(const float* __restrict__ wt, u32x4* __restrict__
                 row = rg * R + fk + 2 * (e >> lt);
                 tap = (tb << lt) + (e & ((1 << lt) - 1));
             }
-            v[e] = (row >= lo && tap < taps && m < M) ? wt[((size_t)(ci0s + row) * taps + tap) * ldwt + m] : 0.f;
+            v[e] = (row >= lo && tap < taps && m < M) ? wt[((size_t)(ci0s + row) * taps + tap) * ldwt + msrc] : 0.f;
         }
         u32x4 o[3];
         pase_split_bf16x3(v, o);
@@ -1078,6 +1128,9 @@ HostPlan make_plan(const PaseConvGemm& p, bool want_x6) {
     pl.tiles_per_seq = (p.Ncols + h.BN - 1) / h.BN;
     pl.ncols_magic = magic_of(p.Ncols);
     pl.cout_magic = magic_of(p.Cout_store);
+    pl.ps_magic = magic_of(p.ps);
+    pl.xPerm = (pl.x6 && p.ps > 1 && p.epilogue == PASE_EPI_STORE && !p.stat_part && p.post_op == PASE_POST_NONE &&
+                p.M == p.ps * p.Cout_store) ? 1 : 0;
     pl.rctx_magic = magic_of(p.r_ctx);
     const long ntot = (long)p.S * p.Ncols;
     h.n_col_tiles = (pl.mode == MODE_PERSEQ) ? p.S * pl.tiles_per_seq : (int)((ntot + h.BN - 1) / h.BN);
@@ -1212,7 +1265,7 @@ extern "C" int pase_pack_x6(const PaseConvGemm* d, void* stream) {
     const long nb = (total + 255) / 256;
     PASE_LAUNCH(pack_x6_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), (hipStream_t)stream, p.wt,
                 reinterpret_cast<u32x4*>(const_cast<void*>(p.wx6)), p.M, p.ldwt, p.Cin, p.taps, pl.CB, pl.xR, lt, pl.xTS,
-                pl.xSteps, pl.n_gc, pl.n_gt, pl.TB, total, h.narrow ? 64 : 128);
+                pl.xSteps, pl.n_gc, pl.n_gt, pl.TB, total, h.narrow ? 64 : 128, pl.xPerm ? p.ps : 1, p.Cout_store);
     PASE_CHECK_LAUNCH();
     return 0;
 }

@@ -91,6 +91,17 @@ __device__ __forceinline__ float pase_half_sum_lane31(float v) {
         if (e__ != hipSuccess) return (int)e__;  \
     } while (0)
 
+// runs of consecutive floats at a 4-byte-aligned address (global_store_dwordx4 / x2: ROCm runs the memory pipeline in
+// unaligned access mode; the packed types tell the compiler not to assume more than dword alignment)
+struct __attribute__((packed, aligned(4))) pase_f4u { float x, y, z, w; };
+struct __attribute__((packed, aligned(4))) pase_f2u { float x, y; };
+__device__ __forceinline__ void pase_store_run4(float* d, const float (&v)[4]) {
+    *reinterpret_cast<pase_f4u*>(d) = pase_f4u{v[0], v[1], v[2], v[3]};
+}
+__device__ __forceinline__ void pase_store_run2(float* d, float a, float b) {
+    *reinterpret_cast<pase_f2u*>(d) = pase_f2u{a, b};
+}
+
 // x = hi + mid + lo with three truncated bf16 pieces (8 + 8 + 8 mantissa bits: exact for normal x);
 // eight values -> three fragments of eight bf16 each (element e of a fragment = piece of x[e])
 __device__ __forceinline__ void pase_split_bf16x3(const float (&x)[8], u32x4 (&out)[3]) {

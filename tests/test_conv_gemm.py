@@ -59,6 +59,9 @@ def test_conv_fwd_reflect(dev, Cin, Cout, k, stride, T, S):
     (6, 5, 30, 4, 10, 2),
     (5, 70, 30, 10, 7, 2),
     (4, 3, 11, 1, 20, 1),
+    (32, 16, 30, 10, 140, 2),   # split-bf16 launch, ps = 10: (channel, phase)-ordered rows, 16-byte runs (quads straddle channels)
+    (16, 20, 8, 4, 150, 3),     # ps = 4: every quad is one channel's four phases
+    (16, 40, 4, 2, 200, 2),     # ps = 2: every quad is two channels x two phases
 ])
 def test_conv_transpose_as_pixel_shuffle(dev, Cin, Cout, k, stride, T, S):
     """nn.ConvTranspose1d(k, stride, padding=(k-stride)//2) == stride-1 conv with stride*Cout rows
