@@ -98,6 +98,10 @@ int pase_pack_wt(const float* w, float* wt, int M, int K, int Cin, int taps, int
 int pase_conv_gemm_stat_tiles(const PaseConvGemm* desc);
 /* the split-K factor the launch will actually use (after clamping) */
 int pase_conv_gemm_splitk(const PaseConvGemm* desc);
+/* which kernel family the launch described by desc runs on: 0 = exact-fp32 matrix pipe (v_mfma_f32_32x32x2_f32),
+ * 2 = split-bf16 channel-minor kernel (conv_x6c.hip; needs desc->wx6), 1 = the round-2 span-major split-bf16
+ * instantiations (only with PASE_X6_LEGACY=1 in the environment: measurement builds).  For tests and bench reports. */
+int pase_conv_gemm_plan_kind(const PaseConvGemm* desc);
 /* bytes of the split-bf16 pack the launch described by desc (wx6 ignored) would read; 0 = this shape only runs on
  * the fp32 matrix pipe */
 long pase_conv_gemm_x6_bytes(const PaseConvGemm* desc);

@@ -105,7 +105,7 @@ def synthetic_batch(seed, B, T, workers_cfg):
     return batch
 
 
-def _ref_step(seed, B, T, fe_name, wk_name):
+def _ref_step(seed, B, T, fe_name, wk_name, double=False):
     """One reference training step (trainer.py:229-232 -> worker_scheduler._base_scheduler) of a
     frontend cfg + workers cfg on a seeded synthetic batch.  Returns (model, param checksums, losses,
     chunk, preds); _base_scheduler has stepped the optimizers, so `.grad` holds the step's gradients
@@ -127,6 +127,17 @@ def _ref_step(seed, B, T, fe_name, wk_name):
                   cls_lst=[w["name"] for w in raw_cfg["cls"]], regr_lst=[w["name"] for w in raw_cfg["regr"]])
     names, sums, sq = param_checksums(model.state_dict())
     batch = synthetic_batch(seed + 1, B, T, raw_cfg)
+    if double:
+        # the same step in fp64: the fp32 initial weights and the fp32 batch converted exactly (the reference modules
+        # are dtype-agnostic; cls_minions.make_labels builds fp32 labels, which BCEWithLogitsLoss needs in the
+        # prediction's dtype -> default dtype fp64 for the duration of the step)
+        model = model.double()
+        for mod in model.modules():        # SincConv_fast keeps n_ / window_ as plain attributes, not buffers
+            for attr in ("n_", "window_"):
+                if torch.is_tensor(getattr(mod, attr, None)):
+                    setattr(mod, attr, getattr(mod, attr).double())
+        batch = {k: v.double() for k, v in batch.items()}
+        torch.set_default_dtype(torch.float64)
     fe_opt = optim.Adam(model.frontend.parameters(), lr=1e-3)
     cls_opt = {w.name: optim.Adam(w.parameters(), lr=5e-4) for w in model.classification_workers}
     regr_opt = {w.name: optim.Adam(w.parameters(), lr=5e-4) for w in model.regression_workers}
@@ -134,7 +145,10 @@ def _ref_step(seed, B, T, fe_name, wk_name):
     model.train()
     random.seed(seed + 2)          # the SPC worker draws its frames from Python's `random`
     h, chunk, preds, labels = model.forward(batch, 1, "cpu")
-    losses, _ = sched(preds, labels, cls_opt, regr_opt, fe_opt, device="cpu")
+    try:
+        losses, _ = sched(preds, labels, cls_opt, regr_opt, fe_opt, device="cpu")
+    finally:
+        torch.set_default_dtype(torch.float32)
     return model, (names, sums, sq), losses, chunk, preds
 
 
@@ -172,16 +186,19 @@ def grad_sample_index(numel, n=GRAD_SAMPLES):
     return (np.arange(n) * st) % numel
 
 
-def gen_pase_step_grads(seed, B, T, fe_name="PASE+.cfg", wk_name="workers+.cfg", out="pase_plus_step_grads.npz"):
+def gen_pase_step_grads(seed, B, T, fe_name="PASE+.cfg", wk_name="workers+.cfg", out="pase_plus_step_grads.npz",
+                        double=False):
     """ELEMENT-WISE reference gradients of the same step as gen_pase_step (same seeds => same step): for
-    every parameter, the gradient at grad_sample_index(numel) flat positions, plus each tensor's max |grad|."""
-    model, _cs, losses, chunk, preds = _ref_step(seed, B, T, fe_name, wk_name)
+    every parameter, the gradient at grad_sample_index(numel) flat positions, plus each tensor's max |grad|.
+    double=True: the same step evaluated by the live reference in fp64 (same fp32 initial weights, same fp32 batch):
+    the TRUTH both fp32 implementations (the reference's own and the HIP path) are measured against."""
+    model, _cs, losses, chunk, preds = _ref_step(seed, B, T, fe_name, wk_name, double=double)
     gnames, vals, offs, gmax = [], [], [0], []
     for n, p in model.named_parameters():
         g = p.grad.detach().reshape(-1).numpy()
         idx = grad_sample_index(g.size)
         gnames.append(n)
-        vals.append(g[idx].astype(np.float32))
+        vals.append(g[idx].astype(np.float64 if double else np.float32))
         offs.append(offs[-1] + idx.size)
         gmax.append(float(np.abs(g).max()))
     np.savez(os.path.join(GOLD, out), seed=seed, B=B, T=T, grad_names=np.array(gnames),
@@ -196,11 +213,22 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["grads"]:          # only the element-wise gradient file
         gen_pase_step_grads(seed=2, B=2, T=8000)
         sys.exit(0)
+    if sys.argv[1:] == ["grads64"]:        # only the fp64-truth gradient files
+        gen_pase_step_grads(seed=2, B=2, T=8000, out="pase_plus_step_grads_f64.npz", double=True)
+        gen_pase_step_grads(seed=4, B=2, T=8000, fe_name="PASE.cfg", wk_name="workers.cfg",
+                            out="pase_step_cfg2_grads_f64.npz", double=True)
+        gen_pase_step_grads(seed=4, B=2, T=8000, fe_name="PASE.cfg", wk_name="workers.cfg",
+                            out="pase_step_cfg2_grads.npz")
+        sys.exit(0)
     gen_sinc()
     gen_wavefe("pase_plus", "PASE+.cfg", seed=2, S=3, T=8000)
     gen_wavefe("pase", "PASE.cfg", seed=3, S=3, T=8000)
     gen_pase_step(seed=2, B=2, T=8000)
     gen_pase_step(seed=4, B=2, T=8000, fe_name="PASE.cfg", wk_name="workers.cfg", out="pase_step_cfg2.npz")
     gen_pase_step_grads(seed=2, B=2, T=8000)
+    gen_pase_step_grads(seed=2, B=2, T=8000, out="pase_plus_step_grads_f64.npz", double=True)
+    gen_pase_step_grads(seed=4, B=2, T=8000, fe_name="PASE.cfg", wk_name="workers.cfg",
+                        out="pase_step_cfg2_grads_f64.npz", double=True)
+    gen_pase_step_grads(seed=4, B=2, T=8000, fe_name="PASE.cfg", wk_name="workers.cfg", out="pase_step_cfg2_grads.npz")
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)))

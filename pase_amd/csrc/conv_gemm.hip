@@ -42,6 +42,7 @@
 
 #include "hip_compat.h"
 #include "pase_amd.h"
+#include "conv_x6c.h"
 
 namespace {
 
@@ -1002,6 +1003,8 @@ struct HostPlan {
     long blocks;
     int n_col_tiles;
     long x6_chunks;     // 16-byte chunks of the split-bf16 pack (0: fp32 plan)
+    bool x6c;           // the launch runs on conv_x6c.hip (channel-minor split-bf16 kernel, two accumulators per tile)
+    PaseX6cPlan c;
 };
 
 // Split-bf16 stage shape for a span-mode launch on the 128 x 128 tile, or false.  Candidates: (R rows x Tq taps) per
@@ -1053,9 +1056,37 @@ unsigned magic_of(int d) {
     return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned long long)d);
 }
 
+// The span-major split-bf16 instantiations of conv_gemm_kernel (round 2: ONE accumulator per tile, truncated operand
+// pieces) carry a systematic error that grows with K (conv_x6c.hip header); they stay in the library for A/B
+// measurements only (PASE_X6_LEGACY=1).  A launch without a conv_x6c plan runs on the exact-fp32 matrix pipe.
+bool legacy_x6() {
+    static const bool on = [] {
+        const char* e = getenv("PASE_X6_LEGACY");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
+
 HostPlan make_plan(const PaseConvGemm& p, bool want_x6) {
     HostPlan h;
     h.x6_chunks = 0;
+    h.x6c = false;
+    if (want_x6 && !legacy_x6()) {
+        if (pase_x6c_plan(p, h.c)) {
+            h.x6c = true;
+            h.pl = ConvPlan{};
+            h.pl.x6 = 1;
+            h.pl.CB = 16;
+            h.pl.splitk = h.c.splitk;
+            h.narrow = h.c.WM == 2;
+            h.BN = h.c.BN;
+            h.n_col_tiles = h.c.n_col_tiles;
+            h.x6_chunks = h.c.pack_chunks;
+            h.blocks = (long)h.c.n_row_tiles * h.c.n_col_tiles * h.c.splitk;
+            return h;
+        }
+        want_x6 = false;
+    }
     h.narrow = (p.tile_hint == 64) || (p.tile_hint == 0 && p.M <= 64);
     const int BM = h.narrow ? 64 : 128;
     h.BN = h.narrow ? 256 : 128;
@@ -1204,6 +1235,7 @@ extern "C" int pase_conv_gemm(const PaseConvGemm* d, void* stream) {
     if (p.ps != 1 && (long)p.M * p.Cout_store >= 0xffffffffL) return -8;      // exact magic division
     if (p.epilogue == PASE_EPI_MSE_CTX && (long)p.M * p.r_ctx >= 0xffffffffL) return -8;
     hipStream_t st = (hipStream_t)stream;
+    if (h.x6c) return pase_x6c_launch(p, h.c, st);
     const dim3 grid((unsigned)h.blocks), block(NTHREADS);
 #define PASE_CONV_LAUNCH(BM_, BN_)                                                                       \
     do {                                                                                                 \
@@ -1246,6 +1278,12 @@ extern "C" int pase_conv_gemm_splitk(const PaseConvGemm* d) {
     return make_plan(*d, d->wx6 != nullptr).pl.splitk;
 }
 
+extern "C" int pase_conv_gemm_plan_kind(const PaseConvGemm* d) {
+    if (d->M <= 0 || d->K <= 0 || d->S <= 0 || d->Ncols <= 0 || d->K != d->Cin * d->taps) return 0;
+    const HostPlan h = make_plan(*d, d->wx6 != nullptr);
+    return h.x6c ? 2 : (h.pl.x6 ? 1 : 0);
+}
+
 extern "C" long pase_conv_gemm_x6_bytes(const PaseConvGemm* d) {
     if (d->M <= 0 || d->K <= 0 || d->S <= 0 || d->Ncols <= 0 || d->K != d->Cin * d->taps) return 0;
     if (d->tapstep != 1 && d->tapstep != -1) return 0;
@@ -1259,6 +1297,7 @@ extern "C" int pase_pack_x6(const PaseConvGemm* d, void* stream) {
     if (p.K != p.Cin * p.taps || p.ldwt < p.M) return -4;
     const HostPlan h = make_plan(p, true);
     if (!h.pl.x6 || h.pl.CB < 1) return -11;
+    if (h.x6c) return pase_x6c_pack(p, h.c, (hipStream_t)stream);
     const ConvPlan& pl = h.pl;
     const int lt = pl.xTq == 8 ? 3 : (pl.xTq == 4 ? 2 : (pl.xTq == 2 ? 1 : 0));
     const long total = h.x6_chunks / 3;

@@ -1,0 +1,28 @@
+// conv_x6c.h -- internal interface between conv_gemm.hip (the C-ABI entry points pase_conv_gemm / pase_pack_x6 /
+// pase_conv_gemm_x6_bytes / ..._stat_tiles / ..._splitk) and conv_x6c.hip (the channel-minor split-bf16 kernel).
+// Not part of the ABI.
+#pragma once
+#include "hip_compat.h"
+#include "pase_amd.h"
+
+struct PaseX6cPlan {
+    int P;              // polyphase factor (= stride): channel' c' = ci * P + b reads x[ci][P * j + b - padLp]
+    int A;              // taps of the stride-1 view: ceil(taps / P)
+    int CinP;           // Cin * P channels'
+    int G;              // 16-channel' k-groups
+    int KGS;            // k-groups per stage (1 or 2)
+    int padLp;          // left pad of the stride-1 view
+    int rev;            // taps reversed in the pack (tapstep == -1)
+    int WM, NBT;        // waves along M (4 / 2), 32-column B tiles per wave (8 / 4)
+    int BM, BN;
+    int n_row_tiles, n_col_tiles, splitk;
+    int steps_total;    // stages * KGS * A MFMA steps (16 k each; k-groups past G are zero in the pack)
+    int xPerm;          // pixel-shuffle launches: tile rows ordered (channel, phase) -> 16-byte output runs
+    long pack_chunks;   // 16-byte chunks of the weight pack
+    unsigned ncols_magic, cout_magic, rctx_magic, ps_magic, seg_magic, p_magic;
+};
+
+// false: the launch has no x6c plan (the caller falls back to the span-major split-bf16 / fp32 kernels)
+bool pase_x6c_plan(const PaseConvGemm& p, PaseX6cPlan& pl);
+int pase_x6c_pack(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st);
+int pase_x6c_launch(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st);

@@ -124,6 +124,47 @@ __device__ __forceinline__ void pase_split_bf16x3(const float (&x)[8], u32x4 (&o
     for (int i = 0; i < 4; ++i) out[2][i] = pase_pack_hi16(__float_as_uint(r[2 * i]), __float_as_uint(r[2 * i + 1]));
 }
 
+// Round-to-nearest pieces (the form the x6c kernels use): hi = bf16_rne(x), mid = bf16_rne(x - hi), lo = bf16_rne(x - hi -
+// mid); both remainders are exact in fp32.  Unlike the truncated pieces above, the dropped part of a product (ml + lm + ll
+// and the rounding of lo) has no preferred sign, so sums of same-signed products carry no systematic error
+// (tools/experiments/x6_accum_probe.hip: mean error / sum|ab| -4e-8 truncated, -4e-9 rounded).  One v_cvt_pk_bf16_f32 per
+// pair and level; same VALU count as the truncating split.
+#ifdef PASE_HIPEMU
+__device__ __forceinline__ unsigned pase_cvt_pk_bf16(float lo, float hi) {
+    auto rne = [](float f) {
+        unsigned u = __float_as_uint(f);
+        if ((u & 0x7f800000u) == 0x7f800000u) return u >> 16;         // inf / nan: keep the top half
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return u >> 16;
+    };
+    return rne(lo) | (rne(hi) << 16);
+}
+#else
+typedef __bf16 pase_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float pase_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pase_cvt_pk_bf16(float lo, float hi) {
+    const pase_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, pase_bf16x2));
+}
+#endif
+__device__ __forceinline__ void pase_split_bf16x3_rne(const float (&x)[8], u32x4 (&out)[3]) {
+    float r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = x[i];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned pk = pase_cvt_pk_bf16(r[2 * i], r[2 * i + 1]);
+            out[s][i] = pk;
+            r[2 * i] -= __uint_as_float(pk << 16);
+            r[2 * i + 1] -= __uint_as_float(pk & 0xffff0000u);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[2][i] = pase_cvt_pk_bf16(r[2 * i], r[2 * i + 1]);
+}
+
 // four values -> three pieces x two dwords (half a fragment)
 __device__ __forceinline__ void pase_split_bf16x3_quad(const float (&x)[4], unsigned (&out)[3][2]) {
     float r[4];

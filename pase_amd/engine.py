@@ -122,12 +122,9 @@ def conv_fwd(a: Act, w2d, bias, *, Cout, taps, stride=1, padL=0, padR=0, pad_mod
     if Tout is None:
         Tout = (Tin + padL + padR - taps) // stride + 1
     y = out if out is not None else _new((S, Cout, Tout), a.t)
-    stat = None
-    if want_stats:
-        stat = _new((K.stat_tiles(M=Cout, S=S, Ncols=Tout, Cin=a.C, taps=taps, stride=stride, padL=padL,
-                                  tapstep=tapstep), Cout, 2), a.t)
-    K.conv_gemm(a.t, w2d, y, S=S, Cin=a.C, Tin=Tin, M=Cout, K=a.C * taps, taps=taps, Ncols=Tout, Tout=Tout,
-                ldw=w2d.shape[1], bias=bias, in_scale=a.scale, in_shift=a.shift, in_alpha=a.alpha, stat_part=stat,
+    stat = K.conv_gemm(a.t, w2d, y, want_stats=want_stats, S=S, Cin=a.C, Tin=Tin, M=Cout, K=a.C * taps, taps=taps,
+                Ncols=Tout, Tout=Tout,
+                ldw=w2d.shape[1], bias=bias, in_scale=a.scale, in_shift=a.shift, in_alpha=a.alpha,
                 x_ctot=a.ctot, x_coff=a.coff, tap_major=tap_major, stride=stride, tapstep=tapstep, padL=padL,
                 pad_mode=pad_mode, y_ctot=y.shape[1], y_coff=out_coff, Cout_store=Cout)
     return y, stat

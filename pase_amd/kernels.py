@@ -46,6 +46,8 @@ def declare(l):
     l.pase_conv_gemm_splitk.restype = C.c_int
     l.pase_conv_gemm_x6_bytes.argtypes = [C.POINTER(PaseConvGemm)]
     l.pase_conv_gemm_x6_bytes.restype = C.c_long
+    l.pase_conv_gemm_plan_kind.argtypes = [C.POINTER(PaseConvGemm)]
+    l.pase_conv_gemm_plan_kind.restype = C.c_int
     l.pase_pack_x6.argtypes = [C.POINTER(PaseConvGemm), C.c_void_p]
     l.pase_pack_x6.restype = C.c_int
     l.pase_abi_sizeof.argtypes = [C.c_int]
@@ -164,6 +166,7 @@ class GemmTimer(object):
 
 
 GEMM_TIMER = None
+LAST_PLAN_KIND = None      # plan kind of the most recent conv_gemm launch (0 fp32 pipe, 2 split-bf16 x6c): tests / reports
 
 
 def pack_wt(w, *, M, K, Cin, taps, ldw=None, tap_major=0):
@@ -193,10 +196,12 @@ def _x6_conv_ok(kw):
     return True
 
 
-def conv_gemm(x, w, y, **kw):
+def conv_gemm(x, w, y, want_stats=False, **kw):
     """see include/pase_amd.h PaseConvGemm.  With splitk > 1 the output is zero-filled here first.
     The kernel reads the K-major pack of the weight: pass it as wt= (e.g. straight from pack_dgrad, or a
-    weight that already is K-major) or it is produced here from `w`."""
+    weight that already is K-major) or it is produced here from `w`.
+    want_stats=True: the (column tiles, M, 2) partial-sum buffer for pase_bn_finalize is allocated here (the tile count
+    is a function of the plan the library picks for the COMPLETE descriptor, split-bf16 pack included) and returned."""
     if kw.get("wt") is None:
         kw["wt"] = pack_wt(w, M=kw["M"], K=kw["K"], Cin=kw["Cin"], taps=kw["taps"], ldw=kw.get("ldw"),
                            tap_major=kw.get("tap_major", 0))
@@ -209,15 +214,27 @@ def conv_gemm(x, w, y, **kw):
             wx6 = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
             d.wx6 = wx6.data_ptr()
             _check(_lib.lib().pase_pack_x6(C.byref(d), _stream()), "pase_pack_x6")
+    stat = None
+    if want_stats:
+        stat = torch.empty(_lib.lib().pase_conv_gemm_stat_tiles(C.byref(d)), d.M, 2, device=x.device, dtype=torch.float32)
+        d.stat_part = stat.data_ptr()
+    elif kw.get("stat_part") is not None:
+        need = _lib.lib().pase_conv_gemm_stat_tiles(C.byref(d))
+        if kw["stat_part"].shape[0] != need:
+            raise ValueError("pase_conv_gemm: stat_part has %d tile rows, the launch writes %d (use want_stats=True)"
+                             % (kw["stat_part"].shape[0], need))
     if d.splitk != 1:
         if _lib.lib().pase_conv_gemm_splitk(C.byref(d)) > 1:
             y.zero_()
+    global LAST_PLAN_KIND
+    LAST_PLAN_KIND = _lib.lib().pase_conv_gemm_plan_kind(C.byref(d))
     ev0 = GEMM_TIMER.start() if GEMM_TIMER is not None else None
     _check(_lib.lib().pase_conv_gemm(C.byref(d), _stream()), "pase_conv_gemm")
     if ev0 is not None:
         GEMM_TIMER.stop("conv_gemm", 2.0 * d.S * d.Ncols * d.M * d.K, ev0,
                         "M%d K%d(Cin%d x %d) N%dx%d s%d ps%d epi%d" % (d.M, d.K, d.Cin, d.taps, d.S, d.Ncols, d.stride,
                                                                     d.ps, d.epilogue))
+    return stat
 
 
 # ======================================================================================

@@ -46,13 +46,25 @@ def _batch(seed, raw, dev):
     return batch
 
 
-@pytest.fixture(scope="module")
-def setup():
+@pytest.fixture(scope="module", params=[True, False], ids=["x6", "fp32pipe"])
+def setup(request):
+    """Both matrix pipes are gated: the split-bf16 contraction (the shipped default) and the exact-fp32 MFMA pipe
+    (K.X6 False) run the same two tests against the same comparator."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from pase_amd import _lib
     _lib.use_library(None, "cuda")
     _lib.lib()
+    from pase_amd import kernels as K
+    saved = K.X6
+    K.X6 = request.param
+    try:
+        yield _make_setup()
+    finally:
+        K.X6 = saved
+
+
+def _make_setup():
     from pase_amd.trainer import trainer
     dev = torch.device("cuda:0")
     fe, wk, raw = _cfgs()
@@ -185,16 +197,16 @@ def test_bs32_ten_adam_steps_track(setup):
     assert ours[-1] < ours[0]              # and it trains
     # parameters after 10 Adam steps: Adam normalises every gradient to a +-lr step, so an element whose gradient is
     # round-off-sized (dense-skip and decoder weights early in training) moves by lr per step in a direction both
-    # implementations pick by round-off.  Hard bound 2 * steps * lr per element; the UPDATE directions must agree.
+    # implementations pick by round-off -- a per-element bound says nothing there.  What must agree is the UPDATE as
+    # a whole: its direction (cosine >= 0.95 per tensor; measured >= 0.98) and its length (within 5 %).
     worst = (1.0, None)
     for n, p in tr.model.named_parameters():
         if is_noise_grad(n):
             continue
-        diff = (p.detach() - P[n].detach()).abs()
-        lr = 1e-3 if n.startswith("frontend.") else 5e-4
-        assert float(diff.max()) <= 2 * 10 * lr + 1e-6, (n, float(diff.max()))
         da, db = (p.detach() - p0[n]).double().flatten(), (P[n].detach() - p0[n]).double().flatten()
         cos = float((da * db).sum() / (da.norm() * db.norm()).clamp_min(1e-30))
         worst = min(worst, (cos, n))
-        assert cos >= 0.8, (n, cos)
+        assert cos >= 0.95, (n, cos)
+        ratio = float(da.norm() / db.norm().clamp_min(1e-30))
+        assert 0.95 <= ratio <= 1.05, (n, ratio)
     print("smallest cosine between the two 10-step updates:", worst)

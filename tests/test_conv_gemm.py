@@ -43,12 +43,9 @@ def test_conv_fwd_reflect(dev, Cin, Cout, k, stride, T, S):
     ref = F.conv1d(xp, w, b, stride=stride)
     Tout = ref.shape[2]
     y = torch.zeros(S, Cout, Tout, device=dev)
-    nt = K.stat_tiles(M=Cout, S=S, Ncols=Tout, Cin=Cin, taps=k, stride=stride, padL=P[0])
-    stat = torch.zeros(nt, Cout, 2, device=dev)
-    K.conv_gemm(x.to(dev), w.reshape(Cout, -1).contiguous().to(dev), y, S=S, Cin=Cin, Tin=T, M=Cout,
-                K=Cin * k, taps=k, Ncols=Tout, Tout=Tout, bias=b.to(dev), in_scale=sc.to(dev),
-                in_shift=sh.to(dev), in_alpha=al.to(dev), stat_part=stat, stride=stride, padL=P[0],
-                pad_mode=K.PAD_REFLECT)
+    stat = K.conv_gemm(x.to(dev), w.reshape(Cout, -1).contiguous().to(dev), y, want_stats=True, S=S, Cin=Cin, Tin=T,
+                       M=Cout, K=Cin * k, taps=k, Ncols=Tout, Tout=Tout, bias=b.to(dev), in_scale=sc.to(dev),
+                       in_shift=sh.to(dev), in_alpha=al.to(dev), stride=stride, padL=P[0], pad_mode=K.PAD_REFLECT)
     torch.testing.assert_close(y.cpu(), ref, **_tol(dev))
     st = stat.cpu().double().sum(0)
     torch.testing.assert_close(st[:, 0], ref.double().sum((0, 2)), rtol=1e-4, atol=1e-3)
@@ -244,10 +241,8 @@ def test_flat_ws_store_bias_stats(dev, xf, S, Cin, Cout, T):
         kw.update(in_alpha=al.to(dev))
     ref = F.conv1d(xin, w[:, :, None], b)
     y = torch.zeros(S, Cout, T, device=dev)
-    nt = K.stat_tiles(M=Cout, S=S, Ncols=T, Cin=Cin, taps=1)
-    stat = torch.zeros(nt, Cout, 2, device=dev)
-    K.conv_gemm(x.to(dev), w.to(dev), y, S=S, Cin=Cin, Tin=T, M=Cout, K=Cin, taps=1, Ncols=T, Tout=T, bias=b.to(dev),
-                stat_part=stat, **kw)
+    stat = K.conv_gemm(x.to(dev), w.to(dev), y, want_stats=True, S=S, Cin=Cin, Tin=T, M=Cout, K=Cin, taps=1, Ncols=T,
+                       Tout=T, bias=b.to(dev), **kw)
     torch.testing.assert_close(y.cpu(), ref, **_tol(dev))
     st = stat.cpu().double().sum(0)
     torch.testing.assert_close(st[:, 0], ref.double().sum((0, 2)), rtol=1e-4, atol=1e-3)
@@ -292,15 +287,13 @@ def test_flat_ws_mse_context_epilogue_wide(dev):
 
 
 @pytest.mark.parametrize("Cin,Cout,k,stride,T,S", [
-    (64, 130, 11, 1, 300, 3),     # 4 rows x 4 taps per step (11 -> 12 taps), 3-slot spans
-    (64, 130, 11, 2, 600, 2),     # stride 2: 6-slot spans
-    (48, 70, 6, 1, 300, 2),       # 8 rows x 2 taps
-    (40, 70, 8, 1, 200, 2),       # 2 rows x 8 taps
-    (64, 70, 3, 1, 300, 2),       # 16 rows x 1 tap
-    (20, 70, 30, 10, 2900, 2),    # 30 taps: 4-step stages
-    (96, 130, 1, 1, 200, 3),      # flat 1x1
-    (1, 40, 251, 1, 700, 2),      # Sinc FIR shape: one row, 16 taps per step, six tap groups, 64-row tile
-    (1, 70, 46, 1, 400, 2),       # one-row plan on the 128-row tile (a single 48-tap group)
+    (64, 130, 11, 1, 300, 3),     # 11 steps per 16-channel group
+    (64, 130, 11, 2, 600, 2),     # stride 2: 128 polyphase channels, 6 taps
+    (48, 70, 6, 1, 300, 2),
+    (40, 70, 8, 1, 200, 2),       # 40 channels: the third k-group is half zeros
+    (64, 70, 3, 1, 300, 2),       # two k-groups per stage
+    (20, 70, 30, 10, 2900, 2),    # stride 10: 200 polyphase channels, 3 taps
+    (96, 130, 1, 1, 200, 3),      # 1x1
 ])
 def test_split_bf16_is_fp32_grade(dev, Cin, Cout, k, stride, T, S):
     """The split-bf16 contraction (PaseConvGemm::wx6: hi+mid+lo pieces, 6 bf16 MFMAs per product) against an fp64
@@ -332,32 +325,26 @@ def test_split_bf16_is_fp32_grade(dev, Cin, Cout, k, stride, T, S):
             err[mode] = ((y.cpu().double() - ref).norm() / ref.norm()).item()
     finally:
         K.X6 = saved
-    assert err[True] < 5e-7, err
-    assert err[True] < 2.0 * err[False] + 1e-8, err
+    # the two-accumulator split contraction (conv_x6c.hip) is a BETTER fp32 evaluation than the k-ordered fma chain of
+    # the fp32 matrix pipe: error against fp64 no larger, and under 4e-7
+    assert err[True] < 4e-7, err
+    assert err[True] < 1.05 * err[False] + 1e-8, err
 
 
 def test_split_bf16_api_contract(dev):
-    """pase_conv_gemm_x6_bytes / pase_pack_x6 / PaseConvGemm::wx6: shapes without a split-bf16 plan report 0 bytes, a pack
-    pointer on such a launch is refused (-11) instead of being ignored, and the pack size follows the documented layout."""
+    """pase_conv_gemm_x6_bytes / pase_pack_x6 / PaseConvGemm::wx6: shapes without a split-bf16 plan report 0 bytes and a
+    pack pointer on such a launch is refused (-11) instead of being ignored (pack layout: tests/test_conv_x6c.py)."""
     import ctypes as C
     from pase_amd import _lib
     lib = _lib.lib()
-    S, Cin, Cout, T = 2, 3, 8, 300                       # 64-row tile, 20 taps x stride 10: no plan
+    S, Cin, Cout, T = 2, 1, 8, 300                       # one input channel (the Sinc FIR): no 16-channel k-group
     x = torch.randn(S, Cin, T, device=dev)
     w = torch.randn(Cout, Cin * 20, device=dev)
-    y = torch.zeros(S, Cout, 29, device=dev)
-    kw = dict(S=S, Cin=Cin, Tin=T, M=Cout, K=Cin * 20, taps=20, Ncols=29, Tout=29, stride=10, padL=0, splitk=1)
+    y = torch.zeros(S, Cout, 281, device=dev)
+    kw = dict(S=S, Cin=Cin, Tin=T, M=Cout, K=Cin * 20, taps=20, Ncols=281, Tout=281, stride=1, padL=0, splitk=1)
     d = K._conv_desc(x, w, y, wt=K.pack_wt(w, M=Cout, K=Cin * 20, Cin=Cin, taps=20), **kw)
     assert lib.pase_conv_gemm_x6_bytes(C.byref(d)) == 0
     junk = torch.zeros(4096, dtype=torch.uint8, device=dev)
     d.wx6 = junk.data_ptr()
     assert lib.pase_pack_x6(C.byref(d), None) == -11
     assert lib.pase_conv_gemm(C.byref(d), None) == -11
-    # 11 taps, 128-row tile: 4 rows x 4 taps per step, 3 steps per stage, ceil(Cin / 4) stages, 2 k-groups x 3 planes x 128 rows
-    Cin, Cout, T = 10, 70, 300
-    x = torch.randn(S, Cin, T, device=dev)
-    w = torch.randn(Cout, Cin * 11, device=dev)
-    y = torch.zeros(S, Cout, T, device=dev)
-    kw = dict(S=S, Cin=Cin, Tin=T, M=Cout, K=Cin * 11, taps=11, Ncols=T, Tout=T, stride=1, padL=5, pad_mode=K.PAD_REFLECT, splitk=1)
-    d = K._conv_desc(x, w, y, wt=K.pack_wt(w, M=Cout, K=Cin * 11, Cin=Cin, taps=11), **kw)
-    assert lib.pase_conv_gemm_x6_bytes(C.byref(d)) == 1 * 3 * 3 * 2 * 3 * 128 * 16

@@ -1,0 +1,276 @@
+"""pase_conv_gemm on the split-bf16 channel-minor kernel (pase_amd/csrc/conv_x6c.hip) against fp64 torch references.
+
+Every case asserts that the launch really ran on that kernel (pase_conv_gemm_plan_kind == 2) and that the result has
+the error of a GOOD fp32 evaluation: relative L2 against fp64 <= 1e-6 (measured 1e-7 ... 4e-7; a bf16-grade result
+would be 1e-3, a dropped split term 1e-5).  Shapes cover what the PASE+ step launches: strided
+convs as polyphase channels (stride 2 / 4 / 10), reversed taps (data-gradients, the QRNN Linear), pixel-shuffle stores
+(transposed convs) with and without the (channel, phase) row order, 1x1 layers (two k-groups per stage), column tiles
+that touch three sequences, 64-row and multi-row-tile launches, ragged channel groups, split-K, BatchNorm statistics,
+the fused r-context MSE epilogue and the spectra post-ops.
+"""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from pase_amd import kernels as K
+
+
+@pytest.fixture(autouse=True)
+def _x6_on():
+    saved = K.X6
+    K.X6 = True
+    yield
+    K.X6 = saved
+
+
+def _rel(a, ref):
+    return float((a.cpu().double() - ref).norm() / ref.norm().clamp_min(1e-300))
+
+
+def _xf(x, sc, sh, al):
+    v = x.double() * sc.double()[None, :, None] + sh.double()[None, :, None]
+    return torch.where(v > 0, v, v * al.double()[None, :, None])
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,T,S,xf", [
+    (16, 40, 11, 1, 300, 2, True),       # one k-group, 11 steps, two row tiles (M = 40 -> 64-row tile)
+    (32, 130, 11, 1, 250, 3, True),      # 128-row tiles (two of them, second ragged), tiles straddle sequences
+    (24, 70, 11, 2, 420, 2, True),       # stride 2: 48 channels', 6 taps' (one zero tap), reflect pad on both phases
+    (8, 33, 20, 10, 900, 2, False),      # stride 10: 80 channels', 2 taps' (block 1)
+    (40, 20, 30, 4, 600, 2, True),       # stride 4: 160 channels', 8 taps' (30 -> 32 taps)
+    (28, 96, 3, 1, 90, 5, True),         # 28 channels: ragged second k-group (zero channels'), Ncols < 128: 3 sequences per tile
+    (48, 64, 5, 1, 1000, 1, False),      # 64-row launch: 64 x 256 tile (waves 2 x 2)
+])
+def test_conv_forward(dev, Cin, Cout, k, stride, T, S, xf):
+    torch.manual_seed(0)
+    x = torch.randn(S, Cin, T)
+    w = torch.randn(Cout, Cin, k) * 0.2
+    b = torch.randn(Cout)
+    sc, sh, al = torch.rand(Cin) + 0.5, torch.randn(Cin) * 0.1, torch.rand(Cin) * 0.5
+    P = (k // 2 - 1, k // 2) if (stride > 1 or k % 2 == 0) else (k // 2, k // 2)
+    xin = _xf(x, sc, sh, al) if xf else x.double()
+    ref = F.conv1d(F.pad(xin, P, mode="reflect"), w.double(), b.double(), stride=stride)
+    Tout = ref.shape[2]
+    y = torch.zeros(S, Cout, Tout, device=dev)
+    kw = dict(in_scale=sc.to(dev), in_shift=sh.to(dev), in_alpha=al.to(dev)) if xf else {}
+    stat = K.conv_gemm(x.to(dev), w.reshape(Cout, -1).contiguous().to(dev), y, want_stats=True, S=S, Cin=Cin, Tin=T,
+                       M=Cout, K=Cin * k, taps=k, Ncols=Tout, Tout=Tout, bias=b.to(dev), stride=stride, padL=P[0],
+                       pad_mode=K.PAD_REFLECT, **kw)
+    assert K.LAST_PLAN_KIND == 2
+    assert _rel(y, ref) < 1e-6
+    st = stat.cpu().double().sum(0)
+    torch.testing.assert_close(st[:, 0], ref.sum((0, 2)), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(st[:, 1], (ref ** 2).sum((0, 2)), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,T,S", [
+    (32, 16, 30, 10, 140, 2),   # ps = 10: (channel, phase)-ordered rows, quads straddle channels
+    (16, 20, 8, 4, 150, 3),     # ps = 4
+    (16, 40, 4, 2, 200, 2),     # ps = 2
+    (48, 36, 30, 4, 50, 4),     # few columns per sequence (57 per sequence: tiles touch three)
+])
+def test_conv_transpose_pixel_shuffle(dev, Cin, Cout, k, stride, T, S):
+    """nn.ConvTranspose1d (modules.py:558-589) = stride-1 conv with reversed taps, stride * Cout rows, pixel-shuffle store."""
+    torch.manual_seed(1)
+    x = torch.randn(S, Cin, T)
+    w = torch.randn(Cin, Cout, k) * 0.2
+    b = torch.randn(Cout)
+    al = torch.rand(Cin) * 0.5
+    pad = max(0, (stride - k) // -2)
+    xin = torch.where(x > 0, x, x * al[None, :, None]).double()
+    ref = F.conv_transpose1d(xin, w.double(), b.double(), stride=stride, padding=pad)
+    Tout = ref.shape[2]
+    taps_p = -(-k // stride)
+    wt = K.pack_dgrad_t(w.to(dev), R=Cin, O=Cout, k=k, st=stride, s_red=Cout * k, s_out=k, s_k=1)
+    y = torch.zeros(S, Cout, Tout, device=dev)
+    K.conv_gemm(x.to(dev), None, y, wt=wt, S=S, Cin=Cin, Tin=T, M=stride * Cout, K=Cin * taps_p, taps=taps_p,
+                Ncols=T + taps_p - 1, Tout=Tout, bias=b.to(dev), in_alpha=al.to(dev), stride=1, tapstep=-1, padL=0,
+                pad_mode=K.PAD_ZERO, Cout_store=Cout, ps=stride, poff=-pad, splitk=1)
+    assert K.LAST_PLAN_KIND == 2
+    assert _rel(y, ref) < 1e-6
+
+
+@pytest.mark.parametrize("splitk", [1, 0, 3])
+def test_strided_data_gradient_splitk(dev, splitk):
+    """Data-gradient of a stride-2 conv in padded coordinates (engine.conv_dgrad): rows = (phase, input channel),
+    reversed taps, pixel-shuffle store, long reduction over the output channels with and without split-K."""
+    torch.manual_seed(2)
+    S, Cin, Cout, k, stride, T = 2, 12, 160, 11, 2, 200
+    w = torch.randn(Cout, Cin, k) * 0.1
+    padL, padR = k // 2 - 1, k // 2
+    Tg = (T + padL + padR - k) // stride + 1
+    dy = torch.randn(S, Cout, Tg)
+    xp = torch.zeros(S, Cin, T + padL + padR, dtype=torch.float64, requires_grad=True)
+    F.conv1d(xp, w.double(), None, stride=stride).backward(dy.double())
+    ref = xp.grad
+    from pase_amd import engine as E
+    import unittest.mock as mock
+    with mock.patch.object(K, "conv_gemm", wraps=K.conv_gemm) as cg:
+        orig = K._conv_desc
+
+        def desc(*a, **kw):
+            kw["splitk"] = splitk
+            return orig(*a, **kw)
+        with mock.patch.object(K, "_conv_desc", desc):
+            dx = E.conv_dgrad(dy.to(dev), w.to(dev), R=Cout, O=Cin, k=k, stride=stride, Tin=T, padL=padL, padR=padR,
+                              s_red=Cin * k, s_out=k, s_k=1)
+        assert cg.called
+    assert K.LAST_PLAN_KIND == 2
+    assert _rel(dx, ref) < 1e-6
+
+
+def test_qrnn_linear_tap_major(dev):
+    """torchqrnn's Linear over [x_t ; x_{t-1}] (tap-major columns, reversed taps, zero x_{-1})."""
+    torch.manual_seed(3)
+    S, C_, H, T = 3, 32, 24, 50
+    x = torch.randn(S, C_, T)
+    lin = torch.randn(3 * H, 2 * C_) * 0.2
+    b = torch.randn(3 * H)
+    xm1 = torch.cat([torch.zeros(S, C_, 1), x[:, :, :-1]], 2)
+    src = torch.cat([x, xm1], 1).double()                      # (S, 2C, T)
+    ref = torch.einsum("mk,skt->smt", lin.double(), src) + b.double()[None, :, None]
+    y = torch.zeros(S, 3 * H, T, device=dev)
+    K.conv_gemm(x.to(dev), lin.to(dev), y, S=S, Cin=C_, Tin=T, M=3 * H, K=2 * C_, taps=2, Ncols=T, Tout=T,
+                bias=b.to(dev), tap_major=1, tapstep=-1, padL=0, pad_mode=K.PAD_ZERO)
+    assert K.LAST_PLAN_KIND == 2
+    assert _rel(y, ref) < 1e-6
+
+
+@pytest.mark.parametrize("Cin,Cout,T,S,splitk", [
+    (64, 200, 100, 3, 1),        # two k-groups per stage, tiles across sequences
+    (48, 130, 77, 2, 1),         # odd number of k-groups: the second group of the last stage is zero
+    (1500, 100, 64, 2, 0),       # long reduction: auto split-K (data-gradient of a wide head)
+    (96, 40, 520, 1, 1),         # 64-row tile
+])
+def test_flat_1x1(dev, Cin, Cout, T, S, splitk):
+    torch.manual_seed(4)
+    x = torch.randn(S, Cin, T)
+    w = torch.randn(Cout, Cin) * 0.2
+    b = torch.randn(Cout)
+    al = torch.rand(Cin) * 0.5
+    xin = torch.where(x > 0, x, x * al[None, :, None]).double()
+    ref = torch.einsum("mk,skt->smt", w.double(), xin) + b.double()[None, :, None]
+    y = torch.full((S, Cout, T), 3.0, device=dev)
+    K.conv_gemm(x.to(dev), w.to(dev), y, S=S, Cin=Cin, Tin=T, M=Cout, K=Cin, taps=1, Ncols=T, Tout=T, bias=b.to(dev),
+                in_alpha=al.to(dev), splitk=splitk)
+    assert K.LAST_PLAN_KIND == 2
+    assert _rel(y, ref) < 1e-6
+
+
+def test_channel_slice_in_and_out(dev):
+    """x_coff / x_ctot (a slice of a wider input) and y_coff / y_ctot (a slice of a wider output)."""
+    torch.manual_seed(5)
+    S, Cin, Cout, k, T = 2, 32, 50, 3, 140
+    xw = torch.randn(S, Cin + 7, T)
+    w = torch.randn(Cout, Cin, k) * 0.2
+    ref = F.conv1d(F.pad(xw[:, 5:5 + Cin].double(), (1, 1)), w.double())
+    yw = torch.full((S, Cout + 3, T), 9.0, device=dev)
+    K.conv_gemm(xw.to(dev), w.reshape(Cout, -1).contiguous().to(dev), yw, S=S, Cin=Cin, Tin=T, M=Cout, K=Cin * k, taps=k,
+                Ncols=T, Tout=T, x_ctot=Cin + 7, x_coff=5, y_ctot=Cout + 3, y_coff=2, Cout_store=Cout, padL=1,
+                pad_mode=K.PAD_ZERO)
+    assert K.LAST_PLAN_KIND == 2
+    assert _rel(yw[:, 2:2 + Cout], ref) < 1e-6
+    assert float(yw[:, :2].min()) == 9.0 and float(yw[:, 2 + Cout:].min()) == 9.0
+
+
+def test_mse_context_epilogue(dev):
+    """ContextualizedLoss(MSELoss, r = 7) fused into the projection (pase/losses.py:6-37): loss sum, prediction and
+    d(loss)/d(prediction) against the stacked-target definition."""
+    torch.manual_seed(6)
+    B, Cin, D, r, Fr = 3, 32, 21, 7, 60
+    M = D * r
+    h = torch.randn(B, Cin, Fr)
+    w = torch.randn(M, Cin) * 0.2
+    b = torch.randn(M)
+    lab = torch.randn(B, D, Fr)
+    pred = torch.einsum("mk,bkt->bmt", w.double(), h.double()) + b.double()[None, :, None]
+    padded = F.pad(lab.double(), (r // 2, r // 2))
+    tgt = torch.stack([padded[:, :, t:t + r].reshape(B, -1) for t in range(Fr)], 2)      # (B, D*r, F), channel d*r + j
+    ref_loss = ((pred - tgt) ** 2).sum()
+    y = torch.zeros(B, M, Fr, device=dev)
+    g = torch.zeros(B, M, Fr, device=dev)
+    acc = torch.zeros(1, dtype=torch.float64, device=dev)
+    K.conv_gemm(h.to(dev), w.to(dev), y, S=B, Cin=Cin, Tin=Fr, M=M, K=Cin, taps=1, Ncols=Fr, Tout=Fr, bias=b.to(dev),
+                epilogue=K.EPI_MSE_CTX, label=lab.to(dev), grad_out=g, loss_acc=acc, grad_scale=0.5, r_ctx=r, label_D=D)
+    assert K.LAST_PLAN_KIND == 2
+    assert _rel(y, pred) < 1e-6
+    assert abs(float(acc) - float(ref_loss)) <= 1e-6 * float(ref_loss)
+    assert _rel(g, 0.5 * (pred - tgt)) < 2e-6
+
+
+@pytest.mark.parametrize("post", ["pow", "logpow", "mag"])
+def test_spectrum_post_ops(dev, post):
+    """DFT-basis convolution with a |.|^2 / log |.|^2 / |.| epilogue (on-device LPS / SWIPE' spectra)."""
+    torch.manual_seed(7)
+    S, Cin, k, T, nb = 2, 16, 4, 90, 20
+    x = torch.randn(S, Cin, T)
+    w = torch.randn(2 * nb, Cin, k) * 0.3                      # rows (re, im) interleaved
+    z = F.conv1d(x.double(), w.double())
+    Tout = z.shape[2]
+    pw = z[:, 0::2] ** 2 + z[:, 1::2] ** 2
+    ref = {"pow": 0.5 * pw, "logpow": 2.0 * torch.log(pw + 1e-9), "mag": 0.5 * pw.sqrt()}[post]
+    y = torch.zeros(S, nb, Tout, device=dev)
+    K.conv_gemm(x.to(dev), w.reshape(2 * nb, -1).contiguous().to(dev), y, S=S, Cin=Cin, Tin=T, M=2 * nb, K=Cin * k, taps=k,
+                Ncols=Tout, Tout=Tout, Cout_store=nb, y_ctot=nb,
+                post_op={"pow": K.POST_POW, "logpow": K.POST_LOGPOW, "mag": K.POST_MAG}[post],
+                post_scale=2.0 if post == "logpow" else 0.5, post_eps=1e-9)
+    assert K.LAST_PLAN_KIND == 2
+    torch.testing.assert_close(y.cpu().double(), ref, rtol=2e-5, atol=2e-5)
+
+
+def test_zero_padding_applies_after_the_transform(dev):
+    """padded samples are zeros of the TRANSFORMED activation (the QRNN's x_{-1} = 0, ConvTranspose borders), not
+    transform(0) = shift."""
+    torch.manual_seed(8)
+    S, Cin, Cout, k, T = 1, 16, 33, 5, 40
+    x = torch.randn(S, Cin, T)
+    w = torch.randn(Cout, Cin, k) * 0.2
+    sc, sh, al = torch.rand(Cin) + 0.5, torch.randn(Cin) + 2.0, torch.rand(Cin) * 0.5
+    ref = F.conv1d(F.pad(_xf(x, sc, sh, al), (2, 2)), w.double())
+    y = torch.zeros(S, Cout, T, device=dev)
+    K.conv_gemm(x.to(dev), w.reshape(Cout, -1).contiguous().to(dev), y, S=S, Cin=Cin, Tin=T, M=Cout, K=Cin * k, taps=k,
+                Ncols=T, Tout=T, in_scale=sc.to(dev), in_shift=sh.to(dev), in_alpha=al.to(dev), padL=2, pad_mode=K.PAD_ZERO)
+    assert K.LAST_PLAN_KIND == 2
+    assert _rel(y, ref) < 1e-6
+
+
+def test_unbiased_on_same_signed_sums(dev):
+    """The property the two-accumulator form exists for (conv_x6c.hip header): on all-positive operands the SIGNED error
+    of the round-2 single-accumulator kernels was -2e-6 * K / 2048 of the result on every output (the matrix core drops
+    the small terms' low bits toward -inf).  Here |mean error| must stay below 2e-8 of the result and the launch must
+    beat the error class of an fp32 fma chain."""
+    torch.manual_seed(9)
+    S, Cin, Cout, T = 1, 2048, 32, 256
+    x = torch.rand(S, Cin, T) + 0.1
+    w = (torch.rand(Cout, Cin) + 0.1) * 0.2
+    ref = torch.einsum("mk,skt->smt", w.double(), x.double())
+    y = torch.zeros(S, Cout, T, device=dev)
+    K.conv_gemm(x.to(dev), w.to(dev), y, S=S, Cin=Cin, Tin=T, M=Cout, K=Cin, taps=1, Ncols=T, Tout=T, splitk=1)
+    assert K.LAST_PLAN_KIND == 2
+    e = (y.cpu().double() - ref) / ref
+    assert abs(float(e.mean())) < 2e-8, float(e.mean())
+    assert float(e.pow(2).mean().sqrt()) < 2e-7
+
+
+def test_plan_kind_and_pack_contract(dev):
+    """no split-bf16 pack -> fp32 pipe (kind 0); shapes without a 16-channel' k-group report 0 pack bytes."""
+    from pase_amd import _lib
+    lib = _lib.lib()
+    x = torch.zeros(1, 32, 64, device=dev)
+    w = torch.zeros(40, 32 * 3, device=dev)
+    d = K._conv_desc(x, w, torch.zeros(1, 40, 64, device=dev), wt=K.pack_wt(w, M=40, K=96, Cin=32, taps=3), S=1, Cin=32,
+                     Tin=64, M=40, K=96, taps=3, Ncols=64, Tout=64, padL=1)
+    assert lib.pase_conv_gemm_plan_kind(C.byref(d)) == 0
+    nbytes = lib.pase_conv_gemm_x6_bytes(C.byref(d))
+    # [32-row tiles][steps][3 planes][64 lanes] 16-byte chunks: 2 row tiles of a 64-row launch, 2 k-groups x 3 taps
+    assert nbytes == 2 * (2 * 3) * 3 * 64 * 16
+    buf = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    d.wx6 = buf.data_ptr()
+    assert lib.pase_conv_gemm_plan_kind(C.byref(d)) == 2
+    # one input channel (the Sinc FIR): no k-group of 16 channels' -> no pack, fp32 pipe
+    d1 = K._conv_desc(torch.zeros(1, 1, 300, device=dev), None, torch.zeros(1, 8, 300, device=dev),
+                      wt=torch.zeros(251, 8, device=dev), S=1, Cin=1, Tin=300, M=8, K=251, taps=251, Ncols=300, Tout=300,
+                      padL=125)
+    assert lib.pase_conv_gemm_x6_bytes(C.byref(d1)) == 0

@@ -107,13 +107,39 @@ def test_trainer_three_adam_steps(dev):
     assert abs(lrs["frontend"] - 1e-3 * (1 - 5 / 20) ** 0.9) < 1e-12
 
 
+# What "fp32-grade" means at step level (round-2 review item): the live reference's OWN fp32 gradients of this step are
+# compared with the same step evaluated by the live reference in fp64 (tests/golden/*_grads_f64.npz, oracle/make_golden.py
+# `grads64`), and so are ours.  Per tensor e_ref = relL2(reference fp32, fp64), e_ours = relL2(HIP path, fp64).
+# The reference's CPU kernels (oneDNN, blocked / pairwise accumulation) land 2e-6 ... 3e-5 from fp64 on the weight
+# tensors; a k-ORDERED fp32 fma chain (what v_mfma_f32_32x32x2_f32 is, bit for bit, and what the split-bf16 sum is
+# equivalent to) over reductions of 1e3 ... 3e5 terms of alternating sign sits at eps * sqrt(N) of the summands, so the
+# bound is   e_ours <= 1.5 * e_ref + FLOOR   with FLOOR the measured chain noise of OUR fp32-MFMA pipe plus margin;
+# both pipes (K.X6 False / True) must meet THE SAME bound, and the split pipe must be no farther from fp64 than
+# 2x the exact-fp32 pipe (+ a 1e-5 floor): that is the statement "the split-bf16 contraction is not narrower than fp32".
+GRAD_FLOOR_WEIGHT = 2e-3       # relL2, weight tensors (B = 2: 300 ... 48 000 positions per BatchNorm channel)
+GRAD_FLOOR_PER_CHANNEL = 6e-3  # relL2, one scalar per channel (BN gamma / beta, PReLU slopes, biases, SincNet vectors)
+_PIPE_ERR = {}                 # (gold, pipe) -> {name: relL2 vs fp64}, to compare the two pipes with each other
+
+
+@pytest.mark.parametrize("x6", [True, False], ids=["x6", "fp32pipe"])
 @pytest.mark.parametrize("gold,fe,wk", [("pase_plus_step.npz", "frontend/PASE+.cfg", "workers/workers+.cfg"),
                                         ("pase_step_cfg2.npz", "frontend/PASE.cfg", "workers/workers.cfg")])
-def test_full_width_golden_step(dev, gold, fe, wk):
+def test_full_width_golden_step(dev, gold, fe, wk, x6):
     """Full-width one step vs the live reference's trainer step: PASE+.cfg + workers+.cfg (12 workers)
-    and PASE.cfg + workers.cfg (decoder, r-less regressors, SPC / LIM / GIM)."""
+    and PASE.cfg + workers.cfg (decoder, r-less regressors, SPC / LIM / GIM); on the split-bf16 pipe (the default)
+    and on the exact-fp32 matrix pipe."""
     if dev.type == "cpu":
         pytest.skip("full-width step is GPU-only")
+    from pase_amd import kernels as K
+    saved = K.X6
+    K.X6 = x6
+    try:
+        _full_width_golden_step(dev, gold, fe, wk, x6)
+    finally:
+        K.X6 = saved
+
+
+def _full_width_golden_step(dev, gold, fe, wk, x6):
     import random
     from pase_amd.trainer import trainer
     g = np.load(os.path.join(GOLD, gold))
@@ -132,7 +158,8 @@ def test_full_width_golden_step(dev, gold, fe, wk):
     assert_close(chunk, g["chunk_emb"], rtol=0, atol=1e-4, what="chunk embedding")
     assert_close(preds["mi"], g["pred_mi"], rtol=1e-4, atol=1e-4)
     assert_close(preds["cmi"], g["pred_cmi"], rtol=1e-4, atol=1e-4)
-    assert_close(preds["mfcc"], g["pred_mfcc"], rtol=1e-4, atol=1e-4)
+    if "pred_mfcc" in g.files:
+        assert_close(preds["mfcc"], g["pred_mfcc"], rtol=1e-4, atol=1e-4)
     assert_close(preds["cchunk"][:, :, :400], g["pred_cchunk_head"], rtol=1e-4, atol=1e-4)
     if "pred_spc" in g.files:
         assert_close(preds["spc"], g["pred_spc"], rtol=1e-4, atol=1e-4)
@@ -152,56 +179,52 @@ def test_full_width_golden_step(dev, gold, fe, wk):
     assert_close(gsq.sqrt(), np.sqrt(g["grad_sq"][keep]), rtol=5e-3, atol=1e-6, what="grad norms")
     psq = torch.tensor([float((params[names[i]].detach().double() ** 2).sum()) for i in keep])
     assert_close(psq.sqrt(), np.sqrt(g["post_sq"][keep]), rtol=1e-4, atol=1e-5, what="post-Adam parameter norms")
-    # ELEMENT-WISE gradients against the live reference's (oracle/make_golden.py:gen_pase_step_grads): every
-    # parameter, sampled at grad_sample_index(numel) -- catches sign / permutation errors confined to wide tiles
-    gfile = os.path.join(GOLD, gold.replace(".npz", "_grads.npz"))
-    if os.path.exists(gfile):
-        from util import grad_sample_index
-        gg = np.load(gfile)
-        offs = gg["grad_offsets"]
-        checked = 0
-        worst = (0.0, 0.0, "")
-        stats = []
-        for i, n in enumerate(str(s) for s in gg["grad_names"]):
-            if is_noise_grad(n):
-                continue
-            ref = gg["grad_values"][offs[i]:offs[i + 1]]
-            got = params[n].grad.detach().reshape(-1)[torch.as_tensor(grad_sample_index(params[n].numel(), int(gg["n_samples"])),
-                                                                      device=dev)]
-            # With every contraction on the exact-fp32 matrix pipe (PASE_X6=0) the check is the tight one: every sampled
-            # element within 2e-3 relative or 1e-3 of the tensor's largest gradient (measured worst relative L2 2.6e-4, 3e-6
-            # on the SincNet vectors) -- the k-ordered fp32 MFMA chain reproduces the CPU reference's first layer bit for
-            # bit.  The split-bf16 contraction is fp32-GRADE (each output 1e-7 from fp64: tests/test_conv_gemm.py::
-            # test_split_bf16_is_fp32_grade; the Sinc layer with its real filters 1.8e-7 per channel against 2.9e-7 for the
-            # fp32 chain) but not bit-compatible with that reference, so the comparison becomes one between two fp32
-            # implementations with different summation orders, like tests/test_bench_config.py (bs32 against torch-ROCm:
-            # worst tensor 2.7e-3 relative L2 with the split contraction, 2.6e-3 on the fp32 pipe).  On this 2-utterance
-            # golden step the measured worst is 5.4e-3 relative L2 / 2.5 % of the largest gradient on a BatchNorm bias
-            # (one scalar per channel summed over positions of alternating sign), 4.0e-3 / 1.7 % on a weight tensor,
-            # 3.0e-3 on the SincNet vectors; moving ONLY the Sinc FIR to the split pipe accounts for 2.9e-3 of it (a 1e-7
-            # change of the first layer's output).  Bounds: 5 % of the largest gradient per element, relative L2 1e-2
-            # (weights) / 2e-2 (per-channel reductions, SincNet vectors); a sign / permutation / missing-term error is O(1).
-            refd = torch.as_tensor(ref).double()
-            gotd = got.cpu().double()
-            gmax = float(gg["grad_absmax"][i])
-            err = float((gotd - refd).abs().max())
-            rel2 = float((gotd - refd).norm() / refd.norm().clamp_min(1e-30))
-            per_channel = n.endswith(("norm.weight", "norm.bias", "act.weight", ".bias", "low_hz_", "band_hz_"))
-            from pase_amd import kernels as K
-            tight = not K.X6
-            ok = (err <= 1e-3 * gmax + 2e-3 * float(refd.abs().max())) if tight else \
-                 (err <= 5e-2 * gmax + 1e-9 and rel2 <= (2e-2 if per_channel else 1e-2))
-            stats.append((rel2, err / max(gmax, 1e-30), n))
-            assert ok or os.environ.get("PASE_GOLDEN_CALIB"), "grad %s: max|err| %.3e of max|g| %.3e, relL2 %.3e" % (n, err, gmax, rel2)
-            worst = max(worst, (rel2, err / max(gmax, 1e-30), n))
-            checked += 1
-        print("worst element-wise gradient agreement (relL2, max|err|/max|g|, name):", worst)
-        if os.environ.get("PASE_GOLDEN_CALIB"):
-            for st_ in sorted(stats, reverse=True)[:10]:
-                print("   relL2 %.3e  max|err|/max|g| %.3e  %s" % st_)
-            for st_ in sorted(stats, key=lambda t: -t[1])[:6]:
-                print("   (by element) relL2 %.3e  max|err|/max|g| %.3e  %s" % st_)
-        assert checked >= 100
+    # ELEMENT-WISE gradients: every parameter, sampled at grad_sample_index(numel) -- the live reference's fp32
+    # gradients (oracle/make_golden.py:gen_pase_step_grads) and the live reference's fp64 gradients of the same step
+    from util import grad_sample_index
+    gg = np.load(os.path.join(GOLD, gold.replace(".npz", "_grads.npz")))
+    g64 = np.load(os.path.join(GOLD, gold.replace(".npz", "_grads_f64.npz")))
+    assert [str(s) for s in gg["grad_names"]] == [str(s) for s in g64["grad_names"]]
+    offs = gg["grad_offsets"]
+    checked = 0
+    stats, bad, mine = [], [], {}
+    for i, n in enumerate(str(s) for s in gg["grad_names"]):
+        if is_noise_grad(n):
+            continue
+        ref32 = torch.as_tensor(gg["grad_values"][offs[i]:offs[i + 1]]).double()
+        truth = torch.as_tensor(g64["grad_values"][offs[i]:offs[i + 1]]).double()
+        idx = torch.as_tensor(grad_sample_index(params[n].numel(), int(gg["n_samples"])), device=dev)
+        got = params[n].grad.detach().reshape(-1)[idx].cpu().double()
+        tn = float(truth.norm().clamp_min(1e-30))
+        e_ref = float((ref32 - truth).norm()) / tn
+        e_ours = float((got - truth).norm()) / tn
+        gmax = float(g64["grad_absmax"][i])
+        emax = float((got - truth).abs().max()) / max(gmax, 1e-30)
+        per_channel = n.endswith(("norm.weight", "norm.bias", "act.weight", ".bias", "low_hz_", "band_hz_"))
+        floor = GRAD_FLOOR_PER_CHANNEL if per_channel else GRAD_FLOOR_WEIGHT
+        mine[n] = e_ours
+        stats.append((e_ours, e_ref, emax, n))
+        # a sign / permutation / missing-term error is O(1) in both measures
+        if not (e_ours <= 1.5 * e_ref + floor and emax <= 10 * (1.5 * e_ref + floor)):
+            bad.append("%s: relL2 vs fp64 %.3e (reference fp32: %.3e), max|err|/max|g| %.3e" % (n, e_ours, e_ref, emax))
+        checked += 1
+    stats.sort(reverse=True)
+    print("gradients vs the fp64 reference step [%s, %s]: worst tensors (ours, reference fp32, max|err|/max|g|, name)"
+          % (gold, "split-bf16" if x6 else "fp32 MFMA"))
+    for st_ in stats[:10]:
+        print("   %.3e  %.3e  %.3e  %s" % st_)
+    med = sorted(s_[0] for s_ in stats)[len(stats) // 2]
+    print("   median relL2 ours %.3e, reference fp32 %.3e" % (med, sorted(s_[1] for s_ in stats)[len(stats) // 2]))
+    assert not bad, "%d tensors out of tolerance: %s" % (len(bad), "; ".join(bad[:4]))
+    assert checked >= (100 if "plus" in gold else 40), checked
+    _PIPE_ERR[(gold, x6)] = mine
+    other = _PIPE_ERR.get((gold, not x6))
+    if other is not None:      # both pipes ran in this session: the split pipe is no farther from fp64 than the fp32 pipe
+        ex6, ef32 = (mine, other) if x6 else (other, mine)
+        worse = [(ex6[n] / max(ef32[n], 1e-30), ex6[n], ef32[n], n) for n in ex6 if ex6[n] > 2.0 * ef32[n] + 1e-5]
+        print("   split-bf16 vs fp32-MFMA distance to fp64: median ratio %.2f" % float(
+            np.median([ex6[n] / max(ef32[n], 1e-30) for n in ex6])))
+        assert not worse, "split-bf16 farther from fp64 than the fp32 pipe: %r" % (sorted(worse, reverse=True)[:4],)
 
 
 def _mini_workers_cfg2():
