@@ -1081,7 +1081,7 @@ HostPlan make_plan(const PaseConvGemm& p, bool want_x6) {
             h.narrow = h.c.WM == 2;
             h.BN = h.c.BN;
             h.n_col_tiles = h.c.n_col_tiles;
-            h.x6_chunks = h.c.pack_chunks;
+            h.x6_chunks = h.c.pack_bytes / 16;
             h.blocks = (long)h.c.n_row_tiles * h.c.n_col_tiles * h.c.splitk;
             return h;
         }

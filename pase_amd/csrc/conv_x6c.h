@@ -19,6 +19,8 @@ struct PaseX6cPlan {
     int steps_total;    // stages * KGS * A MFMA steps (16 k each; k-groups past G are zero in the pack)
     int xPerm;          // pixel-shuffle launches: tile rows ordered (channel, phase) -> 16-byte output runs
     long pack_chunks;   // 16-byte chunks of the weight pack
+    int prm_n;          // channels' of the expanded on-load parameter arrays behind the chunks (3 x prm_n floats)
+    long pack_bytes;    // pack_chunks * 16 + 3 * prm_n * 4, rounded up to 16
     unsigned ncols_magic, cout_magic, rctx_magic, ps_magic, seg_magic, p_magic;
 };
 

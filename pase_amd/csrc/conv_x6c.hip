@@ -42,7 +42,7 @@
 
 namespace {
 
-constexpr int NT = 256;
+constexpr int NT = 512;        // 4 compute waves (one per SIMD) + 4 staging waves
 constexpr int HALO_MAX = 64;      // extra positions a stage holds beyond its BN columns (halo of every sequence touched)
 constexpr int KGS_MAX = 2;
 
@@ -58,93 +58,208 @@ __device__ __forceinline__ unsigned div_magic(unsigned e, unsigned magic) {
 
 __device__ float g_identc[2] = {1.f, 0.f};
 
-template <int WM, int NBT>
+#ifdef PASE_X6C_TRACE   // tools/trace_x6c.py only: per-item phase timestamps (shader clock) of workgroups 0 and 131
+#define X6C_TRACE_ITEMS 64
+__device__ unsigned long long g_x6c_trace[2 * X6C_TRACE_ITEMS * 8];
+#define X6C_STAMP(slot)                                                                                     \
+    do {                                                                                                    \
+        if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 131) && trace_n < X6C_TRACE_ITEMS)               \
+            g_x6c_trace[((blockIdx.x ? 1 : 0) * X6C_TRACE_ITEMS + trace_n) * 8 + (slot)] = clock64();       \
+    } while (0)
+#define X6C_TRACE_NEXT() ++trace_n
+#else
+#define X6C_STAMP(slot)
+#define X6C_TRACE_NEXT()
+#endif
+
+// uniform (scalar-unit) loads of per-channel on-load parameters: the values stay in SGPRs and no vector-memory
+// instruction (and no vmcnt wait, which would drain the prefetched operands) is spent on them
+#ifdef PASE_HIPEMU
+__device__ __forceinline__ void sload8(const float* q, float (&o)[8]) {
+    for (int i = 0; i < 8; ++i) o[i] = q[i];
+}
+__device__ __forceinline__ float sload1(const float* q) { return *q; }
+#else
+typedef float pase_f8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void sload8(const float* q, float (&o)[8]) {
+    pase_f8 v;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(q) : "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = v[i];
+}
+__device__ __forceinline__ float sload1(const float* q) {
+    float v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(q) : "memory");
+    return v;
+}
+#endif
+
+// Activation loads of the staging waves.  They are issued up to two stages before they are consumed, and the only
+// vector-memory operations those waves make, so the wait is an exact count -- but hipcc's own bookkeeping falls back to
+// vmcnt(0) as soon as a load sits behind a (uniform) branch, which here would wait for the loads issued a moment ago
+// (measured: 7 300 cycles per three-step stage instead of 2 000).  The loads are therefore hidden from the compiler
+// (inline asm, cdna_hip_programming.md 5.7 form (ii)): x6c_vmwait<N>() is the wait, x6c_claim() makes the eight
+// registers of a slot "defined" only from that point on.
+#ifdef PASE_HIPEMU
+__device__ __forceinline__ void x6c_gload(float& dst, const float* base, unsigned voff_bytes) {
+    dst = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + voff_bytes);
+}
+template <int N>
+__device__ __forceinline__ void x6c_vmwait() {}
+__device__ __forceinline__ void x6c_claim(float (&)[8]) {}
+#else
+__device__ __forceinline__ void x6c_gload(float& dst, const float* base, unsigned voff_bytes) {
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff_bytes), "s"(base));
+}
+template <int N>
+__device__ __forceinline__ void x6c_vmwait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void x6c_claim(float (&x)[8]) {
+    asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+}
+#endif
+// wait until at most 8 * nslots of this wave's loads are outstanding (nslots: uniform, 0 .. 4)
+__device__ __forceinline__ void x6c_vmwait_slots(int nslots) {
+    if (nslots <= 0) x6c_vmwait<0>();
+    else if (nslots == 1) x6c_vmwait<8>();
+    else if (nslots == 2) x6c_vmwait<16>();
+    else if (nslots == 3) x6c_vmwait<24>();
+    else x6c_vmwait<32>();
+}
+
+// NPOS: positions (16-byte chunks) per (plane, fk) row of a k-group; KGS_T: k-groups a stage buffer holds.
+//   <192, 2>: convolutions (128 columns + up to 64 halo positions)      <128, 3>: 1x1 layers (no halo)
+// The grid is PERSISTENT: workgroup b works through the items b, b + gridDim.x, ... (item = (split-K slice, tile)); the
+// staging waves start on the next item's first stage while the compute waves are still in the epilogue of the current one.
+template <int NPOS, int KGS_T>
 __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6cPlan pl) {
-    constexpr int WN = 4 / WM;
+    constexpr int WM = 4, WN = 1, NBT = 4;
     constexpr int BM = 32 * WM, BN = 32 * NBT * WN;
-    constexpr int NPOS = BN + HALO_MAX;            // positions (16-byte chunks) per (plane, fk) row
     constexpr int NPS = (NPOS + 127) / 128;        // position slots per thread and k-group
-    constexpr int KGS_T = (BN <= 128) ? KGS_MAX : 1;
     constexpr int NSLOT = NPS * KGS_T;
     constexpr int PLANE = 2 * NPOS;                // chunks per plane of one k-group: [fk][pos]
     constexpr int KGC = 3 * PLANE;                 // chunks per k-group
     constexpr int BUF = KGS_T * KGC;               // chunks per stage buffer
-    __shared__ __attribute__((aligned(16))) u32x4 Xs[2 * BUF];
-    float (*red)[BM][2] = reinterpret_cast<float (*)[BM][2]>(Xs);       // epilogue scratch (stage buffers are dead)
-    static_assert(sizeof(float) * WN * BM * 2 <= sizeof(u32x4) * 2 * BUF, "epilogue scratch");
+    constexpr int XR = 3;                          // register sets of the staging waves: loads run XR - 1 stages ahead
+    constexpr int RED_CHUNKS = (int)(sizeof(float) * WN * BM * 2 / 16);
+    // two stage buffers + the epilogue scratch (its own region: the next item's first stage is staged during the epilogue)
+    __shared__ __attribute__((aligned(16))) u32x4 Xs[2 * BUF + RED_CHUNKS];
+    float (*red)[BM][2] = reinterpret_cast<float (*)[BM][2]>(&Xs[2 * BUF]);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = pase_uniform(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
+    // Roles.  Waves 0-3 (one per SIMD) only multiply: A fragments from global memory, B fragments from LDS, MFMA.  Waves
+    // 4-7 only stage: activation loads, on-load transform, operand split, LDS writes, ahead of the compute waves.  The two
+    // kinds of work run on different pipes (matrix core / vector ALU) of the same SIMD concurrently, which an in-order
+    // wave doing both cannot arrange; each role has its own vmcnt counter, so a staging wave waiting for activations from
+    // HBM never holds back a weight fragment.  One barrier per stage joins them.
+    const bool stager = wave >= 4;                 // uniform
+    const int wm = wave & 3, wn = 0;
     const int fr = lane & 31, fk = lane >> 5;
-    const int fkL = wave >> 1;                     // loader: octet of the k-group this wave stages (uniform)
-    const int posL = tid & 127;                    // loader: position within a 128-position slot
+    const int fkL = (wave >> 1) & 1;               // stager: octet of the k-group this wave stages (uniform)
+    const int whalf = wave & 1;                    // stager: which 64 of a slot's 128 positions (uniform)
 
-    // ---- tile decode -----------------------------------------------------------------------
     const int ntot = p.S * p.Ncols;
     const int ntiles = pl.n_row_tiles * pl.n_col_tiles;
-    const int split = blockIdx.x / ntiles;
-    const int tile = xcd_swizzle(blockIdx.x % ntiles, ntiles);
-    const int mt = tile % pl.n_row_tiles;
-    const int nt = tile / pl.n_row_tiles;
-    const int m0 = mt * BM, n0 = nt * BN;
-    const int s0 = (int)div_magic((unsigned)n0, pl.ncols_magic);
-    const int qA = n0 - s0 * p.Ncols;
-    const int lenA = min(BN, p.Ncols - qA);
-    const int ncols_valid = min(BN, ntot - n0);
+    const int nitems = ntiles * pl.splitk;
     const int H = pl.A - 1;                        // halo positions per sequence segment
     const int segL = p.Ncols + H;                  // span positions of a full middle segment
-    const int nseg = (int)div_magic((unsigned)(n0 + ncols_valid - 1), pl.ncols_magic) - s0 + 1;
-    const int span_len = ncols_valid + nseg * H;
-    const int KGS = KGS_T > 1 ? pl.KGS : 1;
-    const int nps_run = (span_len + 127) >> 7;     // position slots that hold data (a 1x1 launch has no halo: one slot less)
-
-    // ---- stage range of this split ----------------------------------------------------------
+    const int KGS = pl.KGS;
     const int GS = (pl.G + KGS - 1) / KGS;         // stages
     const int g_per = (GS + pl.splitk - 1) / pl.splitk;
-    const int g_begin = split * g_per;
-    const int g_end = min(GS, g_begin + g_per);
-    if (g_begin >= g_end) return;                  // uniform for the whole block, before any barrier
     const int nsteps = KGS * pl.A;                 // MFMA steps per stage
+    const bool has_aff = p.in_scale != nullptr, has_alpha = p.in_alpha != nullptr;       // uniform
+    const float* xbase = p.x + (size_t)p.x_coff * p.Tin;
+    const int prm_n = GS * KGS * 16;               // channels' incl. the zero groups that fill the last stage
+    const float* prm = reinterpret_cast<const float*>(reinterpret_cast<const u32x4*>(p.wx6) + pl.pack_chunks);
+    int bsel = 0;                                  // stage buffer of the next stage to be multiplied / first staged
+#ifdef PASE_X6C_TRACE
+    int trace_n = 0;
+#endif
 
-    // ---- loader state: position slot ps -> span index i = posL + 128 ps -> (sequence, time of tap 0) ----
-    int slot_u0[NPS], slot_off[NPS];
-    unsigned slot_valid = 0u, slot_inter = 0u;
+    if (stager) {
+    // ---- loader state.  Slot (k-group kg, position slot ps): this thread stages position
+    //   i = 128 ps + 64 (whalf ^ (kg & 1)) + lane        (odd k-groups swap the wave halves, so that the mostly
+    // empty second position slot -- the halo -- is shared out evenly), eight channels' of octet fkL.
+    // Per position: element offset of tap-0 / phase-0 (sequence and time), whether it is a real position, whether
+    // all its phases are in-range samples.
+    constexpr int NPAR = KGS_T > 1 ? 2 : 1;
+    constexpr unsigned POS_ALL = (1u << (NPAR * NPS)) - 1u;
+    // per-item state of the staging waves (set by setup_item)
+    int g_begin = 0, nst = 0;
+    int pos_u0[NPAR][NPS];
+    unsigned pos_voff[NPAR][NPS];
+    unsigned pos_valid = 0u, pos_inter = 0u;       // bit par * NPS + ps
+    bool all_inter = false;
+    unsigned live = 0u, full = 0u;
+    auto item_range = [&](int item, int& gb, int& ge) __attribute__((always_inline)) {
+        const int split = item / ntiles;
+        gb = split * g_per;
+        ge = min(GS, gb + g_per);
+    };
+    auto setup_item = [&](int item) __attribute__((always_inline)) {
+        const int split = item / ntiles;
+        const int tile = xcd_swizzle(item - split * ntiles, ntiles);
+        const int nt = tile / pl.n_row_tiles;
+        const int n0 = nt * BN;
+        const int s0 = (int)div_magic((unsigned)n0, pl.ncols_magic);
+        const int qA = n0 - s0 * p.Ncols;
+        const int lenA = min(BN, p.Ncols - qA);
+        const int ncols_valid = min(BN, ntot - n0);
+        const int nseg = (int)div_magic((unsigned)(n0 + ncols_valid - 1), pl.ncols_magic) - s0 + 1;
+        const int span_len = ncols_valid + nseg * H;
+        int ge;
+        item_range(item, g_begin, ge);
+        nst = ge - g_begin;
+        pos_valid = 0u;
+        pos_inter = 0u;
 #pragma unroll
-    for (int ps = 0; ps < NPS; ++ps) {
-        const int i = posL + 128 * ps;
-        bool valid = i < span_len;
-        int k, r;
-        if (i < lenA + H) {
-            k = 0;
-            r = i;
-        } else {
-            const int d = i - (lenA + H);
-            const int k1 = (int)div_magic((unsigned)d, pl.seg_magic);
-            k = 1 + k1;
-            r = d - k1 * segL;
+    for (int par = 0; par < NPAR; ++par)
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) {
+            const int i = 128 * ps + 64 * (whalf ^ par) + lane;
+            bool valid = i < span_len;
+            int k, r;
+            if (i < lenA + H) {
+                k = 0;
+                r = i;
+            } else {
+                const int d = i - (lenA + H);
+                const int k1 = (int)div_magic((unsigned)d, pl.seg_magic);
+                k = 1 + k1;
+                r = d - k1 * segL;
+            }
+            const int q = (k == 0 ? qA : 0) + r;
+            const int s = s0 + k;
+            valid = valid && s < p.S;
+            const int u0 = valid ? pl.P * q - pl.padLp : 0;
+            const bool inter = !valid || (u0 >= 0 && u0 + pl.P - 1 < p.Tin);
+            pos_u0[par][ps] = u0;
+            pos_voff[par][ps] = (unsigned)((valid ? s * p.x_ctot * p.Tin : 0) + (inter ? u0 : 0));
+            if (valid) pos_valid |= 1u << (par * NPS + ps);
+            if (inter) pos_inter |= 1u << (par * NPS + ps);
         }
-        const int q = (k == 0 ? qA : 0) + r;
-        const int s = s0 + k;
-        valid = valid && s < p.S;
-        const int u0 = valid ? pl.P * q - pl.padLp : 0;
-        slot_u0[ps] = u0;
-        slot_off[ps] = valid ? s * p.x_ctot * p.Tin : 0;
-        if (valid) slot_valid |= 1u << ps;
-        if (!valid || (u0 >= 0 && u0 + pl.P - 1 < p.Tin)) slot_inter |= 1u << ps;
-    }
-    // wave-uniform: every element this wave stages is an in-range sample (no padding arithmetic in the loader)
-    const bool all_inter = pase_wave_all(slot_inter == ((1u << NPS) - 1u)) != 0;
+        // wave-uniform: every element this wave stages is an in-range sample (no padding arithmetic in the loader) /
+        // which slots hold at least one real position for this wave / which hold only real positions
+        all_inter = pase_wave_all(pos_inter == POS_ALL) != 0;
+        live = 0u;
+        full = 0u;
+#pragma unroll
+        for (int b = 0; b < NPAR * NPS; ++b) {
+            if (!pase_wave_all(!((pos_valid >> b) & 1u))) live |= 1u << b;
+            if (pase_wave_all((pos_valid >> b) & 1u)) full |= 1u << b;
+        }
+        live = (unsigned)pase_uniform((int)live);
+        full = (unsigned)pase_uniform((int)full);
+    };
 
-    const bool has_xf = p.in_scale != nullptr || p.in_alpha != nullptr;       // uniform
-    const float* sc_p = p.in_scale ? p.in_scale : &g_identc[0];
-    const float* sh_p = p.in_scale ? p.in_shift : &g_identc[1];
-    const float* al_p = p.in_alpha ? p.in_alpha : &g_identc[0];
-    const int aff_on = p.in_scale ? 1 : 0, alpha_on = p.in_alpha ? 1 : 0;
+    const bool has_aff = p.in_scale != nullptr, has_alpha = p.in_alpha != nullptr;       // uniform
+    const float* xbase = p.x + (size_t)p.x_coff * p.Tin;
 
-    float xreg[NSLOT][8];
-    unsigned xmask[NSLOT];         // bit e: element e of the slot is a real sample of a real channel
+    float xreg[XR][NSLOT][8];
+    unsigned xmask[XR][NSLOT];         // bit e: element e of the slot is a real sample (general loader path only)
 
     // channel' -> (input channel, phase) of element e of this wave's octet in k-group kg of stage g (all uniform)
     auto chan_of = [&](int g, int kg, int e, int& ci, int& b, bool& ok) __attribute__((always_inline)) {
@@ -154,56 +269,82 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         b = cp - cq * pl.P;
         ci = min(cq, p.Cin - 1);
     };
-    auto load_slot = [&](auto sl_tag, int g) __attribute__((always_inline)) {
-        constexpr int sl = decltype(sl_tag)::value;
-        constexpr int kg = sl / NPS, ps = sl % NPS;
-        const bool v = (slot_valid >> ps) & 1u;
-        unsigned mask = 0u;
+    auto slot_live = [&](int kg, int ps) __attribute__((always_inline)) {
+        return kg < KGS && ((live >> ((kg & (NPAR - 1)) * NPS + ps)) & 1u) != 0;
+    };
+    auto load_slot = [&](auto r_tag, auto sl_tag, int g) __attribute__((always_inline)) {
+        constexpr int sl = decltype(sl_tag)::value, rs = decltype(r_tag)::value;
+        constexpr int kg = sl / NPS, ps = sl % NPS, par = kg & (NPAR - 1);
+        if (all_inter) {
+            // interior: one load per element off a uniform base, no per-element address arithmetic
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            int ci, b;
-            bool chok;
-            chan_of(g, kg, e, ci, b, chok);
-            const int choff = (p.x_coff + ci) * p.Tin;
-            int off;
-            bool ok;
-            if (all_inter) {
-                off = slot_off[ps] + choff + slot_u0[ps] + (v ? b : 0);
-                ok = v;
-            } else {
-                int u = slot_u0[ps] + b;
+            for (int e = 0; e < 8; ++e) {
+                int ci, b;
+                bool chok;
+                chan_of(g, kg, e, ci, b, chok);
+                x6c_gload(xreg[rs][sl][e], xbase + (size_t)ci * p.Tin + b, pos_voff[par][ps] * 4u);
+            }
+        } else {
+            const bool v = (pos_valid >> (par * NPS + ps)) & 1u;
+            unsigned mask = 0u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                int ci, b;
+                bool chok;
+                chan_of(g, kg, e, ci, b, chok);
+                int u = pos_u0[par][ps] + b;
                 if (p.pad_mode == PASE_PAD_REFLECT) {
                     if (u < 0) u = -u;
                     if (u >= p.Tin) u = 2 * (p.Tin - 1) - u;
                 }
-                ok = v && u >= 0 && u < p.Tin;
-                off = ok ? slot_off[ps] + choff + u : choff;
+                const bool ok = v && u >= 0 && u < p.Tin;
+                const bool inter = (pos_inter >> (par * NPS + ps)) & 1u;
+                // pos_voff carries u0 for interior positions only
+                const unsigned off = ok ? pos_voff[par][ps] + (unsigned)(inter ? b : u) : 0u;
+                x6c_gload(xreg[rs][sl][e], xbase + (size_t)ci * p.Tin, off * 4u);
+                if (ok) mask |= 1u << e;
             }
-            xreg[sl][e] = p.x[(unsigned)off];
-            if (ok && chok) mask |= 1u << e;
+            xmask[rs][sl] = mask;
         }
-        xmask[sl] = mask;
     };
     // registers of slot sl (stage g) -> on-load transform -> three bf16 planes -> LDS buffer bsel
-    auto store_slot = [&](auto sl_tag, int g, int bsel) __attribute__((always_inline)) {
-        constexpr int sl = decltype(sl_tag)::value;
-        constexpr int kg = sl / NPS, ps = sl % NPS;
+    auto store_slot = [&](auto r_tag, auto sl_tag, int g, int bsel) __attribute__((always_inline)) {
+        constexpr int sl = decltype(sl_tag)::value, rs = decltype(r_tag)::value;
+        constexpr int kg = sl / NPS, ps = sl % NPS, par = kg & (NPAR - 1);
+        x6c_claim(xreg[rs][sl]);
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float t = xreg[sl][e];
-            if (has_xf) {
-                int ci, b;
-                bool chok;
-                chan_of(g, kg, e, ci, b, chok);
-                t = fmaf(t, sc_p[ci * aff_on], sh_p[ci * aff_on]);
-                t = t > 0.f ? t : t * al_p[ci * alpha_on];
+        for (int e = 0; e < 8; ++e) v[e] = xreg[rs][sl][e];
+        const int c0 = (g * KGS + kg) * 16 + fkL * 8;                    // first channel' of the octet (uniform)
+        const bool chan_full = c0 + 8 <= pl.CinP;                         // uniform
+        // on-load parameters per channel' (expanded by pase_pack_x6 behind the weight chunks, padded to whole stages):
+        // three scalar loads per octet, values stay in SGPRs
+        if (has_aff) {      // uniform
+            float sc[8], sh[8];
+            sload8(prm + c0, sc);
+            sload8(prm + prm_n + c0, sh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+        }
+        if (has_alpha) {
+            float al[8];
+            sload8(prm + 2 * prm_n + c0, al);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * al[e];
+        }
+        // zero padding applies AFTER the transform (skipped when every lane of the wave holds real samples)
+        const bool pos_full = ((full >> (par * NPS + ps)) & 1u) != 0;                     // uniform
+        if (!(all_inter && pos_full && chan_full)) {
+            const bool pv = (pos_valid >> (par * NPS + ps)) & 1u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool ok = (all_inter ? pv : ((xmask[rs][sl] >> e) & 1u) != 0) && (c0 + e < pl.CinP);
+                v[e] = ok ? v[e] : 0.f;
             }
-            v[e] = ((xmask[sl] >> e) & 1u) ? t : 0.f;      // zero padding applies AFTER the transform
         }
         u32x4 o[3];
         pase_split_bf16x3_rne(v, o);
-        const int i = posL + 128 * ps;
+        const int i = 128 * ps + 64 * (whalf ^ par) + lane;
         if (NPS * 128 == NPOS || i < NPOS) {
             u32x4* dst = &Xs[bsel * BUF + kg * KGC + fkL * NPOS + i];
 #pragma unroll
@@ -211,6 +352,96 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         }
     };
 
+        // ---- staging.  Register set r holds stage g_begin + r, + XR, ...: a stage's loads are issued two stages
+        // before its conversion (HBM latency under load exceeds the duration of a short stage).  Stage g + 1 is converted
+        // into the other LDS buffer while the compute waves multiply stage g.  The NEXT item's first stage is staged
+        // before the barrier inside the compute waves' epilogue of the current one (its buffer is free by then).
+        auto load_stage = [&](auto r_tag, int g) __attribute__((always_inline)) {
+            pase_static_for<NSLOT>([&](auto sl) __attribute__((always_inline)) {
+                if (slot_live(decltype(sl)::value / NPS, decltype(sl)::value % NPS)) load_slot(r_tag, sl, g);
+            });
+        };
+        auto store_stage = [&](auto r_tag, int g, int bs) __attribute__((always_inline)) {
+            pase_static_for<NSLOT>([&](auto sl) __attribute__((always_inline)) {
+                if (slot_live(decltype(sl)::value / NPS, decltype(sl)::value % NPS)) store_slot(r_tag, sl, g, bs);
+            });
+        };
+        int nlive = 0;                 // live slots of this wave for the current item: 8 * nlive loads per stage
+        auto prologue = [&](int item) __attribute__((always_inline)) {
+            if (wave == 4) X6C_STAMP(4);
+            setup_item(item);
+            nlive = 0;
+            pase_static_for<NSLOT>([&](auto sl) __attribute__((always_inline)) {
+                if (slot_live(decltype(sl)::value / NPS, decltype(sl)::value % NPS)) ++nlive;
+            });
+            load_stage(std::integral_constant<int, 0>{}, g_begin);
+            if (1 < nst) load_stage(std::integral_constant<int, 1>{}, g_begin + 1);
+            x6c_vmwait_slots(1 < nst ? nlive : 0);         // stage 0 has landed
+            store_stage(std::integral_constant<int, 0>{}, g_begin, bsel);
+            if (2 < nst) load_stage(std::integral_constant<int, 2>{}, g_begin + 2);
+            if (wave == 4) X6C_STAMP(5);
+        };
+        auto next_item = [&](int item) __attribute__((always_inline)) {
+            for (item += gridDim.x; item < nitems; item += gridDim.x) {
+                int gb, ge;
+                item_range(item, gb, ge);
+                if (gb < ge) break;
+            }
+            return item;
+        };
+        const bool spectrum = p.post_op == PASE_POST_POW || p.post_op == PASE_POST_LOGPOW || p.post_op == PASE_POST_MAG;
+        const bool epi_barrier = p.epilogue == PASE_EPI_STORE ? (!spectrum && p.stat_part != nullptr) : true;
+        int item = next_item((int)blockIdx.x - (int)gridDim.x);
+        if (item < nitems) prologue(item);
+        while (item < nitems) {
+            __syncthreads();               // the item's first stage is visible to the compute waves
+            for (int gb = 0; gb < nst; gb += XR) {
+                pase_static_for<XR>([&](auto r) __attribute__((always_inline)) {
+                    constexpr int rn = (decltype(r)::value + 1) % XR;          // register set of stage gi + 1
+                    const int gi = gb + decltype(r)::value;                     // stage (relative) being multiplied
+                    if (gi < nst) {
+                        if (gi + 1 < nst) {
+                            // in flight: stage gi + 1 (set rn, the older one) and stage gi + 2
+                            x6c_vmwait_slots(gi + 2 < nst ? nlive : 0);
+                            store_stage(std::integral_constant<int, rn>{}, g_begin + gi + 1, bsel ^ 1);
+                        }
+                        // set r (stage gi, converted one window ago) is free: stage gi + 3
+                        if (gi + XR < nst) load_stage(r, g_begin + gi + XR);
+                        __syncthreads();
+                        bsel ^= 1;
+                    }
+                });
+            }
+            if (wave == 4) X6C_STAMP(6);
+            X6C_TRACE_NEXT();
+            item = next_item(item);
+            if (item < nitems) prologue(item);
+            // the barrier of the compute waves' epilogue (partial BatchNorm sums / loss partials go through LDS)
+            if (epi_barrier) __syncthreads();
+        }
+        return;
+    }
+
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    // ---- tile decode -----------------------------------------------------------------------
+    const int split = item / ntiles;
+    const int tile = xcd_swizzle(item - split * ntiles, ntiles);
+    const int mt = tile % pl.n_row_tiles;
+    const int nt = tile / pl.n_row_tiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int s0 = (int)div_magic((unsigned)n0, pl.ncols_magic);
+    const int qA = n0 - s0 * p.Ncols;
+    const int lenA = min(BN, p.Ncols - qA);
+    const int ncols_valid = min(BN, ntot - n0);
+    const int nseg = (int)div_magic((unsigned)(n0 + ncols_valid - 1), pl.ncols_magic) - s0 + 1;
+    const int span_len = ncols_valid + nseg * H;
+    const int g_begin = split * g_per;
+    const int g_end = min(GS, g_begin + g_per);
+    if (g_begin >= g_end) continue;                // uniform for the whole block: no barrier is skipped one-sidedly
+    const int nst = g_end - g_begin;
+
+    // ================= compute waves =================
+    if (wave == 0) X6C_STAMP(0);
     // ---- B fragment bases: chunk index of (column, tap 0) inside a (plane, fk) row -----------------------
     int bbase[NBT];
 #pragma unroll
@@ -231,14 +462,19 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             accS[j][r] = 0.f;
         }
 
-    // ---- A fragments: [32-row tile][step][plane][lane] 16-byte chunks, one step ahead ---------------------
+    // ---- A fragments: [32-row tile][step][plane][lane] 16-byte chunks, TWO steps ahead --------------------
     const u32x4* ap = reinterpret_cast<const u32x4*>(p.wx6) +
                       ((size_t)(mt * WM + wm) * (unsigned)pl.steps_total + (size_t)g_begin * (unsigned)nsteps) * 192u + lane;
+    const int nsteps_run = nst * nsteps;
+    int a_issued = 0;
     auto load_a = [&](u32x4 (&a)[3]) __attribute__((always_inline)) {
+        // unconditional (the steps past the end re-read the last fragments): a load behind a branch makes the compiler's
+        // vmcnt bookkeeping fall back to vmcnt(0), which would wait for the fragments issued a moment ago
         a[0] = ap[0];
         a[1] = ap[64];
         a[2] = ap[128];
-        ap += 192;
+        ++a_issued;
+        ap += (a_issued < nsteps_run) ? 192 : 0;
     };
     auto mfma_step = [&](const u32x4 (&a)[3], const u32x4* xb) __attribute__((always_inline)) {
         // plane pairs of the five small terms, smallest first: mm, hl, lh, hm, mh -> accS; hh -> accH
@@ -261,39 +497,17 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         }
     };
 
-    // ---- prologue ---------------------------------------------------------------------------------------
-    u32x4 a0[3], a1[3];
-    pase_static_for<NSLOT>([&](auto sl) __attribute__((always_inline)) {
-        if (decltype(sl)::value / NPS < KGS && decltype(sl)::value % NPS < nps_run) load_slot(sl, g_begin);
-    });
+    // ---- main loop: stage = KGS k-groups x A taps; step st = kg * A + t -------------------------------------
+    u32x4 a0[3], a1[3], a2[3];
     load_a(a0);
-    pase_static_for<NSLOT>([&](auto sl) __attribute__((always_inline)) {
-        if (decltype(sl)::value / NPS < KGS && decltype(sl)::value % NPS < nps_run) store_slot(sl, g_begin, 0);
-    });
-    if (g_begin + 1 < g_end)
-        pase_static_for<NSLOT>([&](auto sl) __attribute__((always_inline)) {
-            if (decltype(sl)::value / NPS < KGS && decltype(sl)::value % NPS < nps_run) load_slot(sl, g_begin + 1);
-        });
+    load_a(a1);
     __syncthreads();
-
-    // ---- main loop: stage g = KGS k-groups x A taps; step st = kg * A + t ---------------------------------
-    int g = g_begin, st = 0, kg = 0, t = 0, bsel = 0;
-    const int nslot_run = NPS * KGS;
+    if (wave == 0) X6C_STAMP(1);
+    int gi = 0, st = 0, kg = 0, t = 0;
     bool done = false;
     auto step = [&](const u32x4 (&acur)[3], u32x4 (&anxt)[3]) __attribute__((always_inline)) {
-        const bool last = (g == g_end - 1) && (st == nsteps - 1);            // uniform
-        if (!last) load_a(anxt);
-        // a slice of the next stage: slot sl is converted at step sl (mod nsteps) of the current stage and its
-        // registers are refilled with the stage after that
-        if (g + 1 < g_end) {
-            pase_static_for<NSLOT>([&](auto sl_tag) __attribute__((always_inline)) {
-                constexpr int sl = decltype(sl_tag)::value;
-                if (sl < nslot_run && sl % NPS < nps_run && (nsteps >= nslot_run ? sl : sl % nsteps) == st) {
-                    store_slot(sl_tag, g + 1, bsel ^ 1);
-                    if (g + 2 < g_end) load_slot(sl_tag, g + 2);
-                }
-            });
-        }
+        const bool last = (gi == nst - 1) && (st == nsteps - 1);            // uniform
+        load_a(anxt);
         mfma_step(acur, &Xs[bsel * BUF + kg * KGC + t]);
         ++st;
         if (++t == pl.A) {
@@ -303,20 +517,41 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         if (st == nsteps) {
             st = 0;
             kg = 0;
-            ++g;
+            ++gi;
             __syncthreads();
             bsel ^= 1;
         }
         done = last;
     };
     while (true) {
-        step(a0, a1);
+        step(a0, a2);
         if (done) break;
         step(a1, a0);
         if (done) break;
+        step(a2, a1);
+        if (done) break;
     }
 
+    if (wave == 0) X6C_STAMP(2);
     // ---- accumulators: hh + (the five small terms) -------------------------------------------------------
+    // From here on the descriptor is read through the kernel-argument segment again (`p` is the first argument): the two
+    // dozen fields only the epilogue needs then do not occupy scalar registers during the main loop (the compiler loads
+    // every by-value field it sees at kernel entry; with ~85 of them live it spilled 180 SGPRs into the loop).
+#if defined(PASE_HIPEMU) || !defined(__HIP_DEVICE_COMPILE__)
+    const PaseConvGemm& pe = p;
+    const PaseX6cPlan& ple = pl;
+#else
+    typedef const __attribute__((address_space(4))) char* kargs_t;      // constant address space: scalar loads
+    kargs_t kargs = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kargs));
+    // (copies, not references: a store through p.y could alias a reference and force a reload after every store; only the
+    //  INTEGER fields are taken from the copy -- a pointer loaded from memory is a generic pointer to the compiler, i.e.
+    //  flat_load / flat_store with a vmcnt(0) lgkmcnt(0) wait behind every access; the six pointers stay kernel arguments)
+    PaseConvGemm pe;
+    PaseX6cPlan ple;
+    __builtin_memcpy(&pe, (const void*)kargs, sizeof(pe));
+    __builtin_memcpy(&ple, (const void*)(kargs + ((sizeof(PaseConvGemm) + 7) & ~(size_t)7)), sizeof(ple));
+#endif
     f32x16 (&acc)[NBT] = accH;
 #pragma unroll
     for (int j = 0; j < NBT; ++j)
@@ -333,43 +568,43 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         const int jj = (wn * NBT + j) * 32 + fr;
         cok[j] = jj < ncols_valid;
         const unsigned n = (unsigned)(n0 + jj);
-        const int s = (int)div_magic(n, pl.ncols_magic);
+        const int s = (int)div_magic(n, ple.ncols_magic);
         cs[j] = cok[j] ? s : 0;
-        cq[j] = cok[j] ? (int)n - s * p.Ncols : 0;
+        cq[j] = cok[j] ? (int)n - s * pe.Ncols : 0;
     }
-    const bool rows_full = m0 + wm * 32 + 32 <= p.M;        // uniform
+    const bool rows_full = m0 + wm * 32 + 32 <= pe.M;        // uniform
 
-    if (p.epilogue == PASE_EPI_STORE &&
-        (p.post_op == PASE_POST_POW || p.post_op == PASE_POST_LOGPOW || p.post_op == PASE_POST_MAG)) {
+    if (pe.epilogue == PASE_EPI_STORE &&
+        (pe.post_op == PASE_POST_POW || pe.post_op == PASE_POST_LOGPOW || pe.post_op == PASE_POST_MAG)) {
         // spectra: accumulator rows r, r + 1 (same lane) are the (re, im) parts of one frequency bin
 #pragma unroll
         for (int j = 0; j < NBT; ++j) {
-            const int pos = cq[j] + p.poff;
-            const int cbase = (cs[j] * p.y_ctot + p.y_coff) * p.Tout + pos;
-            const bool colok = cok[j] && pos >= 0 && pos < p.Tout;
+            const int pos = cq[j] + pe.poff;
+            const int cbase = (cs[j] * pe.y_ctot + pe.y_coff) * pe.Tout + pos;
+            const bool colok = cok[j] && pos >= 0 && pos < pe.Tout;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const int m = rbase + (r & 3) + 8 * (r >> 2);
-                if (m >= p.M) continue;                    // M is even (host-checked)
+                if (m >= pe.M) continue;                    // M is even (host-checked)
                 const float re = acc[j][r], im = acc[j][r + 1];
                 float v = re * re + im * im;
-                v = (p.post_op == PASE_POST_LOGPOW) ? p.post_scale * logf(v + p.post_eps)
-                    : (p.post_op == PASE_POST_MAG ? p.post_scale * sqrtf(v) : v * p.post_scale);
-                if (colok) p.y[(unsigned)(cbase + (m >> 1) * p.Tout)] = v;
+                v = (pe.post_op == PASE_POST_LOGPOW) ? pe.post_scale * logf(v + pe.post_eps)
+                    : (pe.post_op == PASE_POST_MAG ? pe.post_scale * sqrtf(v) : v * pe.post_scale);
+                if (colok) p.y[(unsigned)(cbase + (m >> 1) * pe.Tout)] = v;
             }
         }
-    } else if (p.epilogue == PASE_EPI_STORE) {
-        const bool pshuf = p.ps != 1;
+    } else if (pe.epilogue == PASE_EPI_STORE) {
+        const bool pshuf = pe.ps != 1;
         const float* biasp = (p.bias && split == 0) ? p.bias : nullptr;
         int cbase[NBT], posb[NBT];
         bool colok[NBT];
         bool interior = true;
 #pragma unroll
         for (int j = 0; j < NBT; ++j) {
-            posb[j] = cq[j] * p.ps + p.poff;
-            cbase[j] = (cs[j] * p.y_ctot + p.y_coff) * p.Tout + posb[j];
-            colok[j] = cok[j] && (pshuf || (posb[j] >= 0 && posb[j] < p.Tout));
-            interior = interior && cok[j] && posb[j] >= 0 && posb[j] + p.ps <= p.Tout;
+            posb[j] = cq[j] * pe.ps + pe.poff;
+            cbase[j] = (cs[j] * pe.y_ctot + pe.y_coff) * pe.Tout + posb[j];
+            colok[j] = cok[j] && (pshuf || (posb[j] >= 0 && posb[j] < pe.Tout));
+            interior = interior && cok[j] && posb[j] >= 0 && posb[j] + pe.ps <= pe.Tout;
         }
         float bvs[16];
 #pragma unroll
@@ -379,32 +614,32 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             for (int r = 0; r < 16; ++r) {
                 const int m = rbase + (r & 3) + 8 * (r >> 2);
                 int co = m;
-                if (pshuf) co = pl.xPerm ? (int)div_magic((unsigned)m, pl.ps_magic)
-                                         : m - (int)div_magic((unsigned)m, pl.cout_magic) * p.Cout_store;
-                if (m < p.M) bvs[r] = biasp[co];
+                if (pshuf) co = ple.xPerm ? (int)div_magic((unsigned)m, ple.ps_magic)
+                                         : m - (int)div_magic((unsigned)m, ple.cout_magic) * pe.Cout_store;
+                if (m < pe.M) bvs[r] = biasp[co];
             }
         }
         auto store_rows = [&](auto fast_tag, auto atomic_tag) __attribute__((always_inline)) {
             constexpr bool FAST = decltype(fast_tag)::value;
             constexpr bool ATOMIC = decltype(atomic_tag)::value;
             if constexpr (FAST && !ATOMIC) {
-                if (pl.xPerm) {   // uniform: (channel, phase)-ordered rows -> runs of consecutive output samples
+                if (ple.xPerm) {   // uniform: (channel, phase)-ordered rows -> runs of consecutive output samples
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const int m4 = rbase + 8 * g4;                          // rows m4 .. m4 + 3 (m4 % 4 == 0)
-                        const int co0 = (int)div_magic((unsigned)m4, pl.ps_magic);
-                        const int ph0 = m4 - co0 * p.ps;
-                        const int n1 = min(4, p.ps - ph0);                      // samples left in channel co0
+                        const int co0 = (int)div_magic((unsigned)m4, ple.ps_magic);
+                        const int ph0 = m4 - co0 * pe.ps;
+                        const int n1 = min(4, pe.ps - ph0);                      // samples left in channel co0
 #pragma unroll
                         for (int j = 0; j < NBT; ++j) {
                             float v[4];
 #pragma unroll
                             for (int i = 0; i < 4; ++i) v[i] = acc[j][4 * g4 + i] + bvs[4 * g4 + i];
-                            float* d0 = p.y + (unsigned)(cbase[j] + co0 * p.Tout + ph0);
+                            float* d0 = p.y + (unsigned)(cbase[j] + co0 * pe.Tout + ph0);
                             if (n1 == 4) {
                                 pase_store_run4(d0, v);
                             } else {          // the quad straddles two channels
-                                float* d1 = p.y + (unsigned)(cbase[j] + (co0 + 1) * p.Tout);
+                                float* d1 = p.y + (unsigned)(cbase[j] + (co0 + 1) * pe.Tout);
                                 if (n1 == 2) {
                                     pase_store_run2(d0, v[0], v[1]);
                                     pase_store_run2(d1, v[2], v[3]);
@@ -426,27 +661,27 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = rbase + (r & 3) + 8 * (r >> 2);
-                const bool mok = FAST || m < p.M;
+                const bool mok = FAST || m < pe.M;
                 int ph = 0, co = m;
                 if (pshuf) {   // uniform
-                    if (pl.xPerm) {
-                        co = (int)div_magic((unsigned)m, pl.ps_magic);
-                        ph = m - co * p.ps;
+                    if (ple.xPerm) {
+                        co = (int)div_magic((unsigned)m, ple.ps_magic);
+                        ph = m - co * pe.ps;
                     } else {
-                        ph = (int)div_magic((unsigned)m, pl.cout_magic);
-                        co = m - ph * p.Cout_store;
+                        ph = (int)div_magic((unsigned)m, ple.cout_magic);
+                        co = m - ph * pe.Cout_store;
                     }
                 }
                 const float bv = bvs[r];
-                const int rowoff = co * p.Tout + ph;
+                const int rowoff = co * pe.Tout + ph;
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int j = 0; j < NBT; ++j) {
                     float v = acc[j][r] + bv;
-                    if (!FAST && p.post_op == PASE_POST_LOG) v = p.post_scale * logf(v == 0.f ? p.post_eps : v);
-                    if (!FAST && p.post_op == PASE_POST_RELU) v = fmaxf(v, 0.f);
-                    if (!FAST && p.post_op == PASE_POST_SQRTPOS) v = sqrtf(fmaxf(v, 0.f));
-                    const bool ok = FAST || (mok && colok[j] && (!pshuf || (unsigned)(posb[j] + ph) < (unsigned)p.Tout));
+                    if (!FAST && pe.post_op == PASE_POST_LOG) v = pe.post_scale * logf(v == 0.f ? pe.post_eps : v);
+                    if (!FAST && pe.post_op == PASE_POST_RELU) v = fmaxf(v, 0.f);
+                    if (!FAST && pe.post_op == PASE_POST_SQRTPOS) v = sqrtf(fmaxf(v, 0.f));
+                    const bool ok = FAST || (mok && colok[j] && (!pshuf || (unsigned)(posb[j] + ph) < (unsigned)pe.Tout));
                     if (ok) {
                         float* dst = p.y + (unsigned)(cbase[j] + rowoff);
                         if (ATOMIC) atomicAdd(dst, v);
@@ -466,8 +701,8 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 }
             }
         };
-        const bool fast = rows_full && p.post_op == PASE_POST_NONE && pase_wave_all(interior) != 0;
-        if (pl.splitk > 1) {
+        const bool fast = rows_full && pe.post_op == PASE_POST_NONE && pase_wave_all(interior) != 0;
+        if (ple.splitk > 1) {
             if (fast) store_rows(std::true_type{}, std::true_type{});
             else store_rows(std::false_type{}, std::true_type{});
         } else {
@@ -479,14 +714,14 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             // one partial (sum, sumsq) per (column tile, output row); rows are channels here
             for (int ml = tid; ml < BM; ml += NT) {
                 const int m = m0 + ml;
-                if (m < p.M) {
+                if (m < pe.M) {
                     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                     for (int w = 0; w < WN; ++w) {
                         s1 += red[w][ml][0];
                         s2 += red[w][ml][1];
                     }
-                    float* dst = p.stat_part + ((size_t)nt * p.M + m) * 2;
+                    float* dst = p.stat_part + ((size_t)nt * pe.M + m) * 2;
                     dst[0] = s1;
                     dst[1] = s2;
                 }
@@ -494,7 +729,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         }
     } else {  // PASE_EPI_MSE_CTX: rows m = d * r + j, columns (b, t); target = label[b, d, t + j - r / 2]
         float lsum = 0.f;
-        const int half = p.r_ctx / 2;
+        const int half = pe.r_ctx / 2;
         // Two passes per 16-row block: first ALL its label / bias loads (independent loads in flight), then the
         // arithmetic and the stores (the compiler cannot prove label and grad_out do not alias).
         auto mse_rows = [&](auto fast_tag) __attribute__((always_inline)) {
@@ -505,37 +740,41 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = rbase + (r & 3) + 8 * (r >> 2);
-                const bool mok = FAST || m < p.M;
-                const int d = (int)div_magic((unsigned)m, pl.rctx_magic);
-                jj16[r] = m - d * p.r_ctx;
+                const bool mok = FAST || m < pe.M;
+                const int d = (int)div_magic((unsigned)m, ple.rctx_magic);
+                jj16[r] = m - d * pe.r_ctx;
                 bvs[r] = (mok && p.bias) ? p.bias[m] : 0.f;
-                lrow[r] = d * p.Ncols + jj16[r];
+                lrow[r] = d * pe.Ncols + jj16[r];
             }
+            // all 64 label loads of the tile first (one memory latency instead of four), then the arithmetic and stores
+            float tg[NBT][16];
 #pragma unroll
             for (int j = 0; j < NBT; ++j) {
                 const int tb = cq[j] - half;
-                const int lbase = cs[j] * p.label_D * p.Ncols + tb;
-                const int obase = cs[j] * p.M * p.Ncols + cq[j];
-                float tg[16];
+                const int lbase = cs[j] * pe.label_D * pe.Ncols + tb;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = rbase + (r & 3) + 8 * (r >> 2);
-                    const bool mok = FAST || m < p.M;
-                    tg[r] = 0.f;
-                    if ((FAST || (mok && cok[j])) && (unsigned)(tb + jj16[r]) < (unsigned)p.Ncols)
-                        tg[r] = p.label[(unsigned)(lbase + lrow[r])];
+                    const bool mok = FAST || m < pe.M;
+                    tg[j][r] = 0.f;
+                    if ((FAST || (mok && cok[j])) && (unsigned)(tb + jj16[r]) < (unsigned)pe.Ncols)
+                        tg[j][r] = p.label[(unsigned)(lbase + lrow[r])];
                 }
+            }
+#pragma unroll
+            for (int j = 0; j < NBT; ++j) {
+                const int obase = cs[j] * pe.M * pe.Ncols + cq[j];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = rbase + (r & 3) + 8 * (r >> 2);
-                    const bool mok = FAST || m < p.M;
+                    const bool mok = FAST || m < pe.M;
                     if (FAST || (mok && cok[j])) {
                         const float pred = acc[j][r] + bvs[r];
-                        const float diff = pred - tg[r];
+                        const float diff = pred - tg[j][r];
                         lsum += diff * diff;
-                        const unsigned o = (unsigned)(obase + m * p.Ncols);
+                        const unsigned o = (unsigned)(obase + m * pe.Ncols);
                         if (p.y) p.y[o] = pred;
-                        if (p.grad_out) p.grad_out[o] = diff * p.grad_scale;
+                        if (p.grad_out) p.grad_out[o] = diff * pe.grad_scale;
                     }
                 }
             }
@@ -553,7 +792,22 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             atomicAdd(p.loss_acc, tsum);
         }
     }
+    if (wave == 0) X6C_STAMP(3);
+    X6C_TRACE_NEXT();
+  }   // items
 }
+
+#ifdef PASE_X6C_TRACE
+extern "C" int pase_x6c_trace_read(unsigned long long* host) {
+    hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_x6c_trace), sizeof(unsigned long long) * 2 * X6C_TRACE_ITEMS * 8);
+}
+extern "C" int pase_x6c_trace_reset() {
+    static unsigned long long zeros[2 * X6C_TRACE_ITEMS * 8];
+    hipDeviceSynchronize();
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_x6c_trace), zeros, sizeof(zeros));
+}
+#endif
 
 // weights (K-major fp32 pack wt[k * ldwt + m], k = ci * taps + kk) -> fragment-ordered bf16 planes:
 // out[((rt32 * steps + st) * 3 + plane) * 64 + lane], step st = g * A + a, lane = (fk, row): element e = channel'
@@ -585,6 +839,19 @@ __global__ void pack_x6c_kernel(const float* __restrict__ wt, u32x4* __restrict_
     }
 }
 
+// on-load parameters per channel' behind the weight chunks: [scale | shift | alpha], prm_n floats each (identity where
+// the descriptor has none, and for the zero channels' that pad the last stage)
+__global__ void pack_prm_kernel(const float* in_scale, const float* in_shift, const float* in_alpha, float* out, int Cin,
+                                int CinP, int P, int prm_n) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= prm_n) return;
+    const int ci = min(c / P, Cin - 1);
+    const bool ok = c < CinP;
+    out[c] = (ok && in_scale) ? in_scale[ci] : 1.f;
+    out[prm_n + c] = (ok && in_scale) ? in_shift[ci] : 0.f;
+    out[2 * prm_n + c] = (ok && in_alpha) ? in_alpha[ci] : 1.f;
+}
+
 unsigned magic_of(int d) {
     return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned long long)d);
 }
@@ -613,22 +880,30 @@ bool pase_x6c_plan(const PaseConvGemm& p, PaseX6cPlan& pl) {
     if (const char* e = getenv("PASE_X6C")) {
         if (e[0] == '0') return false;
     }
-    // tile: 64 x 256 (waves 2 x 2) for M <= 64, else 128 x 128 (waves 4 x 1)
+    // tile 128 x 128 (waves 4 x 1).  The operand split is paid once per staged element and shared by BM / 32 row tiles
+    // x A taps: launches of at most 64 rows with fewer than four taps' would spend more issue slots splitting than
+    // multiplying -- they stay on the fp32 matrix pipe
+    if (p.M <= 64 && pl.A < 4) return false;
+    // ... and so do launches with fewer than 128 k (eight MFMA steps per tile): they are store-bound
+    if ((long)pl.CinP * pl.A < 128) return false;
     pl.NBT = 4;
-    pl.WM = p.M <= 64 ? 2 : 4;
-    pl.BM = 32 * pl.WM;
-    pl.BN = 32 * pl.NBT * (4 / pl.WM);
+    pl.WM = 4;
+    pl.BM = 128;
+    pl.BN = 128;
     // every sequence a column tile touches carries its own halo of A - 1 positions
     const int nseg_max = (pl.BN - 2) / p.Ncols + 2;
     if ((long)nseg_max * (pl.A - 1) > HALO_MAX) return false;
-    // two k-groups per stage where a stage would otherwise be shorter than four steps (128-column tile only)
-    pl.KGS = (pl.BN <= 128 && pl.A < 4 && pl.G >= 2) ? 2 : 1;
+    // k-groups per stage: three for 1x1 layers (no halo: 12 KB per k-group), two where a stage would otherwise be
+    // shorter than four steps
+    pl.KGS = pl.A == 1 ? (pl.G >= 3 ? 3 : pl.G) : ((pl.A < 4 && pl.G >= 2) ? 2 : 1);
     const int GS = (pl.G + pl.KGS - 1) / pl.KGS;
     pl.steps_total = GS * pl.KGS * pl.A;
     const long ntot = (long)p.S * p.Ncols;
     pl.n_row_tiles = (p.M + pl.BM - 1) / pl.BM;
     pl.n_col_tiles = (int)((ntot + pl.BN - 1) / pl.BN);
     pl.pack_chunks = (long)pl.n_row_tiles * pl.WM * pl.steps_total * 192;
+    pl.prm_n = GS * pl.KGS * 16;
+    pl.pack_bytes = (pl.pack_chunks * 16 + 3L * pl.prm_n * 4 + 15) / 16 * 16;
     pl.ncols_magic = magic_of(p.Ncols);
     pl.cout_magic = magic_of(p.Cout_store);
     pl.ps_magic = magic_of(p.ps);
@@ -673,13 +948,22 @@ int pase_x6c_pack(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st) 
                 reinterpret_cast<u32x4*>(const_cast<void*>(p.wx6)), p.M, p.ldwt, p.Cin, p.taps, pl.P, pl.A, pl.CinP, pl.rev,
                 pl.steps_total, total, pl.xPerm ? p.ps : 1, p.Cout_store);
     PASE_CHECK_LAUNCH();
+    float* prm = reinterpret_cast<float*>(reinterpret_cast<u32x4*>(const_cast<void*>(p.wx6)) + pl.pack_chunks);
+    PASE_LAUNCH(pack_prm_kernel, dim3((unsigned)((pl.prm_n + 255) / 256)), dim3(256), st, p.in_scale, p.in_shift, p.in_alpha,
+                prm, p.Cin, pl.CinP, pl.P, pl.prm_n);
+    PASE_CHECK_LAUNCH();
     return 0;
 }
 
 int pase_x6c_launch(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st) {
-    const dim3 grid((unsigned)((long)pl.n_row_tiles * pl.n_col_tiles * pl.splitk)), block(NT);
-    if (pl.WM == 2) PASE_LAUNCH((conv_x6c_kernel<2, 4>), grid, block, st, p, pl);
-    else PASE_LAUNCH((conv_x6c_kernel<4, 4>), grid, block, st, p, pl);
+    // persistent grid: one workgroup per CU (8 waves, 74 KB of LDS), items dealt round-robin
+    long nwg = (long)pl.n_row_tiles * pl.n_col_tiles * pl.splitk;
+    long cap = 256;
+    if (const char* e = getenv("PASE_X6C_MAXWG")) cap = atol(e) > 0 ? atol(e) : cap;     // tests: force several items per workgroup
+    if (nwg > cap) nwg = cap;
+    const dim3 grid((unsigned)nwg), block(NT);
+    if (pl.A == 1) PASE_LAUNCH((conv_x6c_kernel<128, 3>), grid, block, st, p, pl);
+    else PASE_LAUNCH((conv_x6c_kernel<192, 2>), grid, block, st, p, pl);
     PASE_CHECK_LAUNCH();
     return 0;
 }
