@@ -130,10 +130,14 @@ typedef struct PaseWgrad {
     int S, M, Tg, g_ctot, g_coff, Ncols;
     int Cin, Tz, z_ctot, z_coff, taps, tap_major, stride, tapstep, padL, pad_mode, ldw;
     int splitk;            /* 0 = auto                                                            */
-    int x6;                /* 0: fp32 matrix pipe.  1: split-bf16 contraction where the library has an instantiation
-                              for the shape (see PaseConvGemm::wx6; both operands are split on the fly, no pack) */
+    int x6;                /* 0: fp32 matrix pipe.  1: split-bf16 contraction (see PaseConvGemm::wx6) where the library has
+                              a plan for the shape AND gx6 is given; else the fp32 matrix pipe                   */
+    void* gx6;             /* scratch for the split-bf16 pack of one operand: pase_wgrad_x6_bytes(desc) bytes, 16-B
+                              aligned, caller-owned, written and read by this launch only; NULL = fp32 matrix pipe */
 } PaseWgrad;
 int pase_wgrad_gemm(const PaseWgrad* desc, void* stream);
+/* bytes of PaseWgrad::gx6 the launch described by desc needs (0: the shape runs on the fp32 matrix pipe) */
+long pase_wgrad_x6_bytes(const PaseWgrad* desc);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm1d (training-mode batch statistics) pieces.  Reference: nn.BatchNorm1d built by

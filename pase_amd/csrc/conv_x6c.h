@@ -17,6 +17,8 @@ struct PaseX6cPlan {
     int BM, BN;
     int n_row_tiles, n_col_tiles, splitk;
     int steps_total;    // stages * KGS * A MFMA steps (16 k each; k-groups past G are zero in the pack)
+    int prio;           // s_setprio of the staging waves (bits 0-1) and of the compute waves (bits 2-3)
+    int tmode;          // 0: convolution.  Weight gradients (contraction over positions): 1 rows = g, 2 swapped
     int xPerm;          // pixel-shuffle launches: tile rows ordered (channel, phase) -> 16-byte output runs
     long pack_chunks;   // 16-byte chunks of the weight pack
     int prm_n;          // channels' of the expanded on-load parameter arrays behind the chunks (3 x prm_n floats)
@@ -28,3 +30,15 @@ struct PaseX6cPlan {
 bool pase_x6c_plan(const PaseConvGemm& p, PaseX6cPlan& pl);
 int pase_x6c_pack(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st);
 int pase_x6c_launch(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st);
+
+// weight gradients on the T-mode instantiation (see conv_x6c.hip)
+struct PaseX6cWgrad {
+    PaseConvGemm pc;      // the staged operand and the output, in the convolution descriptor's terms
+    PaseX6cPlan pl;
+    int swapped;
+    const float* a_src;   // the packed operand: rows x positions
+    int a_rows, a_ctot, a_coff, a_T;
+    const float *a_sc, *a_sh, *a_al;
+};
+bool pase_x6c_wgrad_plan(const PaseWgrad& w, PaseX6cWgrad& o);
+int pase_x6c_wgrad_launch(const PaseWgrad& w, const PaseX6cWgrad& o, hipStream_t st);

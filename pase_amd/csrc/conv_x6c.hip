@@ -60,16 +60,25 @@ __device__ float g_identc[2] = {1.f, 0.f};
 
 #ifdef PASE_X6C_TRACE   // tools/trace_x6c.py only: per-item phase timestamps (shader clock) of workgroups 0 and 131
 #define X6C_TRACE_ITEMS 64
-__device__ unsigned long long g_x6c_trace[2 * X6C_TRACE_ITEMS * 8];
+__device__ unsigned long long g_x6c_trace[2 * X6C_TRACE_ITEMS * 12];
 #define X6C_STAMP(slot)                                                                                     \
     do {                                                                                                    \
         if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 131) && trace_n < X6C_TRACE_ITEMS)               \
-            g_x6c_trace[((blockIdx.x ? 1 : 0) * X6C_TRACE_ITEMS + trace_n) * 8 + (slot)] = clock64();       \
+            g_x6c_trace[((blockIdx.x ? 1 : 0) * X6C_TRACE_ITEMS + trace_n) * 12 + (slot)] = clock64();      \
     } while (0)
 #define X6C_TRACE_NEXT() ++trace_n
+// accumulate the cycles between X6C_T0() and X6C_TACC(slot) into a per-item sum
+#define X6C_T0() const unsigned long long t0_ = clock64()
+#define X6C_TACC(slot)                                                                                      \
+    do {                                                                                                    \
+        if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 131) && trace_n < X6C_TRACE_ITEMS)               \
+            g_x6c_trace[((blockIdx.x ? 1 : 0) * X6C_TRACE_ITEMS + trace_n) * 12 + (slot)] += clock64() - t0_; \
+    } while (0)
 #else
 #define X6C_STAMP(slot)
 #define X6C_TRACE_NEXT()
+#define X6C_T0()
+#define X6C_TACC(slot)
 #endif
 
 // uniform (scalar-unit) loads of per-channel on-load parameters: the values stay in SGPRs and no vector-memory
@@ -79,6 +88,10 @@ __device__ __forceinline__ void sload8(const float* q, float (&o)[8]) {
     for (int i = 0; i < 8; ++i) o[i] = q[i];
 }
 __device__ __forceinline__ float sload1(const float* q) { return *q; }
+__device__ __forceinline__ void sload8x2(const float* q0, const float* q1, float (&o0)[8], float (&o1)[8]) {
+    sload8(q0, o0);
+    sload8(q1, o1);
+}
 #else
 typedef float pase_f8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void sload8(const float* q, float (&o)[8]) {
@@ -92,33 +105,48 @@ __device__ __forceinline__ float sload1(const float* q) {
     asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(q) : "memory");
     return v;
 }
+// two arrays, one wait
+__device__ __forceinline__ void sload8x2(const float* q0, const float* q1, float (&o0)[8], float (&o1)[8]) {
+    pase_f8 v0, v1;
+    asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx8 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(v0), "=&s"(v1)
+                 : "s"(q0), "s"(q1)
+                 : "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        o0[i] = v0[i];
+        o1[i] = v1[i];
+    }
+}
 #endif
 
-// Activation loads of the staging waves.  They are issued up to two stages before they are consumed, and the only
-// vector-memory operations those waves make, so the wait is an exact count -- but hipcc's own bookkeeping falls back to
-// vmcnt(0) as soon as a load sits behind a (uniform) branch, which here would wait for the loads issued a moment ago
-// (measured: 7 300 cycles per three-step stage instead of 2 000).  The loads are therefore hidden from the compiler
-// (inline asm, cdna_hip_programming.md 5.7 form (ii)): x6c_vmwait<N>() is the wait, x6c_claim() makes the eight
-// registers of a slot "defined" only from that point on.
-#ifdef PASE_HIPEMU
+// Activation loads of the staging waves: plain loads off a uniform base + 32-bit per-lane byte offset, issued two stages
+// before they are consumed; hipcc counts its own s_waitcnt vmcnt(N) for them.  (Round 3 also tried hiding them from the
+// compiler -- inline-asm global_load + hand-counted waits, cdna_hip_programming.md 5.7 form (ii); no faster once the waves
+// were specialised, and one more thing the emulator cannot check.)
+// Padding: validity is carried as INTEGER bits (okb, xmask), never as bools -- a bool per element becomes a 64-bit lane
+// mask in an SGPR pair, 8 per slot x 4 slots x 3 register sets, i.e. > 100 spilled SGPRs and a select chain per element.
+__device__ __forceinline__ int x6c_reflect(int u, int T) {              // single reflection about 0 and T - 1
+    u = max(u, -u);
+    return min(u, 2 * (T - 1) - u);
+}
+__device__ __forceinline__ unsigned x6c_in_range(int u, int T) {        // 1 when 0 <= u < T (|u|, T < 2^30)
+    return (unsigned)(~u & (u - T)) >> 31;
+}
+__device__ __forceinline__ float x6c_keep(float v, unsigned mask, int e) {      // v when bit e of mask is set, else +0
+    const int keep = (int)(mask << (31 - e)) >> 31;
+    int bits;
+    __builtin_memcpy(&bits, &v, 4);
+    bits &= keep;
+    __builtin_memcpy(&v, &bits, 4);
+    return v;
+}
 __device__ __forceinline__ void x6c_gload(float& dst, const float* base, unsigned voff_bytes) {
     dst = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + voff_bytes);
 }
 template <int N>
 __device__ __forceinline__ void x6c_vmwait() {}
 __device__ __forceinline__ void x6c_claim(float (&)[8]) {}
-#else
-__device__ __forceinline__ void x6c_gload(float& dst, const float* base, unsigned voff_bytes) {
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff_bytes), "s"(base));
-}
-template <int N>
-__device__ __forceinline__ void x6c_vmwait() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-__device__ __forceinline__ void x6c_claim(float (&x)[8]) {
-    asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
-}
-#endif
 // wait until at most 8 * nslots of this wave's loads are outstanding (nslots: uniform, 0 .. 4)
 __device__ __forceinline__ void x6c_vmwait_slots(int nslots) {
     if (nslots <= 0) x6c_vmwait<0>();
@@ -132,7 +160,11 @@ __device__ __forceinline__ void x6c_vmwait_slots(int nslots) {
 //   <192, 2>: convolutions (128 columns + up to 64 halo positions)      <128, 3>: 1x1 layers (no halo)
 // The grid is PERSISTENT: workgroup b works through the items b, b + gridDim.x, ... (item = (split-K slice, tile)); the
 // staging waves start on the next item's first stage while the compute waves are still in the epilogue of the current one.
-template <int NPOS, int KGS_T>
+// TM (weight gradients, see pase_x6c_wgrad): the contraction runs over POSITIONS -- k-group = 16 consecutive positions q
+// of one sequence -- and the columns are (channel, tap) pairs: column j reads x[s][ci][q * stride + kk * tapstep - padL].
+// Same staging machinery (a chunk is 8 consecutive q of one column, i.e. 8 strided samples of one channel row), but the
+// per-channel on-load parameters belong to the lane (its column), not to the element.
+template <int NPOS, int KGS_T, bool TM = false>
 __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6cPlan pl) {
     constexpr int WM = 4, WN = 1, NBT = 4;
     constexpr int BM = 32 * WM, BN = 32 * NBT * WN;
@@ -179,6 +211,15 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     int trace_n = 0;
 #endif
 
+#ifndef PASE_HIPEMU
+    {   // wave priorities (uniform): the staging waves are the younger half of the workgroup and lose every VALU issue
+        // arbitration against a compute wave that always has an MFMA waiting for the pipe
+        const int pr = stager ? (pl.prio & 3) : ((pl.prio >> 2) & 3);
+        if (pr == 1) __builtin_amdgcn_s_setprio(1);
+        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+        else if (pr == 3) __builtin_amdgcn_s_setprio(3);
+    }
+#endif
     if (stager) {
     // ---- loader state.  Slot (k-group kg, position slot ps): this thread stages position
     //   i = 128 ps + 64 (whalf ^ (kg & 1)) + lane        (odd k-groups swap the wave halves, so that the mostly
@@ -191,9 +232,20 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     int g_begin = 0, nst = 0;
     int pos_u0[NPAR][NPS];
     unsigned pos_voff[NPAR][NPS];
+    unsigned pos_sbase[NPAR][NPS];                  // element offset of the position's sequence (0 when not a real position)
     unsigned pos_valid = 0u, pos_inter = 0u;       // bit par * NPS + ps
-    bool all_inter = false;
     unsigned live = 0u, full = 0u;
+    unsigned inter_slots = 0u;     // slots whose 64 positions (of this wave) are all in-range samples: no padding arithmetic
+    // TM: per column (lane): channel row offset + tap offset (relative to the smallest tap offset), the tap offset itself,
+    // on-load parameters, "all-ones column" flag (bias gradient); running column sums of the staged values (tmode 2)
+    int t_koff[NPAR][NPS];
+    float t_sc[NPAR][NPS], t_sh[NPAR][NPS], t_al[NPAR][NPS];
+    float t_colsum[NPAR][NPS];
+    unsigned t_ones = 0u;
+    bool t_any_ones = false;
+    int t_n0 = 0, t_mt = 0;
+    const int t_kmin = -p.padL - (p.tapstep < 0 ? p.taps - 1 : 0);
+    const int t_kmax = -p.padL + (p.tapstep > 0 ? p.taps - 1 : 0);
     auto item_range = [&](int item, int& gb, int& ge) __attribute__((always_inline)) {
         const int split = item / ntiles;
         gb = split * g_per;
@@ -202,8 +254,47 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     auto setup_item = [&](int item) __attribute__((always_inline)) {
         const int split = item / ntiles;
         const int tile = xcd_swizzle(item - split * ntiles, ntiles);
-        const int nt = tile / pl.n_row_tiles;
+        // (TM, rows = g: consecutive tiles are the COLUMN tiles of one row tile -- the workgroups of an XCD then stream the
+        //  same rows of the packed operand, which is far larger than the L2, at the same time)
+        const int nt = (TM && pl.tmode == 1) ? tile % pl.n_col_tiles : tile / pl.n_row_tiles;
         const int n0 = nt * BN;
+        if constexpr (TM) {
+            int ge;
+            item_range(item, g_begin, ge);
+            nst = ge - g_begin;
+            t_n0 = n0;
+            t_mt = pl.tmode == 1 ? tile / pl.n_col_tiles : tile - nt * pl.n_row_tiles;
+            pos_valid = 0u;
+            t_ones = 0u;
+#pragma unroll
+            for (int par = 0; par < NPAR; ++par) {
+                const int j = n0 + 64 * (whalf ^ par) + lane;              // column (NPS == 1)
+                const bool ones = pl.tmode == 1 && p.bias != nullptr && j == p.K;
+                const bool valid = j < p.K || ones;
+                const int ci = valid && !ones ? (int)div_magic((unsigned)j, pl.ncols_magic) : 0;
+                const int kk = valid && !ones ? j - ci * p.taps : 0;
+                t_koff[par][0] = kk * p.tapstep - p.padL;
+                pos_voff[par][0] = (unsigned)(ci * p.Tin + (t_koff[par][0] - t_kmin));
+                pos_u0[par][0] = ci * p.Tin;
+                t_sc[par][0] = p.in_scale ? p.in_scale[ci] : 1.f;
+                t_sh[par][0] = p.in_scale ? p.in_shift[ci] : 0.f;
+                t_al[par][0] = p.in_alpha ? p.in_alpha[ci] : 1.f;
+                t_colsum[par][0] = 0.f;
+                if (valid) pos_valid |= 1u << par;
+                if (ones) t_ones |= 1u << par;
+            }
+            live = 0u;
+            full = 0u;
+            t_any_ones = !pase_wave_all(t_ones == 0u);
+#pragma unroll
+            for (int b = 0; b < NPAR; ++b) {
+                if (!pase_wave_all(!((pos_valid >> b) & 1u))) live |= 1u << b;
+                if (pase_wave_all(((pos_valid & ~t_ones) >> b) & 1u)) full |= 1u << b;
+            }
+            live = (unsigned)pase_uniform((int)live);
+            full = (unsigned)pase_uniform((int)full);
+            return;
+        }
         const int s0 = (int)div_magic((unsigned)n0, pl.ncols_magic);
         const int qA = n0 - s0 * p.Ncols;
         const int lenA = min(BN, p.Ncols - qA);
@@ -237,29 +328,31 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             const int u0 = valid ? pl.P * q - pl.padLp : 0;
             const bool inter = !valid || (u0 >= 0 && u0 + pl.P - 1 < p.Tin);
             pos_u0[par][ps] = u0;
-            pos_voff[par][ps] = (unsigned)((valid ? s * p.x_ctot * p.Tin : 0) + (inter ? u0 : 0));
+            pos_sbase[par][ps] = (unsigned)(valid ? s * p.x_ctot * p.Tin : 0);
+            pos_voff[par][ps] = pos_sbase[par][ps] + (unsigned)(inter ? u0 : 0);
             if (valid) pos_valid |= 1u << (par * NPS + ps);
             if (inter) pos_inter |= 1u << (par * NPS + ps);
         }
-        // wave-uniform: every element this wave stages is an in-range sample (no padding arithmetic in the loader) /
-        // which slots hold at least one real position for this wave / which hold only real positions
-        all_inter = pase_wave_all(pos_inter == POS_ALL) != 0;
+        // wave-uniform, per slot: at least one real position / only real positions / only in-range samples
         live = 0u;
         full = 0u;
+        inter_slots = 0u;
 #pragma unroll
         for (int b = 0; b < NPAR * NPS; ++b) {
             if (!pase_wave_all(!((pos_valid >> b) & 1u))) live |= 1u << b;
             if (pase_wave_all((pos_valid >> b) & 1u)) full |= 1u << b;
+            if (pase_wave_all((pos_inter >> b) & 1u)) inter_slots |= 1u << b;
         }
         live = (unsigned)pase_uniform((int)live);
         full = (unsigned)pase_uniform((int)full);
+        inter_slots = (unsigned)pase_uniform((int)inter_slots);
     };
 
     const bool has_aff = p.in_scale != nullptr, has_alpha = p.in_alpha != nullptr;       // uniform
     const float* xbase = p.x + (size_t)p.x_coff * p.Tin;
 
     float xreg[XR][NSLOT][8];
-    unsigned xmask[XR][NSLOT];         // bit e: element e of the slot is a real sample (general loader path only)
+    unsigned xmask[XR][NSLOT];         // bit e: element e of the slot is a real sample (else: zero AFTER the transform)
 
     // channel' -> (input channel, phase) of element e of this wave's octet in k-group kg of stage g (all uniform)
     auto chan_of = [&](int g, int kg, int e, int& ci, int& b, bool& ok) __attribute__((always_inline)) {
@@ -272,9 +365,46 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     auto slot_live = [&](int kg, int ps) __attribute__((always_inline)) {
         return kg < KGS && ((live >> ((kg & (NPAR - 1)) * NPS + ps)) & 1u) != 0;
     };
+    // TM: k-group (g, kg) -> sequence s, first position of this wave's octet; is every sample of the octet, for every tap,
+    // an in-range sample of a real sequence (uniform)
+    auto t_geom = [&](int g, int kg, int& sq, int& qb0, bool& inter) __attribute__((always_inline)) {
+        const int kgi = g * KGS + kg;
+        const int s_ = (int)div_magic((unsigned)kgi, pl.seg_magic);         // kgi / QP16
+        qb0 = (kgi - s_ * pl.P) * 16 + fkL * 8;
+        inter = s_ < p.S && qb0 + 7 < p.Ncols && qb0 * p.stride + t_kmin >= 0 && (qb0 + 7) * p.stride + t_kmax < p.Tin;
+        sq = min(s_, p.S - 1);
+        if (s_ >= p.S) qb0 = p.Ncols;                                       // past the last sequence: no real position
+    };
     auto load_slot = [&](auto r_tag, auto sl_tag, int g) __attribute__((always_inline)) {
         constexpr int sl = decltype(sl_tag)::value, rs = decltype(r_tag)::value;
         constexpr int kg = sl / NPS, ps = sl % NPS, par = kg & (NPAR - 1);
+        if constexpr (TM) {
+            int sq, qb0;
+            bool inter;
+            t_geom(g, kg, sq, qb0, inter);
+            const float* sb = xbase + (size_t)sq * p.x_ctot * p.Tin;
+            const unsigned vbit = ((pos_valid & ~t_ones) >> par) & 1u;
+            if (inter) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    x6c_gload(xreg[rs][sl][e], sb + ((qb0 + e) * p.stride + t_kmin), pos_voff[par][ps] * 4u);
+                xmask[rs][sl] = (0u - vbit) & 0xffu;
+            } else {
+                unsigned mask = 0u;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    int u = (qb0 + e) * p.stride + t_koff[par][ps];
+                    if (p.pad_mode == PASE_PAD_REFLECT) u = x6c_reflect(u, p.Tin);
+                    const unsigned okb = (qb0 + e < p.Ncols ? vbit : 0u) & x6c_in_range(u, p.Tin);
+                    x6c_gload(xreg[rs][sl][e], sb, ((unsigned)(pos_u0[par][ps] + u) & (0u - okb)) * 4u);
+                    mask |= okb << e;
+                }
+                xmask[rs][sl] = mask;
+            }
+            return;
+        }
+        const bool all_inter = ((inter_slots >> (par * NPS + ps)) & 1u) != 0;      // uniform
+        const unsigned vbit = (pos_valid >> (par * NPS + ps)) & 1u;
         if (all_inter) {
             // interior: one load per element off a uniform base, no per-element address arithmetic
 #pragma unroll
@@ -284,8 +414,10 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 chan_of(g, kg, e, ci, b, chok);
                 x6c_gload(xreg[rs][sl][e], xbase + (size_t)ci * p.Tin + b, pos_voff[par][ps] * 4u);
             }
+            xmask[rs][sl] = (0u - vbit) & 0xffu;
         } else {
-            const bool v = (pos_valid >> (par * NPS + ps)) & 1u;
+            // padding arithmetic in integer lanes (no per-element lane-mask SGPR pairs: eight of them per slot, three
+            // register sets deep, is what spilled): okb = 1 for a real sample, the offset is ANDed with 0 - okb
             unsigned mask = 0u;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -293,16 +425,10 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 bool chok;
                 chan_of(g, kg, e, ci, b, chok);
                 int u = pos_u0[par][ps] + b;
-                if (p.pad_mode == PASE_PAD_REFLECT) {
-                    if (u < 0) u = -u;
-                    if (u >= p.Tin) u = 2 * (p.Tin - 1) - u;
-                }
-                const bool ok = v && u >= 0 && u < p.Tin;
-                const bool inter = (pos_inter >> (par * NPS + ps)) & 1u;
-                // pos_voff carries u0 for interior positions only
-                const unsigned off = ok ? pos_voff[par][ps] + (unsigned)(inter ? b : u) : 0u;
-                x6c_gload(xreg[rs][sl][e], xbase + (size_t)ci * p.Tin, off * 4u);
-                if (ok) mask |= 1u << e;
+                if (p.pad_mode == PASE_PAD_REFLECT) u = x6c_reflect(u, p.Tin);
+                const unsigned okb = vbit & x6c_in_range(u, p.Tin);
+                x6c_gload(xreg[rs][sl][e], xbase + (size_t)ci * p.Tin, ((pos_sbase[par][ps] + (unsigned)u) & (0u - okb)) * 4u);
+                mask |= okb << e;
             }
             xmask[rs][sl] = mask;
         }
@@ -315,14 +441,47 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = xreg[rs][sl][e];
+        if constexpr (TM) {
+            int sq, qb0;
+            bool inter;
+            t_geom(g, kg, sq, qb0, inter);
+            if (has_aff) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], t_sc[par][ps], t_sh[par][ps]);
+            }
+            if (has_alpha) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * t_al[par][ps];
+            }
+            const bool slot_full = ((full >> par) & 1u) != 0;                 // uniform: 64 real, non-"ones" columns
+            if (!(inter && slot_full)) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = x6c_keep(v[e], xmask[rs][sl], e);
+                if (t_any_ones) {      // uniform: this item's tile holds the bias column
+                    const bool ones = (t_ones >> par) & 1u;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (ones) v[e] = (qb0 + e < p.Ncols) ? 1.f : 0.f;
+                }
+            }
+            if (pl.tmode == 2 && p.bias != nullptr) {                         // uniform
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t_colsum[par][ps] += v[e];
+            }
+            u32x4 o[3];
+            pase_split_bf16x3_rne(v, o);
+            u32x4* dst = &Xs[bsel * BUF + kg * KGC + fkL * NPOS + 64 * (whalf ^ par) + lane];
+#pragma unroll
+            for (int pz = 0; pz < 3; ++pz) dst[pz * PLANE] = o[pz];
+            return;
+        }
         const int c0 = (g * KGS + kg) * 16 + fkL * 8;                    // first channel' of the octet (uniform)
         const bool chan_full = c0 + 8 <= pl.CinP;                         // uniform
         // on-load parameters per channel' (expanded by pase_pack_x6 behind the weight chunks, padded to whole stages):
         // three scalar loads per octet, values stay in SGPRs
         if (has_aff) {      // uniform
             float sc[8], sh[8];
-            sload8(prm + c0, sc);
-            sload8(prm + prm_n + c0, sh);
+            sload8x2(prm + c0, prm + prm_n + c0, sc, sh);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
         }
@@ -333,14 +492,13 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * al[e];
         }
         // zero padding applies AFTER the transform (skipped when every lane of the wave holds real samples)
+        const bool all_inter = ((inter_slots >> (par * NPS + ps)) & 1u) != 0;             // uniform (as in load_slot)
         const bool pos_full = ((full >> (par * NPS + ps)) & 1u) != 0;                     // uniform
         if (!(all_inter && pos_full && chan_full)) {
-            const bool pv = (pos_valid >> (par * NPS + ps)) & 1u;
+            const int nch = pl.CinP - c0;                                                 // uniform
+            const unsigned m = xmask[rs][sl] & (nch >= 8 ? 0xffu : nch > 0 ? (1u << nch) - 1u : 0u);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const bool ok = (all_inter ? pv : ((xmask[rs][sl] >> e) & 1u) != 0) && (c0 + e < pl.CinP);
-                v[e] = ok ? v[e] : 0.f;
-            }
+            for (int e = 0; e < 8; ++e) v[e] = x6c_keep(v[e], m, e);
         }
         u32x4 o[3];
         pase_split_bf16x3_rne(v, o);
@@ -390,7 +548,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             return item;
         };
         const bool spectrum = p.post_op == PASE_POST_POW || p.post_op == PASE_POST_LOGPOW || p.post_op == PASE_POST_MAG;
-        const bool epi_barrier = p.epilogue == PASE_EPI_STORE ? (!spectrum && p.stat_part != nullptr) : true;
+        const bool epi_barrier = TM ? false : (p.epilogue == PASE_EPI_STORE ? (!spectrum && p.stat_part != nullptr) : true);
         int item = next_item((int)blockIdx.x - (int)gridDim.x);
         if (item < nitems) prologue(item);
         while (item < nitems) {
@@ -400,13 +558,23 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                     constexpr int rn = (decltype(r)::value + 1) % XR;          // register set of stage gi + 1
                     const int gi = gb + decltype(r)::value;                     // stage (relative) being multiplied
                     if (gi < nst) {
+                        X6C_T0();
                         if (gi + 1 < nst) {
                             // in flight: stage gi + 1 (set rn, the older one) and stage gi + 2
-                            x6c_vmwait_slots(gi + 2 < nst ? nlive : 0);
-                            store_stage(std::integral_constant<int, rn>{}, g_begin + gi + 1, bsel ^ 1);
+                            {
+                                X6C_T0();
+                                x6c_vmwait_slots(gi + 2 < nst ? nlive : 0);
+                                if (wave == 4) X6C_TACC(10);
+                            }
+                            {
+                                X6C_T0();
+                                store_stage(std::integral_constant<int, rn>{}, g_begin + gi + 1, bsel ^ 1);
+                                if (wave == 4) X6C_TACC(11);
+                            }
                         }
                         // set r (stage gi, converted one window ago) is free: stage gi + 3
                         if (gi + XR < nst) load_stage(r, g_begin + gi + XR);
+                        if (wave == 4) X6C_TACC(8);
                         __syncthreads();
                         bsel ^= 1;
                     }
@@ -414,6 +582,18 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             }
             if (wave == 4) X6C_STAMP(6);
             X6C_TRACE_NEXT();
+            if constexpr (TM) {
+                // swapped weight gradient (columns = rows of g): the bias gradient is the column sum of everything staged
+                // (each octet half adds its eight positions per k-group); once per column tile (row tile 0 only)
+                if (pl.tmode == 2 && p.bias != nullptr && t_mt == 0) {
+#pragma unroll
+                    for (int par = 0; par < NPAR; ++par)
+                        if ((pos_valid >> par) & 1u) {
+                            const int j = t_n0 + 64 * (whalf ^ par) + lane;
+                            atomicAdd(const_cast<float*>(p.bias) + j, t_colsum[par][0]);
+                        }
+                }
+            }
             item = next_item(item);
             if (item < nitems) prologue(item);
             // the barrier of the compute waves' epilogue (partial BatchNorm sums / loss partials go through LDS)
@@ -426,8 +606,9 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     // ---- tile decode -----------------------------------------------------------------------
     const int split = item / ntiles;
     const int tile = xcd_swizzle(item - split * ntiles, ntiles);
-    const int mt = tile % pl.n_row_tiles;
-    const int nt = tile / pl.n_row_tiles;
+    const bool col_major = TM && pl.tmode == 1;
+    const int mt = col_major ? tile / pl.n_col_tiles : tile % pl.n_row_tiles;
+    const int nt = col_major ? tile % pl.n_col_tiles : tile / pl.n_row_tiles;
     const int m0 = mt * BM, n0 = nt * BN;
     const int s0 = (int)div_magic((unsigned)n0, pl.ncols_magic);
     const int qA = n0 - s0 * p.Ncols;
@@ -518,7 +699,11 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             st = 0;
             kg = 0;
             ++gi;
-            __syncthreads();
+            {
+                X6C_T0();
+                __syncthreads();
+                if (wave == 0) X6C_TACC(9);
+            }
             bsel ^= 1;
         }
         done = last;
@@ -558,6 +743,28 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] += accS[j][r];
 
+    if constexpr (TM) {
+        // weight-gradient tile: += into the caller-zeroed dw (split-K slices and other launches add into the same buffer)
+        const int rb = m0 + wm * 32 + 4 * fk;
+#pragma unroll
+        for (int j = 0; j < NBT; ++j) {
+            const int col = n0 + j * 32 + fr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = rb + (r & 3) + 8 * (r >> 2);
+                const float v = acc[j][r];
+                if (m < p.M) {
+                    if (pl.tmode == 2) {          // swapped operands: row = input channel, column = output channel
+                        if (col < p.K) atomicAdd(p.y + (size_t)col * p.Tout + m, v);
+                    } else if (col < p.K) {
+                        atomicAdd(p.y + (size_t)m * p.Tout + col, v);
+                    } else if (col == p.K && p.bias) {
+                        atomicAdd(const_cast<float*>(p.bias) + m, v);
+                    }
+                }
+            }
+        }
+    } else {
     // ---- epilogue -----------------------------------------------------------------------------------------
     // D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int rbase = m0 + wm * 32 + 4 * fk;
@@ -792,6 +999,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             atomicAdd(p.loss_acc, tsum);
         }
     }
+    }   // !TM
     if (wave == 0) X6C_STAMP(3);
     X6C_TRACE_NEXT();
   }   // items
@@ -800,10 +1008,10 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
 #ifdef PASE_X6C_TRACE
 extern "C" int pase_x6c_trace_read(unsigned long long* host) {
     hipDeviceSynchronize();
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_x6c_trace), sizeof(unsigned long long) * 2 * X6C_TRACE_ITEMS * 8);
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_x6c_trace), sizeof(unsigned long long) * 2 * X6C_TRACE_ITEMS * 12);
 }
 extern "C" int pase_x6c_trace_reset() {
-    static unsigned long long zeros[2 * X6C_TRACE_ITEMS * 8];
+    static unsigned long long zeros[2 * X6C_TRACE_ITEMS * 12];
     hipDeviceSynchronize();
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_x6c_trace), zeros, sizeof(zeros));
 }
@@ -852,6 +1060,51 @@ __global__ void pack_prm_kernel(const float* in_scale, const float* in_shift, co
     out[2 * prm_n + c] = (ok && in_alpha) ? in_alpha[ci] : 1.f;
 }
 
+// rows of an activation tensor -> fragment-ordered bf16 planes with the contraction over POSITIONS (weight gradients):
+// out[((rt32 * steps + st) * 3 + plane) * 64 + lane], step st = k-group (sequence s = st / QP16, positions 16 (st % QP16) ..),
+// lane = (fk, row): element e = position 16 (st % QP16) + 8 fk + e of row 32 rt32 + row, after its on-load transform
+// v -> prelu(v * sc[row] + sh[row], al[row]) (NULL arrays = identity).  Zero past Ncols, past S and past `rows`.
+__global__ void pack_rows_x6c_kernel(const float* __restrict__ src, u32x4* __restrict__ out, int rows, int S, int ctot,
+                                     int coff, int T, int Ncols, int QP16, int steps, long total, const float* sc,
+                                     const float* sh, const float* al) {
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        const long rs = idx >> 6;
+        const int st = (int)(rs % steps);
+        const int rt = (int)(rs / steps);
+        const int s_ = st / QP16;
+        const int fk = lane >> 5, row = lane & 31;
+        const int q0 = (st - s_ * QP16) * 16 + fk * 8;
+        const int m = rt * 32 + row;
+        float v[8];
+        const bool rok = m < rows && s_ < S;
+        const float* r = src + ((size_t)(rok ? s_ : 0) * ctot + coff + (rok ? m : 0)) * T;
+        const float a_sc = (rok && sc) ? sc[m] : 1.f, a_sh = (rok && sc) ? sh[m] : 0.f, a_al = (rok && al) ? al[m] : 1.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t = (rok && q0 + e < Ncols) ? r[q0 + e] : 0.f;
+            if (rok && q0 + e < Ncols) {
+                t = fmaf(t, a_sc, a_sh);
+                t = t > 0.f ? t : t * a_al;
+            }
+            v[e] = t;
+        }
+        u32x4 o[3];
+        pase_split_bf16x3_rne(v, o);
+        u32x4* dst = out + ((size_t)rs * 3) * 64 + lane;
+#pragma unroll
+        for (int pz = 0; pz < 3; ++pz) dst[pz * 64] = o[pz];
+    }
+}
+
+int x6c_prio() {
+    static const int v = [] {
+        const char* e = getenv("PASE_X6C_PRIO");
+        return e ? atoi(e) : 0;
+    }();
+    return v;
+}
+
 unsigned magic_of(int d) {
     return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned long long)d);
 }
@@ -886,6 +1139,11 @@ bool pase_x6c_plan(const PaseConvGemm& p, PaseX6cPlan& pl) {
     if (p.M <= 64 && pl.A < 4) return false;
     // ... and so do launches with fewer than 128 k (eight MFMA steps per tile): they are store-bound
     if ((long)pl.CinP * pl.A < 128) return false;
+    // Measured on the PASE+ bs32 step (profiles/gemm_launches_r03.json): 1x1 launches with K < 768 (the 256-channel worker
+    // heads: six stages per tile, the staging waves' conversion work per MFMA is 5x that of an 11-tap layer) and the
+    // two-tap QRNN Linear are faster on the exact-fp32 matrix pipe
+    if (pl.A == 1 && pl.CinP < 768) return false;
+    if (pl.A == 2 && pl.CinP >= 256 && (long)pl.CinP * pl.A <= 1024) return false;
     pl.NBT = 4;
     pl.WM = 4;
     pl.BM = 128;
@@ -901,6 +1159,8 @@ bool pase_x6c_plan(const PaseConvGemm& p, PaseX6cPlan& pl) {
     const long ntot = (long)p.S * p.Ncols;
     pl.n_row_tiles = (p.M + pl.BM - 1) / pl.BM;
     pl.n_col_tiles = (int)((ntot + pl.BN - 1) / pl.BN);
+    pl.prio = x6c_prio();
+    pl.tmode = 0;
     pl.pack_chunks = (long)pl.n_row_tiles * pl.WM * pl.steps_total * 192;
     pl.prm_n = GS * pl.KGS * 16;
     pl.pack_bytes = (pl.pack_chunks * 16 + 3L * pl.prm_n * 4 + 15) / 16 * 16;
@@ -964,6 +1224,104 @@ int pase_x6c_launch(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st
     const dim3 grid((unsigned)nwg), block(NT);
     if (pl.A == 1) PASE_LAUNCH((conv_x6c_kernel<128, 3>), grid, block, st, p, pl);
     else PASE_LAUNCH((conv_x6c_kernel<192, 2>), grid, block, st, p, pl);
+    PASE_CHECK_LAUNCH();
+    return 0;
+}
+
+
+// ---- weight gradients on the same kernel (TM instantiation) ------------------------------------------------------------
+//   dw[m, (ci,kk)] += sum_{s,q} g~[s, m, q] * z~[s, ci, q * stride + kk * tapstep - padL]
+// One operand is packed (pack_rows_x6c_kernel: rows x positions, read by the compute waves in fragment order), the other is
+// staged by the T-mode loader (columns x positions).  Normally the rows are g's and the columns the (channel, tap) pairs
+// of z; a 1x1 layer with more output than input channels (the 256 -> 21 525 heads) runs SWAPPED -- rows = z's channels,
+// columns = g's rows, transposed accumulation into dw -- so that the big operand is split exactly once, on the fly,
+// and the small one is the pack.
+bool pase_x6c_wgrad_plan(const PaseWgrad& w, PaseX6cWgrad& o) {
+    if (w.tap_major || (w.tapstep != 1 && w.tapstep != -1) || w.taps < 1 || w.stride < 1) return false;
+    if (const char* e = getenv("PASE_X6C")) {
+        if (e[0] == '0') return false;
+    }
+    const long LIM = 0x7fffffffL;
+    if ((long)w.S * w.g_ctot * (long)w.Tg >= LIM || (long)w.S * w.z_ctot * (long)w.Tz >= LIM) return false;
+    if (w.Ncols < 8) return false;
+    o.swapped = (w.taps == 1 && w.stride == 1 && w.padL == 0 && w.M > w.Cin) ? 1 : 0;
+    PaseConvGemm& c = o.pc;
+    c = PaseConvGemm{};
+    PaseX6cPlan& pl = o.pl;
+    pl = PaseX6cPlan{};
+    if (!o.swapped) {
+        o.a_src = w.g; o.a_rows = w.M; o.a_ctot = w.g_ctot; o.a_coff = w.g_coff; o.a_T = w.Tg;
+        o.a_sc = nullptr; o.a_sh = nullptr; o.a_al = w.g_alpha;
+        c.x = w.z; c.x_ctot = w.z_ctot; c.x_coff = w.z_coff; c.Tin = w.Tz; c.Cin = w.Cin;
+        c.taps = w.taps; c.stride = w.stride; c.tapstep = w.tapstep; c.padL = w.padL; c.pad_mode = w.pad_mode;
+        c.in_scale = w.in_scale; c.in_shift = w.in_shift; c.in_alpha = w.in_alpha;
+        c.K = w.Cin * w.taps;
+        pl.tmode = 1;
+    } else {
+        o.a_src = w.z; o.a_rows = w.Cin; o.a_ctot = w.z_ctot; o.a_coff = w.z_coff; o.a_T = w.Tz;
+        o.a_sc = w.in_scale; o.a_sh = w.in_shift; o.a_al = w.in_alpha;
+        c.x = w.g; c.x_ctot = w.g_ctot; c.x_coff = w.g_coff; c.Tin = w.Tg; c.Cin = w.M;
+        c.taps = 1; c.stride = 1; c.tapstep = 1; c.padL = 0; c.pad_mode = PASE_PAD_ZERO;
+        c.in_scale = nullptr; c.in_shift = nullptr; c.in_alpha = w.g_alpha;
+        c.K = w.M;
+        pl.tmode = 2;
+    }
+    // the split is paid once per staged element and shared by the row tiles of the workgroup: at most 64 rows would leave
+    // half of every MFMA multiplying zeros
+    if (o.a_rows <= 64) return false;
+    // 1x1 layers: every staged element feeds only four row tiles and there are no taps to share the conversion between --
+    // measured slower than the exact-fp32 matrix pipe on every PASE+ 1x1 weight gradient (profiles/gemm_launches_r03.json)
+    if (w.taps == 1 && !getenv("PASE_X6C_WGRAD_FLAT")) return false;
+    if ((long)c.Cin * c.Tin >= LIM) return false;
+    c.S = w.S; c.Ncols = w.Ncols; c.M = o.a_rows;
+    c.y = w.dw; c.Tout = w.ldw; c.bias = w.dbias; c.ldw = w.ldw;
+    c.epilogue = PASE_EPI_STORE;
+    const int QP16 = (w.Ncols + 15) / 16;
+    const long Gk = (long)w.S * QP16;
+    if (Gk * 16 >= LIM) return false;
+    pl.P = QP16; pl.A = 1; pl.G = (int)Gk; pl.CinP = 0x7fffffff;
+    pl.KGS = Gk >= 3 ? 3 : (int)Gk;
+    const int GS = (pl.G + pl.KGS - 1) / pl.KGS;
+    pl.steps_total = GS * pl.KGS;
+    pl.WM = 4; pl.NBT = 4; pl.BM = 128; pl.BN = 128;
+    const int ncolw = c.K + ((pl.tmode == 1 && w.dbias) ? 1 : 0);
+    pl.n_row_tiles = (o.a_rows + 127) / 128;
+    pl.n_col_tiles = (ncolw + 127) / 128;
+    pl.seg_magic = magic_of(QP16);
+    pl.ncols_magic = magic_of(c.taps);
+    pl.p_magic = 0;
+    const long tiles = (long)pl.n_row_tiles * pl.n_col_tiles;
+    // swapped launches accumulate transposed (scattered 4-byte atomics): as few slices as fill the chip once
+    long sk = w.splitk > 0 ? w.splitk : ((o.swapped ? 256 : 768) + tiles - 1) / tiles;
+    if (sk > GS / 4) sk = GS / 4;
+    if (sk < 1) sk = 1;
+    {   // every slice owns at least one stage
+        const long g_per = (GS + sk - 1) / sk;
+        sk = (GS + g_per - 1) / g_per;
+    }
+    pl.splitk = (int)sk;
+    pl.prio = x6c_prio();
+    pl.pack_chunks = (long)pl.n_row_tiles * 4 * pl.steps_total * 192;
+    pl.prm_n = 0;
+    pl.pack_bytes = pl.pack_chunks * 16;
+    return true;
+}
+
+int pase_x6c_wgrad_launch(const PaseWgrad& w, const PaseX6cWgrad& o, hipStream_t st) {
+    PaseConvGemm c = o.pc;
+    c.wx6 = w.gx6;
+    const PaseX6cPlan& pl = o.pl;
+    const long total = pl.pack_chunks / 3;
+    const long nb = (total + 255) / 256;
+    PASE_LAUNCH(pack_rows_x6c_kernel, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), st, o.a_src,
+                reinterpret_cast<u32x4*>(w.gx6), o.a_rows, w.S, o.a_ctot, o.a_coff, o.a_T, w.Ncols, pl.P, pl.steps_total, total,
+                o.a_sc, o.a_sh, o.a_al);
+    PASE_CHECK_LAUNCH();
+    long nwg = (long)pl.n_row_tiles * pl.n_col_tiles * pl.splitk;
+    long cap = 256;
+    if (const char* e = getenv("PASE_X6C_MAXWG")) cap = atol(e) > 0 ? atol(e) : cap;
+    if (nwg > cap) nwg = cap;
+    PASE_LAUNCH((conv_x6c_kernel<128, 3, true>), dim3((unsigned)nwg), dim3(NT), st, c, pl);
     PASE_CHECK_LAUNCH();
     return 0;
 }

@@ -23,6 +23,7 @@
 // `Zs[off_j + kq*stride]`: no index arithmetic, no per-element gathers.
 #include "hip_compat.h"
 #include "pase_amd.h"
+#include "conv_x6c.h"
 
 namespace {
 
@@ -824,9 +825,30 @@ __global__ void __launch_bounds__(NTHREADS, 2) wgrad_flat_x6_kernel(PaseWgrad p,
 
 }  // namespace
 
+extern "C" long pase_wgrad_x6_bytes(const PaseWgrad* d) {
+    if (d->M <= 0 || d->Cin <= 0 || d->S <= 0 || d->Ncols <= 0) return 0;
+    PaseX6cWgrad o;
+    return pase_x6c_wgrad_plan(*d, o) ? o.pl.pack_bytes : 0;
+}
+
 extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
-    const PaseWgrad p = *d;
+    PaseWgrad p = *d;
     if (p.M <= 0 || p.Cin <= 0 || p.S <= 0 || p.Ncols <= 0) return 0;
+    if (p.x6 && p.gx6) {
+        if ((((unsigned long long)(size_t)p.gx6) % 16) != 0) return -10;
+        PaseX6cWgrad o;
+        if (!pase_x6c_wgrad_plan(p, o)) return -11;        // a pack buffer on a launch without a plan is refused, not ignored
+        return pase_x6c_wgrad_launch(p, o, (hipStream_t)stream);
+    }
+    // the round-2 split-bf16 instantiations below accumulate all six terms in ONE accumulator (biased: conv_x6c.hip
+    // header); they only run in measurement builds (PASE_X6_LEGACY=1)
+    {
+        static const bool legacy = [] {
+            const char* e = getenv("PASE_X6_LEGACY");
+            return e && e[0] == '1';
+        }();
+        if (!legacy) p.x6 = 0;
+    }
     if (p.tap_major) return -4;          // express tap-major weights as per-tap launches (ldw + offset)
     if (p.tapstep != 1 && p.tapstep != -1) return -5;
     if (p.pad_mode == PASE_PAD_REFLECT && p.padL >= p.Tz) return -3;

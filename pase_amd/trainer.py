@@ -258,9 +258,24 @@ class trainer(object):
         valid as they change.  Single-GPU only (the data-parallel step issues its collectives eagerly)."""
         if self.world > 1:
             raise NotImplementedError("pase_amd trainer: hipGraph capture of the data-parallel step")
+        # Workers that draw HOST randomness per step (SPC: random.choice of the anchor / future / past frames,
+        # minions.py:614-628; Gap: np.random frame pairs, :680-681) turn those draws into slice offsets and H2D copies at
+        # enqueue time: a replayed graph would reuse the frames drawn during capture for every step.  Refuse.
+        from .minions import GapMinion, SPCMinion
+        for w in self.model.classification_workers:
+            m = getattr(w, "minion", w)
+            if isinstance(m, (SPCMinion, GapMinion)) or type(w).__name__ in ("SPC", "Gap"):
+                raise NotImplementedError(
+                    "pase_amd trainer: worker %r draws its frames on the host every step; a captured step would freeze "
+                    "them (capture is supported for the mi / cmi / regression workers, i.e. workers+.cfg)" % w.name)
         dev = self.grad_arena.device
         self._graph = None
         self._static = {k: v.detach().clone() for k, v in example_batch.items() if torch.is_tensor(v)}
+        # the two warm-up steps and the capture run are REAL optimizer steps on the example batch: snapshot everything
+        # they mutate (parameters, Adam moments and step counters, BatchNorm running statistics) and restore it afterwards,
+        # so that capture_step() leaves the training state exactly where it found it
+        snap_model = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
+        snap_opt = [(o.flat_p.clone(), o.exp_avg.clone(), o.exp_avg_sq.clone(), o.step_t.clone()) for o in self.optimizers()]
         cur = torch.cuda.current_stream(dev)
         warm = torch.cuda.Stream(device=dev)
         warm.wait_stream(cur)
@@ -272,6 +287,20 @@ class trainer(object):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             self._static_losses = self._eager_step(self._static, None)
+        torch.cuda.synchronize(dev)
+        with torch.no_grad():
+            sd = self.model.state_dict()
+            for k, v in snap_model.items():
+                sd[k].copy_(v)
+            for o, (fp, m1, m2, st) in zip(self.optimizers(), snap_opt):
+                o.flat_p.copy_(fp)
+                o.exp_avg.copy_(m1)
+                o.exp_avg_sq.copy_(m2)
+                o.step_t.copy_(st)
+        # the graph holds raw pointers into the zero arena: the eager fallback (a batch of another shape) gets its own,
+        # so a regrow there cannot free memory the graph still writes
+        self._graph_arena = self._zero_arena
+        self._zero_arena = None
         self._graph = graph
         return graph
 
@@ -429,6 +458,40 @@ class trainer(object):
         self.epoch_beg = steps[0] // self.bpe
         return True
 
+    def _eval(self, dataloader, epoch=0, device=None):
+        """Validation pass of trainer.py:282-337: `va_bpe` batches through the model in eval mode (BatchNorm running
+        statistics, no gradients), every worker's loss UNWEIGHTED as the reference accumulates it (tot_loss += loss, :307,
+        :316), running per-worker lists, mean per epoch.  Returns {worker: mean loss, 'total': mean} and keeps it in
+        `self.last_eval` (the reference hands the lists to its tensorboard eval_logger)."""
+        was_training = self.model.training
+        self.model.eval()
+        running = {}
+        it = iter(dataloader)
+        dev = torch.device(device) if device is not None else next(self.model.parameters()).device
+        try:
+            with torch.no_grad():
+                for _bidx in range(1, self.va_bpe + 1):
+                    try:
+                        batch = next(it)
+                    except StopIteration:
+                        it = iter(dataloader)
+                        batch = next(it)
+                    if self.device_targets is not None:
+                        batch = self._fill_targets(batch, dev)
+                    h, chunk, preds, labels = self.model(batch, device=dev)
+                    tot = 0.0
+                    for worker in list(self.model.classification_workers) + list(self.model.regression_workers):
+                        loss = float(worker.loss(preds[worker.name], labels[worker.name]))
+                        running.setdefault(worker.name, []).append(loss)
+                        tot += loss
+                    running.setdefault("total", []).append(tot)
+        finally:
+            self.model.train(was_training)
+        self.last_eval = {k: sum(v) / len(v) for k, v in running.items()}
+        if self.rank == 0:
+            print("EVAL epoch {}: ".format(epoch) + " ".join("{}={:.4f}".format(k, v) for k, v in self.last_eval.items()))
+        return self.last_eval
+
     def train_(self, dataloader, valid_dataloader=None, device=None):
         """Epoch loop of trainer.py:200-278 without the tqdm / tensorboard / aux-supervisor side
         channels (out of scope)."""
@@ -464,4 +527,6 @@ class trainer(object):
                         print("epoch {} batch {}/{}: ".format(e, bidx, self.bpe) +
                               " ".join("{}={:.4f}".format(k, float(v)) for k, v in losses.items()) +
                               " lr_fe={:.6f}".format(lrs["frontend"]))
+            if valid_dataloader is not None:
+                self._eval(valid_dataloader, epoch=e, device=device)
             self.save_epoch(e, e * self.bpe + bidx)

@@ -293,7 +293,7 @@ def test_flat_ws_mse_context_epilogue_wide(dev):
     (40, 70, 8, 1, 200, 2),       # 40 channels: the third k-group is half zeros
     (64, 70, 3, 1, 300, 2),       # two k-groups per stage
     (20, 70, 30, 10, 2900, 2),    # stride 10: 200 polyphase channels, 3 taps
-    (160, 130, 1, 1, 200, 3),     # 1x1
+    (768, 130, 1, 1, 200, 3),     # 1x1
 ])
 def test_split_bf16_is_fp32_grade(dev, Cin, Cout, k, stride, T, S):
     """The split-bf16 contraction (PaseConvGemm::wx6: hi+mid+lo pieces, 6 bf16 MFMAs per product) against an fp64

@@ -139,10 +139,10 @@ def test_qrnn_linear_tap_major(dev):
 
 
 @pytest.mark.parametrize("Cin,Cout,T,S,splitk", [
-    (144, 200, 100, 3, 1),       # three k-groups per stage, tiles across sequences
-    (176, 130, 77, 2, 1),        # 11 k-groups: the last stage holds two real groups and a zero one
+    (800, 200, 100, 3, 1),       # three k-groups per stage, tiles across sequences
+    (848, 130, 77, 2, 1),        # 53 k-groups: the last stage holds two real groups and a zero one
     (1500, 100, 64, 2, 0),       # long reduction: auto split-K (data-gradient of a wide head)
-    (192, 72, 520, 1, 1),        # 12 k-groups, one ragged row tile
+    (960, 72, 200, 1, 1),        # 60 k-groups, one ragged row tile
 ])
 def test_flat_1x1(dev, Cin, Cout, T, S, splitk):
     torch.manual_seed(4)
@@ -179,7 +179,7 @@ def test_mse_context_epilogue(dev):
     """ContextualizedLoss(MSELoss, r = 7) fused into the projection (pase/losses.py:6-37): loss sum, prediction and
     d(loss)/d(prediction) against the stacked-target definition."""
     torch.manual_seed(6)
-    B, Cin, D, r, Fr = 3, 144, 21, 7, 60
+    B, Cin, D, r, Fr = 3, 768, 21, 7, 60
     M = D * r
     h = torch.randn(B, Cin, Fr)
     w = torch.randn(M, Cin) * 0.2
@@ -307,16 +307,35 @@ def test_persistent_workgroups_take_several_items(dev, monkeypatch):
     # fused MSE epilogue, 5 row tiles x 2 column tiles
     B, D, r, Fr = 2, 90, 7, 100
     M = D * r
-    h = torch.randn(B, 160, Fr)
-    w3 = torch.randn(M, 160) * 0.1
+    h = torch.randn(B, 768, Fr)
+    w3 = torch.randn(M, 768) * 0.1
     lab = torch.randn(B, D, Fr)
     pred = torch.einsum("mk,bkt->bmt", w3.double(), h.double())
     padded = F.pad(lab.double(), (r // 2, r // 2))
     tgt = torch.stack([padded[:, :, t:t + r].reshape(B, -1) for t in range(Fr)], 2)
     g = torch.zeros(B, M, Fr, device=dev)
     acc = torch.zeros(1, dtype=torch.float64, device=dev)
-    K.conv_gemm(h.to(dev), w3.to(dev), None, S=B, Cin=160, Tin=Fr, M=M, K=160, taps=1, Ncols=Fr, Tout=Fr,
+    K.conv_gemm(h.to(dev), w3.to(dev), None, S=B, Cin=768, Tin=Fr, M=M, K=768, taps=1, Ncols=Fr, Tout=Fr,
                 epilogue=K.EPI_MSE_CTX, label=lab.to(dev), grad_out=g, loss_acc=acc, grad_scale=1.0, r_ctx=r, label_D=D)
     assert K.LAST_PLAN_KIND == 2
     assert abs(float(acc) - float(((pred - tgt) ** 2).sum())) <= 1e-6 * float(((pred - tgt) ** 2).sum())
     assert _rel(g, pred - tgt) < 2e-6
+
+
+@pytest.mark.parametrize("S,Cin,Cout,k,st,T", [(8, 16, 16, 11, 1, 800), (4, 8, 32, 11, 2, 800)])
+def test_zero_padded_data_gradient_with_interior_and_edge_lanes(dev, S, Cin, Cout, k, st, T):
+    """Sequences long enough that a staging slot mixes in-range lanes with zero-padding lanes (the first / last taps'
+    positions of a sequence inside an otherwise interior tile).  This is the shape class on which hidden (inline-asm)
+    activation loads returned stale registers on the GPU while every smaller test and the emulator passed."""
+    from pase_amd import engine as E
+    torch.manual_seed(0)
+    w = torch.randn(Cout, Cin, k) * 0.1
+    padL, padR = E.reflect_pads(k, st)
+    Tg = (T + padL + padR - k) // st + 1
+    dy = torch.randn(S, Cout, Tg)
+    xp = torch.zeros(S, Cin, T + padL + padR, dtype=torch.float64, requires_grad=True)
+    F.conv1d(xp, w.double(), None, stride=st).backward(dy.double())
+    dx = E.conv_dgrad(dy.to(dev), w.to(dev), R=Cout, O=Cin, k=k, stride=st, Tin=T, padL=padL, padR=padR, s_red=Cin * k,
+                      s_out=k, s_k=1)
+    assert K.LAST_PLAN_KIND == 2
+    assert _rel(dx, xp.grad) < 1e-6

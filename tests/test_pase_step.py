@@ -110,14 +110,19 @@ def test_trainer_three_adam_steps(dev):
 # What "fp32-grade" means at step level (round-2 review item): the live reference's OWN fp32 gradients of this step are
 # compared with the same step evaluated by the live reference in fp64 (tests/golden/*_grads_f64.npz, oracle/make_golden.py
 # `grads64`), and so are ours.  Per tensor e_ref = relL2(reference fp32, fp64), e_ours = relL2(HIP path, fp64).
-# The reference's CPU kernels (oneDNN, blocked / pairwise accumulation) land 2e-6 ... 3e-5 from fp64 on the weight
-# tensors; a k-ORDERED fp32 fma chain (what v_mfma_f32_32x32x2_f32 is, bit for bit, and what the split-bf16 sum is
-# equivalent to) over reductions of 1e3 ... 3e5 terms of alternating sign sits at eps * sqrt(N) of the summands, so the
-# bound is   e_ours <= 1.5 * e_ref + FLOOR   with FLOOR the measured chain noise of OUR fp32-MFMA pipe plus margin;
-# both pipes (K.X6 False / True) must meet THE SAME bound, and the split pipe must be no farther from fp64 than
-# 2x the exact-fp32 pipe (+ a 1e-5 floor): that is the statement "the split-bf16 contraction is not narrower than fp32".
-GRAD_FLOOR_WEIGHT = 2e-3       # relL2, weight tensors (B = 2: 300 ... 48 000 positions per BatchNorm channel)
-GRAD_FLOOR_PER_CHANNEL = 6e-3  # relL2, one scalar per channel (BN gamma / beta, PReLU slopes, biases, SincNet vectors)
+# Measured (round 3, tests/golden step, B = 2): median over the 120 tensors 2.7e-6 (reference) / 3.2e-6 (split-bf16) /
+# 3.3e-6 (fp32 MFMA); on PASE.cfg + workers.cfg every tensor of both pipes is within 1.5x of the reference's own error.
+# What remains on PASE+ are a few encoder tensors at 2e-4 ... 1e-3: freshly initialised PReLU slopes are 0 (a ReLU), so an
+# activation whose pre-activation differs from the fp64 value in the last bit AND straddles zero flips its backward mask --
+# one flipped element moves a per-channel sum over 300 ... 19 200 signed terms by 1e-3 ... 1e-2 of itself.  Every fp32
+# evaluation order has such flips (which elements flip is luck: the CPU reference has none on this batch, the k-ordered
+# fp32 MFMA chain a few at 1e-4, the split-bf16 forward a few at 1e-3; `PASE_X6_ONLY=fwd|bwd` shows they come from the
+# forward convolutions alone, whose outputs are CLOSER to fp64 than the fp32 chain's: tests/test_conv_x6c.py).  Hence
+#   e_ours <= 1.5 * e_ref + FLOOR,  FLOOR = a handful of mask flips; a sign / permutation / missing-term error is O(1),
+# and the round-2 single-accumulator kernels (systematic error, 3e-3 ... 5e-3 on ALL encoder tensors) fail it;
+# both pipes must meet THE SAME bound and the split pipe's MEDIAN distance to fp64 must not exceed the fp32 pipe's.
+GRAD_FLOOR_WEIGHT = 1.5e-3       # relL2, weight tensors
+GRAD_FLOOR_PER_CHANNEL = 3e-3    # relL2, one scalar per channel (BN gamma / beta, PReLU slopes, biases, SincNet vectors)
 _PIPE_ERR = {}                 # (gold, pipe) -> {name: relL2 vs fp64}, to compare the two pipes with each other
 
 
@@ -221,10 +226,9 @@ def _full_width_golden_step(dev, gold, fe, wk, x6):
     other = _PIPE_ERR.get((gold, not x6))
     if other is not None:      # both pipes ran in this session: the split pipe is no farther from fp64 than the fp32 pipe
         ex6, ef32 = (mine, other) if x6 else (other, mine)
-        worse = [(ex6[n] / max(ef32[n], 1e-30), ex6[n], ef32[n], n) for n in ex6 if ex6[n] > 2.0 * ef32[n] + 1e-5]
-        print("   split-bf16 vs fp32-MFMA distance to fp64: median ratio %.2f" % float(
-            np.median([ex6[n] / max(ef32[n], 1e-30) for n in ex6])))
-        assert not worse, "split-bf16 farther from fp64 than the fp32 pipe: %r" % (sorted(worse, reverse=True)[:4],)
+        ratio = float(np.median([ex6[n] / max(ef32[n], 1e-30) for n in ex6]))
+        print("   split-bf16 vs fp32-MFMA distance to fp64: median ratio %.2f" % ratio)
+        assert ratio <= 1.25, ratio
 
 
 def _mini_workers_cfg2():
@@ -388,6 +392,46 @@ def test_trainer_epoch_loop_checkpoints_and_resume(dev, tmp_path):
         assert torch.equal(p.detach().cpu(), q.detach().cpu()), n
 
 
+def test_trainer_eval_pass_matches_the_oracle(dev, tmp_path):
+    """trainer._eval (trainer.py:282-337): eval-mode forward (BatchNorm running statistics), unweighted per-worker losses
+    averaged over va_bpe validation batches, parameters / running statistics untouched, training mode restored; and
+    train_ runs it once per epoch when a validation loader is given."""
+    from pase_amd.trainer import trainer
+    seed_all(5)
+    cfg = dict(fe_lr=1e-3, min_lr=5e-4, epoch=1, bpe=1, va_bpe=3, log_freq=1, save_path=str(tmp_path / "ck"))
+    tr = quiet(trainer, frontend_cfg=dict(MINI_FE), minions_cfg=with_losses(mini_workers()), cfg=cfg, lr_mode="poly",
+               device=dev)
+    m = tr.model
+    randomize_affine(m)
+    m.train()
+    quiet(tr.train_step, {k: v.to(dev) for k, v in _mini_batch(seed=50).items()})     # running statistics off their init
+    val = [_mini_batch(seed=60 + i) for i in range(2)]          # shorter than va_bpe: the iterator restarts
+    P = oracle_params(m)
+    raw = mini_workers()
+    want = {}
+    for i in range(3):
+        b = val[i % 2]
+        h, chunk, preds, labels = O.pase_forward(P, MINI_FE, raw, b, False)
+        lo = {}
+        for grp in ("cls", "regr"):          # UNWEIGHTED, as trainer._eval sums them (trainer.py:305-317)
+            for w in raw[grp]:
+                lo[w["name"]] = float(O.ctx_loss(preds[w["name"]], labels[w["name"]], w["loss"], w.get("r")))
+        lo["total"] = sum(lo.values())
+        for k, v in lo.items():
+            want.setdefault(k, []).append(float(v))
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    got = quiet(tr._eval, val, 0, dev)
+    assert m.training
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd0[k]), k
+    assert set(got) == set(want)
+    for k in want:
+        ref = sum(want[k]) / len(want[k])
+        assert abs(got[k] - ref) <= 2e-4 * max(1.0, abs(ref)), (k, got[k], ref)
+    quiet(tr.train_, [_mini_batch(seed=70)], val, dev)
+    assert tr.last_eval is not None and "total" in tr.last_eval
+
+
 @pytest.mark.gpu
 def test_captured_step_matches_eager_steps():
     """trainer.capture_step: the hipGraph replay of the fused step (side streams, arenas, multi-tensor commits, Adam
@@ -404,12 +448,11 @@ def test_captured_step_matches_eager_steps():
     ex = {k: v.to(dev) for k, v in _mini_batch(seed=30).items()}
     snap = {k: v.clone() for k, v in b.model.state_dict().items()}
     b.capture_step(ex)
-    # capture runs warm-up steps: put model / optimizer state back to the common start
-    with torch.no_grad():
-        for k, v in b.model.state_dict().items():
-            v.copy_(snap[k])
+    # capture runs warm-up steps on the example batch and must leave the training state where it found it
+    for k, v in b.model.state_dict().items():
+        assert torch.equal(v, snap[k]), k
     for opt in b.optimizers():
-        opt.exp_avg.zero_(); opt.exp_avg_sq.zero_(); opt.step_t.zero_()
+        assert int(opt.step_t.item()) == 0 and float(opt.exp_avg.abs().max()) == 0.0
     for step in range(4):
         batch = {k: v.to(dev) for k, v in _mini_batch(seed=40 + step).items()}
         if step == 2:
@@ -422,3 +465,27 @@ def test_captured_step_matches_eager_steps():
         if not is_noise_grad(n):
             assert_close(q, p, rtol=0, atol=2e-5, what=n)
     assert int(b.frontend_optim.step_t.item()) == 4
+    # a batch of another shape falls back to the eager step on its OWN zero arena (the graph keeps raw pointers into its)
+    small = {k: v[:1].contiguous() for k, v in batch.items()}
+    b.train_step(small)
+    assert b._zero_arena is not b._graph_arena
+    lb2 = b.train_step(batch)                      # and the graph still replays
+    assert torch.isfinite(lb2["total"])
+
+
+@pytest.mark.gpu
+def test_capture_refuses_workers_with_host_randomness():
+    """SPC / Gap draw their frames with `random` / `numpy.random` on the host at every step (minions.py:614-628, 680-681):
+    a captured step would freeze the draw of the capture run."""
+    from pase_amd.trainer import trainer
+    from util import MINI_FE_PLAIN
+    dev = torch.device("cuda:0")
+    seed_all(0)
+    tr = quiet(trainer, frontend_cfg=dict(MINI_FE_PLAIN), minions_cfg=with_losses(_mini_workers_cfg2()),
+               cfg=dict(fe_lr=1e-3, min_lr=5e-4, epoch=1, bpe=10), lr_mode="poly", device=dev)
+    g = torch.Generator().manual_seed(3)
+    batch = {k: (torch.randn(2, 1, 8000, generator=g) * 0.3).to(dev) for k in ("chunk", "chunk_ctxt", "chunk_rand", "cchunk")}
+    batch["lps"] = torch.randn(2, 9, 50, generator=g).to(dev)
+    batch["prosody"] = torch.randn(2, 4, 50, generator=g).to(dev)
+    with pytest.raises(NotImplementedError):
+        tr.capture_step(batch)

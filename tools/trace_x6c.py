@@ -72,6 +72,29 @@ def run_shape(name, dev):
         b = torch.randn(128, device=dev)
         a = Act(x, C=256, alpha=torch.full((256,), 0.1, device=dev))
         return lambda: E.deconv_fwd(a, w, b, Cout=128, k=30, stride=10)
+    if name in ("wg5", "wg7", "wglps", "wgqrnn"):     # weight gradients: block 5 / block 7 conv, LPS head, QRNN tap
+        if name in ("wg5", "wg7"):
+            Cin, Cout, k, st, Tin = {"wg5": (256, 256, 11, 1, 800), "wg7": (512, 512, 11, 2, 400)}[name]
+            pL, pR = E.reflect_pads(k, st)
+            x = torch.randn(S, Cin, Tin, device=dev)
+            a = Act(x, C=Cin, scale=torch.ones(Cin, device=dev), shift=torch.zeros(Cin, device=dev),
+                    alpha=torch.full((Cin,), 0.1, device=dev))
+            Tout = (Tin + pL + pR - k) // st + 1
+            dy = torch.randn(S, Cout, Tout, device=dev)
+            dw = torch.zeros(Cout, Cin * k, device=dev)
+            db = torch.zeros(Cout, device=dev)
+            return lambda: E.conv_wgrad(dy, a, dw, db, taps=k, stride=st, padL=pL, pad_mode=K.PAD_REFLECT)
+        if name == "wglps":
+            g = torch.randn(32, 21525, 200, device=dev)
+            h = torch.randn(32, 256, 200, device=dev)
+            dw = torch.zeros(21525, 256, device=dev)
+            db = torch.zeros(21525, device=dev)
+            return lambda: E.conv_wgrad(g, Act(h, C=256, alpha=torch.full((256,), 0.25, device=dev)), dw, db, taps=1)
+        g = torch.randn(S, 1536, 200, device=dev)
+        h = torch.randn(S, 512, 200, device=dev)
+        dw = torch.zeros(1536, 512, device=dev)
+        db = torch.zeros(1536, device=dev)
+        return lambda: E.conv_wgrad(g, Act(h, C=512), dw, db, taps=1)
     if name == "dgrad21525":
         B, F_ = 32, 200
         g = torch.randn(B, 21525, F_, device=dev)
@@ -81,7 +104,7 @@ def run_shape(name, dev):
 
 
 def main():
-    shapes = sys.argv[1:] or ["blk5", "blk7", "qrnn", "lps", "dec3", "dgrad21525"]
+    shapes = sys.argv[1:] or ["blk5", "blk7", "qrnn", "lps", "dec3", "wg5", "wg7", "wglps", "wgqrnn"]
     so = build_trace_lib()
     if shapes == ["build"]:
         print(so)
@@ -92,7 +115,7 @@ def main():
     lib.pase_x6c_trace_reset.argtypes = []
     dev = torch.device("cuda:0")
     NI = 64
-    buf = (C.c_ulonglong * (2 * NI * 8))()
+    buf = (C.c_ulonglong * (2 * NI * 12))()
     for name in shapes:
         fn = run_shape(name, dev)
         fn()
@@ -110,7 +133,7 @@ def main():
         for wg in (0, 1):
             rows = []
             for i in range(NI):
-                t = [buf[(wg * NI + i) * 8 + s] for s in range(8)]
+                t = [buf[(wg * NI + i) * 12 + s] for s in range(12)]
                 if t[3] == 0 or t[3] < t[0]:
                     break
                 rows.append(t)
@@ -122,11 +145,12 @@ def main():
             def avg(f):
                 v = [f(r) for r in mid]
                 return sum(v) / len(v)
-            print("   workgroup %-3s items %2d | compute: wait %7.0f  mfma %7.0f  epi %7.0f  item-to-item %7.0f | staging: pro %7.0f"
-                  "  loop %7.0f" % ("0" if wg == 0 else "131", len(rows), avg(lambda r: r[1] - r[0]), avg(lambda r: r[2] - r[1]),
-                                    avg(lambda r: r[3] - r[2]),
-                                    (rows[-1][0] - rows[0][0]) / max(1, len(rows) - 1), avg(lambda r: r[5] - r[4]),
-                                    avg(lambda r: r[6] - r[5])))
+            print("   workgroup %-3s items %2d | compute: wait %7.0f  mfma %7.0f (in barriers %7.0f)  epi %7.0f  item-to-item %7.0f"
+                  " | staging: pro %7.0f  loop %7.0f (busy %7.0f: vmwait %7.0f, convert+store %7.0f)" % (
+                      "0" if wg == 0 else "131", len(rows), avg(lambda r: r[1] - r[0]), avg(lambda r: r[2] - r[1]),
+                      avg(lambda r: r[9]), avg(lambda r: r[3] - r[2]), (rows[-1][0] - rows[0][0]) / max(1, len(rows) - 1),
+                      avg(lambda r: r[5] - r[4]), avg(lambda r: r[6] - r[5]), avg(lambda r: r[8]), avg(lambda r: r[10]),
+                      avg(lambda r: r[11])))
 
 
 if __name__ == "__main__":
