@@ -137,10 +137,10 @@ def main():
                 if t[3] == 0 or t[3] < t[0]:
                     break
                 rows.append(t)
-            if len(rows) < 3:
-                print("   workgroup %s: %d items traced" % ("0" if wg == 0 else "131", len(rows)))
+            if len(rows) < 1:
+                print("   workgroup %s: no items traced" % ("0" if wg == 0 else "131"))
                 continue
-            mid = rows[1:-1]
+            mid = rows[1:-1] if len(rows) >= 3 else rows
 
             def avg(f):
                 v = [f(r) for r in mid]
