@@ -138,6 +138,10 @@ typedef struct PaseWgrad {
 int pase_wgrad_gemm(const PaseWgrad* desc, void* stream);
 /* bytes of PaseWgrad::gx6 the launch described by desc needs (0: the shape runs on the fp32 matrix pipe) */
 long pase_wgrad_x6_bytes(const PaseWgrad* desc);
+/* which kernel a launch with x6 = 1 and a gx6 scratch runs on: 0 fp32 matrix pipe; split-bf16 position contraction with
+ * 1 rows = g (packed), columns = (channel, tap) of z staged; 2 1x1 layer, rows = z channels (packed), columns = g staged;
+ * 3 rows = (channel, tap) read from row-major bf16 planes of z, columns = g staged */
+int pase_wgrad_plan_kind(const PaseWgrad* desc);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm1d (training-mode batch statistics) pieces.  Reference: nn.BatchNorm1d built by

@@ -18,7 +18,13 @@ struct PaseX6cPlan {
     int n_row_tiles, n_col_tiles, splitk;
     int steps_total;    // stages * KGS * A MFMA steps (16 k each; k-groups past G are zero in the pack)
     int prio;           // s_setprio of the staging waves (bits 0-1) and of the compute waves (bits 2-3)
-    int tmode;          // 0: convolution.  Weight gradients (contraction over positions): 1 rows = g, 2 swapped
+    int tmode;          // 0: convolution.  Weight gradients (contraction over positions): 1 rows = g (packed), columns =
+                        // (channel, tap) of z (staged);  2 1x1 swapped: rows = z channels (packed), columns = g rows (staged);
+                        // 3 rows = (channel, tap) read at 2-byte granularity from row-major bf16 planes of z, columns = g rows
+    int t_taps, t_tapstep, t_padL, t_stride;   // tmode 3: the layer's taps (the staged operand's descriptor says taps = 1)
+    int t_lseg, t_hh, t_dmin;                  // tmode 3: plane row = S segments of t_lseg = 16 QP16 + t_hh elements
+    int t_vec;                                 // T-mode: the staged operand's 8-position chunks are 16-byte aligned
+    long t_plane;                              // tmode 3: elements per plane
     int xPerm;          // pixel-shuffle launches: tile rows ordered (channel, phase) -> 16-byte output runs
     long pack_chunks;   // 16-byte chunks of the weight pack
     int prm_n;          // channels' of the expanded on-load parameter arrays behind the chunks (3 x prm_n floats)

@@ -141,6 +141,18 @@ __device__ __forceinline__ float x6c_keep(float v, unsigned mask, int e) {      
     __builtin_memcpy(&v, &bits, 4);
     return v;
 }
+// 16 bytes at 2-byte granularity (one global_load_dwordx4: global accesses need no alignment on gfx950)
+struct __attribute__((packed, aligned(2))) X6cU16 { u32x4 v; };
+__device__ __forceinline__ u32x4 x6c_load16u(const unsigned short* q) {
+#ifdef PASE_HIPEMU
+    u32x4 v;
+    __builtin_memcpy(&v, q, 16);
+    return v;
+#else
+    return reinterpret_cast<const X6cU16*>(q)->v;
+#endif
+}
+struct alignas(16) X6cF4 { float x, y, z, w; };
 __device__ __forceinline__ void x6c_gload(float& dst, const float* base, unsigned voff_bytes) {
     dst = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + voff_bytes);
 }
@@ -175,8 +187,12 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     constexpr int BUF = KGS_T * KGC;               // chunks per stage buffer
     constexpr int XR = 3;                          // register sets of the staging waves: loads run XR - 1 stages ahead
     constexpr int RED_CHUNKS = (int)(sizeof(float) * WN * BM * 2 / 16);
+    // TM, transposed accumulation (modes 2 / 3): each compute wave turns 64 columns x 32 rows of its tile through a private
+    // [64][33]-float LDS block so that the atomics run along the rows of dw
+    constexpr int TR_FLOATS = 64 * 33;
+    constexpr int TR_CHUNKS = TM ? (4 * TR_FLOATS * 4 + 15) / 16 : 0;
     // two stage buffers + the epilogue scratch (its own region: the next item's first stage is staged during the epilogue)
-    __shared__ __attribute__((aligned(16))) u32x4 Xs[2 * BUF + RED_CHUNKS];
+    __shared__ __attribute__((aligned(16))) u32x4 Xs[2 * BUF + RED_CHUNKS + TR_CHUNKS];
     float (*red)[BM][2] = reinterpret_cast<float (*)[BM][2]>(&Xs[2 * BUF]);
 
     const int tid = threadIdx.x;
@@ -244,6 +260,13 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     unsigned t_ones = 0u;
     bool t_any_ones = false;
     int t_n0 = 0, t_mt = 0;
+    // TM, pl.t_vec (g staged, modes 2 / 3): row-coalesced mapping -- slot sl of this lane is column
+    //   n0 + 32 (wave - 4) + 16 (sl >> 1) + (lane & 15),   chunk c = 4 (sl & 1) + (lane >> 4) of the stage's 8 (kg = c >> 1, fk = c & 1)
+    // so one load instruction covers 16 rows x 128 contiguous bytes (whole cache lines, each fetched once) instead of 64 rows x
+    // 32 bytes, and a 16-lane group of the LDS write covers 16 consecutive columns of one (kg, fk) row (conflict-free)
+    unsigned v_voff[2] = {0u, 0u};
+    bool v_ok[2] = {false, false};
+    float v_al[2] = {1.f, 1.f}, v_sum[2] = {0.f, 0.f};
     const int t_kmin = -p.padL - (p.tapstep < 0 ? p.taps - 1 : 0);
     const int t_kmax = -p.padL + (p.tapstep > 0 ? p.taps - 1 : 0);
     auto item_range = [&](int item, int& gb, int& ge) __attribute__((always_inline)) {
@@ -264,6 +287,19 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             nst = ge - g_begin;
             t_n0 = n0;
             t_mt = pl.tmode == 1 ? tile / pl.n_col_tiles : tile - nt * pl.n_row_tiles;
+            if (pl.t_vec) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int j = n0 + 32 * (wave - 4) + 16 * h + (lane & 15);
+                    v_ok[h] = j < p.K;
+                    v_voff[h] = (unsigned)((v_ok[h] ? j : 0) * p.Tin);
+                    v_al[h] = p.in_alpha ? p.in_alpha[v_ok[h] ? j : 0] : 1.f;
+                    v_sum[h] = 0.f;
+                }
+                live = 3u;
+                full = 0u;
+                return;
+            }
             pos_valid = 0u;
             t_ones = 0u;
 #pragma unroll
@@ -379,6 +415,24 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         constexpr int sl = decltype(sl_tag)::value, rs = decltype(r_tag)::value;
         constexpr int kg = sl / NPS, ps = sl % NPS, par = kg & (NPAR - 1);
         if constexpr (TM) {
+            if (pl.t_vec) {
+                constexpr int h = (sl >> 1) & 1;
+                const int c = (sl & 1) * 4 + (lane >> 4);
+                const int kgi = g * KGS + (c >> 1);
+                const int s_ = (int)div_magic((unsigned)kgi, pl.seg_magic);
+                const int qv = (kgi - s_ * pl.P) * 16 + (c & 1) * 8;
+                const bool ok = v_ok[h] && s_ < p.S && qv < p.Ncols;            // Ncols % 8 == 0: whole chunks only
+                unsigned off = ok ? (unsigned)(s_ * p.x_ctot * p.Tin + qv) + v_voff[h] : 0u;
+#ifdef PASE_X6C_TRACE
+                if (pl.prio & 64) off = (unsigned)(lane & 15) * 8u;      // ablation: every load hits the same two cache lines
+#endif
+                const X6cF4* q4 = reinterpret_cast<const X6cF4*>(reinterpret_cast<const char*>(xbase) + (size_t)off * 4u);
+                const X6cF4 lo = q4[0], hi = q4[1];
+                xreg[rs][sl][0] = lo.x; xreg[rs][sl][1] = lo.y; xreg[rs][sl][2] = lo.z; xreg[rs][sl][3] = lo.w;
+                xreg[rs][sl][4] = hi.x; xreg[rs][sl][5] = hi.y; xreg[rs][sl][6] = hi.z; xreg[rs][sl][7] = hi.w;
+                xmask[rs][sl] = ok ? 0xffu : 0u;
+                return;
+            }
             int sq, qb0;
             bool inter;
             t_geom(g, kg, sq, qb0, inter);
@@ -442,6 +496,26 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = xreg[rs][sl][e];
         if constexpr (TM) {
+            if (pl.t_vec) {
+                constexpr int h = (sl >> 1) & 1;
+                const int c = (sl & 1) * 4 + (lane >> 4);
+                if (has_alpha) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * v_al[h];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = x6c_keep(v[e], xmask[rs][sl], e);
+                if (p.bias != nullptr) {                                      // uniform
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v_sum[h] += v[e];
+                }
+                u32x4 o[3];
+                pase_split_bf16x3_rne(v, o);
+                u32x4* dst = &Xs[bsel * BUF + (c >> 1) * KGC + (c & 1) * NPOS + 32 * (wave - 4) + 16 * h + (lane & 15)];
+#pragma unroll
+                for (int pz = 0; pz < 3; ++pz) dst[pz * PLANE] = o[pz];
+                return;
+            }
             int sq, qb0;
             bool inter;
             t_geom(g, kg, sq, qb0, inter);
@@ -464,7 +538,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                         if (ones) v[e] = (qb0 + e < p.Ncols) ? 1.f : 0.f;
                 }
             }
-            if (pl.tmode == 2 && p.bias != nullptr) {                         // uniform
+            if (pl.tmode >= 2 && p.bias != nullptr) {                         // uniform
 #pragma unroll
                 for (int e = 0; e < 8; ++e) t_colsum[par][ps] += v[e];
             }
@@ -585,7 +659,12 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             if constexpr (TM) {
                 // swapped weight gradient (columns = rows of g): the bias gradient is the column sum of everything staged
                 // (each octet half adds its eight positions per k-group); once per column tile (row tile 0 only)
-                if (pl.tmode == 2 && p.bias != nullptr && t_mt == 0) {
+                if (pl.t_vec && p.bias != nullptr && t_mt == 0) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        if (v_ok[h])
+                            atomicAdd(const_cast<float*>(p.bias) + t_n0 + 32 * (wave - 4) + 16 * h + (lane & 15), v_sum[h]);
+                } else if (pl.tmode >= 2 && p.bias != nullptr && t_mt == 0) {
 #pragma unroll
                     for (int par = 0; par < NPAR; ++par)
                         if ((pos_valid >> par) & 1u) {
@@ -643,20 +722,59 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             accS[j][r] = 0.f;
         }
 
-    // ---- A fragments: [32-row tile][step][plane][lane] 16-byte chunks, TWO steps ahead --------------------
-    const u32x4* ap = reinterpret_cast<const u32x4*>(p.wx6) +
-                      ((size_t)(mt * WM + wm) * (unsigned)pl.steps_total + (size_t)g_begin * (unsigned)nsteps) * 192u + lane;
+    // ---- A fragments, TWO steps ahead: three uniform plane pointers + one per-lane byte offset ----------------------
+    //   packs (convolutions, tmode 1 / 2): [32-row tile][step][plane][lane] 16-byte chunks, 3072 bytes per step
+    //   tmode 3: row (ci, kk) of the weight gradient = phase b / shift d of channel ci in row-major bf16 planes of z~
+    //     (pack_zplanes_kernel: [plane][ci * stride + b][s][t_lseg]); the k-group (s, q0) of that row starts at element
+    //     s * t_lseg + q0 + (d - dmin): consecutive k-groups are 16 elements apart, t_hh more across a sequence boundary
+    const char* ab[3];
+    unsigned a_loff;
+    int a_adv, a_q16 = 0, a_wrap = 0x7fffffff, a_hh2 = 0;
+    if (TM && pl.tmode == 3) {
+        const int j = min(m0 + wm * 32 + fr, p.M - 1);
+        const int ci = (int)div_magic((unsigned)j, pl.p_magic);
+        const int kk = j - ci * pl.t_taps;
+        const int o = kk * pl.t_tapstep - pl.t_padL;
+        const int d = o >= 0 ? o / pl.t_stride : -((-o + pl.t_stride - 1) / pl.t_stride);
+        const int b = o - d * pl.t_stride;
+        const int kgi0 = g_begin * KGS;
+        const int sq = (int)div_magic((unsigned)kgi0, pl.seg_magic);
+        a_q16 = kgi0 - sq * pl.P;
+        a_wrap = pl.P;
+        a_hh2 = 2 * pl.t_hh;
+        a_adv = 32;
+        // (each plane holds the rows twice, the second copy one element later: a row whose shift d - dmin is odd reads that
+        //  copy, so every fragment address is a multiple of 4 bytes -- 2-byte-aligned 16-byte loads run at half rate)
+        const int sh = d - pl.t_dmin, odd = sh & 1;
+        a_loff = 2u * (unsigned)(odd * (int)(pl.t_plane / 2) + ((ci * pl.t_stride + b) * p.S) * pl.t_lseg + sh - odd + fk * 8);
+#pragma unroll
+        for (int pz = 0; pz < 3; ++pz)
+            ab[pz] = reinterpret_cast<const char*>(p.wx6) + 2 * ((size_t)pz * pl.t_plane + (size_t)sq * pl.t_lseg + (size_t)a_q16 * 16);
+    } else {
+        a_adv = 3072;
+        a_loff = 16u * (unsigned)lane;
+#pragma unroll
+        for (int pz = 0; pz < 3; ++pz)
+            ab[pz] = reinterpret_cast<const char*>(p.wx6) + 16 * (((size_t)(mt * WM + wm) * (unsigned)pl.steps_total +
+                                                                  (size_t)g_begin * (unsigned)nsteps) * 192u + 64u * pz);
+    }
     const int nsteps_run = nst * nsteps;
     int a_issued = 0;
     auto load_a = [&](u32x4 (&a)[3]) __attribute__((always_inline)) {
         // unconditional (the steps past the end re-read the last fragments): a load behind a branch makes the compiler's
         // vmcnt bookkeeping fall back to vmcnt(0), which would wait for the fragments issued a moment ago
-        a[0] = ap[0];
-        a[1] = ap[64];
-        a[2] = ap[128];
+#pragma unroll
+        for (int pz = 0; pz < 3; ++pz) a[pz] = x6c_load16u(reinterpret_cast<const unsigned short*>(ab[pz] + a_loff));
         ++a_issued;
-        ap += (a_issued < nsteps_run) ? 192 : 0;
+        const bool wrap = a_q16 + 1 == a_wrap;
+        a_q16 = wrap ? 0 : a_q16 + 1;
+        const int adv = (a_issued < nsteps_run) ? a_adv + (wrap ? a_hh2 : 0) : 0;
+#pragma unroll
+        for (int pz = 0; pz < 3; ++pz) ab[pz] += adv;
     };
+    // (Requesting the next unit's B fragments explicitly before each block of 12 MFMAs -- software pipelining by hand, pinned
+    //  with sched barriers -- measured 4 ... 14 % SLOWER on every convolution of the PASE+ step than leaving the order of
+    //  the 12 ds_read_b128 and 24 MFMAs of a step to the compiler.)
     auto mfma_step = [&](const u32x4 (&a)[3], const u32x4* xb) __attribute__((always_inline)) {
         // plane pairs of the five small terms, smallest first: mm, hl, lh, hm, mh -> accS; hh -> accH
         constexpr int PZA[5] = {1, 0, 2, 0, 1}, PZB[5] = {1, 2, 0, 1, 0};
@@ -745,6 +863,30 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
 
     if constexpr (TM) {
         // weight-gradient tile: += into the caller-zeroed dw (split-K slices and other launches add into the same buffer)
+        if (pl.tmode >= 2) {
+            // swapped operands: tile row = input channel (x tap) -> a COLUMN of dw, tile column = output channel -> a row.
+            // Through LDS (wave-private block, LDS operations of one wave execute in order): lanes 0-31 / 32-63 then add
+            // 32 consecutive elements of two rows of dw per instruction instead of 64 elements 4 * ldw bytes apart.
+            float* tr = reinterpret_cast<float*>(&Xs[2 * BUF + RED_CHUNKS]) + wm * TR_FLOATS;
+            const int mrow = m0 + wm * 32 + fr;                       // dw column of this lane in the read pass
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                pase_wave_sync();                                     // the previous half has been read
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        tr[(jj * 32 + fr) * 33 + (r & 3) + 8 * (r >> 2) + 4 * fk] = acc[half * 2 + jj][r];
+                pase_wave_sync();
+#pragma unroll 8
+                for (int cc = 0; cc < 64; cc += 2) {
+                    const int cl = cc + fk;
+                    const int col = n0 + half * 64 + cl;
+                    const float v = tr[cl * 33 + fr];
+                    if (mrow < p.M && col < p.K) atomicAdd(p.y + (size_t)col * p.Tout + mrow, v);
+                }
+            }
+        } else {
         const int rb = m0 + wm * 32 + 4 * fk;
 #pragma unroll
         for (int j = 0; j < NBT; ++j) {
@@ -754,15 +896,14 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 const int m = rb + (r & 3) + 8 * (r >> 2);
                 const float v = acc[j][r];
                 if (m < p.M) {
-                    if (pl.tmode == 2) {          // swapped operands: row = input channel, column = output channel
-                        if (col < p.K) atomicAdd(p.y + (size_t)col * p.Tout + m, v);
-                    } else if (col < p.K) {
+                    if (col < p.K) {
                         atomicAdd(p.y + (size_t)m * p.Tout + col, v);
                     } else if (col == p.K && p.bias) {
                         atomicAdd(const_cast<float*>(p.bias) + m, v);
                     }
                 }
             }
+        }
         }
     } else {
     // ---- epilogue -----------------------------------------------------------------------------------------
@@ -1097,6 +1238,46 @@ __global__ void pack_rows_x6c_kernel(const float* __restrict__ src, u32x4* __res
     }
 }
 
+// tmode 3: z~ (on-load transform applied, padding materialised) as three row-major bf16 planes,
+//   out[plane][r = ci * st + b][s][i],  i in [0, lseg):  z~[s][ci][st * (i + dmin) + b]   (reflected / zero outside [0, T))
+// followed by a zero tail (the k-groups a last stage runs past the last sequence read on into the next row, or into the tail).
+// One thread per 8 consecutive elements of a plane (t_plane % 8 == 0: 16-byte stores).
+__global__ void pack_zplanes_kernel(const float* __restrict__ src, u32x4* __restrict__ out, int Cin, int S, int ctot, int coff,
+                                    int T, int st, int lseg, int dmin, int pad_mode, long t_plane, const float* sc,
+                                    const float* sh, const float* al) {
+    const long ngroups = t_plane / 8;
+    const long body = (long)Cin * st * S * lseg;
+    const long half = t_plane / 2;              // second copy: element i = element i + 1 of the first
+    for (long gidx = (long)blockIdx.x * blockDim.x + threadIdx.x; gidx < ngroups; gidx += (long)gridDim.x * blockDim.x) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            long idx = gidx * 8 + e;
+            if (idx >= half) idx = idx - half + 1;
+            float t = 0.f;
+            if (idx < body) {
+                const long rs = idx / lseg;
+                const int i = (int)(idx - rs * lseg);
+                const int s_ = (int)(rs % S);
+                const int r = (int)(rs / S);
+                const int ci = r / st, b = r - ci * st;
+                int u = st * (i + dmin) + b;
+                if (pad_mode == PASE_PAD_REFLECT) u = x6c_reflect(u, T);
+                if (u >= 0 && u < T) {
+                    t = src[((size_t)s_ * ctot + coff + ci) * T + u];
+                    if (sc) t = fmaf(t, sc[ci], sh[ci]);
+                    if (al) t = t > 0.f ? t : t * al[ci];
+                }
+            }
+            v[e] = t;
+        }
+        u32x4 o[3];
+        pase_split_bf16x3_rne(v, o);
+#pragma unroll
+        for (int pz = 0; pz < 3; ++pz) out[(pz * t_plane) / 8 + gidx] = o[pz];
+    }
+}
+
 int x6c_prio() {
     static const int v = [] {
         const char* e = getenv("PASE_X6C_PRIO");
@@ -1136,14 +1317,15 @@ bool pase_x6c_plan(const PaseConvGemm& p, PaseX6cPlan& pl) {
     // tile 128 x 128 (waves 4 x 1).  The operand split is paid once per staged element and shared by BM / 32 row tiles
     // x A taps: launches of at most 64 rows with fewer than four taps' would spend more issue slots splitting than
     // multiplying -- they stay on the fp32 matrix pipe
-    if (p.M <= 64 && pl.A < 4) return false;
+    const bool force = getenv("PASE_X6C_FORCE") != nullptr;      // measurement runs: skip the routing rules below
+    if (!force && p.M <= 64 && pl.A < 4) return false;
     // ... and so do launches with fewer than 128 k (eight MFMA steps per tile): they are store-bound
-    if ((long)pl.CinP * pl.A < 128) return false;
+    if (!force && (long)pl.CinP * pl.A < 128) return false;
     // Measured on the PASE+ bs32 step (profiles/gemm_launches_r03.json): 1x1 launches with K < 768 (the 256-channel worker
-    // heads: six stages per tile, the staging waves' conversion work per MFMA is 5x that of an 11-tap layer) and the
-    // two-tap QRNN Linear are faster on the exact-fp32 matrix pipe
-    if (pl.A == 1 && pl.CinP < 768) return false;
-    if (pl.A == 2 && pl.CinP >= 256 && (long)pl.CinP * pl.A <= 1024) return false;
+    // heads: six stages per tile, the staging waves' conversion work per MFMA is 5x that of an 11-tap layer) are faster on
+    // the exact-fp32 matrix pipe unless they have thousands of row tiles to amortise a column tile's staging over (the
+    // 21 525-channel heads: 0.81 -> 0.75 ms) or hardly any columns at all (the 128-column classifier launches)
+    if (!force && pl.A == 1 && pl.CinP < 768 && p.M < 8192 && (long)p.S * p.Ncols > 128) return false;
     pl.NBT = 4;
     pl.WM = 4;
     pl.BM = 128;
@@ -1245,11 +1427,38 @@ bool pase_x6c_wgrad_plan(const PaseWgrad& w, PaseX6cWgrad& o) {
     if ((long)w.S * w.g_ctot * (long)w.Tg >= LIM || (long)w.S * w.z_ctot * (long)w.Tz >= LIM) return false;
     if (w.Ncols < 8) return false;
     o.swapped = (w.taps == 1 && w.stride == 1 && w.padL == 0 && w.M > w.Cin) ? 1 : 0;
+    // layers with taps: rows = (channel, tap) straight out of row-major planes of z~, columns = g's channels (mode 3), unless
+    // g has too few channels to fill the 128-column tile or PASE_X6C_WGRAD_MODE=1 asks for the staged-Toeplitz orientation
+    // Measured on the PASE+ bs32 step (profiles/gemm_launches_r03.json): mode 3 wins on stride-1 layers with >= 256 output
+    // channels (block 5: 1.01 -> 0.93 ms); strided layers lose to the cost of writing the planes (the decoder's stride-10
+    // ConvTranspose1d: 1.6 GB of planes for a 1.7 ms launch) or tie
+    bool toep = w.taps > 1 && w.M >= 96;
+    if (const char* e = getenv("PASE_X6C_WGRAD_MODE")) toep = toep && e[0] == '3';
+    else toep = toep && w.stride == 1 && w.M >= 256;
     PaseConvGemm& c = o.pc;
     c = PaseConvGemm{};
     PaseX6cPlan& pl = o.pl;
     pl = PaseX6cPlan{};
-    if (!o.swapped) {
+    const int QP16 = (w.Ncols + 15) / 16;
+    if (toep) {
+        o.swapped = 1;
+        o.a_src = w.z; o.a_rows = w.Cin * w.taps; o.a_ctot = w.z_ctot; o.a_coff = w.z_coff; o.a_T = w.Tz;
+        o.a_sc = w.in_scale; o.a_sh = w.in_shift; o.a_al = w.in_alpha;
+        c.x = w.g; c.x_ctot = w.g_ctot; c.x_coff = w.g_coff; c.Tin = w.Tg; c.Cin = w.M;
+        c.taps = 1; c.stride = 1; c.tapstep = 1; c.padL = 0; c.pad_mode = PASE_PAD_ZERO;
+        c.in_scale = nullptr; c.in_shift = nullptr; c.in_alpha = w.g_alpha;
+        c.K = w.M;
+        pl.tmode = 3;
+        pl.t_taps = w.taps; pl.t_tapstep = w.tapstep; pl.t_padL = w.padL; pl.t_stride = w.stride;
+        const int omin = (w.tapstep > 0 ? 0 : -(w.taps - 1)) - w.padL, omax = (w.tapstep > 0 ? w.taps - 1 : 0) - w.padL;
+        auto fdiv = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
+        pl.t_dmin = fdiv(omin, w.stride);
+        pl.t_hh = (fdiv(omax, w.stride) - pl.t_dmin + 1) & ~1;           // even: the parity of a row's shift is the same in
+        pl.t_lseg = QP16 * 16 + pl.t_hh;                                   // every sequence segment
+        const long body = (long)w.Cin * w.stride * w.S * pl.t_lseg;
+        if (body >= (1L << 29)) return false;
+        pl.t_plane = 2 * ((body + 4L * (16 + pl.t_hh) + 64 + 15) / 16 * 16);   // two copies (see the A-fragment loads)
+    } else if (!o.swapped) {
         o.a_src = w.g; o.a_rows = w.M; o.a_ctot = w.g_ctot; o.a_coff = w.g_coff; o.a_T = w.Tg;
         o.a_sc = nullptr; o.a_sh = nullptr; o.a_al = w.g_alpha;
         c.x = w.z; c.x_ctot = w.z_ctot; c.x_coff = w.z_coff; c.Tin = w.Tz; c.Cin = w.Cin;
@@ -1266,21 +1475,25 @@ bool pase_x6c_wgrad_plan(const PaseWgrad& w, PaseX6cWgrad& o) {
         c.K = w.M;
         pl.tmode = 2;
     }
+    // g staged (modes 2 / 3): 8-position chunks start on 16-byte boundaries when the rows do
+    pl.t_vec = (pl.tmode >= 2 && w.Tg % 4 == 0 && w.Ncols % 8 == 0 && (long)w.S * QP16 >= 4 &&
+                (reinterpret_cast<uintptr_t>(w.g) & 15) == 0 && !getenv("PASE_X6C_NOVEC")) ? 1 : 0;
     // the split is paid once per staged element and shared by the row tiles of the workgroup: at most 64 rows would leave
     // half of every MFMA multiplying zeros
     if (o.a_rows <= 64) return false;
     // 1x1 layers: every staged element feeds only four row tiles and there are no taps to share the conversion between --
     // measured slower than the exact-fp32 matrix pipe on every PASE+ 1x1 weight gradient (profiles/gemm_launches_r03.json)
-    if (w.taps == 1 && !getenv("PASE_X6C_WGRAD_FLAT")) return false;
+    // (... except the swapped orientation on aligned rows of >= 1024 output channels: the 21 525-channel heads 0.68 -> 0.59 ms,
+    //  the QRNN's 1536-channel Linear 0.33 -> 0.27 ms)
+    if (w.taps == 1 && !getenv("PASE_X6C_WGRAD_FLAT") && !(o.swapped && pl.t_vec && w.M >= 1024)) return false;
     if ((long)c.Cin * c.Tin >= LIM) return false;
     c.S = w.S; c.Ncols = w.Ncols; c.M = o.a_rows;
     c.y = w.dw; c.Tout = w.ldw; c.bias = w.dbias; c.ldw = w.ldw;
     c.epilogue = PASE_EPI_STORE;
-    const int QP16 = (w.Ncols + 15) / 16;
     const long Gk = (long)w.S * QP16;
     if (Gk * 16 >= LIM) return false;
     pl.P = QP16; pl.A = 1; pl.G = (int)Gk; pl.CinP = 0x7fffffff;
-    pl.KGS = Gk >= 3 ? 3 : (int)Gk;
+    pl.KGS = Gk >= 4 ? 4 : (int)Gk;
     const int GS = (pl.G + pl.KGS - 1) / pl.KGS;
     pl.steps_total = GS * pl.KGS;
     pl.WM = 4; pl.NBT = 4; pl.BM = 128; pl.BN = 128;
@@ -1289,11 +1502,26 @@ bool pase_x6c_wgrad_plan(const PaseWgrad& w, PaseX6cWgrad& o) {
     pl.n_col_tiles = (ncolw + 127) / 128;
     pl.seg_magic = magic_of(QP16);
     pl.ncols_magic = magic_of(c.taps);
-    pl.p_magic = 0;
+    pl.p_magic = pl.tmode == 3 ? magic_of(pl.t_taps) : 0;
     const long tiles = (long)pl.n_row_tiles * pl.n_col_tiles;
-    // swapped launches accumulate transposed (scattered 4-byte atomics): as few slices as fill the chip once
-    long sk = w.splitk > 0 ? w.splitk : ((o.swapped ? 256 : 768) + tiles - 1) / tiles;
-    if (sk > GS / 4) sk = GS / 4;
+    // split-K over the persistent grid of 256 workgroups (items dealt round-robin): rounds x (1 / slices + flush), where the
+    // flush of a 128 x 128 tile costs about 13k cycles as row-contiguous atomics and about 50k transposed (modes 2 / 3),
+    // against 768 cycles per k-group of MFMA work
+    long sk = 1;
+    if (w.splitk > 0) sk = w.splitk;
+    else {
+        const double flush = (pl.tmode >= 2 ? 50e3 : 13e3) / (768.0 * (double)pl.G);
+        double best = 1e30;
+        const long max_sk = GS / 4 < 1 ? 1 : GS / 4;
+        for (long k = 1; k <= max_sk && k <= 256; ++k) {
+            const long rounds = (tiles * k + 255) / 256;
+            const double est = (double)rounds * (1.0 / (double)k + flush);
+            if (est < best * 0.98) {
+                best = est;
+                sk = k;
+            }
+        }
+    }
     if (sk < 1) sk = 1;
     {   // every slice owns at least one stage
         const long g_per = (GS + sk - 1) / sk;
@@ -1303,7 +1531,7 @@ bool pase_x6c_wgrad_plan(const PaseWgrad& w, PaseX6cWgrad& o) {
     pl.prio = x6c_prio();
     pl.pack_chunks = (long)pl.n_row_tiles * 4 * pl.steps_total * 192;
     pl.prm_n = 0;
-    pl.pack_bytes = pl.pack_chunks * 16;
+    pl.pack_bytes = pl.tmode == 3 ? 3 * pl.t_plane * 2 : pl.pack_chunks * 16;
     return true;
 }
 
@@ -1311,17 +1539,24 @@ int pase_x6c_wgrad_launch(const PaseWgrad& w, const PaseX6cWgrad& o, hipStream_t
     PaseConvGemm c = o.pc;
     c.wx6 = w.gx6;
     const PaseX6cPlan& pl = o.pl;
-    const long total = pl.pack_chunks / 3;
-    const long nb = (total + 255) / 256;
-    PASE_LAUNCH(pack_rows_x6c_kernel, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), st, o.a_src,
-                reinterpret_cast<u32x4*>(w.gx6), o.a_rows, w.S, o.a_ctot, o.a_coff, o.a_T, w.Ncols, pl.P, pl.steps_total, total,
-                o.a_sc, o.a_sh, o.a_al);
+    if (pl.tmode == 3) {
+        const long nb = (pl.t_plane / 8 + 255) / 256;
+        PASE_LAUNCH(pack_zplanes_kernel, dim3((unsigned)(nb < 32768 ? nb : 32768)), dim3(256), st, o.a_src,
+                    reinterpret_cast<u32x4*>(w.gx6), w.Cin, w.S, o.a_ctot, o.a_coff, o.a_T, w.stride, pl.t_lseg, pl.t_dmin,
+                    w.pad_mode, pl.t_plane, o.a_sc, o.a_sh, o.a_al);
+    } else {
+        const long total = pl.pack_chunks / 3;
+        const long nb = (total + 255) / 256;
+        PASE_LAUNCH(pack_rows_x6c_kernel, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), st, o.a_src,
+                    reinterpret_cast<u32x4*>(w.gx6), o.a_rows, w.S, o.a_ctot, o.a_coff, o.a_T, w.Ncols, pl.P, pl.steps_total,
+                    total, o.a_sc, o.a_sh, o.a_al);
+    }
     PASE_CHECK_LAUNCH();
     long nwg = (long)pl.n_row_tiles * pl.n_col_tiles * pl.splitk;
     long cap = 256;
     if (const char* e = getenv("PASE_X6C_MAXWG")) cap = atol(e) > 0 ? atol(e) : cap;
     if (nwg > cap) nwg = cap;
-    PASE_LAUNCH((conv_x6c_kernel<128, 3, true>), dim3((unsigned)nwg), dim3(NT), st, c, pl);
+    PASE_LAUNCH((conv_x6c_kernel<128, 4, true>), dim3((unsigned)nwg), dim3(NT), st, c, pl);
     PASE_CHECK_LAUNCH();
     return 0;
 }

@@ -55,6 +55,14 @@ __device__ __forceinline__ int pase_uniform(int v) { return __builtin_amdgcn_rea
 #define PASE_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 #endif
 
+// All lanes of this wave have executed everything before this point (LDS exchanged between the lanes of ONE wave needs no
+// workgroup barrier: a wave's LDS operations execute in order; the compiler just must not move them across)
+#ifdef PASE_HIPEMU
+__device__ __forceinline__ void pase_wave_sync() { (void)__shfl_xor(0, 1); }
+#else
+__device__ __forceinline__ void pase_wave_sync() { __builtin_amdgcn_wave_barrier(); }
+#endif
+
 #ifdef PASE_HIPEMU
 __device__ __forceinline__ int pase_wave_all(int pred) {
     int v = pred ? 1 : 0;

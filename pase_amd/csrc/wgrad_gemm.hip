@@ -831,6 +831,12 @@ extern "C" long pase_wgrad_x6_bytes(const PaseWgrad* d) {
     return pase_x6c_wgrad_plan(*d, o) ? o.pl.pack_bytes : 0;
 }
 
+extern "C" int pase_wgrad_plan_kind(const PaseWgrad* d) {
+    if (d->M <= 0 || d->Cin <= 0 || d->S <= 0 || d->Ncols <= 0) return 0;
+    PaseX6cWgrad o;
+    return pase_x6c_wgrad_plan(*d, o) ? o.pl.tmode : 0;
+}
+
 extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
     PaseWgrad p = *d;
     if (p.M <= 0 || p.Cin <= 0 || p.S <= 0 || p.Ncols <= 0) return 0;

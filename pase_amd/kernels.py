@@ -52,6 +52,8 @@ def declare(l):
     l.pase_pack_x6.restype = C.c_int
     l.pase_wgrad_x6_bytes.argtypes = [C.POINTER(PaseWgrad)]
     l.pase_wgrad_x6_bytes.restype = C.c_long
+    l.pase_wgrad_plan_kind.argtypes = [C.POINTER(PaseWgrad)]
+    l.pase_wgrad_plan_kind.restype = C.c_int
     l.pase_abi_sizeof.argtypes = [C.c_int]
     l.pase_abi_sizeof.restype = C.c_int
     if l.pase_abi_sizeof(0) != C.sizeof(PaseConvGemm):
@@ -169,6 +171,7 @@ class GemmTimer(object):
 
 GEMM_TIMER = None
 LAST_WGRAD_X6 = None       # did the most recent wgrad_gemm launch run on the split-bf16 kernel
+LAST_WGRAD_KIND = None     # ... and in which orientation (pase_wgrad_plan_kind: 0 fp32 pipe, 1 / 2 / 3)
 LAST_PLAN_KIND = None      # plan kind of the most recent conv_gemm launch (0 fp32 pipe, 2 split-bf16 x6c): tests / reports
 
 
@@ -338,8 +341,9 @@ def wgrad_gemm(g, z, dw, *, S, M, Tg, Ncols, Cin, Tz, taps, ldw=None, dbias=None
     d.ldw = Cin * taps if ldw is None else ldw
     d.splitk = splitk
     d.x6 = 1 if (X6 and os.environ.get("PASE_X6_WGRAD", "1") != "0") else 0
-    global LAST_WGRAD_X6
+    global LAST_WGRAD_X6, LAST_WGRAD_KIND
     LAST_WGRAD_X6 = False
+    LAST_WGRAD_KIND = 0
     if d.x6:
         # split-bf16 contraction (conv_x6c.hip, T-mode): one operand is packed into this scratch by the launch itself
         nbytes = _lib.lib().pase_wgrad_x6_bytes(C.byref(d))
@@ -347,6 +351,7 @@ def wgrad_gemm(g, z, dw, *, S, M, Tg, Ncols, Cin, Tz, taps, ldw=None, dbias=None
             gx6 = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
             d.gx6 = gx6.data_ptr()
             LAST_WGRAD_X6 = True
+            LAST_WGRAD_KIND = _lib.lib().pase_wgrad_plan_kind(C.byref(d))
     ev0 = GEMM_TIMER.start() if GEMM_TIMER is not None else None
     _check(_lib.lib().pase_wgrad_gemm(C.byref(d), _stream()), "pase_wgrad_gemm")
     if ev0 is not None:

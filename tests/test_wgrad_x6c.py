@@ -14,6 +14,14 @@ import torch.nn.functional as F
 from pase_amd import kernels as K
 
 
+@pytest.fixture(params=["1", "3"], ids=["staged-toeplitz", "plane-rows"])
+def wmode(request, monkeypatch):
+    """layers with taps: mode 1 stages the (channel, tap) columns of z, mode 3 reads (channel, tap) ROWS at 2-byte granularity
+    out of row-major bf16 planes of z and stages g"""
+    monkeypatch.setenv("PASE_X6C_WGRAD_MODE", request.param)
+    return request.param
+
+
 @pytest.fixture(autouse=True)
 def _x6_on(monkeypatch):
     # the library routes 1x1 weight gradients to the fp32 matrix pipe (faster there on every PASE+ shape); the T-mode
@@ -36,11 +44,13 @@ def _xf(x, sc, sh, al):
 
 @pytest.mark.parametrize("Cin,Cout,k,st,T,S", [
     (12, 130, 11, 1, 90, 3),       # two row tiles (second ragged), 132 + 1 columns: a second column tile for the bias column
-    (20, 70, 11, 2, 168, 2),       # stride 2, reflect padding on both sides, Ncols = 84 (not a multiple of 16)
+    (20, 100, 11, 2, 168, 2),      # stride 2, reflect padding on both sides, Ncols = 84 (not a multiple of 16)
     (6, 96, 20, 10, 400, 2),       # stride 10 (block 1 shape)
     (40, 200, 3, 1, 50, 4),        # short sequences: most k-groups touch the padding
+    (24, 130, 11, 1, 96, 3),       # aligned rows of g, whole chunks: the row-coalesced staging path (mode 3), two column tiles
+    (16, 140, 11, 2, 160, 3),      # ... with stride 2 (two phase rows per channel in the planes)
 ])
-def test_conv_weight_gradient(dev, Cin, Cout, k, st, T, S):
+def test_conv_weight_gradient(dev, wmode, Cin, Cout, k, st, T, S):
     torch.manual_seed(0)
     x = torch.randn(S, Cin, T)
     sc, sh, al = torch.rand(Cin) + 0.5, torch.randn(Cin) * 0.1, torch.rand(Cin) * 0.5
@@ -54,15 +64,15 @@ def test_conv_weight_gradient(dev, Cin, Cout, k, st, T, S):
     db = torch.zeros(Cout, device=dev)
     K.wgrad_gemm(g.to(dev), x.to(dev), dw, S=S, M=Cout, Tg=y.shape[2], Ncols=y.shape[2], Cin=Cin, Tz=T, taps=k, dbias=db,
                  in_scale=sc.to(dev), in_shift=sh.to(dev), in_alpha=al.to(dev), stride=st, padL=P[0], pad_mode=K.PAD_REFLECT)
-    assert K.LAST_WGRAD_X6
+    assert K.LAST_WGRAD_X6 and K.LAST_WGRAD_KIND == int(wmode)
     assert _rel(dw.view(Cout, Cin, k), w.grad) < 1e-6
     assert _rel(db, b.grad) < 1e-6
 
 
-def test_conv_transpose_weight_gradient(dev):
+def test_conv_transpose_weight_gradient(dev, wmode):
     """nn.ConvTranspose1d weight gradient: G = PReLU(layer input) at the low rate (g_alpha), Z = dY, zero padding."""
     torch.manual_seed(2)
-    S, Cin, Cout, k, st, T = 2, 70, 6, 30, 4, 24
+    S, Cin, Cout, k, st, T = 2, 100, 6, 30, 4, 24
     z_in = torch.randn(S, Cin, T)
     al = torch.rand(Cin) * 0.5
     w = torch.randn(Cin, Cout, k, dtype=torch.float64, requires_grad=True)
@@ -74,14 +84,14 @@ def test_conv_transpose_weight_gradient(dev):
     dw = torch.zeros(Cin, Cout * k, device=dev)
     K.wgrad_gemm(z_in.to(dev), g.to(dev), dw, S=S, M=Cin, Tg=T, Ncols=T, Cin=Cout, Tz=y.shape[2], taps=k, stride=st,
                  padL=pad, pad_mode=K.PAD_ZERO, g_alpha=al.to(dev))
-    assert K.LAST_WGRAD_X6
+    assert K.LAST_WGRAD_X6 and K.LAST_WGRAD_KIND == int(wmode)
     assert _rel(dw.view(Cin, Cout, k), w.grad) < 1e-6
 
 
-def test_reversed_taps(dev):
+def test_reversed_taps(dev, wmode):
     """tapstep = -1 (the QRNN's x_{t-1} tap as its own launch: taps = 1 shifted; here a 3-tap reversed window)."""
     torch.manual_seed(3)
-    S, Cin, M, k, T = 2, 24, 80, 3, 60
+    S, Cin, M, k, T = 2, 24, 100, 3, 60
     z = torch.randn(S, Cin, T)
     g = torch.randn(S, M, T)
     zp = F.pad(z.double(), (k - 1, 0))
@@ -90,12 +100,13 @@ def test_reversed_taps(dev):
     dw = torch.zeros(M, Cin * k, device=dev)
     K.wgrad_gemm(g.to(dev), z.to(dev), dw, S=S, M=M, Tg=T, Ncols=T, Cin=Cin, Tz=T, taps=k, tapstep=-1, padL=0,
                  pad_mode=K.PAD_ZERO)
-    assert K.LAST_WGRAD_X6
+    assert K.LAST_WGRAD_X6 and K.LAST_WGRAD_KIND == int(wmode)
     assert _rel(dw.view(M, Cin, k), ref) < 1e-6
 
 
 @pytest.mark.parametrize("S,Cin,Cout,T,gx,zx", [
     (3, 84, 273, 200, 0, 0),        # swapped: 273 output channels > 84 inputs; three column tiles, one ragged
+    (3, 70, 200, 64, 4, 1),         # swapped, row-coalesced staging of a channel slice of g
     (2, 130, 150, 36, 5, 7),        # swapped, channel slices of wider tensors on both operands
     (5, 256, 96, 20, 0, 3),         # normal orientation (rows = g): bias through the ones column
     (1, 200, 300, 52, 2, 0),        # one sequence, Ncols not a multiple of 16
