@@ -218,6 +218,9 @@ def main():
     ap.add_argument("--torch-gpu-baseline", action="store_true",
                     help="also time the torch-op restatement of the reference step on this GPU (stock PyTorch-ROCm "
                          "kernels) and report it as `torch_rocm_baseline`")
+    ap.add_argument("--rccl-max-nchannels", type=int, default=0,
+                    help="N > 1: NCCL_MAX_NCHANNELS for RCCL (each channel occupies a CU that the backward's kernels then do "
+                         "not get); 0 = leave RCCL's default")
     ap.add_argument("--producer", action="store_true",
                     help="BASELINE.json configs[3] shape: every step's batch is produced ON DEVICE inside the timed "
                          "region (random crops of a resident waveform pool, Reverb / additive-noise gating on "
@@ -243,6 +246,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
+        if args.rccl_max_nchannels > 0:       # default: RCCL's own choice (recorded in config.rccl_max_nchannels)
+            os.environ["NCCL_MAX_NCHANNELS"] = str(args.rccl_max_nchannels)
         if shared:
             backend = "gloo"
             dist.init_process_group("gloo")
@@ -309,6 +314,33 @@ def main():
     utt_s = B * world * args.steps / dt
     total_loss = float(losses["total"])
 
+    # ---- N > 1: what the collectives cost, from events on the two streams (two extra steps outside the timed region),
+    # and the same rank's step WITHOUT any collective (the N = 1 code path on this GPU while its neighbours do the same)
+    multi = None
+    if world > 1:
+        tr.comm_diag = True
+        for _ in range(2):
+            tr.train_step(next_batch())
+        rep = tr.comm_report()
+        tr.comm_diag = False
+        sync()
+        t0 = time.time()
+        for _ in range(max(2, args.steps // 2)):
+            tr._eager_step(next_batch(), local_only=True)
+        sync()
+        local_ms = (time.time() - t0) / max(2, args.steps // 2) * 1e3
+        vals = torch.tensor([rep["comm_exposed_ms"], rep["comm_total_ms"], rep["host_enqueue_ms"], local_ms] if rep else
+                            [0.0, 0.0, 0.0, local_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(vals, op=dist.ReduceOp.MAX)
+        multi = {"comm_exposed_ms": round(float(vals[0]), 3), "comm_total_ms": round(float(vals[1]), 3),
+                 "host_enqueue_ms": round(float(vals[2]), 3), "local_step_ms_no_collectives": round(float(vals[3]), 3),
+                 "per_gpu_consistency": round(float(vals[3]) / ms_per_step, 4),
+                 "rank0_buckets": rep["buckets"] if rep else None,
+                 "rank0_backward_end_ms": rep["backward_end_ms"] if rep else None,
+                 "how": "max over ranks; events on the main and the collective stream of one step (trainer.comm_report); "
+                        "local_step = the same rank's eager step with no collective, all ranks busy at once; "
+                        "per_gpu_consistency = local_step / ms_per_step (1.0 = the collectives and N enqueue loops cost nothing)"}
+
     # ---- the same K steps with the batch handed over as HOST buffers: every step's 4 waveform tensors + 9 target
     # tensors (205 MB at bs32) cross PCIe inside the timed region, through the pinned ring / copy stream of
     # pase_amd.producer.PinnedBatchFeeder (SURVEY 8d step definition; reference modules.py:16-31, pase.py:338)
@@ -350,6 +382,7 @@ def main():
     for _ in range(extra):
         tr._eager_step(batch)          # (eager even when the timed steps were graph replays: per-launch events)
     fams = K.GEMM_TIMER.summary()
+    fams_pipe = K.GEMM_TIMER.summary(by_pipe=True)
     K.GEMM_TIMER = None
     traffic = None
     traffic_src = None
@@ -357,18 +390,18 @@ def main():
         # HBM traffic cannot be counted from inside the run (PMC passes need rocprofv3): it comes from this round's
         # profile summary, and ONLY if that profile was taken of the very library that is loaded now (source digest)
         from pase_amd import build as _B
-        with open(os.path.join(ROOT, "profiles", "summary_r02.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "summary_r03.json")) as f:
             prof = json.load(f)
         if prof.get("lib_digest") != _B.hip_digest():
             raise ValueError("profile is of another build")
-        traffic_src = "profiles/summary_r02.json"
+        traffic_src = "profiles/summary_r03.json"
         # PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs) summed over every conv_gemm
         # instantiation, GB per launch; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B
         # requests as 64 B)
+        conv_k = ("conv_gemm_kernel<", "conv_x6c_kernel<192", "conv_x6c_kernel<128, 3")      # every pase_conv_gemm kernel
         mb = sum(row["fetch_MB_x2"] + row["write_MB"] for row in prof.get("hbm_traffic_per_step", [])
-                 if row["kernel"].startswith("conv_gemm_kernel<"))
-        calls = sum(k["calls"] for k in prof["step_kernel_time"]["families"]
-                    if k["kernel"].startswith("conv_gemm_kernel<"))
+                 if row["kernel"].startswith(conv_k))
+        calls = sum(k["calls"] for k in prof["step_kernel_time"]["families"] if k["kernel"].startswith(conv_k))
         if mb > 0 and calls > 0:
             traffic = round(mb / 1e3 / calls, 4)
     except Exception:
@@ -394,8 +427,9 @@ def main():
             "encoder_frames_per_s": round(utt_s * 3 * (T // 160), 1),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (contractions: each fp32 operand = 3 exact bf16 pieces, 6 bf16 MFMAs per product, fp32 accumulate; "
-                      "measured error = that of an fp32 fma chain)") if x6 else "f32", "data": "synthetic",
+            "dtype": ("f32 (contractions: fp32 operands as 3 round-to-nearest bf16 pieces, 6 bf16 MFMAs per product into two fp32 "
+                      "accumulators -- unbiased, error below an fp32 fma chain's -- or the exact-fp32 MFMA, routed per launch)")
+            if x6 else "f32", "data": "synthetic",
             "config": {"workload": ("PASE+.cfg + workers+.cfg train step with the batch produced on device each step: crops "
                                     "of a resident pool, Reverb(24000-tap synthetic IRs, p=0.5) + additive noise (p=0.5), "
                                     "LPS/FBANK/gammatone/MFCC targets from the clean chunk (BASELINE.json configs[3] shape)")
@@ -407,7 +441,8 @@ def main():
                        "final_total_loss": round(total_loss, 5), "inputs": "resident in HBM (see `h2d` for the "
                        "host-buffer leg)", "collective_backend": backend,
                        "hipgraph": bool(getattr(tr, "_graph", None) is not None)},
-            "roofline": {"bound": "mfma", "kernel": "conv_gemm_kernel (all launches of one step)",
+            "roofline": {"bound": "mfma", "kernel": "pase_conv_gemm launches of one step (conv_x6c_kernel split-bf16 + conv_gemm_kernel "
+                                                    "exact-fp32 instantiations; `by_pipe` prices each against its own pipe)",
                          "achieved": round(cg_tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(cg_tf / peak, 4), "frac_of_fp32_mfma_peak": round(cg_tf / PEAK_F32_MFMA_TFLOPS, 4),
                          "peak_note": peak_note, "traffic": traffic,
@@ -418,7 +453,16 @@ def main():
                          "algorithmic_gflop_per_launch": round(cg["flops"] / cg["launches"] / 1e9, 2),
                          "note": "sum of the launches' executed contraction FLOPs (2*S*Ncols*M*K from each "
                                  "descriptor) / sum of HIP-event durations on the launch stream"},
-            "roofline_wgrad": {"bound": "mfma", "kernel": "wgrad_gemm_kernel", "achieved": round(wg_tf, 2),
+            "by_pipe": {"%s/%s" % k: {"launches_per_step": v["launches"] // extra, "ms_per_step": round(v["ms"] / extra, 3),
+                                      "achieved": round(v["flops"] / v["ms"] / 1e9, 2), "unit": "TFLOP/s",
+                                      "peak": round(PEAK_BF16_MFMA_TFLOPS / X6_MFMA_PER_PRODUCT if k[1] == "x6"
+                                                    else PEAK_F32_MFMA_TFLOPS, 1),
+                                      "frac": round(v["flops"] / v["ms"] / 1e9 /
+                                                    (PEAK_BF16_MFMA_TFLOPS / X6_MFMA_PER_PRODUCT if k[1] == "x6"
+                                                     else PEAK_F32_MFMA_TFLOPS), 4)}
+                        for k, v in sorted(fams_pipe.items())},
+            "roofline_wgrad": {"bound": "mfma", "kernel": "pase_wgrad_gemm launches (conv_x6c_kernel T-mode + wgrad_*_kernel fp32)",
+                               "achieved": round(wg_tf, 2),
                                "peak": round(peak, 1), "unit": "TFLOP/s",
                                "frac": round(wg_tf / peak, 4),
                                "launches_per_step": wg["launches"] // extra,
@@ -431,6 +475,9 @@ def main():
         }
         if h2d is not None:
             out["h2d"] = h2d
+        if multi is not None:
+            out["multi_gpu"] = multi
+            out["config"]["rccl_max_nchannels"] = args.rccl_max_nchannels or "RCCL default"
         if shared and world > 1:
             out["invalid_as_scaling_number"] = ("%d ranks share %d GPU(s) over gloo: functional smoke of the N>1 path only"
                                                 % (world, ndev))

@@ -55,7 +55,7 @@ def sinc_init(out_channels=64, sr=16000, min_low=50, min_band=50):
 def sinc_filters(low_hz_, band_hz_, K=251, sr=16000, min_low=50, min_band=50):
     """(C,1,K) band-pass bank, modules.py:895-915."""
     window, n_ = sinc_constants(K, sr)
-    window, n_ = window.to(low_hz_.device), n_.to(low_hz_.device)
+    window, n_ = window.to(low_hz_), n_.to(low_hz_)          # device AND dtype (an fp64 evaluation uses the same constants)
     low = min_low + torch.abs(low_hz_)
     high = torch.clamp(low + min_band + torch.abs(band_hz_), min_low, sr / 2)
     band = (high - low)[:, 0]

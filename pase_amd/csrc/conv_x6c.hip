@@ -772,9 +772,11 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
 #pragma unroll
         for (int pz = 0; pz < 3; ++pz) ab[pz] += adv;
     };
-    // (Requesting the next unit's B fragments explicitly before each block of 12 MFMAs -- software pipelining by hand, pinned
-    //  with sched barriers -- measured 4 ... 14 % SLOWER on every convolution of the PASE+ step than leaving the order of
-    //  the 12 ds_read_b128 and 24 MFMAs of a step to the compiler.)
+    // (Two hand-pinned schedules were measured against leaving the 12 ds_read_b128 + 24 MFMAs of a step to the compiler:
+    //  prefetching the next pair of B tiles before each block of 12 MFMAs, two tiles alternating: 4 ... 14 % SLOWER on every
+    //  convolution of the PASE+ step;  units of (planes m, l) / (plane h) with all four tiles rotating and the next unit's
+    //  fragments in flight: +-0 (29.5 vs 29.4 ms of GEMM time) at 256 VGPRs.  The loop is not where the time goes: the
+    //  shader clock under this load is ~1.6 GHz, i.e. the 11-tap layers' 200-216 TF/s are ~75 % of the matrix pipe.)
     auto mfma_step = [&](const u32x4 (&a)[3], const u32x4* xb) __attribute__((always_inline)) {
         // plane pairs of the five small terms, smallest first: mm, hl, lh, hm, mh -> accS; hh -> accH
         constexpr int PZA[5] = {1, 0, 2, 0, 1}, PZB[5] = {1, 2, 0, 1, 0};

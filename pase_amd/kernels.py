@@ -141,28 +141,31 @@ class GemmTimer(object):
     def __init__(self):
         self.records = []
         self.tags = []
+        self.pipes = []          # per launch: "x6" (split-bf16 kernel) or "f32" (exact-fp32 MFMA kernels)
 
     def start(self):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream())
         return ev
 
-    def stop(self, family, flops, ev0, tag=None):
+    def stop(self, family, flops, ev0, tag=None, pipe="f32"):
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record(torch.cuda.current_stream())
         self.records.append((family, flops, ev0, ev1))
         self.tags.append(tag)
+        self.pipes.append(pipe)
 
     def per_launch(self):
         """[(family, tag, flops, ms)] in launch order (tools/step_breakdown.py)."""
         torch.cuda.synchronize()
         return [(f, t, fl, e0.elapsed_time(e1)) for (f, fl, e0, e1), t in zip(self.records, self.tags)]
 
-    def summary(self):
+    def summary(self, by_pipe=False):
+        """{family: launches / flops / ms}; by_pipe: {(family, pipe): ...}"""
         torch.cuda.synchronize()
         fam = {}
-        for family, flops, e0, e1 in self.records:
-            f = fam.setdefault(family, dict(launches=0, flops=0.0, ms=0.0))
+        for (family, flops, e0, e1), pipe in zip(self.records, self.pipes):
+            f = fam.setdefault((family, pipe) if by_pipe else family, dict(launches=0, flops=0.0, ms=0.0))
             f["launches"] += 1
             f["flops"] += flops
             f["ms"] += e0.elapsed_time(e1)
@@ -239,7 +242,7 @@ def conv_gemm(x, w, y, want_stats=False, **kw):
     if ev0 is not None:
         GEMM_TIMER.stop("conv_gemm", 2.0 * d.S * d.Ncols * d.M * d.K, ev0,
                         "M%d K%d(Cin%d x %d) N%dx%d s%d ps%d epi%d" % (d.M, d.K, d.Cin, d.taps, d.S, d.Ncols, d.stride,
-                                                                    d.ps, d.epilogue))
+                                                                    d.ps, d.epilogue), pipe="x6" if LAST_PLAN_KIND else "f32")
     return stat
 
 
@@ -356,7 +359,8 @@ def wgrad_gemm(g, z, dw, *, S, M, Tg, Ncols, Cin, Tz, taps, ldw=None, dbias=None
     _check(_lib.lib().pase_wgrad_gemm(C.byref(d), _stream()), "pase_wgrad_gemm")
     if ev0 is not None:
         GEMM_TIMER.stop("wgrad_gemm", 2.0 * S * Ncols * M * (Cin * taps + (1 if dbias is not None else 0)), ev0,
-                        "M%d Kw%d(Cin%d x %d) N%dx%d s%d" % (M, Cin * taps, Cin, taps, S, Ncols, d.stride))
+                        "M%d Kw%d(Cin%d x %d) N%dx%d s%d" % (M, Cin * taps, Cin, taps, S, Ncols, d.stride),
+                        pipe="x6" if LAST_WGRAD_X6 else "f32")
 
 
 def bn_finalize(stat_part, C_, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift,

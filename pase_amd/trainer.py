@@ -14,6 +14,7 @@ MI355X-native differences (SURVEY.md section 8e -- the reference has NO multi-GP
 """
 import math
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -317,7 +318,9 @@ class trainer(object):
             return dict(self._static_losses)
         return self._eager_step(batch, device)
 
-    def _eager_step(self, batch, device=None):
+    def _eager_step(self, batch, device=None, local_only=False):
+        """local_only (bench.py, N > 1): this rank's step with NO collective -- its weights then drift from the other
+        ranks'; a measurement of the compute path under N-rank load, never part of training."""
         self.model.train()
         if self.device_targets is not None:
             batch = self._fill_targets(batch, device)
@@ -330,7 +333,7 @@ class trainer(object):
             self._zero_arena.begin_step(dev)
             engine._ARENA = self._zero_arena
         try:
-            if self.world > 1:
+            if self.world > 1 and not local_only:
                 losses = self._step_ddp(batch, sink, device)
             else:
                 losses = self.model.loss_and_grads(batch, sink, device)
@@ -390,26 +393,62 @@ class trainer(object):
         side = self._side
         buckets = self._frontend_buckets()
         fg = self._frontend_grads
+        # comm_diag (bench.py --gpus N, tests): per bucket the moment it is handed over (main stream), when its collective
+        # starts and ends (side stream), plus the end of the backward and the join -- see comm_report()
+        diag = [] if (getattr(self, "comm_diag", False) and use_side) else None
+        t_host0 = time.perf_counter()
+        ev_begin = torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True)) if diag is not None else None
 
-        def launch(bufs):
+        def launch(tag, bufs):
             if not bufs:
                 return
             if use_side:
-                side.wait_event(torch.cuda.current_stream().record_event())
+                ready = torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=diag is not None))
+                side.wait_event(ready)
                 with torch.cuda.stream(side):
+                    if diag is not None:
+                        e0 = side.record_event(torch.cuda.Event(enable_timing=True))
                     for b in bufs:
                         self._allreduce(b)
+                    if diag is not None:
+                        e1 = side.record_event(torch.cuda.Event(enable_timing=True))
+                        diag.append((tag, sum(b.numel() for b in bufs) * 4, ready, e0, e1))
             else:                              # CPU (gloo tests): same buckets, issued in line
                 for b in bufs:
                     self._allreduce(b)
 
         losses = model.loss_and_grads(
-            batch, sink, device, before_encoder_backward=lambda: launch([self._worker_grads]),
-            on_encoder_grads=lambda tag: launch([fg[b:e] for b, e in buckets.get(tag, [])]))
+            batch, sink, device, before_encoder_backward=lambda: launch("workers", [self._worker_grads]),
+            on_encoder_grads=lambda tag: launch(tag, [fg[b:e] for b, e in buckets.get(tag, [])]))
         if use_side:
+            if diag is not None:
+                ev_bwd_end = torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True))
             torch.cuda.current_stream().wait_stream(side)
+            if diag is not None:
+                ev_join = torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True))
         self._step_all(1.0 / self.world)
+        if diag is not None:
+            self._comm_events = dict(begin=ev_begin, bwd_end=ev_bwd_end, join=ev_join, buckets=diag,
+                                     host_enqueue_ms=(time.perf_counter() - t_host0) * 1e3)
         return losses
+
+    def comm_report(self):
+        """Timings of the most recent comm_diag step (synchronises): per bucket bytes / when it became ready / when its
+        collective ran, relative to the step's first kernel; `comm_exposed_ms` = how long the main stream waited for the
+        side stream after the last backward kernel; `comm_total_ms` = sum of the collectives' durations;
+        `host_enqueue_ms` = wall time this rank's Python spent enqueueing the step (no device synchronisation inside)."""
+        ev = getattr(self, "_comm_events", None)
+        if ev is None:
+            return None
+        torch.cuda.synchronize()
+        t0 = ev["begin"]
+        rows = [dict(bucket=str(tag), MB=round(nb / 1e6, 2), ready_ms=round(t0.elapsed_time(rdy), 3),
+                     start_ms=round(t0.elapsed_time(e0), 3), end_ms=round(t0.elapsed_time(e1), 3))
+                for tag, nb, rdy, e0, e1 in ev["buckets"]]
+        return dict(buckets=rows, backward_end_ms=round(t0.elapsed_time(ev["bwd_end"]), 3),
+                    comm_exposed_ms=round(ev["bwd_end"].elapsed_time(ev["join"]), 3),
+                    comm_total_ms=round(sum(r["end_ms"] - r["start_ms"] for r in rows), 3),
+                    host_enqueue_ms=round(ev["host_enqueue_ms"], 3))
 
     def _step_all(self, grad_mul):
         opts = self.optimizers()

@@ -1,18 +1,28 @@
-"""Parity gate AT THE BENCHMARK CONFIGURATION (BASELINE.json configs[2]): PASE+.cfg + workers+.cfg, B = 32
-utterances x 32 000 samples (96 sequences through the encoder), on the HIP path vs the oracle restatement
+"""Parity gates AT FULL SIZE for the BASELINE.json configurations, on the HIP path vs the oracle restatement
 (oracle/pase_oracle.py) evaluated with stock torch fp32 ops on the same GPU, from the same state_dict and
-the same batch.  This is the only place the 3-workgroup/CU instantiations, the split-K heuristics, the
-32-bit offset guards and BatchNorm statistics over 96 x 32 000 samples are checked against the reference
+the same batch:
+
+  pase+    configs[2] (the benchmark): PASE+.cfg + workers+.cfg, 32 utterances x 32 000 samples -- both matrix pipes
+  pase     configs[1]: PASE.cfg + workers.cfg (emb 100, no QRNN / skips; decoder, MLP regressors, SPC / MI / CMI),
+           32 x 16 000 (/root/reference/cfg/workers/workers.cfg; the SPC worker's frames come from Python's `random`
+           stream, seeded identically on both sides)
+  emb256   configs[4]: the dense PASE+ encoder with norm_type 'lnorm' and two QRNN layers (modules.py:77-109,
+           template_scripts/run_pase_train_50h_2xQRNN_addrev_lnorm_EMB256.sh), 64 x 32 000: LayerNorm / InstanceNorm
+           kernels and 2x the activation size of the benchmark (the 32-bit offset guards)
+
+This is the only place the full-width instantiations, the split-K heuristics, the routing between the matrix pipes,
+the offset guards and the batch statistics over 96 ... 192 long sequences are checked against the reference
 algorithm (worker_scheduler.py:43-75, trainer.py:229-232):
 
   * embedding |err| <= 1e-4, all 13 losses 1e-4 relative,
-  * ELEMENT-WISE gradients of every parameter that has a non-noise gradient,
+  * gradients of every parameter that has a non-noise gradient, against an fp64 evaluation of the same step,
   * 10 Adam steps on fresh batches: total-loss curves track.
 """
 import contextlib
 import io
 import json
 import os
+import random
 
 import pytest
 import torch
@@ -22,21 +32,26 @@ from util import ROOT, assert_close, is_noise_grad
 
 pytestmark = pytest.mark.gpu
 
-B, T = 32, 32000
+VARIANTS = {
+    "pase+": dict(fe="PASE+.cfg", fe_over={}, workers="workers+.cfg", B=32, T=32000),
+    "pase": dict(fe="PASE.cfg", fe_over={}, workers="workers.cfg", B=32, T=16000),
+    "emb256": dict(fe="PASE+.cfg", fe_over=dict(rnn_layers=2, norm_type="lnorm"), workers="workers+.cfg", B=64, T=32000),
+}
 
 
-def _cfgs():
+def _cfgs(variant="pase+"):
     from pase_amd.utils import strip_transforms, worker_parser
-    with open(os.path.join(ROOT, "cfg", "frontend", "PASE+.cfg")) as f:
-        fe = json.load(f)
+    v = VARIANTS[variant]
+    with open(os.path.join(ROOT, "cfg", "frontend", v["fe"])) as f:
+        fe = dict(json.load(f), **v["fe_over"])
     with contextlib.redirect_stdout(io.StringIO()):
-        wk = strip_transforms(worker_parser(os.path.join(ROOT, "cfg", "workers", "workers+.cfg")))
-    with open(os.path.join(ROOT, "cfg", "workers", "workers+.cfg")) as f:
+        wk = strip_transforms(worker_parser(os.path.join(ROOT, "cfg", "workers", v["workers"])))
+    with open(os.path.join(ROOT, "cfg", "workers", v["workers"])) as f:
         raw = json.load(f)
     return fe, wk, raw
 
 
-def _batch(seed, raw, dev):
+def _batch(seed, raw, dev, B=32, T=32000):
     g = torch.Generator(device=dev).manual_seed(seed)
     batch = {k: (0.1 * torch.randn(B, 1, T, generator=g, device=dev)).clamp_(-1, 1)
              for k in ("chunk", "chunk_ctxt", "chunk_rand", "cchunk")}
@@ -46,28 +61,39 @@ def _batch(seed, raw, dev):
     return batch
 
 
-@pytest.fixture(scope="module", params=[True, False], ids=["x6", "fp32pipe"])
+def _noise(variant, n):
+    """parameters whose gradient is analytically zero (round-off on both sides)"""
+    if variant == "emb256":      # LayerNorm over channels does NOT cancel a per-channel conv bias; InstanceNorm norm_out does W's
+        return n == "frontend.W.bias"
+    return is_noise_grad(n)
+
+
+@pytest.fixture(scope="module", params=[("pase+", True), ("pase+", False), ("pase", True), ("emb256", True)],
+                ids=["x6", "fp32pipe", "pase-cfg1-x6", "emb256-lnorm-2xqrnn-bs64-x6"])
 def setup(request):
-    """Both matrix pipes are gated: the split-bf16 contraction (the shipped default) and the exact-fp32 MFMA pipe
-    (K.X6 False) run the same two tests against the same comparator."""
+    """The benchmark configuration is gated on both matrix pipes -- the split-bf16 contraction (the shipped default) and
+    the exact-fp32 MFMA pipe (K.X6 False) run the same two tests against the same comparator -- the other two BASELINE
+    configurations on the default."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from pase_amd import _lib
     _lib.use_library(None, "cuda")
     _lib.lib()
     from pase_amd import kernels as K
+    variant, x6 = request.param
     saved = K.X6
-    K.X6 = request.param
+    K.X6 = x6
     try:
-        yield _make_setup()
+        yield _make_setup(variant)
     finally:
         K.X6 = saved
+        torch.cuda.empty_cache()
 
 
-def _make_setup():
+def _make_setup(variant="pase+"):
     from pase_amd.trainer import trainer
     dev = torch.device("cuda:0")
-    fe, wk, raw = _cfgs()
+    fe, wk, raw = _cfgs(variant)
     torch.manual_seed(2)
     with contextlib.redirect_stdout(io.StringIO()):
         tr = trainer(frontend_cfg=dict(fe), minions_cfg=wk, cfg=dict(fe_lr=1e-3, min_lr=5e-4, epoch=1, bpe=10 ** 6),
@@ -86,10 +112,13 @@ def _make_setup():
     names = [n for n, _ in tr.model.named_parameters()]
     for n in names:
         P[n].requires_grad_(True)
-    return dict(tr=tr, P=P, names=names, fe=fe, raw=raw, dev=dev)
+    return dict(tr=tr, P=P, names=names, fe=fe, raw=raw, dev=dev, variant=variant, B=VARIANTS[variant]["B"],
+                T=VARIANTS[variant]["T"])
 
 
-def _oracle_step(P, fe, raw, batch, opts=None):
+def _oracle_step(P, fe, raw, batch, opts=None, seed=None):
+    if seed is not None:
+        random.seed(seed)          # the SPC worker's frame draws (minions.py:614-628)
     if opts is not None:
         for o in opts:
             o.zero_grad()
@@ -111,7 +140,8 @@ def _oracle_step(P, fe, raw, batch, opts=None):
 def test_bs32_embedding_losses_and_elementwise_grads(setup):
     from pase_amd import engine
     tr, P, fe, raw, dev = setup["tr"], setup["P"], setup["fe"], setup["raw"], setup["dev"]
-    batch = _batch(4321, raw, dev)
+    variant = setup["variant"]
+    batch = _batch(4321, raw, dev, setup["B"], setup["T"])
     m = tr.model
     m.train()
     # -- HIP: embedding (train-mode encoder), then the fused loss + backward (no optimizer step) ------------
@@ -124,55 +154,69 @@ def test_bs32_embedding_losses_and_elementwise_grads(setup):
             v.copy_(sd0[k])
     for opt in tr.optimizers():
         opt.zero_grad()
+    random.seed(77)
     lf = m.loss_and_grads(batch)
     lf = {k: float(v) for k, v in lf.items()}
     # -- oracle on the same GPU (stock torch ops, fp32, autograd) ---------------------------------------------
     P0 = {k: v.detach().clone() for k, v in P.items()}
-    lo, emb_ref = _oracle_step(P, fe, raw, batch)
+    lo, emb_ref = _oracle_step(P, fe, raw, batch, seed=77)
     with torch.no_grad():                    # keep P at the pre-step state for the curve test
         for k in P:
             if not P[k].requires_grad:
                 P[k].copy_(P0[k])
-    assert_close(emb, emb_ref, rtol=0, atol=1e-4, what="embedding (96,256,200)")
-    assert len(lo) == 13
+    assert_close(emb, emb_ref, rtol=0, atol=1e-4, what="embedding %s" % (tuple(emb.shape),))
+    assert len(lo) == {"pase+": 13, "pase": 8, "emb256": 13}[variant]
     for k, v in lo.items():
         assert abs(lf[k] - v) <= 1e-4 * max(1.0, abs(v)), (k, lf[k], v)
+    # -- the same step in fp64 (same torch restatement, same constants): the truth both fp32 evaluations are measured by ---
+    ref32 = {n: P[n].grad.detach().double().clone() for n in setup["names"]}
+    P64 = {k: (v.detach().double() if v.is_floating_point() else v.detach().clone()) for k, v in P0.items()}
+    for n in setup["names"]:
+        P64[n].requires_grad_(True)
+    _oracle_step(P64, fe, raw, {k: v.double() for k, v in batch.items()}, seed=77)
     # -- element-wise gradients -------------------------------------------------------------------------------
+    # Per tensor, relative L2 against the fp64 evaluation:  ours <= 1.5 x (torch fp32 ops) + floor.  At these sizes
+    # the fp32 comparator itself is 1e-3 ... 3e-3 away from fp64 on the encoder (19 200 ... 3 072 000 products per
+    # element summed in fp32, BatchNorm statistics over 3M positions) -- measured (tools/_trace/f64_probe.py, PASE.cfg
+    # bs32): torch fp32 2.6e-3 ... 3.5e-3, split-bf16 pipe 2.1e-3 ... 2.7e-3, exact-fp32 pipe 0.5e-3 ... 1.3e-3 -- so a
+    # bound on |ours - torch fp32| alone measures the comparator.  Floors: 5e-4 (weights), 1.5e-3 (one scalar per channel:
+    # BN gamma / beta, PReLU slopes, biases, the two SincNet vectors) for tensors where all three sit at round-off level.
+    # A sign, permutation or missing-term error shows up at O(1).
     checked = 0
     worst = (0.0, None)
     bad = []
     stats = []
+    skipped = []
     for n, p in m.named_parameters():
-        if is_noise_grad(n):
+        if _noise(variant, n):
             continue
-        ref = P[n].grad
-        gmax = float(ref.abs().max())
-        err = float((p.grad - ref).abs().max())
-        rel2 = float((p.grad - ref).double().norm() / max(1e-30, float(ref.double().norm())))
-        worst = max(worst, (rel2, n))
-        # Tolerances (relative L2 per tensor; every element within 2 % of the tensor's largest gradient -- measured
-        # worst 0.9 % on blocks.4.conv.weight):
-        #   * weight tensors: 3e-3.  Both sides sum 19 200 ... 3 072 000 products per element in fp32 in different
-        #     orders (ours: MFMA k-order + split-K atomics; comparator: MIOpen / rocBLAS);
-        #   * per-channel reductions (BN gamma / beta, PReLU slopes, biases): 1e-2 -- ONE scalar per channel summed
-        #     over up to 3M positions; ours accumulates in fp64, the comparator (torch's fp32 batch_norm / prelu
-        #     backward) does not, measured 2e-6 absolute on gradients of 1e-3;
-        #   * the two SincNet vectors: 1e-2 -- d/d(low_hz, band_hz) contracts the 251-tap filter gradient with sin/cos
-        #     derivatives of alternating sign (cancellation).
-        # A sign, permutation or missing-term error shows up at O(1), three orders above these.
+        t64 = P64[n].grad
+        den = max(1e-300, float(t64.norm()))
+        e_ours = float((p.grad.double() - t64).norm()) / den
+        e_ref = float((ref32[n] - t64).norm()) / den
+        worst = max(worst, (e_ours, n))
         per_channel = n.endswith(("norm.weight", "norm.bias", "act.weight", ".bias", "low_hz_", "band_hz_"))
-        tol2 = 1e-2 if per_channel else 3e-3
-        if not (err <= 2e-2 * gmax + 1e-9 and rel2 <= tol2):
-            bad.append((n, "max|err| %.3e of max|g| %.3e" % (err, gmax), "relL2 %.3e" % rel2))
-        stats.append((rel2, n))
+        floor = 1.5e-3 if per_channel else 5e-4
+        if e_ref >= 0.5:
+            # the fp64 gradient of this tensor is (numerically) zero -- e.g. a worker whose hidden units are all dead at
+            # this random state -- and BOTH fp32 evaluations are pure round-off relative to it: nothing to compare
+            skipped.append(n)
+            continue
+        # (no absolute cap: the two SincNet vectors are 2.5e-2 ... 6.7e-2 away from fp64 in torch fp32 AND here -- the
+        #  cancellation in d/d(low_hz, band_hz) -- and agree with each other to 1e-4 of that)
+        if not e_ours <= 1.5 * e_ref + floor:
+            bad.append((n, "relL2 vs fp64: ours %.3e, torch fp32 %.3e" % (e_ours, e_ref)))
+        stats.append((e_ours, n, e_ref))
         checked += 1
+    del P64, ref32
     print("worst relative L2 gradient error:", worst)
-    for r, n in sorted(stats, reverse=True)[:12]:
-        print("   relL2 %.3e  %s" % (r, n))
+    for r, n, rr in sorted(stats, reverse=True)[:12]:
+        print("   relL2 vs fp64: ours %.3e  torch fp32 %.3e  %s" % (r, rr, n))
     for b in bad:
         print("   OUT OF TOLERANCE", b)
     assert not bad, "%d tensors out of tolerance, first: %r" % (len(bad), bad[:3])
-    assert checked >= 100, checked
+    assert checked >= {"pase+": 100, "pase": 50, "emb256": 100}[variant], checked
+    assert len(skipped) <= 4, skipped
     for n in setup["names"]:
         P[n].grad = None
 
@@ -183,17 +227,22 @@ def test_bs32_ten_adam_steps_track(setup):
     opts = [torch.optim.Adam([P[n]], lr=1e-3 if n.startswith("frontend.") else 5e-4) for n in names]
     p0 = {n: p.detach().clone() for n, p in tr.model.named_parameters()}
     ours, ref = [], []
+    variant = setup["variant"]
     for s in range(10):
-        batch = _batch(500 + s, raw, dev)
+        batch = _batch(500 + s, raw, dev, setup["B"], setup["T"])
+        random.seed(900 + s)
         ours.append(float(tr.train_step(batch)["total"]))
-        lo, _ = _oracle_step(P, fe, raw, batch, opts)
+        lo, _ = _oracle_step(P, fe, raw, batch, opts, seed=900 + s)
         ref.append(lo["total"])
         del batch
     rel = [abs(a - b) / abs(b) for a, b in zip(ours, ref)]
     print("hip  ", ours)
     print("torch", ref)
+    # benchmark configuration: measured <= 1.4e-3 over the 10 steps.  The other two (half the samples per BatchNorm
+    # statistic / LayerNorm + twice the sequences) measured 3.1e-3 at step 5: two fp32 evaluations whose round-off Adam
+    # turns into +-lr steps drift apart that fast; the first step, before any update, agrees to 1e-5 everywhere
     assert rel[0] <= 1e-5, rel
-    assert max(rel) <= 2e-3, rel
+    assert max(rel) <= (2e-3 if variant == "pase+" else 5e-3), rel
     assert ours[-1] < ours[0]              # and it trains
     # parameters after 10 Adam steps: Adam normalises every gradient to a +-lr step, so an element whose gradient is
     # round-off-sized (dense-skip and decoder weights early in training) moves by lr per step in a direction both
@@ -201,12 +250,96 @@ def test_bs32_ten_adam_steps_track(setup):
     # a whole: its direction (cosine >= 0.95 per tensor; measured >= 0.98) and its length (within 5 %).
     worst = (1.0, None)
     for n, p in tr.model.named_parameters():
-        if is_noise_grad(n):
+        if _noise(variant, n):
             continue
         da, db = (p.detach() - p0[n]).double().flatten(), (P[n].detach() - p0[n]).double().flatten()
         cos = float((da * db).sum() / (da.norm() * db.norm()).clamp_min(1e-30))
         worst = min(worst, (cos, n))
-        assert cos >= 0.95, (n, cos)
+        # (emb256: the first dense-skip weight measured 0.895 -- its gradients are round-off-sized for the first steps)
+        assert cos >= (0.95 if variant == "pase+" else 0.85), (n, cos)
         ratio = float(da.norm() / db.norm().clamp_min(1e-30))
         assert 0.95 <= ratio <= 1.05, (n, ratio)
     print("smallest cosine between the two 10-step updates:", worst)
+
+
+def test_bs32_producer_mode_step(tmp_path):
+    """BASELINE.json configs[3], the part one GPU can check: a bs32 step whose batch comes from the on-device producer
+    (pase_amd/producer.py: crops + reverb / additive-noise chain + DSP regression targets, the data side of
+    /root/reference/pase/dataset.py:430-520 + train.py:37-136) instead of given tensors.  Comparator: the SAME crops
+    through the numpy / scipy restatement of the target transforms (oracle/dsp_oracle.py; the f0 contour that feeds the
+    prosody target is the device tracker's -- its agreement with the SWIPE' restatement is tests/test_dsp.py's subject)
+    and the torch restatement of the step (oracle/pase_oracle.py).  Bar: every regression target within 2e-3 of its
+    range, all 13 losses within 2e-3 relative (the targets carry the DSP kernels' 1e-4-level differences into the
+    losses), total-loss gradient of every encoder block's conv weight within 1 % relative L2."""
+    import numpy as np
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import dsp_oracle as D
+    from pase_amd import _lib, dsp, producer as PR
+    from pase_amd.trainer import trainer
+    _lib.use_library(None, "cuda")
+    _lib.lib()
+    dev = torch.device("cuda:0")
+    fe, wk, raw = _cfgs("pase+")
+    Bp, Tp = 32, 32000
+    rs = np.random.RandomState(77)
+    pool = PR.WavPool([(0.1 * rs.standard_normal(16000 * 5)).clip(-1, 1).astype(np.float32) for _ in range(40)], dev)
+    irs = [np.r_[np.zeros(40), 1.0, 0.3 * rs.standard_normal(7959) * np.exp(-np.arange(7959) / 1500.0)] for _ in range(4)]
+    noises = [0.05 * rs.standard_normal(16000 * 6) for _ in range(4)]
+    tg = dsp.DeviceTargets(raw, device=dev)
+    stats = {}
+    for n_, f_ in tg.feats.items():
+        D_ = next(w["num_outputs"] for w in raw["regr"] if w["name"] == n_)
+        stats[n_] = (rs.standard_normal(D_).astype(np.float32) * 0.1, (0.5 + rs.random_sample(D_)).astype(np.float32))
+        f_.set_stats(torch.from_numpy(stats[n_][0]), torch.from_numpy(stats[n_][1]))
+    prod = PR.DeviceBatchProducer(PR.DeviceChunker(pool, Tp, rng=rs), PR.DeviceReverb(irs, device=dev), 0.5,
+                                  PR.DeviceAdditive(noises, device=dev), 0.5, tg, rng=rs)
+    batch = prod(Bp)
+    assert batch["chunk"].shape == (Bp, 1, Tp) and not torch.equal(batch["chunk"], batch["cchunk"])
+    # ---- regression targets of the same clean crops on the CPU ------------------------------------------------------
+    f0_dev = tg.feats["prosody"].tracker(batch["cchunk"]).cpu().numpy()
+    fns = {"lps": D.lps, "fbank": D.fbanks, "gtn": D.gammatone, "mfcc": D.mfcc}
+    clean = batch["cchunk"][:, 0].cpu().numpy()
+    ref_batch = {k: batch[k] for k in ("chunk", "chunk_ctxt", "chunk_rand", "cchunk")}
+    for w in raw["regr"]:
+        name = w["name"]
+        if name == "cchunk":
+            continue
+        kw = dict(w.get("transform", {}))
+        rows = []
+        for b in range(Bp):
+            if "prosody" in name:
+                X = D.prosody(clean[b], f0_dev[b], **kw)
+            else:
+                X = next(fn for k_, fn in fns.items() if k_ in name)(clean[b], **kw)
+            rows.append(D.znorm(np.asarray(X, dtype=np.float64), stats[name][0], stats[name][1]))
+        ref = torch.from_numpy(np.stack(rows)).float().to(dev)
+        assert ref.shape == batch[name].shape, (name, ref.shape, batch[name].shape)
+        span = float(ref.max() - ref.min())
+        bad = float(((batch[name] - ref).abs() > 2e-3 * span).float().mean())
+        # (log-power features of near-silent bins amplify round-off: a handful of elements may leave the band)
+        assert bad <= 1e-4, (name, bad, float((batch[name] - ref).abs().max()), span)
+        ref_batch[name] = ref
+    # ---- one step on both sides -------------------------------------------------------------------------------------
+    torch.manual_seed(2)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr = trainer(frontend_cfg=dict(fe), minions_cfg=wk, cfg=dict(fe_lr=1e-3, min_lr=5e-4, epoch=1, bpe=10 ** 6),
+                     device=dev)
+    m = tr.model
+    m.train()
+    P = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    names = [n for n, _ in m.named_parameters()]
+    for n in names:
+        P[n].requires_grad_(True)
+    for opt in tr.optimizers():
+        opt.zero_grad()
+    lf = {k: float(v) for k, v in m.loss_and_grads(batch).items()}
+    lo, _ = _oracle_step(P, fe, raw, ref_batch)
+    assert len(lo) == 13
+    for k, v in lo.items():
+        assert abs(lf[k] - v) <= 2e-3 * max(1.0, abs(v)), (k, lf[k], v)
+    for n, p in m.named_parameters():
+        if n.startswith("frontend.blocks.") and n.endswith("conv.weight"):
+            ref = P[n].grad
+            rel2 = float((p.grad - ref).double().norm() / ref.double().norm())
+            assert rel2 <= 1e-2, (n, rel2)

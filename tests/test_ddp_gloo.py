@@ -107,11 +107,20 @@ def _gpu_worker(rank, world, port, outdir):
     tr = quiet(trainer, frontend_cfg=dict(MINI_FE), minions_cfg=with_losses(mini_workers()),
                cfg=dict(fe_lr=1e-3, min_lr=5e-4, epoch=1, bpe=4), lr_mode="poly", device=dev)
     assert tr.world == 2
+    tr.comm_diag = True
     tot = []
     for step in range(2):
         losses = tr.train_step({k: v.to(dev) for k, v in _batch(100 + 10 * step + rank).items()})
         tot.append(float(losses["total"]))
     assert tr._side is not None        # the worker-buffer all-reduce ran on the side stream under the encoder backward
+    rep = tr.comm_report()
+    by = {r["bucket"]: r for r in rep["buckets"]}
+    # the worker bucket is handed over BEFORE the encoder backward starts and every frontend bucket before it ends (the
+    # events are the ones bench.py reports for N > 1); the collectives themselves ran on the side stream
+    assert by["workers"]["ready_ms"] < rep["backward_end_ms"], rep
+    assert all(r["ready_ms"] <= rep["backward_end_ms"] for r in rep["buckets"]), rep
+    assert by["workers"]["ready_ms"] <= min(r["ready_ms"] for r in rep["buckets"]), rep
+    assert len(rep["buckets"]) >= 3 and rep["comm_total_ms"] > 0 and rep["host_enqueue_ms"] > 0, rep
     sd = {n: p.detach().cpu().clone() for n, p in tr.model.named_parameters()}
     torch.save({"params": sd, "total": tot}, os.path.join(outdir, "rank%d.pt" % rank))
     dist.destroy_process_group()

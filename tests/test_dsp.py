@@ -269,8 +269,8 @@ def test_natural_spline_matrix_matches_scipy():
 def test_swipe_tracker_vs_oracle(dev, T):
     """Device SWIPE' vs oracle/swipe_oracle.py (the published algorithm in fp64): fp32 strengths can flip the
     arg-max between neighbouring 1/96-octave candidates and move frames across the 0.3 threshold, so: voicing
-    decisions agree on >= 97 % of the frames, and on the commonly voiced frames f0 agrees within 1.5 % on >= 97 %
-    (median error < 0.1 %).  Prosody with the tracker attached then equals the oracle's Prosody of the same contour."""
+    decisions agree on >= 99.5 % of the frames, and on the commonly voiced frames f0 agrees within 1.5 % on >= 99.5 %
+    (median error < 0.1 %; measured 100 % / 100 % on these signals).  Prosody with the tracker attached then equals the oracle's Prosody of the same contour."""
     from oracle import swipe_oracle as SW
     B = 3
     x = _voiced_test_signal(B, T, 5)
@@ -289,8 +289,8 @@ def test_swipe_tracker_vs_oracle(dev, T):
         relerr += list(r)
         close += int((r <= 0.015).sum())
     assert n_v > 0.4 * B * f0.shape[1]
-    assert agree_v >= 0.97 * B * f0.shape[1], (agree_v, B * f0.shape[1])
-    assert close >= 0.97 * n_v, (close, n_v)
+    assert agree_v >= 0.995 * B * f0.shape[1], (agree_v, B * f0.shape[1])
+    assert close >= 0.995 * n_v, (close, n_v)
     assert np.median(relerr) < 1e-3
     pro = dsp.Prosody(device=dev, tracker=tr)
     got = pro(torch.from_numpy(x).reshape(B, 1, T).to(dev)).cpu().numpy()
@@ -316,7 +316,7 @@ def test_swipe_and_prosody_full_size():
         both = v_o & v_d
         n_v += int(both.sum())
         close += int((np.abs(f0[b][both] - want[both]) / want[both] <= 0.015).sum())
-    assert agree >= 0.97 * B * 201 and close >= 0.97 * n_v and n_v > 0.4 * B * 201, (agree, close, n_v)
+    assert agree >= 0.995 * B * 201 and close >= 0.995 * n_v and n_v > 0.4 * B * 201, (agree, close, n_v)
     got = dsp.Prosody(device="cuda", tracker=tr)(xd).cpu().numpy()
     want = np.stack([O.prosody(x[b], f0[b]) for b in range(B)])
     np.testing.assert_allclose(got, want, atol=3e-5)
