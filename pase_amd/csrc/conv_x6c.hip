@@ -1356,20 +1356,19 @@ bool pase_x6c_plan(const PaseConvGemm& p, PaseX6cPlan& pl) {
     pl.p_magic = magic_of(pl.P);
     pl.xPerm = (p.ps > 1 && p.epilogue == PASE_EPI_STORE && !p.stat_part && p.post_op == PASE_POST_NONE &&
                 p.M == p.ps * p.Cout_store) ? 1 : 0;
-    // split-K (data-gradients of the wide heads, decoder layers on few columns): rounds of 512 workgroup slots
+    // split-K (data gradients of the wide heads, decoder layers whose tiles do not fill whole rounds): the persistent grid
+    // deals (slice, tile) items round-robin to 256 workgroups, so a launch takes ceil(items / 256) item times; an item of a
+    // 1/sk slice costs 1/sk of the tile plus the atomic flush (~2 stages)
     const long tiles = (long)pl.n_row_tiles * pl.n_col_tiles;
     int splitk = 1;
     if (p.splitk > 1) splitk = p.splitk;
     else if (p.splitk == 0 && !p.stat_part && p.epilogue == PASE_EPI_STORE && p.post_op == PASE_POST_NONE && GS >= 8) {
-        const double flush = 2.0 / (double)GS;               // the atomic tile flush is worth ~2 stages
+        const double flush = 2.0 / (double)GS;
         double best = 1e30;
         const int max_split = GS / 4 < 1 ? 1 : GS / 4;
-        const long slots = 512;
         for (int sk = 1; sk <= max_split && sk <= 64; ++sk) {
-            const long W = tiles * sk;
-            const long full = W / slots, tail = W % slots;
-            const double tc = tail == 0 ? 0.0 : (tail <= 256 ? 0.55 : 1.0);
-            const double est = ((double)full + tc) * (1.0 / sk + (sk > 1 ? flush : 0.0));
+            const long rounds = (tiles * sk + 255) / 256;
+            const double est = (double)rounds * (1.0 / sk + (sk > 1 ? flush : 0.0));
             if (est < best * 0.97) {
                 best = est;
                 splitk = sk;

@@ -274,10 +274,10 @@ def side_streams(like, n):
     import os
     if not like.is_cuda or os.environ.get("PASE_SIDE_STREAMS", "1") == "0":
         return []
-    key = (like.device.index, n)
-    if key not in _SIDE:
-        _SIDE[key] = [torch.cuda.Stream(device=like.device) for _ in range(n)]
-    return _SIDE[key]
+    pool = _SIDE.setdefault(like.device.index, [])       # ONE pool per device: side_streams(x, 3) is a prefix of (x, 4)
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=like.device))
+    return pool[:n]
 
 
 class GradSink:

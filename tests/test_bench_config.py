@@ -217,6 +217,7 @@ def test_bs32_embedding_losses_and_elementwise_grads(setup):
     assert not bad, "%d tensors out of tolerance, first: %r" % (len(bad), bad[:3])
     assert checked >= {"pase+": 100, "pase": 50, "emb256": 100}[variant], checked
     assert len(skipped) <= 4, skipped
+    setup["dead"] = set(skipped)          # their Adam updates are +-lr steps in round-off directions on both sides
     for n in setup["names"]:
         P[n].grad = None
 
@@ -250,7 +251,7 @@ def test_bs32_ten_adam_steps_track(setup):
     # a whole: its direction (cosine >= 0.95 per tensor; measured >= 0.98) and its length (within 5 %).
     worst = (1.0, None)
     for n, p in tr.model.named_parameters():
-        if _noise(variant, n):
+        if _noise(variant, n) or n in setup.get("dead", ()):
             continue
         da, db = (p.detach() - p0[n]).double().flatten(), (P[n].detach() - p0[n]).double().flatten()
         cos = float((da * db).sum() / (da.norm() * db.norm()).clamp_min(1e-30))
