@@ -1164,7 +1164,16 @@ extern "C" int pase_x6c_trace_reset() {
 // out[((rt32 * steps + st) * 3 + plane) * 64 + lane], step st = g * A + a, lane = (fk, row): element e = channel'
 // 16 g + 8 fk + e at tap' a.  Zero for channels' past Cin * P, taps past the real count and rows past M.
 __global__ void pack_x6c_kernel(const float* __restrict__ wt, u32x4* __restrict__ out, int M, int ldwt, int Cin, int taps,
-                                int P, int A, int CinP, int rev, int steps, long total, int perm_ps, int perm_cout) {
+                                int P, int A, int CinP, int rev, int steps, long total, int perm_ps, int perm_cout,
+                                const float* in_scale, const float* in_shift, const float* in_alpha, float* prm, int prm_n) {
+    // the on-load parameters expanded per channel' behind the chunks (same launch: one pack launch per GEMM launch)
+    for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < prm_n; c += (long)gridDim.x * blockDim.x) {
+        const int ci = min((int)c / P, Cin - 1);
+        const bool ok = c < CinP;
+        prm[c] = (ok && in_scale) ? in_scale[ci] : 1.f;
+        prm[prm_n + c] = (ok && in_scale) ? in_shift[ci] : 0.f;
+        prm[2 * prm_n + c] = (ok && in_alpha) ? in_alpha[ci] : 1.f;
+    }
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int lane = (int)(idx & 63);
         const long rs = idx >> 6;
@@ -1192,17 +1201,6 @@ __global__ void pack_x6c_kernel(const float* __restrict__ wt, u32x4* __restrict_
 
 // on-load parameters per channel' behind the weight chunks: [scale | shift | alpha], prm_n floats each (identity where
 // the descriptor has none, and for the zero channels' that pad the last stage)
-__global__ void pack_prm_kernel(const float* in_scale, const float* in_shift, const float* in_alpha, float* out, int Cin,
-                                int CinP, int P, int prm_n) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= prm_n) return;
-    const int ci = min(c / P, Cin - 1);
-    const bool ok = c < CinP;
-    out[c] = (ok && in_scale) ? in_scale[ci] : 1.f;
-    out[prm_n + c] = (ok && in_scale) ? in_shift[ci] : 0.f;
-    out[2 * prm_n + c] = (ok && in_alpha) ? in_alpha[ci] : 1.f;
-}
-
 // rows of an activation tensor -> fragment-ordered bf16 planes with the contraction over POSITIONS (weight gradients):
 // out[((rt32 * steps + st) * 3 + plane) * 64 + lane], step st = k-group (sequence s = st / QP16, positions 16 (st % QP16) ..),
 // lane = (fk, row): element e = position 16 (st % QP16) + 8 fk + e of row 32 rt32 + row, after its on-load transform
@@ -1389,11 +1387,8 @@ int pase_x6c_pack(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st) 
     const long nb = (total + 255) / 256;
     PASE_LAUNCH(pack_x6c_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), st, p.wt,
                 reinterpret_cast<u32x4*>(const_cast<void*>(p.wx6)), p.M, p.ldwt, p.Cin, p.taps, pl.P, pl.A, pl.CinP, pl.rev,
-                pl.steps_total, total, pl.xPerm ? p.ps : 1, p.Cout_store);
-    PASE_CHECK_LAUNCH();
-    float* prm = reinterpret_cast<float*>(reinterpret_cast<u32x4*>(const_cast<void*>(p.wx6)) + pl.pack_chunks);
-    PASE_LAUNCH(pack_prm_kernel, dim3((unsigned)((pl.prm_n + 255) / 256)), dim3(256), st, p.in_scale, p.in_shift, p.in_alpha,
-                prm, p.Cin, pl.CinP, pl.P, pl.prm_n);
+                pl.steps_total, total, pl.xPerm ? p.ps : 1, p.Cout_store, p.in_scale, p.in_shift, p.in_alpha,
+                reinterpret_cast<float*>(reinterpret_cast<u32x4*>(const_cast<void*>(p.wx6)) + pl.pack_chunks), pl.prm_n);
     PASE_CHECK_LAUNCH();
     return 0;
 }

@@ -177,7 +177,7 @@ def test_bs32_embedding_losses_and_elementwise_grads(setup):
     # -- element-wise gradients -------------------------------------------------------------------------------
     # Per tensor, relative L2 against the fp64 evaluation:  ours <= 1.5 x (torch fp32 ops) + floor.  At these sizes
     # the fp32 comparator itself is 1e-3 ... 3e-3 away from fp64 on the encoder (19 200 ... 3 072 000 products per
-    # element summed in fp32, BatchNorm statistics over 3M positions) -- measured (tools/_trace/f64_probe.py, PASE.cfg
+    # element summed in fp32, BatchNorm statistics over 3M positions) -- measured (tools/f64_probe.py, PASE.cfg
     # bs32): torch fp32 2.6e-3 ... 3.5e-3, split-bf16 pipe 2.1e-3 ... 2.7e-3, exact-fp32 pipe 0.5e-3 ... 1.3e-3 -- so a
     # bound on |ours - torch fp32| alone measures the comparator.  Floors: 5e-4 (weights), 1.5e-3 (one scalar per channel:
     # BN gamma / beta, PReLU slopes, biases, the two SincNet vectors) for tensors where all three sit at round-off level.
