@@ -280,6 +280,52 @@ def side_streams(like, n):
     return pool[:n]
 
 
+_WSTREAM = {}
+_WKEEP = {}
+
+
+def wgrad_stream(like):
+    """The ONE side stream weight-gradient launches go to (PASE_WGRAD_STREAM=0: none): layer n's weight gradient then runs
+    beside layer n's data gradient and layer n-1's elementwise backward.  Every GEMM kernel is a persistent grid of one
+    workgroup per CU, so the two never share a CU -- the second kernel's workgroups start on the CUs the first one's last
+    round leaves idle (measured: step 33.4 -> 32.7 ms from the encoder blocks alone).  None while per-launch timing is on."""
+    import os
+    if not like.is_cuda or K.GEMM_TIMER is not None or os.environ.get("PASE_WGRAD_STREAM", "1") == "0":
+        return None
+    ws = _WSTREAM.get(like.device.index)
+    if ws is None:
+        ws = _WSTREAM[like.device.index] = torch.cuda.Stream(device=like.device)
+    return ws
+
+
+def on_wgrad_stream(like, fn, keep=()):
+    """Run fn() (weight-gradient launches) on the weight-gradient stream, ordered after everything enqueued on the current
+    stream so far; `keep`: tensors fn reads that the caller may drop before the stream has run.  The caller joins with
+    join_wgrad_stream() before the gradients are consumed."""
+    ws = wgrad_stream(like)
+    cur = torch.cuda.current_stream() if ws is not None else None
+    # only the step's main stream forks: a worker that already runs on one of the head side streams keeps its weight
+    # gradients in line (nested forks bought nothing and broke hipGraph capture of the small configurations)
+    if ws is None or (_ARENA is not None and _ARENA.stream is not None and cur.cuda_stream != _ARENA.stream.cuda_stream):
+        fn()
+        return
+    ws.wait_event(cur.record_event())
+    with torch.cuda.stream(ws):
+        fn()
+    # The operands must outlive the side stream's kernels.  Not Tensor.record_stream (its deferred-free events are not
+    # graph-capture safe: capture_end segfaulted on the mini configuration): hold references until the forking stream
+    # joins -- after that, memory the caching allocator hands back to that stream is ordered behind the side stream's work.
+    _WKEEP.setdefault((like.device.index, cur.cuda_stream), []).extend(t for t in keep if t is not None)
+
+
+def join_wgrad_stream(like):
+    ws = wgrad_stream(like)
+    if ws is not None:
+        cur = torch.cuda.current_stream()
+        if _WKEEP.pop((like.device.index, cur.cuda_stream), None) is not None:      # this stream has forked since its last join
+            cur.wait_stream(ws)
+
+
 class GradSink:
     """Where parameter gradients go.  direct=True: accumulate straight into param.grad (the fused
     trainer zeroes one flat buffer per step and lets the wgrad kernels add into views of it);
@@ -496,7 +542,7 @@ def encoder_backward(fe, ctx, demb, sink, want_dx=False, on_ready=None):
     ain = ctx.ain
     ccat = ain.C
     dwcat = _zeros((emb, ccat), x)
-    conv_wgrad(dyemb, ain, dwcat, sink.buf(fe.W.bias), taps=1)
+    on_wgrad_stream(x, lambda: conv_wgrad(dyemb, ain, dwcat, sink.buf(fe.W.bias), taps=1), keep=(dyemb, ain.t))
     cw = fe.W.in_channels
     pairs = [(fe.W.weight, dwcat[:, :cw])]
     if fe.denseskips_on:
@@ -505,7 +551,7 @@ def encoder_backward(fe, ctx, demb, sink, want_dx=False, on_ready=None):
             c = p.weight.shape[1]
             pairs.append((p.weight, dwcat[:, off:off + c]))
             off += c
-    sink.add_many(pairs)
+    on_wgrad_stream(x, lambda: sink.add_many(pairs), keep=(dwcat,))
     dacat = conv_dgrad(dyemb, ctx.wcat, R=emb, O=ccat, k=1, stride=1, Tin=F_, padL=0, padR=0, s_red=ccat, s_out=1,
                        s_k=1)  # (S, ccat, F)
     # gradient w.r.t. the last block's activation
@@ -521,11 +567,14 @@ def encoder_backward(fe, ctx, demb, sink, want_dx=False, on_ready=None):
         cin = inp.C
         # Linear over [x_t ; x_{t-1}] (tap-major columns): one wgrad per tap into the two column halves
         dwq = sink.buf(layer.linear.weight)
-        conv_wgrad(dgates, inp, dwq, sink.buf(layer.linear.bias), taps=1, padL=0, pad_mode=K.PAD_ZERO)
         # x_{t-1} tap: sum_q dG[q] x[q-1] = sum_q dG[q+1] x[q] -- shift the GRADIENT left by one (its padding is a
         # true zero; the input's would have to be a zero of the activated tensor) and stay on the 1x1 kernel
         dg_next = torch.nn.functional.pad(dgates[:, :, 1:], (0, 1))
-        conv_wgrad(dg_next, inp, dwq, None, taps=1, padL=0, pad_mode=K.PAD_ZERO, dw_col_off=cin)
+
+        def wq(dgates=dgates, dg_next=dg_next, inp=inp, dwq=dwq, layer=layer, cin=cin):
+            conv_wgrad(dgates, inp, dwq, sink.buf(layer.linear.bias), taps=1, padL=0, pad_mode=K.PAD_ZERO)
+            conv_wgrad(dg_next, inp, dwq, None, taps=1, padL=0, pad_mode=K.PAD_ZERO, dw_col_off=cin)
+        on_wgrad_stream(x, wq, keep=(dgates, dg_next, inp.t))
         # dX[s,ci,u] = sum_{o,r} Wq[o, r*cin+ci] * dG[s,o,u+r]
         wt = K.pack_dgrad_t(layer.linear.weight, R=3 * H, O=cin, k=2, st=1, s_red=2 * cin, s_out=1, s_k=cin)
         dxl = _new((S, cin, F_), x)
@@ -533,7 +582,11 @@ def encoder_backward(fe, ctx, demb, sink, want_dx=False, on_ready=None):
                     stride=1, tapstep=1, padL=0, pad_mode=K.PAD_ZERO)
         dsrc, dsrc_ctot, dsrc_coff = dxl, cin, 0
     if on_ready is not None:
+        join_wgrad_stream(x)
         on_ready("head")
+    # Weight gradients of the conv blocks go to the weight-gradient stream (wgrad_stream above); data-parallel, each
+    # bucket is handed over ON that stream; joined at the end.
+    wside = wgrad_stream(x)
     # ---- conv blocks, last to first -----------------------------------------------------------------
     dsrc_Tp, dsrc_padL, dsrc_mode = F_, 0, K.PAD_ZERO
     nb = len(fe.blocks)
@@ -577,9 +630,17 @@ def encoder_backward(fe, ctx, demb, sink, want_dx=False, on_ready=None):
             sink.add(conv.band_hz_, dband)
         else:
             dbias = sink.buf(blk.conv.bias) if (rec["has_bn"] or rec.get("kind") in ("in", "ln")) else None
-            conv_wgrad(dy, inp, sink.buf(blk.conv.weight).view(C, -1), dbias, taps=taps, stride=blk.stride,
-                       padL=rec["padL"], pad_mode=K.PAD_REFLECT)
-        if on_ready is not None:
+            def wg(dy=dy, inp=inp, blk=blk, C=C, dbias=dbias, taps=taps, rec=rec, n=n):
+                conv_wgrad(dy, inp, sink.buf(blk.conv.weight).view(C, -1), dbias, taps=taps, stride=blk.stride,
+                           padL=rec["padL"], pad_mode=K.PAD_REFLECT)
+                # (the fork event also covers the per-channel sums sink.add_cols committed above: a bucket handed over on
+                #  the side stream is complete)
+                if on_ready is not None and wside is not None:
+                    on_ready(n)
+            on_wgrad_stream(x, wg, keep=(dy, inp.t))
+        if on_ready is not None and (wside is None or blk.sincnet):
+            if wside is not None:          # (block 0's bucket also carries the small blocks' gradients from the side stream)
+                torch.cuda.current_stream().wait_stream(wside)
             on_ready(n)
         if n > 0 or want_dx:
             cin = inp.C
@@ -588,6 +649,7 @@ def encoder_backward(fe, ctx, demb, sink, want_dx=False, on_ready=None):
                               padL=rec["padL"], padR=rec["padR"], s_red=cin * taps, s_out=taps, s_k=1)
             dsrc_ctot, dsrc_coff = cin, 0
             dsrc_Tp, dsrc_padL, dsrc_mode = dsrc.shape[2], rec["padL"], K.PAD_REFLECT
+    join_wgrad_stream(x)
     if not want_dx:
         return None
     # gradient w.r.t. the input waveform (saliency / adversarial use through the drop-in alias): fold the reflect
@@ -717,7 +779,8 @@ def worker_backward(layers, out_conv, ctx, dpred, sink, need_dinput=True):
         have_dz = True
     else:
         dpred = dpred.contiguous()
-        conv_wgrad(dpred, cur, sink.buf(out_conv.weight).view(nout, -1), sink.buf(out_conv.bias), taps=1)
+        on_wgrad_stream(x, lambda: conv_wgrad(dpred, cur, sink.buf(out_conv.weight).view(nout, -1),
+                                              sink.buf(out_conv.bias), taps=1), keep=(dpred, cur.t))
         dsrc = GradSrc(conv_dgrad(dpred, out_conv.weight, R=nout, O=cur.C, k=1, stride=1, Tin=T, padL=0, padR=0,
                                   s_red=cur.C, s_out=1, s_k=1), ctot=cur.C, Tp=T)
         have_dz = False
@@ -739,9 +802,11 @@ def worker_backward(layers, out_conv, ctx, dpred, sink, need_dinput=True):
             # dW[ci, co, kk] = sum_{s,t} act(in)[s,ci,t] * dz[s,co,t*st + kk - pad]
             if inp.scale is not None:
                 raise NotImplementedError("deconv wgrad with an affine on-load input")
-            K.wgrad_gemm(inp.t, dz, sink.buf(dc.weight).view(cin, -1), S=B, M=cin, Tg=inp.T, Ncols=inp.T, Cin=C,
-                         Tz=Tz, taps=k, ldw=C * k, g_ctot=inp.ctot, g_coff=inp.coff, stride=st, tapstep=1, padL=pad,
-                         pad_mode=K.PAD_ZERO, g_alpha=inp.alpha)
+            def wd(inp=inp, dz=dz, dc=dc, cin=cin, C=C, Tz=Tz, k=k, st=st, pad=pad):
+                K.wgrad_gemm(inp.t, dz, sink.buf(dc.weight).view(cin, -1), S=B, M=cin, Tg=inp.T, Ncols=inp.T, Cin=C,
+                             Tz=Tz, taps=k, ldw=C * k, g_ctot=inp.ctot, g_coff=inp.coff, stride=st, tapstep=1, padL=pad,
+                             pad_mode=K.PAD_ZERO, g_alpha=inp.alpha)
+            on_wgrad_stream(x, wd, keep=(inp.t, dz))
             last = blk is layers[0]
             if need_dinput or not last:
                 din, _ = conv_fwd(Act(dz, C=C), dc.weight.view(cin, -1), None, Cout=cin, taps=k, stride=st, padL=pad,
@@ -750,7 +815,9 @@ def worker_backward(layers, out_conv, ctx, dpred, sink, need_dinput=True):
         else:
             k = blk.context
             cin = inp.C
-            conv_wgrad(dz, inp, sink.buf(blk.W.weight).view(C, -1), None, taps=k, padL=k // 2, pad_mode=K.PAD_ZERO)
+            on_wgrad_stream(x, lambda dz=dz, inp=inp, blk=blk, C=C, k=k: conv_wgrad(
+                dz, inp, sink.buf(blk.W.weight).view(C, -1), None, taps=k, padL=k // 2, pad_mode=K.PAD_ZERO),
+                keep=(dz, inp.t))
             last = blk is layers[0]
             if need_dinput or not last:
                 din = conv_dgrad(dz, blk.W.weight, R=C, O=cin, k=k, stride=1, Tin=inp.T, padL=k // 2, padR=k // 2,
@@ -758,6 +825,7 @@ def worker_backward(layers, out_conv, ctx, dpred, sink, need_dinput=True):
                 dsrc = GradSrc(din, ctot=cin, Tp=din.shape[2], padL=k // 2)
     if len(ctx.recs) == 0 and ctx.head1:
         raise NotImplementedError("1-output worker without hidden layers")
+    join_wgrad_stream(x)
     return dsrc if need_dinput else None
 
 
@@ -801,7 +869,8 @@ def mlp_group_step(workers, a: Act, targets, sink, accs=None):
             K.ctx_loss(pred, tgt, dpred, acc, B=B, M=nout, F=F_, r_ctx=(r if r not in (None, 1) else 0),
                        label_D=tgt.shape[1], loss_type=LOSS_TYPES[loss.loss_name], grad_scale=gscale)
         out[w.name] = (acc, numel)
-        # head backward
+        # head backward (in line: forking the wide heads' weight gradients to the weight-gradient stream measured +0.9 ms per
+        # step -- the narrow heads already run underneath the wide ones)
         conv_wgrad(dpred, cur, sink.buf(oc.weight).view(nout, -1), sink.buf(oc.bias), taps=1)
         dA = conv_dgrad(dpred, oc.weight, R=nout, O=h, k=1, stride=1, Tin=F_, padL=0, padR=0, s_red=h, s_out=1, s_k=1)
         _, sums = act_backward(z_all, C=h, T=F_, S=B, has_bn=False, alpha=blk.act.weight, dsrc=dA, dsrc_ctot=h, Tp=F_,
@@ -834,6 +903,7 @@ def mlp_group_step(workers, a: Act, targets, sink, accs=None):
             head(*it)
     # stacked first layer: one wgrad, one dgrad
     dw1 = _zeros((htot, cin), x)
+
     conv_wgrad(dz_all, a, dw1, None, taps=1)
     sink.add_many([(w.blocks[0].W.weight, dw1[off:off + h]) for w, h, off in zip(workers, hs, offs)])
     dx = conv_dgrad(dz_all, w1cat, R=htot, O=cin, k=1, stride=1, Tin=F_, padL=0, padR=0, s_red=cin, s_out=1, s_k=1)
