@@ -772,11 +772,14 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
 #pragma unroll
         for (int pz = 0; pz < 3; ++pz) ab[pz] += adv;
     };
-    // (Two hand-pinned schedules were measured against leaving the 12 ds_read_b128 + 24 MFMAs of a step to the compiler:
-    //  prefetching the next pair of B tiles before each block of 12 MFMAs, two tiles alternating: 4 ... 14 % SLOWER on every
-    //  convolution of the PASE+ step;  units of (planes m, l) / (plane h) with all four tiles rotating and the next unit's
-    //  fragments in flight: +-0 (29.5 vs 29.4 ms of GEMM time) at 256 VGPRs.  The loop is not where the time goes: the
-    //  shader clock under this load is ~1.6 GHz, i.e. the 11-tap layers' 200-216 TF/s are ~75 % of the matrix pipe.)
+    // (Three hand-pinned schedules were measured against leaving the 12 ds_read_b128 + 24 MFMAs of a step to the compiler:
+    //  (1) prefetching the next pair of B tiles before each block of 12 MFMAs, two tiles alternating: 4 ... 14 % SLOWER on
+    //  every convolution of the PASE+ step;  (2) units of (planes m, l) / (plane h) with all four tiles rotating and the next
+    //  unit's fragments in flight: +-0 (29.5 vs 29.4 ms of GEMM time) at 256 VGPRs;  (3) the same units as single asm blocks
+    //  of 12 back-to-back MFMAs, same-accumulator products adjacent, one s_waitcnt in front: +-0 (30.3 ms on a box that gives
+    //  29.9 ... 30.7).  An 11-tap layer runs a step in ~1050-1100 s_memtime ticks against 768 MFMA-pipe cycles with 1 % of
+    //  the loop in barriers, the staging waves 47 % busy, LDS bank conflicts 0.3 % and no change when every A fragment load
+    //  hits L1 (tools/trace_x6c.py ablations) -- what holds the pipe at ~70 % inside the loop is not identified.)
     auto mfma_step = [&](const u32x4 (&a)[3], const u32x4* xb) __attribute__((always_inline)) {
         // plane pairs of the five small terms, smallest first: mm, hl, lh, hm, mh -> accS; hh -> accH
         constexpr int PZA[5] = {1, 0, 2, 0, 1}, PZB[5] = {1, 2, 0, 1, 0};
