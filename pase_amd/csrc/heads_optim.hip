@@ -32,8 +32,10 @@ __global__ void __launch_bounds__(NT) head1_fwd_kernel(const float* z, const flo
     __shared__ double sh[NT / 64];
     const long total = (long)S * T;
     double lsum = 0.0;
+    const bool small = total < 0x7fffffffL;              // uniform: 32-bit index arithmetic (a fifth of the 64-bit division)
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
-        const int s = (int)(i / T), t = (int)(i % T);
+        const int s = small ? (int)((unsigned)i / (unsigned)T) : (int)(i / T);
+        const int t = (int)(i - (long)s * T);
         const float* zp = z + (size_t)s * C * T + t;
         float acc = bias ? bias[0] : 0.f;
         // channels are T floats apart: eight independent loads in flight, accumulated in channel order
@@ -94,28 +96,33 @@ __global__ void __launch_bounds__(NT) head1_bwd_kernel(const float* z, const flo
     const long i0 = ch * per, i1 = (i0 + per < total) ? i0 + per : total;
     const float wc = w[c];
     const float al = in_alpha ? in_alpha[c] : 1.f;
-    double s_w = 0.0, s_a = 0.0, s_b = 0.0;
-    for (long i = i0 + threadIdx.x; i < i1; i += NT) {
-        const int s = (int)(i / T), t = (int)(i % T);
+    double s_w = 0.0, s_a = 0.0, s_b = 0.0, s_z = 0.0;
+    // (s, t) of element i walked incrementally: one 64-bit division per thread instead of two per element (they were most
+    // of this kernel's instructions), and sum dz -- the hidden layer's conv-bias gradient -- taken in the same pass
+    long i = i0 + threadIdx.x;
+    int s = i < i1 ? (int)(i / T) : 0;
+    int t = i < i1 ? (int)(i - (long)s * T) : 0;
+    for (; i < i1; i += NT) {
         const size_t o = ((size_t)s * C + c) * (size_t)T + t;
         const float zv = z[o];
         const float g = dy[i];
         const float act = zv > 0.f ? zv : zv * al;
         const float dact = wc * g;
-        dz[o] = zv > 0.f ? dact : dact * al;
+        const float dzv = zv > 0.f ? dact : dact * al;
+        dz[o] = dzv;
         s_w += (double)(g * act);
         if (!(zv > 0.f)) s_a += (double)(dact * zv);
         s_b += (double)g;
+        s_z += (double)dzv;
+        t += NT;
+        while (t >= T) {
+            t -= T;
+            ++s;
+        }
     }
     s_w = block_sum_d(s_w, sh);
     s_a = block_sum_d(s_a, sh);
     s_b = block_sum_d(s_b, sh);
-    // also sum dz per channel (= gradient of the hidden layer's conv bias)
-    double s_z = 0.0;
-    for (long i = i0 + threadIdx.x; i < i1; i += NT) {
-        const int s = (int)(i / T), t = (int)(i % T);
-        s_z += (double)dz[((size_t)s * C + c) * (size_t)T + t];
-    }
     s_z = block_sum_d(s_z, sh);
     if (threadIdx.x == 0) {
         atomicAdd(sums + (size_t)c * 3 + 0, s_w);
