@@ -447,6 +447,34 @@ def _encoder_forward(fe, x, training, S):
     if skips:
         ccat = fe.W.in_channels + sum(b.fmaps for b in fe.blocks[:-1])
         acat = _new((S, ccat, F_), x)
+    def pool_skips():
+        # dense skips: mean-pool each block's activation to the frame rate (the ONE 1x1 GEMM over the concatenated channels
+        # follows below: pool-then-project == project-then-pool for a bias-free 1x1 conv)
+        off = fe.W.in_channels
+        ctx.skip_off = []
+        for n, blk in enumerate(fe.blocks[:-1]):
+            rec = ctx.blocks[n]
+            Tn = rec["y"].shape[2]
+            d = Tn // F_
+            if "amat" in rec:
+                K.bn_act_pool(rec["amat"], acat, None, None, None, S=S, C_=blk.fmaps, T=Tn, F=F_, d=d, o_ctot=ccat,
+                              o_coff=off)
+            else:
+                K.bn_act_pool(rec["y"], acat, rec["scale"], rec["shift"], blk.act.weight, S=S, C_=blk.fmaps, T=Tn,
+                              F=F_, d=d, o_ctot=ccat, o_coff=off)
+            ctx.skip_off.append((off, d))
+            off += blk.fmaps
+
+    # The pooling passes (HBM-bound, 0.5 ms per bs32 step) only feed the concatenated GEMM after the QRNN stack: on the
+    # GPU they run on their own stream beside the QRNN's GEMM + scan (PASE_POOL_STREAM=0: in line, after the stack)
+    pool_stream = None
+    if skips and x.is_cuda and K.GEMM_TIMER is None and __import__("os").environ.get("PASE_POOL_STREAM", "1") != "0":
+        pool_stream = _WSTREAM.get(("pool", x.device.index))
+        if pool_stream is None:
+            pool_stream = _WSTREAM[("pool", x.device.index)] = torch.cuda.Stream(device=x.device)
+        pool_stream.wait_event(torch.cuda.current_stream().record_event())
+        with torch.cuda.stream(pool_stream):
+            pool_skips()
     rnn_in = cur
     if fe.rnn_pool:
         layers = fe.rnn.layers
@@ -469,23 +497,12 @@ def _encoder_forward(fe, x, training, S):
                       o_coff=0)
         rnn_in = Act(acat, C=cur.C)
 
-    # ---- dense skips: mean-pool each block's activation to the frame rate, then ONE 1x1 GEMM over the
-    # concatenated channels (pool-then-project == project-then-pool for a bias-free 1x1 conv) -------
+    # ---- dense skips: the pooled activations (pool_skips above) + ONE 1x1 GEMM over the concatenated channels -------
     if skips:
-        off = fe.W.in_channels
-        ctx.skip_off = []
-        for n, blk in enumerate(fe.blocks[:-1]):
-            rec = ctx.blocks[n]
-            Tn = rec["y"].shape[2]
-            d = Tn // F_
-            if "amat" in rec:
-                K.bn_act_pool(rec["amat"], acat, None, None, None, S=S, C_=blk.fmaps, T=Tn, F=F_, d=d, o_ctot=ccat,
-                              o_coff=off)
-            else:
-                K.bn_act_pool(rec["y"], acat, rec["scale"], rec["shift"], blk.act.weight, S=S, C_=blk.fmaps, T=Tn,
-                              F=F_, d=d, o_ctot=ccat, o_coff=off)
-            ctx.skip_off.append((off, d))
-            off += blk.fmaps
+        if pool_stream is not None:
+            torch.cuda.current_stream().wait_stream(pool_stream)
+        else:
+            pool_skips()
         wcat = torch.cat([fe.W.weight.view(emb, -1)] + [p.weight.view(emb, -1) for p in fe.denseskips], dim=1)
         ain = Act(acat, C=ccat)
     else:
