@@ -469,9 +469,12 @@ def _encoder_forward(fe, x, training, S):
     # GPU they run on their own stream beside the QRNN's GEMM + scan (PASE_POOL_STREAM=0: in line, after the stack)
     pool_stream = None
     if skips and x.is_cuda and K.GEMM_TIMER is None and __import__("os").environ.get("PASE_POOL_STREAM", "1") != "0":
-        pool_stream = _WSTREAM.get(("pool", x.device.index))
-        if pool_stream is None:
-            pool_stream = _WSTREAM[("pool", x.device.index)] = torch.cuda.Stream(device=x.device)
+        # (one of the head side streams, idle during the encoder forward -- NOT a stream of its own: HIP multiplexes streams
+        #  onto a few hardware queues, and one more stream put the host-buffer feeder's copy stream behind compute work:
+        #  +4 ms per step in the host-buffer mode)
+        ss = side_streams(x, 1)
+        pool_stream = ss[0] if ss else None
+    if pool_stream is not None:
         pool_stream.wait_event(torch.cuda.current_stream().record_event())
         with torch.cuda.stream(pool_stream):
             pool_skips()
