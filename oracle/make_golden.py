@@ -105,7 +105,24 @@ def synthetic_batch(seed, B, T, workers_cfg):
     return batch
 
 
-def _ref_step(seed, B, T, fe_name, wk_name, double=False):
+def perturb_affine(module, seed=123):
+    """BatchNorm affines and PReLU slopes moved off their init values -- the SAME seeded draw, in named_parameters order,
+    as tests/util.py:randomize_affine applies to the HIP model.  At init every encoder PReLU slope is 0 (a ReLU): a forward
+    value that differs from the fp64 one in the last bit can flip a backward mask, which hides everything below ~1e-3 in the
+    gradient comparison; with slopes in [0.05, 0.4] a flip changes a gradient element by at most (1 - slope) of a value that
+    is itself ~0, so two fp32 evaluations of the step agree to ~1e-5 and the gate can be that tight."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            if n.endswith("norm.weight"):
+                p.copy_(torch.empty(p.shape).uniform_(0.5, 1.5, generator=g))
+            elif n.endswith("norm.bias"):
+                p.copy_(torch.empty(p.shape).normal_(0, 0.2, generator=g))
+            elif n.endswith("act.weight"):
+                p.copy_(torch.empty(p.shape).uniform_(0.05, 0.4, generator=g))
+
+
+def _ref_step(seed, B, T, fe_name, wk_name, double=False, perturb=False):
     """One reference training step (trainer.py:229-232 -> worker_scheduler._base_scheduler) of a
     frontend cfg + workers cfg on a seeded synthetic batch.  Returns (model, param checksums, losses,
     chunk, preds); _base_scheduler has stepped the optimizers, so `.grad` holds the step's gradients
@@ -125,6 +142,8 @@ def _ref_step(seed, B, T, fe_name, wk_name, double=False):
     seed_all(seed)
     model = quiet(pase, frontend_cfg=fe_cfg, minions_cfg=minions_cfg,
                   cls_lst=[w["name"] for w in raw_cfg["cls"]], regr_lst=[w["name"] for w in raw_cfg["regr"]])
+    if perturb:
+        perturb_affine(model)
     names, sums, sq = param_checksums(model.state_dict())
     batch = synthetic_batch(seed + 1, B, T, raw_cfg)
     if double:
@@ -152,9 +171,9 @@ def _ref_step(seed, B, T, fe_name, wk_name, double=False):
     return model, (names, sums, sq), losses, chunk, preds
 
 
-def gen_pase_step(seed, B, T, fe_name="PASE+.cfg", wk_name="workers+.cfg", out="pase_plus_step.npz"):
+def gen_pase_step(seed, B, T, fe_name="PASE+.cfg", wk_name="workers+.cfg", out="pase_plus_step.npz", perturb=False):
     """losses, gradient norms, post-Adam norms of one reference step."""
-    model, (names, sums, sq), losses, chunk, preds = _ref_step(seed, B, T, fe_name, wk_name)
+    model, (names, sums, sq), losses, chunk, preds = _ref_step(seed, B, T, fe_name, wk_name, perturb=perturb)
     gnames = [n for n, p in model.named_parameters()]
     gsq = np.array([float((p.grad.double() ** 2).sum()) for n, p in model.named_parameters()])
     gsum = np.array([float(p.grad.double().sum()) for n, p in model.named_parameters()])
@@ -187,12 +206,12 @@ def grad_sample_index(numel, n=GRAD_SAMPLES):
 
 
 def gen_pase_step_grads(seed, B, T, fe_name="PASE+.cfg", wk_name="workers+.cfg", out="pase_plus_step_grads.npz",
-                        double=False):
+                        double=False, perturb=False):
     """ELEMENT-WISE reference gradients of the same step as gen_pase_step (same seeds => same step): for
     every parameter, the gradient at grad_sample_index(numel) flat positions, plus each tensor's max |grad|.
     double=True: the same step evaluated by the live reference in fp64 (same fp32 initial weights, same fp32 batch):
     the TRUTH both fp32 implementations (the reference's own and the HIP path) are measured against."""
-    model, _cs, losses, chunk, preds = _ref_step(seed, B, T, fe_name, wk_name, double=double)
+    model, _cs, losses, chunk, preds = _ref_step(seed, B, T, fe_name, wk_name, double=double, perturb=perturb)
     gnames, vals, offs, gmax = [], [], [0], []
     for n, p in model.named_parameters():
         g = p.grad.detach().reshape(-1).numpy()
@@ -206,10 +225,25 @@ def gen_pase_step_grads(seed, B, T, fe_name="PASE+.cfg", wk_name="workers+.cfg",
              n_samples=GRAD_SAMPLES, loss_total=float(losses["total"]))
 
 
+def gen_perturbed():
+    """The two full-width steps again with BN affines / PReLU slopes off their init values (perturb_affine): fp32 step,
+    element-wise fp32 gradients and the fp64 truth.  These are the TIGHT live-reference gradient gates
+    (tests/test_pase_step.py::test_full_width_golden_step[*-perturbed])."""
+    for seed, fe, wk, stem in ((2, "PASE+.cfg", "workers+.cfg", "pase_plus_step_perturbed"),
+                               (4, "PASE.cfg", "workers.cfg", "pase_step_cfg2_perturbed")):
+        gen_pase_step(seed=seed, B=2, T=8000, fe_name=fe, wk_name=wk, out=stem + ".npz", perturb=True)
+        gen_pase_step_grads(seed=seed, B=2, T=8000, fe_name=fe, wk_name=wk, out=stem + "_grads.npz", perturb=True)
+        gen_pase_step_grads(seed=seed, B=2, T=8000, fe_name=fe, wk_name=wk, out=stem + "_grads_f64.npz", double=True,
+                            perturb=True)
+
+
 if __name__ == "__main__":
     ref_shim.install()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
+    if sys.argv[1:] == ["perturbed"]:      # only the perturbed-slope steps
+        gen_perturbed()
+        sys.exit(0)
     if sys.argv[1:] == ["grads"]:          # only the element-wise gradient file
         gen_pase_step_grads(seed=2, B=2, T=8000)
         sys.exit(0)
@@ -230,5 +264,6 @@ if __name__ == "__main__":
     gen_pase_step_grads(seed=4, B=2, T=8000, fe_name="PASE.cfg", wk_name="workers.cfg",
                         out="pase_step_cfg2_grads_f64.npz", double=True)
     gen_pase_step_grads(seed=4, B=2, T=8000, fe_name="PASE.cfg", wk_name="workers.cfg", out="pase_step_cfg2_grads.npz")
+    gen_perturbed()
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)))
