@@ -86,6 +86,12 @@ typedef struct PaseConvGemm {
                               hh + hm + mh + hl + lh + mm on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
                               (dropped terms <= 3 * 2^-24 |a b|: the error of an fp32 fma chain).  wt is then
                               only the source of the pack.                                        */
+    int x6_ctl;            /* split-bf16 plan control (0 = the library's routing).  bit 0: take the split-bf16 kernel
+                              wherever it has a plan, skipping the measured per-shape routing rules (A/B runs; the
+                              library itself reads NO environment variables)                                    */
+    int max_wg;            /* cap on the persistent grid of the split-bf16 kernel (0 = one workgroup per CU, 256):
+                              data-parallel runs leave CUs to the RCCL channel kernels this way; tests use it to make
+                              every workgroup walk several (split-K slice, tile) items                       */
 } PaseConvGemm;
 
 int pase_conv_gemm(const PaseConvGemm* desc, void* stream);
@@ -99,8 +105,7 @@ int pase_conv_gemm_stat_tiles(const PaseConvGemm* desc);
 /* the split-K factor the launch will actually use (after clamping) */
 int pase_conv_gemm_splitk(const PaseConvGemm* desc);
 /* which kernel family the launch described by desc runs on: 0 = exact-fp32 matrix pipe (v_mfma_f32_32x32x2_f32),
- * 2 = split-bf16 channel-minor kernel (conv_x6c.hip; needs desc->wx6), 1 = the round-2 span-major split-bf16
- * instantiations (only with PASE_X6_LEGACY=1 in the environment: measurement builds).  For tests and bench reports. */
+ * 2 = split-bf16 channel-minor kernel (conv_x6c.hip; needs desc->wx6).  For tests and bench reports. */
 int pase_conv_gemm_plan_kind(const PaseConvGemm* desc);
 /* bytes of the split-bf16 pack the launch described by desc (wx6 ignored) would read; 0 = this shape only runs on
  * the fp32 matrix pipe */
@@ -130,17 +135,23 @@ typedef struct PaseWgrad {
     int S, M, Tg, g_ctot, g_coff, Ncols;
     int Cin, Tz, z_ctot, z_coff, taps, tap_major, stride, tapstep, padL, pad_mode, ldw;
     int splitk;            /* 0 = auto                                                            */
-    int x6;                /* 0: fp32 matrix pipe.  1: split-bf16 contraction (see PaseConvGemm::wx6) where the library has
-                              a plan for the shape AND gx6 is given; else the fp32 matrix pipe                   */
-    void* gx6;             /* scratch for the split-bf16 pack of one operand: pase_wgrad_x6_bytes(desc) bytes, 16-B
+    int x6;                /* 0: fp32 matrix pipe.  bit 0: split-bf16 contraction (see PaseConvGemm::wx6) where the library
+                              has a plan for the shape AND gx6 is given; else the fp32 matrix pipe.  Measurement / test
+                              controls (the library reads no environment variables): bits 4-7 force an orientation
+                              (pase_wgrad_plan_kind value, 0 = the library's routing); bit 8: 1x1 layers may take the split
+                              kernel in either orientation; bit 9: no row-coalesced staging                          */
+    void* gx6;             /* scratch for the split-bf16 operands: pase_wgrad_x6_bytes(desc) bytes, 16-B
                               aligned, caller-owned, written and read by this launch only; NULL = fp32 matrix pipe */
+    int max_wg;            /* cap on the persistent grid (0 = 256), see PaseConvGemm::max_wg                      */
 } PaseWgrad;
 int pase_wgrad_gemm(const PaseWgrad* desc, void* stream);
 /* bytes of PaseWgrad::gx6 the launch described by desc needs (0: the shape runs on the fp32 matrix pipe) */
 long pase_wgrad_x6_bytes(const PaseWgrad* desc);
 /* which kernel a launch with x6 = 1 and a gx6 scratch runs on: 0 fp32 matrix pipe; split-bf16 position contraction with
  * 1 rows = g (packed), columns = (channel, tap) of z staged; 2 1x1 layer, rows = z channels (packed), columns = g staged;
- * 3 rows = (channel, tap) read from row-major bf16 planes of z, columns = g staged */
+ * 3 rows = (channel, tap) read from row-major bf16 planes of z, columns = g staged;
+ * 4 rows = g (packed), columns = (channel, tap) COPIED out of pre-split phase-decomposed bf16 planes of z~ (no conversion
+ *   in the GEMM: the default for every layer with taps) */
 int pase_wgrad_plan_kind(const PaseWgrad* desc);
 
 /* ------------------------------------------------------------------------------------------

@@ -955,48 +955,6 @@ __global__ void __launch_bounds__(256) pack_wt_kernel(const float* w, float* wt,
     }
 }
 
-// wt (K-major fp32, k = ci * taps + tap) -> the three bf16 planes of the x6 weight slab, 16-byte chunks
-// [row tile][stage g][step][k-group fk][plane][tile row]; element e of a chunk = (row rg*R + fk + 2*(e / Tq),
-// tap tb*Tq + e % Tq) of step (rg, tb).  Zero for taps past the real count, for the rows of a ragged last channel
-// group that the previous stage already covered, and for tile rows past M.
-__global__ void pack_x6_kernel(const float* __restrict__ wt, u32x4* __restrict__ out, int M, int ldwt, int Cin,
-                               int taps, int CB, int R, int lt, int tsn, int steps, int n_gc, int n_gt, int TB, long total,
-                               int BM, int perm_ps, int perm_cout) {
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int ml = (int)(idx % BM);
-        const int fk = (int)((idx / BM) % 2);
-        const int st = (int)((idx / (2 * BM)) % steps);
-        const long gi = idx / (2L * BM * steps);
-        const int g = (int)(gi % ((long)n_gc * n_gt));           // stage = (channel group gc, tap group gt)
-        const int rt = (int)(gi / ((long)n_gc * n_gt));
-        const int gc = g / n_gt, gt = g - gc * n_gt;
-        const int rg = st / tsn, tb = st - rg * tsn;
-        const int ci0 = gc * CB, ci0s = n_gt == 1 ? min(ci0, Cin - CB) : ci0, lo = ci0 - ci0s;
-        const int m = rt * BM + ml;
-        // (channel, phase) row order of the pixel-shuffle launches: tile row m = co * ps + phase reads source column
-        // phase * Cout + co of the (phase, channel)-ordered pack
-        const int msrc = perm_ps > 1 ? (m % perm_ps) * perm_cout + m / perm_ps : m;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            int row, tap;
-            if (R == 1) {                      // one row, 16 taps per step
-                row = 0;
-                tap = gt * TB + 16 * st + 8 * fk + e;
-            } else {
-                row = rg * R + fk + 2 * (e >> lt);
-                tap = (tb << lt) + (e & ((1 << lt) - 1));
-            }
-            v[e] = (row >= lo && tap < taps && m < M) ? wt[((size_t)(ci0s + row) * taps + tap) * ldwt + msrc] : 0.f;
-        }
-        u32x4 o[3];
-        pase_split_bf16x3(v, o);
-        u32x4* dst = out + ((((size_t)rt * n_gc * n_gt + g) * steps + st) * 2 + fk) * 3 * BM + ml;
-#pragma unroll
-        for (int pz = 0; pz < 3; ++pz) dst[pz * BM] = o[pz];
-    }
-}
-
 struct HostPlan {
     ConvPlan pl;
     int BN, narrow;
@@ -1007,71 +965,18 @@ struct HostPlan {
     PaseX6cPlan c;
 };
 
-// Split-bf16 stage shape for a span-mode launch on the 128 x 128 tile, or false.  Candidates: (R rows x Tq taps) per
-// 16-deep step with R * Tq = 16; the taps are padded to a multiple of Tq (zero weights) and a stage holds as many
-// row groups as fit X6_STEPS steps.  Score = useful fraction of the padded taps x a penalty for short stages.
-bool plan_x6(const PaseConvGemm& p, int BN, ConvPlan& pl, int max_steps) {
-    double best = 0.0;
-    for (int R = 2; R <= 16; R *= 2) {
-        const int Tq = 16 / R;
-        const int TBp = (p.taps + Tq - 1) / Tq * Tq, tsn = TBp / Tq;
-        if (tsn > max_steps) continue;
-        for (int rg = max_steps / tsn; rg >= 1; --rg) {
-            const int CB = R * rg;
-            if (CB > p.Cin) continue;
-            const int SPANV = (BN - 1) * p.stride + (pl.mode == MODE_SEG ? 2 : 1) * TBp;
-            int tl = 8;
-            while ((NTHREADS >> tl) < CB) --tl;
-            const int nslots = (SPANV + 1 + (1 << tl) - 1) >> tl;
-            if (nslots > XPT) continue;
-            const int steps = rg * tsn;
-            const double eff = (double)p.taps / TBp * (steps >= 3 ? 1.0 : (steps == 2 ? 0.93 : 0.8));
-            if (eff > best) {
-                best = eff;
-                pl.CB = CB; pl.TB = TBp; pl.SPANV = SPANV; pl.tl = tl; pl.nslots = nslots;
-                pl.xR = R; pl.xTq = Tq; pl.xTS = tsn; pl.xSteps = steps;
-            }
-            break;
-        }
-    }
-    // one row, 16 taps per step, tap groups of max_steps steps (long filters on too few channels for the patterns above;
-    // forward taps only)
-    if (p.tapstep == 1 && p.taps >= 32) {
-        const int taps_p = (p.taps + 15) / 16 * 16;
-        const int steps = taps_p / 16 < max_steps ? taps_p / 16 : max_steps;
-        const int TB = 16 * steps;
-        const int SPANV = (BN - 1) * p.stride + (pl.mode == MODE_SEG ? 2 : 1) * TB;
-        const int nslots = (SPANV + 1 + NTHREADS - 1) / NTHREADS;
-        const double eff = (double)p.taps / taps_p * (steps >= 3 ? 1.0 : (steps == 2 ? 0.93 : 0.8));
-        if (nslots <= XPT && eff > best) {
-            best = eff;
-            pl.CB = 1; pl.TB = TB; pl.SPANV = SPANV; pl.tl = 8; pl.nslots = nslots;
-            pl.xR = 1; pl.xTq = 16; pl.xTS = steps; pl.xSteps = steps; pl.xTaps = taps_p;
-        }
-    }
-    return best >= 0.85;
-}
-
 unsigned magic_of(int d) {
     return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned long long)d);
 }
 
-// The span-major split-bf16 instantiations of conv_gemm_kernel (round 2: ONE accumulator per tile, truncated operand
-// pieces) carry a systematic error that grows with K (conv_x6c.hip header); they stay in the library for A/B
-// measurements only (PASE_X6_LEGACY=1).  A launch without a conv_x6c plan runs on the exact-fp32 matrix pipe.
-bool legacy_x6() {
-    static const bool on = [] {
-        const char* e = getenv("PASE_X6_LEGACY");
-        return e && e[0] == '1';
-    }();
-    return on;
-}
-
+// Split-bf16 launches run on conv_x6c.hip (two accumulators per tile, round-to-nearest pieces); a launch without a plan
+// there runs on the exact-fp32 matrix pipe.  (Round 2's span-major split instantiations of conv_gemm_kernel -- one accumulator,
+// truncated pieces: systematically biased, see the conv_x6c.hip header -- are no longer built.)
 HostPlan make_plan(const PaseConvGemm& p, bool want_x6) {
     HostPlan h;
     h.x6_chunks = 0;
     h.x6c = false;
-    if (want_x6 && !legacy_x6()) {
+    if (want_x6) {
         if (pase_x6c_plan(p, h.c)) {
             h.x6c = true;
             h.pl = ConvPlan{};
@@ -1102,29 +1007,13 @@ HostPlan make_plan(const PaseConvGemm& p, bool want_x6) {
     pl.x6 = pl.xR = pl.xTq = pl.xTS = pl.xSteps = pl.xTaps = 0;
     // (the 4-step slab costs 12 KB of LDS and 12 VGPRs more: only where 3 steps cannot hold the padded taps;
     //  64-row tiles have a split-bf16 instantiation for the one-row plan only -- the Sinc FIR)
-    if (want_x6 && !flat &&
-        (plan_x6(p, h.BN, pl, X6_STEPS) || (!h.narrow && plan_x6(p, h.BN, pl, X6_STEPS_LONG))) &&
-        (!h.narrow || (pl.xR == 1 && pl.nslots <= 3))) {
-        pl.x6 = 1;
-        pl.nslots = pl.nslots <= 3 ? 3 : (pl.nslots <= 6 ? 6 : 12);
-        if (pl.xSteps > X6_STEPS && pl.nslots < 6) pl.nslots = 6;      // the 4-step instantiations are 6 / 12 slots
-        pl.SPAN = pl.nslots << pl.tl;
-    } else if (flat) {
-        if (want_x6 && !h.narrow && p.Cin >= 16) {
-            // flat 1x1 on the bf16 pipe: a 16-deep step = 16 channel rows (lane half fk takes rows fk, fk + 2, ...)
-            pl.x6 = 1;
-            pl.xR = 16; pl.xTq = 1; pl.xTS = 1;
-        }
+    if (flat) {
         pl.TB = 1;
         pl.SPANV = pl.SPAN = h.BN;
         pl.CB = XS_FLAT / h.BN;
         if (pl.CB > KG_FLAT) pl.CB = KG_FLAT;
         if (pl.CB > p.Cin) pl.CB = p.Cin;
         if (pl.CB > 1) pl.CB &= ~1;
-        if (pl.x6) {
-            pl.CB &= ~15;
-            pl.xSteps = pl.CB / 16;
-        }
         const int TPR = h.BN / 4;
         pl.tl = 0;
         while ((1 << pl.tl) < TPR) ++pl.tl;
@@ -1153,7 +1042,6 @@ HostPlan make_plan(const PaseConvGemm& p, bool want_x6) {
     }
     pl.n_gc = pl.CB ? (p.Cin + pl.CB - 1) / pl.CB : 0;
     pl.n_gt = (p.taps + pl.TB - 1) / pl.TB;
-    if (pl.x6) h.x6_chunks = (long)((p.M + BM - 1) / BM) * pl.n_gc * pl.n_gt * pl.xSteps * 2 * 3 * BM;
     const int RA = NTHREADS / (BM / 4);
     pl.PA = (pl.CB * pl.TB + RA - 1) / RA;
     pl.tiles_per_seq = (p.Ncols + h.BN - 1) / h.BN;
@@ -1250,20 +1138,7 @@ extern "C" int pase_conv_gemm(const PaseConvGemm* d, void* stream) {
         else if (h.pl.nslots == 6) PASE_LAUNCH((conv_gemm_kernel<BM_, BN_, 6, 0>), grid, block, st, p, h.pl);  \
         else PASE_LAUNCH((conv_gemm_kernel<BM_, BN_, 12, 0>), grid, block, st, p, h.pl);                 \
     } while (0)
-    if (h.pl.x6) {
-        // the kernel sees the convolution with its taps padded to the plan's multiple (zero weights in the pack)
-        PaseConvGemm q = p;
-        q.taps = h.pl.xR == 1 ? h.pl.xTaps : h.pl.TB;
-        q.K = p.Cin * q.taps;
-        if (h.narrow) PASE_LAUNCH((conv_gemm_kernel<64, 256, 3, 0, 2, -1, 3>), grid, block, st, q, h.pl);
-        else if (h.pl.xvec) PASE_LAUNCH((conv_gemm_kernel<128, 128, NS_FLAT, 1, 2, -1, 3>), grid, block, st, q, h.pl);
-        else if (h.pl.xSteps > X6_STEPS && h.pl.nslots <= 6)
-            PASE_LAUNCH((conv_gemm_kernel<128, 128, 6, 0, 2, -1, 4>), grid, block, st, q, h.pl);
-        else if (h.pl.xSteps > X6_STEPS) PASE_LAUNCH((conv_gemm_kernel<128, 128, 12, 0, 2, -1, 4>), grid, block, st, q, h.pl);
-        else if (h.pl.nslots == 3) PASE_LAUNCH((conv_gemm_kernel<128, 128, 3, 0, 2, -1, 3>), grid, block, st, q, h.pl);
-        else if (h.pl.nslots == 6) PASE_LAUNCH((conv_gemm_kernel<128, 128, 6, 0, 2, -1, 3>), grid, block, st, q, h.pl);
-        else PASE_LAUNCH((conv_gemm_kernel<128, 128, 12, 0, 2, -1, 3>), grid, block, st, q, h.pl);
-    } else if (h.narrow) PASE_CONV_LAUNCH(64, 256);
+    if (h.narrow) PASE_CONV_LAUNCH(64, 256);
     else PASE_CONV_LAUNCH(128, 128);
 #undef PASE_CONV_LAUNCH
     PASE_CHECK_LAUNCH();
@@ -1281,7 +1156,7 @@ extern "C" int pase_conv_gemm_splitk(const PaseConvGemm* d) {
 extern "C" int pase_conv_gemm_plan_kind(const PaseConvGemm* d) {
     if (d->M <= 0 || d->K <= 0 || d->S <= 0 || d->Ncols <= 0 || d->K != d->Cin * d->taps) return 0;
     const HostPlan h = make_plan(*d, d->wx6 != nullptr);
-    return h.x6c ? 2 : (h.pl.x6 ? 1 : 0);
+    return h.x6c ? 2 : 0;
 }
 
 extern "C" long pase_conv_gemm_x6_bytes(const PaseConvGemm* d) {
@@ -1296,15 +1171,6 @@ extern "C" int pase_pack_x6(const PaseConvGemm* d, void* stream) {
     if (!p.wx6 || !p.wt || (((unsigned long long)(size_t)p.wx6) % 16) != 0) return -10;
     if (p.K != p.Cin * p.taps || p.ldwt < p.M) return -4;
     const HostPlan h = make_plan(p, true);
-    if (!h.pl.x6 || h.pl.CB < 1) return -11;
-    if (h.x6c) return pase_x6c_pack(p, h.c, (hipStream_t)stream);
-    const ConvPlan& pl = h.pl;
-    const int lt = pl.xTq == 8 ? 3 : (pl.xTq == 4 ? 2 : (pl.xTq == 2 ? 1 : 0));
-    const long total = h.x6_chunks / 3;
-    const long nb = (total + 255) / 256;
-    PASE_LAUNCH(pack_x6_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), (hipStream_t)stream, p.wt,
-                reinterpret_cast<u32x4*>(const_cast<void*>(p.wx6)), p.M, p.ldwt, p.Cin, p.taps, pl.CB, pl.xR, lt, pl.xTS,
-                pl.xSteps, pl.n_gc, pl.n_gt, pl.TB, total, h.narrow ? 64 : 128, pl.xPerm ? p.ps : 1, p.Cout_store);
-    PASE_CHECK_LAUNCH();
-    return 0;
+    if (!h.x6c) return -11;
+    return pase_x6c_pack(p, h.c, (hipStream_t)stream);
 }

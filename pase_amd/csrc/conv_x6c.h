@@ -24,6 +24,10 @@ struct PaseX6cPlan {
     int t_taps, t_tapstep, t_padL, t_stride;   // tmode 3: the layer's taps (the staged operand's descriptor says taps = 1)
     int t_lseg, t_hh, t_dmin;                  // tmode 3: plane row = S segments of t_lseg = 16 QP16 + t_hh elements
     int t_vec;                                 // T-mode: the staged operand's 8-position chunks are 16-byte aligned
+    int zp;                                    // tmode 1 with the staged operand PRE-SPLIT ("ZP"): the (channel, tap) columns are
+                                               // COPIED out of phase-decomposed bf16 planes of z~ (pack_zph_kernel), no conversion
+    int zp_rows;                               // ... rows of a plane: Cin * stride (+ 1: the all-ones row of the bias column)
+    long zp_off;                               // ... byte offset of the planes inside PaseWgrad::gx6 (behind the pack of g)
     long t_plane;                              // tmode 3: elements per plane
     int xPerm;          // pixel-shuffle launches: tile rows ordered (channel, phase) -> 16-byte output runs
     long pack_chunks;   // 16-byte chunks of the weight pack

@@ -176,7 +176,13 @@ __device__ __forceinline__ void x6c_vmwait_slots(int nslots) {
 // of one sequence -- and the columns are (channel, tap) pairs: column j reads x[s][ci][q * stride + kk * tapstep - padL].
 // Same staging machinery (a chunk is 8 consecutive q of one column, i.e. 8 strided samples of one channel row), but the
 // per-channel on-load parameters belong to the lane (its column), not to the element.
-template <int NPOS, int KGS_T, bool TM = false>
+// ZP (TM only, pl.zp): the staged operand is PRE-SPLIT -- phase-decomposed bf16 planes of z~ with the on-load transform and
+// the padding already applied (pack_zph_kernel): plane[pz][row = ci * stride + b][s][i] = piece pz of z~[s][ci][stride * (i +
+// dmin) + b].  Column (ci, kk) with kk * tapstep - padL = d * stride + b is then row (ci, b) shifted by d, a chunk (8 consecutive
+// positions of one column) is 16 contiguous bytes of a plane at 2-byte granularity, and staging is three 16-byte loads + three
+// ds_write_b128 per slot: no conversion, no padding arithmetic, no per-element loads (the round-3 T-mode spent 1.9k cycles of
+// staging-wave issue per 768 cycles of MFMA on exactly those).  The bias column is one more plane row holding 1.0.
+template <int NPOS, int KGS_T, bool TM = false, bool ZP = false>
 __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6cPlan pl) {
     constexpr int WM = 4, WN = 1, NBT = 4;
     constexpr int BM = 32 * WM, BN = 32 * NBT * WN;
@@ -264,6 +270,9 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     //   n0 + 32 (wave - 4) + 16 (sl >> 1) + (lane & 15),   chunk c = 4 (sl & 1) + (lane >> 4) of the stage's 8 (kg = c >> 1, fk = c & 1)
     // so one load instruction covers 16 rows x 128 contiguous bytes (whole cache lines, each fetched once) instead of 64 rows x
     // 32 bytes, and a 16-lane group of the LDS write covers 16 consecutive columns of one (kg, fk) row (conflict-free)
+    unsigned zp_col[NPAR];          // ZP: element offset of this lane's column inside a plane (row, shift, octet)
+#pragma unroll
+    for (int par = 0; par < NPAR; ++par) zp_col[par] = 0u;
     unsigned v_voff[2] = {0u, 0u};
     bool v_ok[2] = {false, false};
     float v_al[2] = {1.f, 1.f}, v_sum[2] = {0.f, 0.f};
@@ -298,6 +307,35 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 }
                 live = 3u;
                 full = 0u;
+                return;
+            }
+            if constexpr (ZP) {
+                // column j = (ci, kk): plane row ci * stride + b shifted by d, where kk * tapstep - padL = d * stride + b;
+                // column K (bias gradient) = the all-ones row.  Columns past the end alias the last real one: their products
+                // land in accumulator columns the epilogue never stores.
+                pos_valid = 0u;
+#pragma unroll
+                for (int par = 0; par < NPAR; ++par) {
+                    const int j = n0 + 64 * (whalf ^ par) + lane;
+                    const bool ones = p.bias != nullptr && j == p.K;
+                    const bool valid = j < p.K || ones;
+                    const int jj = min(j, p.K - 1);
+                    const int ci = (int)div_magic((unsigned)jj, pl.ncols_magic);
+                    const int kk = jj - ci * p.taps;
+                    const int ob = kk * p.tapstep - p.padL - pl.t_dmin * p.stride;   // >= 0: dmin = floor(min offset / stride)
+                    const int db = (int)div_magic((unsigned)ob, pl.ps_magic);          // d - dmin
+                    const int b = ob - db * p.stride;
+                    const int row = ones ? pl.zp_rows - 1 : ci * p.stride + b;
+                    const int sh = ones ? 0 : db;
+                    zp_col[par] = (unsigned)(row * p.S) * (unsigned)pl.t_lseg + (unsigned)(sh + fkL * 8);
+                    if (valid) pos_valid |= 1u << par;
+                }
+                live = 0u;
+                full = 0u;
+#pragma unroll
+                for (int b = 0; b < NPAR; ++b)
+                    if (!pase_wave_all(!((pos_valid >> b) & 1u))) live |= 1u << b;
+                live = (unsigned)pase_uniform((int)live);
                 return;
             }
             pos_valid = 0u;
@@ -387,8 +425,10 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     const bool has_aff = p.in_scale != nullptr, has_alpha = p.in_alpha != nullptr;       // uniform
     const float* xbase = p.x + (size_t)p.x_coff * p.Tin;
 
-    float xreg[XR][NSLOT][8];
-    unsigned xmask[XR][NSLOT];         // bit e: element e of the slot is a real sample (else: zero AFTER the transform)
+    float xreg[XR][ZP ? 1 : NSLOT][8];
+    unsigned xmask[XR][ZP ? 1 : NSLOT];         // bit e: element e of the slot is a real sample (else: zero AFTER the transform)
+    u32x4 xpl[XR][ZP ? NSLOT : 1][3];           // ZP: the slot's three plane chunks as loaded
+    const unsigned short* zpb = reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(p.wx6) + pl.zp_off);
 
     // channel' -> (input channel, phase) of element e of this wave's octet in k-group kg of stage g (all uniform)
     auto chan_of = [&](int g, int kg, int e, int& ci, int& b, bool& ok) __attribute__((always_inline)) {
@@ -414,6 +454,17 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     auto load_slot = [&](auto r_tag, auto sl_tag, int g) __attribute__((always_inline)) {
         constexpr int sl = decltype(sl_tag)::value, rs = decltype(r_tag)::value;
         constexpr int kg = sl / NPS, ps = sl % NPS, par = kg & (NPAR - 1);
+        if constexpr (ZP) {
+            // k-group (uniform): sequence s, first position 16 q16; past the last sequence the pack of g holds zeros and any
+            // finite value will do here
+            const int kgi = g * KGS + kg;
+            const int s_ = (int)div_magic((unsigned)kgi, pl.seg_magic);
+            const int q16 = kgi - s_ * pl.P;
+            const unsigned off = zp_col[par] + (unsigned)(min(s_, p.S - 1) * pl.t_lseg + q16 * 16);
+#pragma unroll
+            for (int pz = 0; pz < 3; ++pz) xpl[rs][sl][pz] = x6c_load16u(zpb + (size_t)pz * (size_t)pl.t_plane + off);
+            return;
+        } else
         if constexpr (TM) {
             if (pl.t_vec) {
                 constexpr int h = (sl >> 1) & 1;
@@ -491,6 +542,12 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     auto store_slot = [&](auto r_tag, auto sl_tag, int g, int bsel) __attribute__((always_inline)) {
         constexpr int sl = decltype(sl_tag)::value, rs = decltype(r_tag)::value;
         constexpr int kg = sl / NPS, ps = sl % NPS, par = kg & (NPAR - 1);
+        if constexpr (ZP) {
+            u32x4* dst = &Xs[bsel * BUF + kg * KGC + fkL * NPOS + 64 * (whalf ^ par) + lane];
+#pragma unroll
+            for (int pz = 0; pz < 3; ++pz) dst[pz * PLANE] = xpl[rs][sl][pz];
+            return;
+        } else {
         x6c_claim(xreg[rs][sl]);
         float v[8];
 #pragma unroll
@@ -581,6 +638,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             u32x4* dst = &Xs[bsel * BUF + kg * KGC + fkL * NPOS + i];
 #pragma unroll
             for (int pz = 0; pz < 3; ++pz) dst[pz * PLANE] = o[pz];
+        }
         }
     };
 
@@ -1281,13 +1339,56 @@ __global__ void pack_zplanes_kernel(const float* __restrict__ src, u32x4* __rest
     }
 }
 
-int x6c_prio() {
-    static const int v = [] {
-        const char* e = getenv("PASE_X6C_PRIO");
-        return e ? atoi(e) : 0;
-    }();
-    return v;
+// ZP (tmode 1 with pl.zp): z~ (on-load transform applied, padding materialised) as three phase-decomposed bf16 planes,
+//   out[plane][row = ci * st + b][s][i],  i in [0, lseg):  piece of z~[s][ci][st * (i + dmin) + b]   (reflected / zero outside
+//   [0, T)),  plus -- `ones` -- a last row of 1.0 (the bias column of the weight gradient).
+// Workgroup (s, ci): thread -> (8-position group gq, phase b) with b fastest, so that the eight loads of a wave walk a
+// contiguous stretch of the source row (every byte of a fetched line is used within the eight instructions) and each thread
+// writes one 16-byte chunk per plane into row ci * st + b.  grid = (S, Cin [+ 1]).
+__global__ void pack_zph_kernel(const float* __restrict__ src, u32x4* __restrict__ out, int Cin, int S, int ctot, int coff,
+                                int T, int st, int lseg, int dmin, int pad_mode, long t_plane, const float* sc,
+                                const float* sh, const float* al, int ones) {
+    const int s_ = blockIdx.x;
+    const int ci = blockIdx.y;
+    const int ngrp = lseg / 8;
+    const size_t pstride = (size_t)(t_plane / 8);
+    if (ones && ci == Cin) {
+        u32x4* orow = out + ((size_t)(Cin * st) * S + s_) * (size_t)ngrp;
+        const u32x4 one = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}, zero = {0u, 0u, 0u, 0u};
+        for (int gq = threadIdx.x; gq < ngrp; gq += blockDim.x) {
+            orow[gq] = one;
+            orow[pstride + gq] = zero;
+            orow[2 * pstride + gq] = zero;
+        }
+        return;
+    }
+    const float* row = src + ((size_t)s_ * ctot + coff + ci) * T;
+    const float a_sc = sc ? sc[ci] : 1.f, a_sh = sc ? sh[ci] : 0.f, a_al = al ? al[ci] : 1.f;
+    for (int idx = threadIdx.x; idx < ngrp * st; idx += blockDim.x) {
+        const int gq = idx / st, b = idx - gq * st;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int u = st * (gq * 8 + e + dmin) + b;
+            if (pad_mode == PASE_PAD_REFLECT) u = x6c_reflect(u, T);
+            float t = 0.f;
+            if (u >= 0 && u < T) {
+                t = fmaf(row[u], a_sc, a_sh);
+                t = t > 0.f ? t : t * a_al;
+            }
+            v[e] = t;
+        }
+        u32x4 o[3];
+        pase_split_bf16x3_rne(v, o);
+        u32x4* orow = out + ((size_t)(ci * st + b) * S + s_) * (size_t)ngrp + gq;
+#pragma unroll
+        for (int pz = 0; pz < 3; ++pz) orow[pz * pstride] = o[pz];
+    }
 }
+
+// (wave priorities: s_setprio of either role changed nothing on the PASE+ step -- DESIGN.md 3.0; the plan field stays for
+//  the trace build's ablations)
+int x6c_prio() { return 0; }
 
 unsigned magic_of(int d) {
     return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned long long)d);
@@ -1314,13 +1415,10 @@ bool pase_x6c_plan(const PaseConvGemm& p, PaseX6cPlan& pl) {
     if (pl.CinP < 16) return false;
     pl.G = (pl.CinP + 15) / 16;
     if (pl.G * 16 * 4 > pl.CinP * 5) return false;          // more than 25 % zero channels'
-    if (const char* e = getenv("PASE_X6C")) {
-        if (e[0] == '0') return false;
-    }
     // tile 128 x 128 (waves 4 x 1).  The operand split is paid once per staged element and shared by BM / 32 row tiles
     // x A taps: launches of at most 64 rows with fewer than four taps' would spend more issue slots splitting than
     // multiplying -- they stay on the fp32 matrix pipe
-    const bool force = getenv("PASE_X6C_FORCE") != nullptr;      // measurement runs: skip the routing rules below
+    const bool force = (p.x6_ctl & 1) != 0;      // measurement runs: skip the routing rules below
     if (!force && p.M <= 64 && pl.A < 4) return false;
     // ... and so do launches with fewer than 128 k (eight MFMA steps per tile): they are store-bound
     if (!force && (long)pl.CinP * pl.A < 128) return false;
@@ -1399,8 +1497,7 @@ int pase_x6c_pack(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st) 
 int pase_x6c_launch(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st) {
     // persistent grid: one workgroup per CU (8 waves, 74 KB of LDS), items dealt round-robin
     long nwg = (long)pl.n_row_tiles * pl.n_col_tiles * pl.splitk;
-    long cap = 256;
-    if (const char* e = getenv("PASE_X6C_MAXWG")) cap = atol(e) > 0 ? atol(e) : cap;     // tests: force several items per workgroup
+    const long cap = p.max_wg > 0 ? p.max_wg : 256;      // data-parallel runs leave CUs to RCCL; tests force several items per workgroup
     if (nwg > cap) nwg = cap;
     const dim3 grid((unsigned)nwg), block(NT);
     if (pl.A == 1) PASE_LAUNCH((conv_x6c_kernel<128, 3>), grid, block, st, p, pl);
@@ -1419,9 +1516,6 @@ int pase_x6c_launch(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st
 // and the small one is the pack.
 bool pase_x6c_wgrad_plan(const PaseWgrad& w, PaseX6cWgrad& o) {
     if (w.tap_major || (w.tapstep != 1 && w.tapstep != -1) || w.taps < 1 || w.stride < 1) return false;
-    if (const char* e = getenv("PASE_X6C")) {
-        if (e[0] == '0') return false;
-    }
     const long LIM = 0x7fffffffL;
     if ((long)w.S * w.g_ctot * (long)w.Tg >= LIM || (long)w.S * w.z_ctot * (long)w.Tz >= LIM) return false;
     if (w.Ncols < 8) return false;
@@ -1431,9 +1525,12 @@ bool pase_x6c_wgrad_plan(const PaseWgrad& w, PaseX6cWgrad& o) {
     // Measured on the PASE+ bs32 step (profiles/gemm_launches_r03.json): mode 3 wins on stride-1 layers with >= 256 output
     // channels (block 5: 1.01 -> 0.93 ms); strided layers lose to the cost of writing the planes (the decoder's stride-10
     // ConvTranspose1d: 1.6 GB of planes for a 1.7 ms launch) or tie
-    bool toep = w.taps > 1 && w.M >= 96;
-    if (const char* e = getenv("PASE_X6C_WGRAD_MODE")) toep = toep && e[0] == '3';
-    else toep = toep && w.stride == 1 && w.M >= 256;
+    // (PaseWgrad::x6 bits 4-7 force an orientation for A/B runs and tests; 0 = the routing below)
+    const int force_mode = (w.x6 >> 4) & 15;
+    bool toep = w.taps > 1 && w.M >= 96 && force_mode == 3;
+    // Round 4: the pre-split staged operand (mode 4, "ZP") replaces both the staged-Toeplitz orientation with its on-the-fly
+    // conversion (mode 1) and the plane-rows orientation (mode 3) on every layer with taps
+    const bool want_zp = force_mode == 0 || force_mode == 4;
     PaseConvGemm& c = o.pc;
     c = PaseConvGemm{};
     PaseX6cPlan& pl = o.pl;
@@ -1465,6 +1562,22 @@ bool pase_x6c_wgrad_plan(const PaseWgrad& w, PaseX6cWgrad& o) {
         c.in_scale = w.in_scale; c.in_shift = w.in_shift; c.in_alpha = w.in_alpha;
         c.K = w.Cin * w.taps;
         pl.tmode = 1;
+        if (want_zp) {
+            // pre-split staged operand: plane[pz][ci * stride + b][s][i] = piece pz of z~[s][ci][stride * (i + dmin) + b],
+            // i in [0, lseg), lseg = 16 QP16 + (shifts of a phase row, rounded up to 8); + one all-ones row for the bias column
+            auto fdiv = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
+            const int omin = (w.tapstep > 0 ? 0 : -(w.taps - 1)) - w.padL, omax = (w.tapstep > 0 ? w.taps - 1 : 0) - w.padL;
+            pl.t_dmin = fdiv(omin, w.stride);
+            pl.t_hh = (fdiv(omax, w.stride) - pl.t_dmin + 1 + 7) & ~7;
+            pl.t_lseg = QP16 * 16 + pl.t_hh;
+            pl.zp_rows = w.Cin * w.stride + (w.dbias ? 1 : 0);
+            const long body = (long)pl.zp_rows * w.S * pl.t_lseg;
+            if (body < (1L << 30) && (long)w.padL + w.taps < (1L << 20)) {
+                pl.zp = 1;
+                pl.t_plane = body;                                  // a multiple of 8 (lseg is)
+                pl.ps_magic = magic_of(w.stride);
+            }
+        }
     } else {
         o.a_src = w.z; o.a_rows = w.Cin; o.a_ctot = w.z_ctot; o.a_coff = w.z_coff; o.a_T = w.Tz;
         o.a_sc = w.in_scale; o.a_sh = w.in_shift; o.a_al = w.in_alpha;
@@ -1476,7 +1589,7 @@ bool pase_x6c_wgrad_plan(const PaseWgrad& w, PaseX6cWgrad& o) {
     }
     // g staged (modes 2 / 3): 8-position chunks start on 16-byte boundaries when the rows do
     pl.t_vec = (pl.tmode >= 2 && w.Tg % 4 == 0 && w.Ncols % 8 == 0 && (long)w.S * QP16 >= 4 &&
-                (reinterpret_cast<uintptr_t>(w.g) & 15) == 0 && !getenv("PASE_X6C_NOVEC")) ? 1 : 0;
+                (reinterpret_cast<uintptr_t>(w.g) & 15) == 0 && !(w.x6 & 512)) ? 1 : 0;
     // the split is paid once per staged element and shared by the row tiles of the workgroup: at most 64 rows would leave
     // half of every MFMA multiplying zeros
     if (o.a_rows <= 64) return false;
@@ -1484,7 +1597,7 @@ bool pase_x6c_wgrad_plan(const PaseWgrad& w, PaseX6cWgrad& o) {
     // measured slower than the exact-fp32 matrix pipe on every PASE+ 1x1 weight gradient (profiles/gemm_launches_r03.json)
     // (... except the swapped orientation on aligned rows of >= 1024 output channels: the 21 525-channel heads 0.68 -> 0.59 ms,
     //  the QRNN's 1536-channel Linear 0.33 -> 0.27 ms)
-    if (w.taps == 1 && !getenv("PASE_X6C_WGRAD_FLAT") && !(o.swapped && pl.t_vec && w.M >= 1024)) return false;
+    if (w.taps == 1 && !(w.x6 & 256) && !(o.swapped && pl.t_vec && w.M >= 1024)) return false;
     if ((long)c.Cin * c.Tin >= LIM) return false;
     c.S = w.S; c.Ncols = w.Ncols; c.M = o.a_rows;
     c.y = w.dw; c.Tout = w.ldw; c.bias = w.dbias; c.ldw = w.ldw;
@@ -1531,6 +1644,10 @@ bool pase_x6c_wgrad_plan(const PaseWgrad& w, PaseX6cWgrad& o) {
     pl.pack_chunks = (long)pl.n_row_tiles * 4 * pl.steps_total * 192;
     pl.prm_n = 0;
     pl.pack_bytes = pl.tmode == 3 ? 3 * pl.t_plane * 2 : pl.pack_chunks * 16;
+    if (pl.zp) {
+        pl.zp_off = pl.pack_bytes;
+        pl.pack_bytes += 3 * pl.t_plane * 2;
+    }
     return true;
 }
 
@@ -1551,11 +1668,19 @@ int pase_x6c_wgrad_launch(const PaseWgrad& w, const PaseX6cWgrad& o, hipStream_t
                     total, o.a_sc, o.a_sh, o.a_al);
     }
     PASE_CHECK_LAUNCH();
+    if (pl.zp) {
+        // one workgroup per (sequence, channel): all its phase rows; the ones row (bias column) is the last plane row
+        PASE_LAUNCH(pack_zph_kernel, dim3((unsigned)w.S, (unsigned)(w.Cin + (w.dbias ? 1 : 0))), dim3(256), st, w.z,
+                    reinterpret_cast<u32x4*>(reinterpret_cast<char*>(w.gx6) + pl.zp_off), w.Cin, w.S, w.z_ctot, w.z_coff, w.Tz,
+                    w.stride, pl.t_lseg, pl.t_dmin, w.pad_mode, pl.t_plane, w.in_scale, w.in_shift, w.in_alpha,
+                    w.dbias ? 1 : 0);
+        PASE_CHECK_LAUNCH();
+    }
     long nwg = (long)pl.n_row_tiles * pl.n_col_tiles * pl.splitk;
-    long cap = 256;
-    if (const char* e = getenv("PASE_X6C_MAXWG")) cap = atol(e) > 0 ? atol(e) : cap;
+    const long cap = w.max_wg > 0 ? w.max_wg : 256;
     if (nwg > cap) nwg = cap;
-    PASE_LAUNCH((conv_x6c_kernel<128, 4, true>), dim3((unsigned)nwg), dim3(NT), st, c, pl);
+    if (pl.zp) PASE_LAUNCH((conv_x6c_kernel<128, 4, true, true>), dim3((unsigned)nwg), dim3(NT), st, c, pl);
+    else PASE_LAUNCH((conv_x6c_kernel<128, 4, true>), dim3((unsigned)nwg), dim3(NT), st, c, pl);
     PASE_CHECK_LAUNCH();
     return 0;
 }

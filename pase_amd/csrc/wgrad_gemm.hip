@@ -646,183 +646,6 @@ __global__ void __launch_bounds__(NTHREADS, 2) wgrad_flat_kernel(PaseWgrad p, Wg
     }
 }
 
-// ---- the same 1x1 contraction on the bf16 matrix pipe (PaseWgrad::x6): both operands are contiguous along the
-// reduction, so BOTH are split into their three bf16 pieces by the staging threads (a float4 = half a fragment:
-// one ds_write_b64 per piece) and the MFMA loop is 12 ds_read_b128 + 24 v_mfma_f32_32x32x16_bf16 per 16-deep stage,
-// no VALU.  LDS image per operand and buffer: [2 k-groups][3 planes][128 rows][8 bf16] = 12 KB.
-constexpr int BKX = 16;                 // reduction positions per stage of the split-bf16 1x1 kernel
-
-template <int BM, int BN>
-__global__ void __launch_bounds__(NTHREADS, 2) wgrad_flat_x6_kernel(PaseWgrad p, WgradPlan pl) {
-    constexpr int WAVES_N = BN / 64;
-    constexpr int TPR = BKX / 4;             // threads per row (one float4 each)
-    constexpr int RPP = NTHREADS / TPR;      // rows per pass (64)
-    constexpr int GS = BM / RPP, ZSL = BN / RPP;
-    constexpr int A_BUF = (BKX / 8) * 3 * BM, Z_BUF = (BKX / 8) * 3 * BN;   // 16-byte chunks per buffer
-    __shared__ __attribute__((aligned(16))) u32x4 AsX[2 * A_BUF];
-    __shared__ __attribute__((aligned(16))) u32x4 ZsX[2 * Z_BUF];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = pase_uniform(tid >> 6);
-    const int wm = wave / WAVES_N;
-    const int wn = wave % WAVES_N;
-    const int fr = lane & 31;
-    const int fk = lane >> 5;
-
-    const int tiles = pl.n_row_tiles * pl.n_col_tiles;
-    const int tile = blockIdx.x % tiles;
-    const int split = blockIdx.x / tiles;
-    const int mt = tile % pl.n_row_tiles;
-    const int ct = tile / pl.n_row_tiles;
-    const int m0 = mt * BM;
-    const int j0 = ct * BN;
-    const int Kw = p.Cin;
-    const int c_begin = split * pl.kt_per_split;
-    const int c_end = min(pl.n_chunks, c_begin + pl.kt_per_split);
-    if (c_begin >= c_end) return;
-    const int ntot = p.S * p.Ncols;
-
-    // thread -> rows r0 + 64*i, time steps k4 .. k4+3 of the chunk = half (tid & 1) of k-group (tid & 3) >> 1
-    const int k4 = (tid % TPR) * 4;
-    const int r0 = tid / TPR;
-    unsigned goff[GS], zoff[ZSL];
-    float g_al[GS], z_sc[ZSL], z_sh[ZSL], z_al[ZSL];
-    const bool has_ga = p.g_alpha != nullptr;
-    const bool has_aff = p.in_scale != nullptr, has_al = p.in_alpha != nullptr;
-#pragma unroll
-    for (int i = 0; i < GS; ++i) {
-        const int m = min(m0 + r0 + RPP * i, p.M - 1);          // rows past M re-read row M-1 (never stored)
-        goff[i] = (unsigned)((p.g_coff + m) * p.Tg);
-        g_al[i] = has_ga ? p.g_alpha[m] : 1.f;
-    }
-#pragma unroll
-    for (int i = 0; i < ZSL; ++i) {
-        const int j = min(j0 + r0 + RPP * i, Kw - 1);
-        zoff[i] = (unsigned)((p.z_coff + j) * p.Tz);
-        z_sc[i] = has_aff ? p.in_scale[j] : 1.f;
-        z_sh[i] = has_aff ? p.in_shift[j] : 0.f;
-        z_al[i] = has_al ? p.in_alpha[j] : 1.f;
-    }
-    WF4 areg[GS], zreg[ZSL];
-    bool valid_next = true;
-    const bool do_rowsum = p.dbias && ct == 0;
-    float rs[GS];
-#pragma unroll
-    for (int i = 0; i < GS; ++i) rs[i] = 0.f;
-
-    auto load_stage = [&](int c) __attribute__((always_inline)) {
-        const int n = c * BKX + k4;                              // 4 consecutive n share a sequence (Ncols % 4 == 0)
-        valid_next = n < ntot;
-        const unsigned nn = (unsigned)min(n, ntot - 4);
-        int s = (int)div_magic(nn, pl.ncols_magic);
-        int q = (int)nn - s * p.Ncols;
-        if (q < 0) { --s; q += p.Ncols; }
-        const float* gb = p.g + (unsigned)(s * p.g_ctot * p.Tg + q);
-        const float* zb = p.z + (unsigned)(s * p.z_ctot * p.Tz + q);
-#pragma unroll
-        for (int i = 0; i < GS; ++i) areg[i] = *reinterpret_cast<const WF4*>(gb + goff[i]);
-#pragma unroll
-        for (int i = 0; i < ZSL; ++i) zreg[i] = *reinterpret_cast<const WF4*>(zb + zoff[i]);
-    };
-    auto prelu = [&](float v, float al) __attribute__((always_inline)) { return v > 0.f ? v : v * al; };
-    const int kgs = (tid % TPR) >> 1;                            // k-group of this thread's float4
-    const int sub = kgs * 3;                                     // ... in planes
-    const int rsw = 4 * kgs;                                     // row XOR: the two k-groups of a row are one bank apart
-    const int halfb = (tid & 1) * 8;
-    auto store_stage = [&](int buf) __attribute__((always_inline)) {
-        const float keep = valid_next ? 1.f : 0.f;               // chunk tail beyond S*Ncols contributes zero
-#pragma unroll
-        for (int i = 0; i < GS; ++i) {
-            const int r = r0 + RPP * i;
-            float v[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (has_ga ? prelu(v[e], g_al[i]) : v[e]) * keep;
-            if (do_rowsum) rs[i] += (v[0] + v[1]) + (v[2] + v[3]);
-            unsigned o[3][2];
-            pase_split_bf16x3_quad(v, o);
-            unsigned char* dst = reinterpret_cast<unsigned char*>(&AsX[buf * A_BUF + sub * BM + (r ^ rsw)]) + halfb;
-#pragma unroll
-            for (int pz = 0; pz < 3; ++pz) *reinterpret_cast<uint2*>(dst + pz * BM * 16) = make_uint2(o[pz][0], o[pz][1]);
-        }
-#pragma unroll
-        for (int i = 0; i < ZSL; ++i) {
-            const int r = r0 + RPP * i;
-            float v[4] = {zreg[i].x, zreg[i].y, zreg[i].z, zreg[i].w};
-            if (has_aff || has_al) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = prelu(fmaf(v[e], z_sc[i], z_sh[i]), z_al[i]);
-            }
-            unsigned o[3][2];
-            pase_split_bf16x3_quad(v, o);
-            unsigned char* dst = reinterpret_cast<unsigned char*>(&ZsX[buf * Z_BUF + sub * BN + (r ^ rsw)]) + halfb;
-#pragma unroll
-            for (int pz = 0; pz < 3; ++pz) *reinterpret_cast<uint2*>(dst + pz * BN * 16) = make_uint2(o[pz][0], o[pz][1]);
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    load_stage(c_begin);
-    store_stage(0);
-    __syncthreads();
-    for (int c = c_begin; c < c_end; ++c) {
-        const int cur = (c - c_begin) & 1;
-        const bool has_next = c + 1 < c_end;
-        if (has_next) load_stage(c + 1);
-        const u32x4* aL = &AsX[cur * A_BUF + fk * 3 * BM + wm * 64 + (fr ^ (4 * fk))];
-        const u32x4* zL = &ZsX[cur * Z_BUF + fk * 3 * BN + wn * 64 + (fr ^ (4 * fk))];
-        u32x4 fa[3][2], fb[3][2];
-#pragma unroll
-        for (int pz = 0; pz < 3; ++pz) {
-            fa[pz][0] = aL[pz * BM];
-            fa[pz][1] = aL[pz * BM + 32];
-            fb[pz][0] = zL[pz * BN];
-            fb[pz][1] = zL[pz * BN + 32];
-        }
-        constexpr int PZA[6] = {1, 0, 2, 0, 1, 0}, PZB[6] = {1, 2, 0, 1, 0, 0};   // smallest terms first
-#pragma unroll
-        for (int pi = 0; pi < 6; ++pi) {
-            acc[0][0] = pase_mfma_bf16_32x32x16(fa[PZA[pi]][0], fb[PZB[pi]][0], acc[0][0]);
-            acc[0][1] = pase_mfma_bf16_32x32x16(fa[PZA[pi]][0], fb[PZB[pi]][1], acc[0][1]);
-            acc[1][0] = pase_mfma_bf16_32x32x16(fa[PZA[pi]][1], fb[PZB[pi]][0], acc[1][0]);
-            acc[1][1] = pase_mfma_bf16_32x32x16(fa[PZA[pi]][1], fb[PZB[pi]][1], acc[1][1]);
-        }
-        if (has_next) store_stage(cur ^ 1);
-        __syncthreads();
-    }
-    if (do_rowsum) {
-#pragma unroll
-        for (int i = 0; i < GS; ++i) {
-            float v = rs[i];
-            v += __shfl_xor(v, 1);
-            v += __shfl_xor(v, 2);
-            const int m = m0 + r0 + RPP * i;
-            if ((tid % TPR) == 0 && m < p.M) atomicAdd(p.dbias + m, v);
-        }
-    }
-
-    const int rbase = m0 + wm * 64 + 4 * (lane >> 5);
-    const int jb = j0 + wn * 64 + fr;
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = rbase + a * 32 + (r & 3) + 8 * (r >> 2);
-            if (m >= p.M) continue;
-            const unsigned rowoff = (unsigned)(m * p.ldw);
-            if (jb < Kw) atomicAdd(p.dw + (rowoff + (unsigned)jb), acc[a][0][r]);
-            if (jb + 32 < Kw) atomicAdd(p.dw + (rowoff + (unsigned)(jb + 32)), acc[a][1][r]);
-        }
-    }
-}
-
 }  // namespace
 
 extern "C" long pase_wgrad_x6_bytes(const PaseWgrad* d) {
@@ -834,7 +657,7 @@ extern "C" long pase_wgrad_x6_bytes(const PaseWgrad* d) {
 extern "C" int pase_wgrad_plan_kind(const PaseWgrad* d) {
     if (d->M <= 0 || d->Cin <= 0 || d->S <= 0 || d->Ncols <= 0) return 0;
     PaseX6cWgrad o;
-    return pase_x6c_wgrad_plan(*d, o) ? o.pl.tmode : 0;
+    return pase_x6c_wgrad_plan(*d, o) ? (o.pl.zp ? 4 : o.pl.tmode) : 0;
 }
 
 extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
@@ -846,15 +669,9 @@ extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
         if (!pase_x6c_wgrad_plan(p, o)) return -11;        // a pack buffer on a launch without a plan is refused, not ignored
         return pase_x6c_wgrad_launch(p, o, (hipStream_t)stream);
     }
-    // the round-2 split-bf16 instantiations below accumulate all six terms in ONE accumulator (biased: conv_x6c.hip
-    // header); they only run in measurement builds (PASE_X6_LEGACY=1)
-    {
-        static const bool legacy = [] {
-            const char* e = getenv("PASE_X6_LEGACY");
-            return e && e[0] == '1';
-        }();
-        if (!legacy) p.x6 = 0;
-    }
+    // from here on: the exact-fp32 matrix pipe (round 2's single-accumulator split-bf16 instantiations of the kernels below
+    // were biased -- conv_x6c.hip header -- and are no longer built)
+    p.x6 = 0;
     if (p.tap_major) return -4;          // express tap-major weights as per-tap launches (ldw + offset)
     if (p.tapstep != 1 && p.tapstep != -1) return -5;
     if (p.pad_mode == PASE_PAD_REFLECT && p.padL >= p.Tz) return -3;
@@ -893,11 +710,6 @@ extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
     };
     pl.zshift = 0;
     bool use_zv = false;
-    // split-bf16 launches take the 64 x 256 tile whenever its span slab fits: half the split G slab (24 KB) and
-    // measurably faster than 128 x 128 on every PASE+ layer (127-158 vs 111-141 TFLOP/s fp32-equivalent)
-    const bool x6_can = p.x6 && !pl.flat && (p.Tg % 4) == 0 && (p.Ncols % 4) == 0 &&
-                        (((unsigned long long)(size_t)p.g) % 16) == 0 && (long)p.S * p.g_ctot * (long)p.Tg < 0x7fffffffL;
-    if (x6_can && (need(256) <= ZPT_SMALL * NTHREADS || (zv_ok && need_zv(256) <= ZV_SLOTS * 4 * NTHREADS))) narrow = true;
     if (narrow && need(256) > ZPT_LARGE * NTHREADS && !(zv_ok && need_zv(256) <= ZV_SLOTS * 4 * NTHREADS)) narrow = false;
     if (!narrow && need(128) > ZPT_LARGE * NTHREADS && !(zv_ok && need_zv(128) <= ZV_SLOTS * 4 * NTHREADS)) return -6;
     const bool small = need(narrow ? 256 : 128) <= ZPT_SMALL * NTHREADS;
@@ -914,8 +726,7 @@ extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
     pl.n_col_tiles = (Nw + BNv - 1) / BNv;
     const long kred = (long)p.S * p.Ncols;
     pl.chunks_per_seq = (p.Ncols + BKQ - 1) / BKQ;
-    const bool flat_x6 = flat_fast && p.x6;
-    const int bkq = flat_x6 ? BKX : BKQ;                 // reduction positions per stage
+    const int bkq = BKQ;                                 // reduction positions per stage
     pl.n_chunks = pl.flat ? (int)((kred + bkq - 1) / bkq) : p.S * pl.chunks_per_seq;
     pl.span_magic = (unsigned)((0x100000000ULL + pl.SPANW - 1) / (unsigned long long)pl.SPANW);
     pl.ncols_magic = (unsigned)((0x100000000ULL + p.Ncols - 1) / (unsigned long long)p.Ncols);
@@ -935,8 +746,7 @@ extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
         const double flush = 3.0 * (BKQ / bkq) / (double)pl.n_chunks;   // atomic tile flush ~ 3 (32-deep) stages of work
         for (int sk = 1; sk <= max_split && sk <= 2048; ++sk) {
             const long W = (long)tiles * sk;
-            // (the split-bf16 1x1 kernel fits three workgroups per CU: 168 VGPRs, 48 KB of LDS)
-            const long slots = flat_x6 ? 768 : 512;
+            const long slots = 512;
             const long full = W / slots, tail = W % slots;
             const double tc = tail == 0 ? 0.0 : (tail <= 256 ? 0.55 : 1.0);
             const double est = ((double)full + tc) * (1.0 / sk + flush);   // rounds x (work + flush) per workgroup
@@ -947,26 +757,8 @@ extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
     pl.kt_per_split = (pl.n_chunks + splitk - 1) / splitk;
     splitk = (pl.n_chunks + pl.kt_per_split - 1) / pl.kt_per_split;
     const dim3 grid((unsigned)(tiles * splitk)), block(NTHREADS);
-    if (flat_x6) {
-        PASE_LAUNCH((wgrad_flat_x6_kernel<128, 128>), grid, block, st, p, pl);
-        PASE_CHECK_LAUNCH();
-        return 0;
-    }
     if (flat_fast) {
         PASE_LAUNCH((wgrad_flat_kernel<128, 128>), grid, block, st, p, pl);
-        PASE_CHECK_LAUNCH();
-        return 0;
-    }
-    // split-bf16 instantiations (LDS: 48 / 24 KB of split G slab + the span slab must leave two workgroups per CU)
-    const bool x6 = p.x6 && pl.gvec && !pl.flat;
-    if (x6 && use_zv && narrow) {
-        PASE_LAUNCH((wgrad_gemm_kernel<64, 256, 5, 1, 1>), grid, block, st, p, pl);
-        PASE_CHECK_LAUNCH();
-        return 0;
-    }
-    if (x6 && !use_zv && small) {
-        if (narrow) PASE_LAUNCH((wgrad_gemm_kernel<64, 256, ZPT_SMALL, 0, 1>), grid, block, st, p, pl);
-        else PASE_LAUNCH((wgrad_gemm_kernel<128, 128, ZPT_SMALL, 0, 1>), grid, block, st, p, pl);
         PASE_CHECK_LAUNCH();
         return 0;
     }

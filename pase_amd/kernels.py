@@ -34,6 +34,7 @@ class PaseConvGemm(C.Structure):
         ("tile_hint", C.c_int), ("post_op", C.c_int), ("post_scale", C.c_float), ("post_eps", C.c_float),
         ("splitk", C.c_int),
         ("wx6", C.c_void_p),
+        ("x6_ctl", C.c_int), ("max_wg", C.c_int),
     ]
 
 
@@ -121,7 +122,19 @@ def _conv_desc(x, w, y, *, S, Cin, Tin, M, K, taps, Ncols, Tout, ldw=None, bias=
     d.epilogue, d.r_ctx, d.label_D = epilogue, r_ctx, label_D
     d.tile_hint = tile_hint
     d.splitk = splitk
+    # measurement / test controls travel in the descriptor (the C library reads no environment variables)
+    d.x6_ctl = 1 if os.environ.get("PASE_X6C_FORCE") else 0
+    d.max_wg = _max_wg()
     return d
+
+
+MAX_WG = 0      # cap on the persistent grids of the split-bf16 kernels (0 = one workgroup per CU); the data-parallel trainer sets
+                # it to 256 - reserved CUs so that RCCL's channel kernels find free CUs beside the GEMMs
+
+
+def _max_wg():
+    e = os.environ.get("PASE_X6C_MAXWG")
+    return int(e) if e else MAX_WG
 
 
 def stat_tiles(*, M, S, Ncols, Cin, taps, stride=1, padL=0, tapstep=1, tile_hint=0):
@@ -258,7 +271,7 @@ class PaseWgrad(C.Structure):
         ("Cin", C.c_int), ("Tz", C.c_int), ("z_ctot", C.c_int), ("z_coff", C.c_int), ("taps", C.c_int),
         ("tap_major", C.c_int), ("stride", C.c_int), ("tapstep", C.c_int), ("padL", C.c_int),
         ("pad_mode", C.c_int), ("ldw", C.c_int), ("splitk", C.c_int), ("x6", C.c_int),
-        ("gx6", C.c_void_p),
+        ("gx6", C.c_void_p), ("max_wg", C.c_int),
     ]
 
 
@@ -344,6 +357,11 @@ def wgrad_gemm(g, z, dw, *, S, M, Tg, Ncols, Cin, Tz, taps, ldw=None, dbias=None
     d.ldw = Cin * taps if ldw is None else ldw
     d.splitk = splitk
     d.x6 = 1 if (X6 and os.environ.get("PASE_X6_WGRAD", "1") != "0") else 0
+    if d.x6:      # orientation forcing / 1x1 layers on the split kernel / no row-coalesced staging: tests and A/B tools
+        d.x6 |= (int(os.environ.get("PASE_X6C_WGRAD_MODE", "0")) & 15) << 4
+        d.x6 |= 256 if os.environ.get("PASE_X6C_WGRAD_FLAT") else 0
+        d.x6 |= 512 if os.environ.get("PASE_X6C_NOVEC") else 0
+    d.max_wg = _max_wg()
     global LAST_WGRAD_X6, LAST_WGRAD_KIND
     LAST_WGRAD_X6 = False
     LAST_WGRAD_KIND = 0

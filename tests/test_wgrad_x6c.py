@@ -14,10 +14,11 @@ import torch.nn.functional as F
 from pase_amd import kernels as K
 
 
-@pytest.fixture(params=["1", "3"], ids=["staged-toeplitz", "plane-rows"])
+@pytest.fixture(params=["4", "1", "3"], ids=["presplit-planes", "staged-toeplitz", "plane-rows"])
 def wmode(request, monkeypatch):
-    """layers with taps: mode 1 stages the (channel, tap) columns of z, mode 3 reads (channel, tap) ROWS at 2-byte granularity
-    out of row-major bf16 planes of z and stages g"""
+    """layers with taps: mode 4 (the default) copies the (channel, tap) columns out of pre-split phase-decomposed bf16 planes
+    of z~; mode 1 stages them from fp32 with the conversion in the GEMM; mode 3 reads (channel, tap) ROWS at 2-byte
+    granularity out of row-major bf16 planes of z and stages g"""
     monkeypatch.setenv("PASE_X6C_WGRAD_MODE", request.param)
     return request.param
 
