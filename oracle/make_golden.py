@@ -105,7 +105,7 @@ def synthetic_batch(seed, B, T, workers_cfg):
     return batch
 
 
-def perturb_affine(module, seed=123):
+def perturb_affine(module, seed=123, smooth=False):
     """BatchNorm affines and PReLU slopes moved off their init values -- the SAME seeded draw, in named_parameters order,
     as tests/util.py:randomize_affine applies to the HIP model.  At init every encoder PReLU slope is 0 (a ReLU): a forward
     value that differs from the fp64 one in the last bit can flip a backward mask, which hides everything below ~1e-3 in the
@@ -120,6 +120,12 @@ def perturb_affine(module, seed=123):
                 p.copy_(torch.empty(p.shape).normal_(0, 0.2, generator=g))
             elif n.endswith("act.weight"):
                 p.copy_(torch.empty(p.shape).uniform_(0.05, 0.4, generator=g))
+                if smooth:
+                    # slope exactly 1: PReLU is the identity, the step has NO kink left (the perturbed draw above still has
+                    # one of height 1 - slope at every activation: measured, the reference's own fp32 step is 5.5e-3 away from
+                    # its fp64 self on blocks.2.norm.bias there).  Every contraction, BatchNorm, scan, loss and the slope
+                    # gradient itself are still evaluated; what is left of discrete events is the sign of the L1 loss.
+                    p.fill_(1.0)
 
 
 def _ref_step(seed, B, T, fe_name, wk_name, double=False, perturb=False):
@@ -143,7 +149,7 @@ def _ref_step(seed, B, T, fe_name, wk_name, double=False, perturb=False):
     model = quiet(pase, frontend_cfg=fe_cfg, minions_cfg=minions_cfg,
                   cls_lst=[w["name"] for w in raw_cfg["cls"]], regr_lst=[w["name"] for w in raw_cfg["regr"]])
     if perturb:
-        perturb_affine(model)
+        perturb_affine(model, smooth=(perturb == "smooth"))
     names, sums, sq = param_checksums(model.state_dict())
     batch = synthetic_batch(seed + 1, B, T, raw_cfg)
     if double:
@@ -225,24 +231,28 @@ def gen_pase_step_grads(seed, B, T, fe_name="PASE+.cfg", wk_name="workers+.cfg",
              n_samples=GRAD_SAMPLES, loss_total=float(losses["total"]))
 
 
-def gen_perturbed():
+def gen_perturbed(only=None):
     """The two full-width steps again with BN affines / PReLU slopes off their init values (perturb_affine): fp32 step,
-    element-wise fp32 gradients and the fp64 truth.  These are the TIGHT live-reference gradient gates
-    (tests/test_pase_step.py::test_full_width_golden_step[*-perturbed])."""
-    for seed, fe, wk, stem in ((2, "PASE+.cfg", "workers+.cfg", "pase_plus_step_perturbed"),
-                               (4, "PASE.cfg", "workers.cfg", "pase_step_cfg2_perturbed")):
-        gen_pase_step(seed=seed, B=2, T=8000, fe_name=fe, wk_name=wk, out=stem + ".npz", perturb=True)
-        gen_pase_step_grads(seed=seed, B=2, T=8000, fe_name=fe, wk_name=wk, out=stem + "_grads.npz", perturb=True)
+    element-wise fp32 gradients and the fp64 truth; and the "smooth" variant (slopes = 1: no kink) -- the TIGHT live-reference
+    gradient gate (tests/test_pase_step.py::test_full_width_golden_step[*-smooth])."""
+    for seed, fe, wk, stem, mode in ((2, "PASE+.cfg", "workers+.cfg", "pase_plus_step_perturbed", True),
+                                     (4, "PASE.cfg", "workers.cfg", "pase_step_cfg2_perturbed", True),
+                                     (2, "PASE+.cfg", "workers+.cfg", "pase_plus_step_smooth", "smooth"),
+                                     (4, "PASE.cfg", "workers.cfg", "pase_step_cfg2_smooth", "smooth")):
+        if only and only not in stem:
+            continue
+        gen_pase_step(seed=seed, B=2, T=8000, fe_name=fe, wk_name=wk, out=stem + ".npz", perturb=mode)
+        gen_pase_step_grads(seed=seed, B=2, T=8000, fe_name=fe, wk_name=wk, out=stem + "_grads.npz", perturb=mode)
         gen_pase_step_grads(seed=seed, B=2, T=8000, fe_name=fe, wk_name=wk, out=stem + "_grads_f64.npz", double=True,
-                            perturb=True)
+                            perturb=mode)
 
 
 if __name__ == "__main__":
     ref_shim.install()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    if sys.argv[1:] == ["perturbed"]:      # only the perturbed-slope steps
-        gen_perturbed()
+    if sys.argv[1:2] == ["perturbed"]:     # only the perturbed-slope steps (optionally: only files whose stem contains argv[2])
+        gen_perturbed(sys.argv[2] if len(sys.argv) > 2 else None)
         sys.exit(0)
     if sys.argv[1:] == ["grads"]:          # only the element-wise gradient file
         gen_pase_step_grads(seed=2, B=2, T=8000)

@@ -26,6 +26,8 @@ struct PaseX6cPlan {
     int t_vec;                                 // T-mode: the staged operand's 8-position chunks are 16-byte aligned
     int zp;                                    // tmode 1 with the staged operand PRE-SPLIT ("ZP"): the (channel, tap) columns are
                                                // COPIED out of phase-decomposed bf16 planes of z~ (pack_zph_kernel), no conversion
+    int zp_n, zp_rem;                          // ... taps = stride * zp_n + zp_rem: GEMM column r of a channel is tap
+                                               //     kk0 + stride * dd (taps of ONE phase adjacent: zp_tap_of in conv_x6c.hip)
     int zp_rows;                               // ... rows of a plane: Cin * stride (+ 1: the all-ones row of the bias column)
     long zp_off;                               // ... byte offset of the planes inside PaseWgrad::gx6 (behind the pack of g)
     long t_plane;                              // tmode 3: elements per plane

@@ -58,6 +58,23 @@ __device__ __forceinline__ unsigned div_magic(unsigned e, unsigned magic) {
 
 __device__ float g_identc[2] = {1.f, 0.f};
 
+// ZP weight gradients of strided layers: the GEMM columns of one channel are its taps ordered PHASE BY PHASE -- column r is tap
+// kk0 + stride * dd, where the first `rem` phases (kk0 < rem) hold n + 1 taps and the others n (taps = stride * n + rem).
+// Consecutive columns (= consecutive lanes of the staging waves) then read the SAME plane row at consecutive shifts, i.e.
+// overlapping 16-byte windows 2 bytes apart, which the memory pipeline coalesces; in natural tap order consecutive lanes
+// cycle through the `stride` phase rows (52 KB apart) and every lane is its own request (measured: the stride-4 / stride-10
+// decoder layers 1.6x SLOWER than the fp32-staged form).  Stride 1: the identity.
+__device__ __forceinline__ int zp_tap_of(int r, const PaseX6cPlan& pl) {
+    const int n1 = pl.zp_n + 1, head = pl.zp_rem * n1;
+    if (r < head) {
+        const int kk0 = (int)div_magic((unsigned)r, pl.rctx_magic);           // r / (n + 1)
+        return kk0 + pl.t_stride * (r - kk0 * n1);
+    }
+    const int r2 = r - head;
+    const int q = (int)div_magic((unsigned)r2, pl.cout_magic);                // r2 / n
+    return pl.zp_rem + q + pl.t_stride * (r2 - q * pl.zp_n);
+}
+
 #ifdef PASE_X6C_TRACE   // tools/trace_x6c.py only: per-item phase timestamps (shader clock) of workgroups 0 and 131
 #define X6C_TRACE_ITEMS 64
 __device__ unsigned long long g_x6c_trace[2 * X6C_TRACE_ITEMS * 12];
@@ -321,7 +338,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                     const bool valid = j < p.K || ones;
                     const int jj = min(j, p.K - 1);
                     const int ci = (int)div_magic((unsigned)jj, pl.ncols_magic);
-                    const int kk = jj - ci * p.taps;
+                    const int kk = zp_tap_of(jj - ci * p.taps, pl);
                     const int ob = kk * p.tapstep - p.padL - pl.t_dmin * p.stride;   // >= 0: dmin = floor(min offset / stride)
                     const int db = (int)div_magic((unsigned)ob, pl.ps_magic);          // d - dmin
                     const int b = ob - db * p.stride;
@@ -954,13 +971,18 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
 #pragma unroll
         for (int j = 0; j < NBT; ++j) {
             const int col = n0 + j * 32 + fr;
+            int dcol = col;                                   // column of dw
+            if (ZP && pl.t_stride > 1 && col < p.K) {         // phase-ordered GEMM columns (zp_tap_of)
+                const int ci = (int)div_magic((unsigned)col, pl.ncols_magic);
+                dcol = ci * p.taps + zp_tap_of(col - ci * p.taps, pl);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = rb + (r & 3) + 8 * (r >> 2);
                 const float v = acc[j][r];
                 if (m < p.M) {
                     if (col < p.K) {
-                        atomicAdd(p.y + (size_t)m * p.Tout + col, v);
+                        atomicAdd(p.y + (size_t)m * p.Tout + dcol, v);
                     } else if (col == p.K && p.bias) {
                         atomicAdd(const_cast<float*>(p.bias) + m, v);
                     }
@@ -1530,7 +1552,10 @@ bool pase_x6c_wgrad_plan(const PaseWgrad& w, PaseX6cWgrad& o) {
     bool toep = w.taps > 1 && w.M >= 96 && force_mode == 3;
     // Round 4: the pre-split staged operand (mode 4, "ZP") replaces both the staged-Toeplitz orientation with its on-the-fly
     // conversion (mode 1) and the plane-rows orientation (mode 3) on every layer with taps
-    const bool want_zp = force_mode == 0 || force_mode == 4;
+    // (... except stride >= 8 unless forced: a phase row then carries only 2-3 taps, 64 staging lanes read ~22 different plane
+    //  rows per load instruction and the memory pipeline is request-bound -- the decoder's stride-10 layer 1.81 vs 1.48 ms;
+    //  the fp32-staged mode 1 reads 64 ADJACENT samples per instruction there)
+    const bool want_zp = force_mode == 4 || (force_mode == 0 && w.stride < 8);
     PaseConvGemm& c = o.pc;
     c = PaseConvGemm{};
     PaseX6cPlan& pl = o.pl;
@@ -1576,6 +1601,11 @@ bool pase_x6c_wgrad_plan(const PaseWgrad& w, PaseX6cWgrad& o) {
                 pl.zp = 1;
                 pl.t_plane = body;                                  // a multiple of 8 (lseg is)
                 pl.ps_magic = magic_of(w.stride);
+                pl.t_stride = w.stride;
+                pl.zp_n = w.taps / w.stride;
+                pl.zp_rem = w.taps % w.stride;
+                pl.rctx_magic = magic_of(pl.zp_n + 1);
+                pl.cout_magic = magic_of(pl.zp_n);
             }
         }
     } else {

@@ -87,8 +87,10 @@ def test_encoder_golden(tag, cfgfile):
 @pytest.mark.parametrize("gold,fe,wk", [("pase_plus_step.npz", "frontend/PASE+.cfg", "workers/workers+.cfg"),
                                         ("pase_step_cfg2.npz", "frontend/PASE.cfg", "workers/workers.cfg"),
                                         ("pase_plus_step_perturbed.npz", "frontend/PASE+.cfg", "workers/workers+.cfg"),
-                                        ("pase_step_cfg2_perturbed.npz", "frontend/PASE.cfg", "workers/workers.cfg")],
-                         ids=["plus", "cfg2", "plus-perturbed", "cfg2-perturbed"])
+                                        ("pase_step_cfg2_perturbed.npz", "frontend/PASE.cfg", "workers/workers.cfg"),
+                                        ("pase_plus_step_smooth.npz", "frontend/PASE+.cfg", "workers/workers+.cfg"),
+                                        ("pase_step_cfg2_smooth.npz", "frontend/PASE.cfg", "workers/workers.cfg")],
+                         ids=["plus", "cfg2", "plus-perturbed", "cfg2-perturbed", "plus-smooth", "cfg2-smooth"])
 def test_pase_step_golden(gold, fe, wk):
     """oracle full step (all workers, losses, grads) == live reference trainer step, for PASE+.cfg +
     workers+.cfg (BASELINE configs[2]) and PASE.cfg + workers.cfg incl. the SPC worker (configs[1])."""
@@ -100,9 +102,9 @@ def test_pase_step_golden(gold, fe, wk):
     seed_all(int(g["seed"]))
     model = quiet(pase, frontend_cfg=dict(fe_cfg), minions_cfg=with_losses(load_cfg(wk)),
                   cls_lst=[w["name"] for w in raw["cls"]], regr_lst=[w["name"] for w in raw["regr"]])
-    if "perturbed" in gold:      # BN affines / PReLU slopes off init, the draw of make_golden.perturb_affine
+    if "perturbed" in gold or "smooth" in gold:      # BN affines / PReLU slopes off init, the draw of make_golden.perturb_affine
         from util import randomize_affine
-        randomize_affine(model)
+        randomize_affine(model, smooth="smooth" in gold)
     sd = model.state_dict()
     assert list(sd.keys()) == [str(s) for s in g["param_names"]]
     assert_close(torch.tensor([float((v.double() ** 2).sum()) for v in sd.values()]), g["param_sq"], rtol=1e-7,

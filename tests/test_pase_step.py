@@ -124,10 +124,19 @@ def test_trainer_three_adam_steps(dev):
 GRAD_FLOOR_WEIGHT = 1.5e-3       # relL2, weight tensors
 GRAD_FLOOR_PER_CHANNEL = 3e-3    # relL2, one scalar per channel (BN gamma / beta, PReLU slopes, biases, SincNet vectors)
 # The "*_perturbed" goldens (round-3 review item 2) are the same two live-reference steps with the BatchNorm affines and the
-# PReLU slopes moved off their init values (oracle/make_golden.py:perturb_affine == util.randomize_affine, same seed): no
-# slope is 0, a last-bit forward difference can no longer flip a ReLU mask, and the floor drops to 2e-5 -- every tensor of
-# both pipes must be as close to the live reference's fp64 step as the live reference's own fp32 step is (x 1.5).
-GRAD_FLOOR_PERTURBED = 2e-5
+# PReLU slopes moved off their init values (oracle/make_golden.py:perturb_affine == util.randomize_affine, same seed).  They
+# exercise the affine / slope gradient paths with non-trivial values, but they do NOT remove the discrete events: a PReLU
+# with slope a still has a kink of height 1 - a (0.6 ... 0.95 here), and the L1 loss of the decoder has a sign.  Measured
+# (round 4): on the perturbed PASE+ golden the LIVE REFERENCE's own fp32 step is 5.5e-3 away from its fp64 self on
+# blocks.2.norm.bias and 4.4e-3 on blocks.2.conv.weight -- more than at init -- while the HIP path is at 2e-6 there; on the
+# perturbed PASE.cfg golden the split pipe has one flip in the upper encoder (1.4e-4 on the blocks below it) and the fp32 pipe
+# one in the decoder (1.4e-3 on deconv.weight), each absent on the other pipe.  They are gated like the init-state goldens.
+# The "*_smooth" goldens are the TIGHT gate: same perturbed affines, every PReLU slope exactly 1 (identity: no kink anywhere;
+# every contraction, BatchNorm, scan, loss and the slope gradients themselves are still evaluated).  There the live
+# reference's fp32 step is within 1.2e-6 (median) / 4.5e-5 (worst regular tensor) of its fp64 self, and every tensor of both
+# pipes must be within 1.5 x that + 2e-5; tensors whose fp64 gradient is analytically zero there (BatchNorm betas feeding
+# another BatchNorm through a linear map: |truth| < 1e-9) are skipped like the other noise gradients.
+GRAD_FLOOR_SMOOTH = 2e-5
 _PIPE_ERR = {}                 # (gold, pipe) -> {name: relL2 vs fp64}, to compare the two pipes with each other
 
 
@@ -135,8 +144,10 @@ _PIPE_ERR = {}                 # (gold, pipe) -> {name: relL2 vs fp64}, to compa
 @pytest.mark.parametrize("gold,fe,wk", [("pase_plus_step.npz", "frontend/PASE+.cfg", "workers/workers+.cfg"),
                                         ("pase_step_cfg2.npz", "frontend/PASE.cfg", "workers/workers.cfg"),
                                         ("pase_plus_step_perturbed.npz", "frontend/PASE+.cfg", "workers/workers+.cfg"),
-                                        ("pase_step_cfg2_perturbed.npz", "frontend/PASE.cfg", "workers/workers.cfg")],
-                         ids=["plus", "cfg2", "plus-perturbed", "cfg2-perturbed"])
+                                        ("pase_step_cfg2_perturbed.npz", "frontend/PASE.cfg", "workers/workers.cfg"),
+                                        ("pase_plus_step_smooth.npz", "frontend/PASE+.cfg", "workers/workers+.cfg"),
+                                        ("pase_step_cfg2_smooth.npz", "frontend/PASE.cfg", "workers/workers.cfg")],
+                         ids=["plus", "cfg2", "plus-perturbed", "cfg2-perturbed", "plus-smooth", "cfg2-smooth"])
 def test_full_width_golden_step(dev, gold, fe, wk, x6):
     """Full-width one step vs the live reference's trainer step: PASE+.cfg + workers+.cfg (12 workers)
     and PASE.cfg + workers.cfg (decoder, r-less regressors, SPC / LIM / GIM); on the split-bf16 pipe (the default)
@@ -163,10 +174,11 @@ def _full_width_golden_step(dev, gold, fe, wk, x6):
     batch = synthetic_batch(int(g["seed"]) + 1, int(g["B"]), int(g["T"]), raw["regr"])
     batch = {k: v.to(dev) for k, v in batch.items()}
     m = tr.model
-    perturbed = "perturbed" in gold
+    perturbed = "perturbed" in gold or "smooth" in gold
+    smooth = "smooth" in gold
     if perturbed:
         from util import randomize_affine
-        randomize_affine(m)          # the draw the live reference model got before its step (make_golden.perturb_affine)
+        randomize_affine(m, smooth=smooth)   # the draw the live reference model got before its step (make_golden.perturb_affine)
     # same starting point as the live reference: per-tensor checksums of the state_dict (initial weights + perturbation)
     sd_now = m.state_dict()
     for k_, s_, q_ in zip((str(s) for s in g["param_names"]), g["param_sum"], g["param_sq"]):
@@ -196,7 +208,11 @@ def _full_width_golden_step(dev, gold, fe, wk, x6):
         assert abs(float(losses[k]) - v) <= 1e-4 * max(1.0, abs(v)), (k, float(losses[k]), v)
     names = [str(s) for s in g["grad_names"]]
     params = dict(m.named_parameters())
-    keep = [i for i, n in enumerate(names) if not is_noise_grad(n)]
+    zero_names = set()
+    if smooth:      # gradients that are analytically zero with identity activations: Adam turns their round-off into +-lr steps
+        g64z = np.load(os.path.join(GOLD, gold.replace(".npz", "_grads_f64.npz")))
+        zero_names = {str(n_) for n_, a_ in zip(g64z["grad_names"], g64z["grad_absmax"]) if float(a_) < 1e-9}
+    keep = [i for i, n in enumerate(names) if not is_noise_grad(n) and n not in zero_names]
     gsq = torch.tensor([float((params[names[i]].grad.double() ** 2).sum()) for i in keep])
     assert_close(gsq.sqrt(), np.sqrt(g["grad_sq"][keep]), rtol=5e-3, atol=1e-6, what="grad norms")
     psq = torch.tensor([float((params[names[i]].detach().double() ** 2).sum()) for i in keep])
@@ -209,9 +225,9 @@ def _full_width_golden_step(dev, gold, fe, wk, x6):
     assert [str(s) for s in gg["grad_names"]] == [str(s) for s in g64["grad_names"]]
     offs = gg["grad_offsets"]
     checked = 0
-    stats, bad, mine = [], [], {}
+    stats, bad, mine, direct = [], [], {}, []
     for i, n in enumerate(str(s) for s in gg["grad_names"]):
-        if is_noise_grad(n):
+        if is_noise_grad(n) or n in zero_names:
             continue
         ref32 = torch.as_tensor(gg["grad_values"][offs[i]:offs[i + 1]]).double()
         truth = torch.as_tensor(g64["grad_values"][offs[i]:offs[i + 1]]).double()
@@ -223,9 +239,11 @@ def _full_width_golden_step(dev, gold, fe, wk, x6):
         gmax = float(g64["grad_absmax"][i])
         emax = float((got - truth).abs().max()) / max(gmax, 1e-30)
         per_channel = n.endswith(("norm.weight", "norm.bias", "act.weight", ".bias", "low_hz_", "band_hz_"))
-        floor = GRAD_FLOOR_PERTURBED if perturbed else (GRAD_FLOOR_PER_CHANNEL if per_channel else GRAD_FLOOR_WEIGHT)
+        floor = GRAD_FLOOR_SMOOTH if smooth else (GRAD_FLOOR_PER_CHANNEL if per_channel else GRAD_FLOOR_WEIGHT)
         mine[n] = e_ours
+        e_dir = float((got - ref32).norm()) / tn          # distance between the two fp32 evaluations themselves
         stats.append((e_ours, e_ref, emax, n))
+        direct.append((e_dir, n))
         # a sign / permutation / missing-term error is O(1) in both measures
         if not (e_ours <= 1.5 * e_ref + floor and emax <= 10 * (1.5 * e_ref + floor)):
             bad.append("%s: relL2 vs fp64 %.3e (reference fp32: %.3e), max|err|/max|g| %.3e" % (n, e_ours, e_ref, emax))
@@ -235,12 +253,15 @@ def _full_width_golden_step(dev, gold, fe, wk, x6):
           % (gold, "split-bf16" if x6 else "fp32 MFMA"))
     for st_ in stats[:10]:
         print("   %.3e  %.3e  %.3e  %s" % st_)
+    direct.sort(reverse=True)
+    print("   HIP path vs the live reference's fp32 gradients directly (relL2 / |fp64 truth|): median %.3e; worst %s"
+          % (direct[len(direct) // 2][0], ", ".join("%.2e %s" % d_ for d_ in direct[:6])))
     med = sorted(s_[0] for s_ in stats)[len(stats) // 2]
     print("   median relL2 ours %.3e, reference fp32 %.3e" % (med, sorted(s_[1] for s_ in stats)[len(stats) // 2]))
     assert not bad, "%d tensors out of tolerance: %s" % (len(bad), "; ".join(bad[:4]))
-    assert checked >= (100 if "plus" in gold else 40), checked
-    if perturbed:      # no mask flips to excuse: the median distance to fp64 is the reference's own, within 1.5x
-        assert med <= 1.5 * sorted(s_[1] for s_ in stats)[len(stats) // 2], med
+    assert checked >= (100 if "plus" in gold else 40) - (8 if smooth else 0), checked
+    if smooth:         # no mask flips to excuse: the median distance to fp64 is the reference's own, within 1.5x
+        assert med <= 1.5 * sorted(s_[1] for s_ in stats)[len(stats) // 2] + 1e-6, med
     _PIPE_ERR[(gold, x6)] = mine
     other = _PIPE_ERR.get((gold, not x6))
     if other is not None:      # both pipes ran in this session: the split pipe is no farther from fp64 than the fp32 pipe

@@ -55,8 +55,9 @@ def with_losses(cfg):
     return cfg
 
 
-def randomize_affine(module, seed=123):
-    """give BN affine / PReLU slopes non-trivial values so every term of the backward is exercised"""
+def randomize_affine(module, seed=123, smooth=False):
+    """give BN affine / PReLU slopes non-trivial values so every term of the backward is exercised
+    (smooth: slopes exactly 1 -- no kink -- as oracle/make_golden.py:perturb_affine(smooth=True))"""
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for n, p in module.named_parameters():
@@ -66,6 +67,8 @@ def randomize_affine(module, seed=123):
                 p.copy_(torch.empty(p.shape).normal_(0, 0.2, generator=g))
             elif n.endswith("act.weight"):
                 p.copy_(torch.empty(p.shape).uniform_(0.05, 0.4, generator=g))
+                if smooth:
+                    p.fill_(1.0)
 
 
 def oracle_params(module):
