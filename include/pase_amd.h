@@ -86,8 +86,15 @@ typedef struct PaseConvGemm {
                               hh + hm + mh + hl + lh + mm on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
                               (dropped terms <= 3 * 2^-24 |a b|: the error of an fp32 fma chain).  wt is then
                               only the source of the pack.                                        */
+    const void* xp6;       /* split-bf16 launches only, NULL = the kernel splits the activation while staging it.  Else: the
+                              PRE-SPLIT activation written by pase_pack_xp() for THIS descriptor (pase_conv_gemm_xp_bytes()
+                              > 0): channel-minor bf16 planes with the on-load transform and the padding applied, in the
+                              chunk order of the kernel's LDS image -- staging becomes a copy.  The library asks for it on
+                              stride-1 launches with one or two taps and >= 1024 rows, where a column tile is re-staged by
+                              every row tile (the 256 -> 21 525 heads: 169 times)                                 */
     int x6_ctl;            /* split-bf16 plan control (0 = the library's routing).  bit 0: take the split-bf16 kernel
-                              wherever it has a plan, skipping the measured per-shape routing rules (A/B runs; the
+                              wherever it has a plan, skipping the measured per-shape routing rules; bit 1: ask for the
+                              pre-split activation on every stride-1 launch; bit 2: never (A/B runs and tests; the
                               library itself reads NO environment variables)                                    */
     int max_wg;            /* cap on the persistent grid of the split-bf16 kernel (0 = one workgroup per CU, 256):
                               data-parallel runs leave CUs to the RCCL channel kernels this way; tests use it to make
@@ -114,6 +121,11 @@ long pase_conv_gemm_x6_bytes(const PaseConvGemm* desc);
  * fragment order of the launch desc describes (tile, stage and tap padding are functions of the descriptor: pack and
  * launch must see the same one).  Like pase_pack_wt it runs once per weight use. */
 int pase_pack_x6(const PaseConvGemm* desc, void* stream);
+/* bytes of PaseConvGemm::xp6 the launch described by desc (xp6 ignored) wants; 0 = the launch splits while staging */
+long pase_conv_gemm_xp_bytes(const PaseConvGemm* desc);
+/* desc->xp6 (pase_conv_gemm_xp_bytes(desc) bytes, 16-B aligned, caller-owned scratch, read by that one launch) <-
+ * act(bn(desc->x)) split into three bf16 planes; once per launch, before pase_conv_gemm */
+int pase_pack_xp(const PaseConvGemm* desc, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * pase_wgrad_gemm -- weight (+bias) gradient contraction, split-K with fp32 atomics.

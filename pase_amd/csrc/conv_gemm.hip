@@ -1166,6 +1166,22 @@ extern "C" long pase_conv_gemm_x6_bytes(const PaseConvGemm* d) {
     return h.pl.CB >= 1 ? h.x6_chunks * 16 : 0;
 }
 
+extern "C" long pase_conv_gemm_xp_bytes(const PaseConvGemm* d) {
+    if (d->M <= 0 || d->K <= 0 || d->S <= 0 || d->Ncols <= 0 || d->K != d->Cin * d->taps) return 0;
+    if (d->tapstep != 1 && d->tapstep != -1) return 0;
+    const HostPlan h = make_plan(*d, true);
+    return h.x6c ? h.c.xp_plane * 3 * 16 : 0;
+}
+
+extern "C" int pase_pack_xp(const PaseConvGemm* d, void* stream) {
+    const PaseConvGemm p = *d;
+    if (!p.xp6 || !p.x || (((unsigned long long)(size_t)p.xp6) % 16) != 0) return -10;
+    if (p.K != p.Cin * p.taps) return -4;
+    const HostPlan h = make_plan(p, true);
+    if (!h.x6c) return -11;
+    return pase_x6c_pack_xp(p, h.c, (hipStream_t)stream);
+}
+
 extern "C" int pase_pack_x6(const PaseConvGemm* d, void* stream) {
     const PaseConvGemm p = *d;
     if (!p.wx6 || !p.wt || (((unsigned long long)(size_t)p.wx6) % 16) != 0) return -10;

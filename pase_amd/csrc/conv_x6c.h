@@ -31,6 +31,9 @@ struct PaseX6cPlan {
     int zp_rows;                               // ... rows of a plane: Cin * stride (+ 1: the all-ones row of the bias column)
     long zp_off;                               // ... byte offset of the planes inside PaseWgrad::gx6 (behind the pack of g)
     long t_plane;                              // tmode 3: elements per plane
+    int xp;             // convolution launches: the activation is pre-split (PaseConvGemm::xp6, pase_pack_xp): staging = copy
+    int xp_tpad;        // ... padded positions per sequence: Ncols + A - 1
+    long xp_plane;      // ... 16-byte chunks per plane: G * 2 * S * xp_tpad
     int xPerm;          // pixel-shuffle launches: tile rows ordered (channel, phase) -> 16-byte output runs
     long pack_chunks;   // 16-byte chunks of the weight pack
     int prm_n;          // channels' of the expanded on-load parameter arrays behind the chunks (3 x prm_n floats)
@@ -42,6 +45,7 @@ struct PaseX6cPlan {
 bool pase_x6c_plan(const PaseConvGemm& p, PaseX6cPlan& pl);
 int pase_x6c_pack(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st);
 int pase_x6c_launch(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st);
+int pase_x6c_pack_xp(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st);
 
 // weight gradients on the T-mode instantiation (see conv_x6c.hip)
 struct PaseX6cWgrad {

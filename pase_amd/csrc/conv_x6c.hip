@@ -199,6 +199,13 @@ __device__ __forceinline__ void x6c_vmwait_slots(int nslots) {
 // positions of one column) is 16 contiguous bytes of a plane at 2-byte granularity, and staging is three 16-byte loads + three
 // ds_write_b128 per slot: no conversion, no padding arithmetic, no per-element loads (the round-3 T-mode spent 1.9k cycles of
 // staging-wave issue per 768 cycles of MFMA on exactly those).  The bias column is one more plane row holding 1.0.
+// ZP on a convolution launch (!TM, pl.xp; "XP"): the ACTIVATION is pre-split -- channel-minor bf16 planes with the on-load
+// transform and the (zero / reflect) padding applied, written once by pase_pack_xp in the LDS image's own chunk order
+//   plane[pz][k-group g][octet fk][s][up]  = 16-byte chunk: pieces pz of channels 16 g + 8 fk .. + 7 at padded position up
+// (up = q + tap, Tpad = Ncols + A - 1 per sequence; stride-1 launches only).  A wave's staging load is then 64 consecutive
+// chunks = 1 KB contiguous.  Worth it where every staged element used to be converted many times over -- a column tile is
+// re-staged by each of the M / 128 row tiles that need it (169 times on the 21 525-row heads) -- and the k-loop has one or
+// two taps to amortise the conversion over.
 template <int NPOS, int KGS_T, bool TM = false, bool ZP = false>
 __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6cPlan pl) {
     constexpr int WM = 4, WN = 1, NBT = 4;
@@ -272,6 +279,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     int pos_u0[NPAR][NPS];
     unsigned pos_voff[NPAR][NPS];
     unsigned pos_sbase[NPAR][NPS];                  // element offset of the position's sequence (0 when not a real position)
+    unsigned pos_xoff[NPAR][NPS];                   // XP: chunk offset s * Tpad + up of the position inside a (g, fk) row
     unsigned pos_valid = 0u, pos_inter = 0u;       // bit par * NPS + ps
     unsigned live = 0u, full = 0u;
     unsigned inter_slots = 0u;     // slots whose 64 positions (of this wave) are all in-range samples: no padding arithmetic
@@ -419,6 +427,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             const int u0 = valid ? pl.P * q - pl.padLp : 0;
             const bool inter = !valid || (u0 >= 0 && u0 + pl.P - 1 < p.Tin);
             pos_u0[par][ps] = u0;
+            pos_xoff[par][ps] = (unsigned)(valid ? s * pl.xp_tpad + q : 0);
             pos_sbase[par][ps] = (unsigned)(valid ? s * p.x_ctot * p.Tin : 0);
             pos_voff[par][ps] = pos_sbase[par][ps] + (unsigned)(inter ? u0 : 0);
             if (valid) pos_valid |= 1u << (par * NPS + ps);
@@ -446,6 +455,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     unsigned xmask[XR][ZP ? 1 : NSLOT];         // bit e: element e of the slot is a real sample (else: zero AFTER the transform)
     u32x4 xpl[XR][ZP ? NSLOT : 1][3];           // ZP: the slot's three plane chunks as loaded
     const unsigned short* zpb = reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(p.wx6) + pl.zp_off);
+    const u32x4* xpc = reinterpret_cast<const u32x4*>(p.xp6);
 
     // channel' -> (input channel, phase) of element e of this wave's octet in k-group kg of stage g (all uniform)
     auto chan_of = [&](int g, int kg, int e, int& ci, int& b, bool& ok) __attribute__((always_inline)) {
@@ -471,7 +481,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     auto load_slot = [&](auto r_tag, auto sl_tag, int g) __attribute__((always_inline)) {
         constexpr int sl = decltype(sl_tag)::value, rs = decltype(r_tag)::value;
         constexpr int kg = sl / NPS, ps = sl % NPS, par = kg & (NPAR - 1);
-        if constexpr (ZP) {
+        if constexpr (ZP && TM) {
             // k-group (uniform): sequence s, first position 16 q16; past the last sequence the pack of g holds zeros and any
             // finite value will do here
             const int kgi = g * KGS + kg;
@@ -525,6 +535,15 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             }
             return;
         }
+        if constexpr (ZP && !TM) {
+            // XP: three aligned 16-byte chunks; k-groups past the last real one (stage padding) carry zero weights: any
+            // finite data will do -> clamp (uniform)
+            const int gidx = min(g * KGS + kg, pl.G - 1);
+            const unsigned off = (unsigned)((gidx * 2 + fkL) * p.S) * (unsigned)pl.xp_tpad + pos_xoff[par][ps];
+#pragma unroll
+            for (int pz = 0; pz < 3; ++pz) xpl[rs][sl][pz] = xpc[(size_t)pz * (size_t)pl.xp_plane + off];
+            return;
+        } else {
         const bool all_inter = ((inter_slots >> (par * NPS + ps)) & 1u) != 0;      // uniform
         const unsigned vbit = (pos_valid >> (par * NPS + ps)) & 1u;
         if (all_inter) {
@@ -554,15 +573,19 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             }
             xmask[rs][sl] = mask;
         }
+        }
     };
     // registers of slot sl (stage g) -> on-load transform -> three bf16 planes -> LDS buffer bsel
     auto store_slot = [&](auto r_tag, auto sl_tag, int g, int bsel) __attribute__((always_inline)) {
         constexpr int sl = decltype(sl_tag)::value, rs = decltype(r_tag)::value;
         constexpr int kg = sl / NPS, ps = sl % NPS, par = kg & (NPAR - 1);
         if constexpr (ZP) {
-            u32x4* dst = &Xs[bsel * BUF + kg * KGC + fkL * NPOS + 64 * (whalf ^ par) + lane];
+            const int i = 128 * ps + 64 * (whalf ^ par) + lane;
+            if (NPS * 128 == NPOS || i < NPOS) {
+                u32x4* dst = &Xs[bsel * BUF + kg * KGC + fkL * NPOS + i];
 #pragma unroll
-            for (int pz = 0; pz < 3; ++pz) dst[pz * PLANE] = xpl[rs][sl][pz];
+                for (int pz = 0; pz < 3; ++pz) dst[pz * PLANE] = xpl[rs][sl][pz];
+            }
             return;
         } else {
         x6c_claim(xreg[rs][sl]);
@@ -1361,6 +1384,39 @@ __global__ void pack_zplanes_kernel(const float* __restrict__ src, u32x4* __rest
     }
 }
 
+// XP: the activation of a stride-1 convolution launch as channel-minor bf16 planes in the LDS image's chunk order,
+//   out[plane][g][fk][s][up]: 16-byte chunk = pieces of act(bn(x[s][16 g + 8 fk + e][up - padLp])), e = 0 .. 7
+// (zero / reflected outside [0, Tin), zero for channels past Cin).  Thread = one padded position of one (g, fk, s) row: the
+// eight channel loads of a wave are 256 contiguous bytes each, its three stores 1 KB each.  grid = (position blocks, 2 G, S).
+__global__ void pack_xcm_kernel(const float* __restrict__ x, u32x4* __restrict__ out, int Cin, int S, int ctot, int coff,
+                                int Tin, int tpad, int padLp, int pad_mode, long plane, const float* sc, const float* sh,
+                                const float* al) {
+    const int up = blockIdx.x * blockDim.x + threadIdx.x;
+    if (up >= tpad) return;
+    const int gf = blockIdx.y, s_ = blockIdx.z;
+    const int c0 = gf * 8;                                  // (16 g + 8 fk)
+    int u = up - padLp;
+    if (pad_mode == PASE_PAD_REFLECT) u = x6c_reflect(u, Tin);
+    const bool in = u >= 0 && u < Tin;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = c0 + e;
+        float t = 0.f;
+        if (in && c < Cin) {
+            t = x[((size_t)s_ * ctot + coff + c) * Tin + u];
+            if (sc) t = fmaf(t, sc[c], sh[c]);
+            if (al) t = t > 0.f ? t : t * al[c];
+        }
+        v[e] = t;
+    }
+    u32x4 o[3];
+    pase_split_bf16x3_rne(v, o);
+    u32x4* dst = out + ((size_t)gf * S + s_) * (size_t)tpad + up;
+#pragma unroll
+    for (int pz = 0; pz < 3; ++pz) dst[(size_t)pz * (size_t)plane] = o[pz];
+}
+
 // ZP (tmode 1 with pl.zp): z~ (on-load transform applied, padding materialised) as three phase-decomposed bf16 planes,
 //   out[plane][row = ci * st + b][s][i],  i in [0, lseg):  piece of z~[s][ci][st * (i + dmin) + b]   (reflected / zero outside
 //   [0, T)),  plus -- `ones` -- a last row of 1.0 (the bias column of the weight gradient).
@@ -1448,7 +1504,12 @@ bool pase_x6c_plan(const PaseConvGemm& p, PaseX6cPlan& pl) {
     // heads: six stages per tile, the staging waves' conversion work per MFMA is 5x that of an 11-tap layer) are faster on
     // the exact-fp32 matrix pipe unless they have thousands of row tiles to amortise a column tile's staging over (the
     // 21 525-channel heads: 0.81 -> 0.75 ms) or hardly any columns at all (the 128-column classifier launches)
-    if (!force && pl.A == 1 && pl.CinP < 768 && p.M < 8192 && (long)p.S * p.Ncols > 128) return false;
+    // Round 4: with the activation pre-split once per launch (XP, see the kernel) the conversion no longer scales with the row
+    // tiles; launches with >= 1024 rows and one or two taps take it (x6_ctl bit 1 forces it on any stride-1 launch, bit 2 forbids
+    // it), which also lifts the K < 768 rule for them (the stacked 2304-row first layers of the MLP heads)
+    const bool xp_ok = pl.P == 1 && (long)pl.G * 2 * p.S * (long)(p.Ncols + pl.A - 1) < (1L << 27);
+    const bool xp_want = xp_ok && !(p.x6_ctl & 4) && ((p.x6_ctl & 2) || (pl.A <= 2 && p.M >= 1024));
+    if (!force && pl.A == 1 && pl.CinP < 768 && p.M < 8192 && (long)p.S * p.Ncols > 128 && !xp_want) return false;
     pl.NBT = 4;
     pl.WM = 4;
     pl.BM = 128;
@@ -1466,6 +1527,9 @@ bool pase_x6c_plan(const PaseConvGemm& p, PaseX6cPlan& pl) {
     pl.n_col_tiles = (int)((ntot + pl.BN - 1) / pl.BN);
     pl.prio = x6c_prio();
     pl.tmode = 0;
+    pl.xp_tpad = p.Ncols + pl.A - 1;
+    pl.xp_plane = xp_want ? (long)pl.G * 2 * p.S * pl.xp_tpad : 0;
+    pl.xp = (xp_want && p.xp6 != nullptr) ? 1 : 0;
     pl.pack_chunks = (long)pl.n_row_tiles * pl.WM * pl.steps_total * 192;
     pl.prm_n = GS * pl.KGS * 16;
     pl.pack_bytes = (pl.pack_chunks * 16 + 3L * pl.prm_n * 4 + 15) / 16 * 16;
@@ -1522,8 +1586,20 @@ int pase_x6c_launch(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st
     const long cap = p.max_wg > 0 ? p.max_wg : 256;      // data-parallel runs leave CUs to RCCL; tests force several items per workgroup
     if (nwg > cap) nwg = cap;
     const dim3 grid((unsigned)nwg), block(NT);
-    if (pl.A == 1) PASE_LAUNCH((conv_x6c_kernel<128, 3>), grid, block, st, p, pl);
+    if (pl.xp) {
+        if (pl.A == 1) PASE_LAUNCH((conv_x6c_kernel<128, 3, false, true>), grid, block, st, p, pl);
+        else PASE_LAUNCH((conv_x6c_kernel<192, 2, false, true>), grid, block, st, p, pl);
+    } else if (pl.A == 1) PASE_LAUNCH((conv_x6c_kernel<128, 3>), grid, block, st, p, pl);
     else PASE_LAUNCH((conv_x6c_kernel<192, 2>), grid, block, st, p, pl);
+    PASE_CHECK_LAUNCH();
+    return 0;
+}
+
+int pase_x6c_pack_xp(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st) {
+    if (!pl.xp) return -11;
+    const dim3 grid((unsigned)((pl.xp_tpad + 255) / 256), (unsigned)(2 * pl.G), (unsigned)p.S);
+    PASE_LAUNCH(pack_xcm_kernel, grid, dim3(256), st, p.x, reinterpret_cast<u32x4*>(const_cast<void*>(p.xp6)), p.Cin, p.S,
+                p.x_ctot, p.x_coff, p.Tin, pl.xp_tpad, pl.padLp, p.pad_mode, pl.xp_plane, p.in_scale, p.in_shift, p.in_alpha);
     PASE_CHECK_LAUNCH();
     return 0;
 }

@@ -33,7 +33,7 @@ class PaseConvGemm(C.Structure):
         ("epilogue", C.c_int), ("r_ctx", C.c_int), ("label_D", C.c_int),
         ("tile_hint", C.c_int), ("post_op", C.c_int), ("post_scale", C.c_float), ("post_eps", C.c_float),
         ("splitk", C.c_int),
-        ("wx6", C.c_void_p),
+        ("wx6", C.c_void_p), ("xp6", C.c_void_p),
         ("x6_ctl", C.c_int), ("max_wg", C.c_int),
     ]
 
@@ -51,6 +51,10 @@ def declare(l):
     l.pase_conv_gemm_plan_kind.restype = C.c_int
     l.pase_pack_x6.argtypes = [C.POINTER(PaseConvGemm), C.c_void_p]
     l.pase_pack_x6.restype = C.c_int
+    l.pase_conv_gemm_xp_bytes.argtypes = [C.POINTER(PaseConvGemm)]
+    l.pase_conv_gemm_xp_bytes.restype = C.c_long
+    l.pase_pack_xp.argtypes = [C.POINTER(PaseConvGemm), C.c_void_p]
+    l.pase_pack_xp.restype = C.c_int
     l.pase_wgrad_x6_bytes.argtypes = [C.POINTER(PaseWgrad)]
     l.pase_wgrad_x6_bytes.restype = C.c_long
     l.pase_wgrad_plan_kind.argtypes = [C.POINTER(PaseWgrad)]
@@ -123,7 +127,7 @@ def _conv_desc(x, w, y, *, S, Cin, Tin, M, K, taps, Ncols, Tout, ldw=None, bias=
     d.tile_hint = tile_hint
     d.splitk = splitk
     # measurement / test controls travel in the descriptor (the C library reads no environment variables)
-    d.x6_ctl = 1 if os.environ.get("PASE_X6C_FORCE") else 0
+    d.x6_ctl = (1 if os.environ.get("PASE_X6C_FORCE") else 0) | {"1": 2, "0": 4}.get(os.environ.get("PASE_X6C_XP", ""), 0)
     d.max_wg = _max_wg()
     return d
 
@@ -188,6 +192,7 @@ class GemmTimer(object):
 GEMM_TIMER = None
 LAST_WGRAD_X6 = None       # did the most recent wgrad_gemm launch run on the split-bf16 kernel
 LAST_WGRAD_KIND = None     # ... and in which orientation (pase_wgrad_plan_kind: 0 fp32 pipe, 1 / 2 / 3)
+LAST_XP = None             # did the most recent conv_gemm launch stage a pre-split activation (pase_pack_xp)
 LAST_PLAN_KIND = None      # plan kind of the most recent conv_gemm launch (0 fp32 pipe, 2 split-bf16 x6c): tests / reports
 
 
@@ -228,6 +233,8 @@ def conv_gemm(x, w, y, want_stats=False, **kw):
         kw["wt"] = pack_wt(w, M=kw["M"], K=kw["K"], Cin=kw["Cin"], taps=kw["taps"], ldw=kw.get("ldw"),
                            tap_major=kw.get("tap_major", 0))
     d = _conv_desc(x, w, y, **kw)
+    global LAST_XP
+    LAST_XP = False
     if X6 and os.environ.get("PASE_X6_CONV", "1") != "0" and _x6_conv_ok(kw):
         # contraction on the bf16 matrix pipe with both operands split into three bf16 pieces (fp32-grade result,
         # see PaseConvGemm::wx6) for the launch shapes the library has a split-bf16 plan for
@@ -236,6 +243,13 @@ def conv_gemm(x, w, y, want_stats=False, **kw):
             wx6 = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
             d.wx6 = wx6.data_ptr()
             _check(_lib.lib().pase_pack_x6(C.byref(d), _stream()), "pase_pack_x6")
+            # ... and, where the library asks for it, the activation pre-split once for this launch (staging = copy)
+            xbytes = _lib.lib().pase_conv_gemm_xp_bytes(C.byref(d))
+            if xbytes > 0:
+                xp6 = torch.empty(xbytes, dtype=torch.uint8, device=x.device)
+                d.xp6 = xp6.data_ptr()
+                _check(_lib.lib().pase_pack_xp(C.byref(d), _stream()), "pase_pack_xp")
+                LAST_XP = True
     stat = None
     if want_stats:
         stat = torch.empty(_lib.lib().pase_conv_gemm_stat_tiles(C.byref(d)), d.M, 2, device=x.device, dtype=torch.float32)

@@ -17,11 +17,14 @@ import torch.nn.functional as F
 from pase_amd import kernels as K
 
 
-@pytest.fixture(autouse=True)
-def _x6_on():
+@pytest.fixture(autouse=True, params=["split-on-load", "presplit"])
+def _x6_on(request, monkeypatch):
+    """every case twice: the activation split while it is staged (the default of most shapes), and pre-split by pase_pack_xp
+    (forced on every stride-1 launch: PaseConvGemm::x6_ctl bit 1) so that staging is a copy"""
     saved = K.X6
     K.X6 = True
-    yield
+    monkeypatch.setenv("PASE_X6C_XP", "1" if request.param == "presplit" else "0")
+    yield request.param
     K.X6 = saved
 
 
@@ -43,7 +46,7 @@ def _xf(x, sc, sh, al):
     (56, 96, 3, 1, 90, 5, True),         # 56 channels: ragged second k-group (zero channels'), Ncols < 128: 3 sequences per tile
     (48, 64, 5, 1, 1000, 1, False),      # 64-row launch: half of the 128-row tile is zero weights
 ])
-def test_conv_forward(dev, Cin, Cout, k, stride, T, S, xf):
+def test_conv_forward(dev, _x6_on, Cin, Cout, k, stride, T, S, xf):
     torch.manual_seed(0)
     x = torch.randn(S, Cin, T)
     w = torch.randn(Cout, Cin, k) * 0.2
@@ -59,6 +62,7 @@ def test_conv_forward(dev, Cin, Cout, k, stride, T, S, xf):
                        M=Cout, K=Cin * k, taps=k, Ncols=Tout, Tout=Tout, bias=b.to(dev), stride=stride, padL=P[0],
                        pad_mode=K.PAD_REFLECT, **kw)
     assert K.LAST_PLAN_KIND == 2
+    assert K.LAST_XP == (_x6_on == "presplit" and stride == 1)      # pre-split activations: stride-1 launches only
     assert _rel(y, ref) < 1e-6
     st = stat.cpu().double().sum(0)
     torch.testing.assert_close(st[:, 0], ref.sum((0, 2)), rtol=1e-5, atol=1e-4)
@@ -144,7 +148,7 @@ def test_qrnn_linear_tap_major(dev):
     (1500, 100, 64, 2, 0),       # long reduction: auto split-K (data-gradient of a wide head)
     (960, 72, 200, 1, 1),        # 60 k-groups, one ragged row tile
 ])
-def test_flat_1x1(dev, Cin, Cout, T, S, splitk):
+def test_flat_1x1(dev, _x6_on, Cin, Cout, T, S, splitk):
     torch.manual_seed(4)
     x = torch.randn(S, Cin, T)
     w = torch.randn(Cout, Cin) * 0.2
@@ -156,7 +160,37 @@ def test_flat_1x1(dev, Cin, Cout, T, S, splitk):
     K.conv_gemm(x.to(dev), w.to(dev), y, S=S, Cin=Cin, Tin=T, M=Cout, K=Cin, taps=1, Ncols=T, Tout=T, bias=b.to(dev),
                 in_alpha=al.to(dev), splitk=splitk)
     assert K.LAST_PLAN_KIND == 2
+    assert K.LAST_XP == (_x6_on == "presplit")
     assert _rel(y, ref) < 1e-6
+
+
+def test_presplit_activation_is_the_default_of_wide_1x1_and_2tap_launches(dev, monkeypatch):
+    """>= 1024 rows and one or two taps: the library asks for the pre-split activation by itself (pase_conv_gemm_xp_bytes > 0),
+    also for K < 768 (the stacked first layers of the MLP heads: M = 2304, K = 256), with an on-load affine + PReLU, a channel
+    slice of a wider input and reversed taps (the QRNN Linear's shape)."""
+    monkeypatch.delenv("PASE_X6C_XP")
+    torch.manual_seed(14)
+    S, Cin, Cout, T = 2, 136, 1030, 150
+    xw = torch.randn(S, Cin + 9, T)
+    sc, sh, al = torch.rand(Cin) + 0.5, torch.randn(Cin) * 0.1, torch.rand(Cin) * 0.5
+    xin = _xf(xw[:, 3:3 + Cin], sc, sh, al)
+    w = torch.randn(Cout, Cin) * 0.2
+    ref = torch.einsum("mk,skt->smt", w.double(), xin)
+    y = torch.zeros(S, Cout, T, device=dev)
+    K.conv_gemm(xw.to(dev), w.to(dev), y, S=S, Cin=Cin, Tin=T, M=Cout, K=Cin, taps=1, Ncols=T, Tout=T, x_ctot=Cin + 9, x_coff=3,
+                in_scale=sc.to(dev), in_shift=sh.to(dev), in_alpha=al.to(dev))
+    assert K.LAST_PLAN_KIND == 2 and K.LAST_XP
+    assert _rel(y, ref) < 1e-6
+    # two reversed taps, zero padding on the left (causal): y[t] = w0 x[t] + w1 x[t - 1]
+    w2 = torch.randn(Cout, 2 * Cin) * 0.2           # tap-major columns [x_t ; x_{t-1}]
+    xz = F.pad(xin, (1, 0))
+    ref2 = torch.einsum("mk,skt->smt", w2[:, :Cin].double(), xz[:, :, 1:]) + torch.einsum("mk,skt->smt", w2[:, Cin:].double(), xz[:, :, :-1])
+    y2 = torch.zeros(S, Cout, T, device=dev)
+    K.conv_gemm(xw.to(dev), w2.to(dev), y2, S=S, Cin=Cin, Tin=T, M=Cout, K=2 * Cin, taps=2, tap_major=1, tapstep=-1, padL=0,
+                pad_mode=K.PAD_ZERO, Ncols=T, Tout=T, x_ctot=Cin + 9, x_coff=3, in_scale=sc.to(dev), in_shift=sh.to(dev),
+                in_alpha=al.to(dev))
+    assert K.LAST_PLAN_KIND == 2 and K.LAST_XP
+    assert _rel(y2, ref2) < 1e-6
 
 
 def test_channel_slice_in_and_out(dev):
