@@ -94,8 +94,9 @@ typedef struct PaseConvGemm {
                               every row tile (the 256 -> 21 525 heads: 169 times)                                 */
     int x6_ctl;            /* split-bf16 plan control (0 = the library's routing).  bit 0: take the split-bf16 kernel
                               wherever it has a plan, skipping the measured per-shape routing rules; bit 1: ask for the
-                              pre-split activation on every stride-1 launch; bit 2: never (A/B runs and tests; the
-                              library itself reads NO environment variables)                                    */
+                              pre-split activation on every stride-1 launch; bit 2: never; bit 3: keep the one-channel
+                              (SincNet) layer off its window-image kernel (A/B runs and tests; the library itself reads
+                              NO environment variables)                                                          */
     int max_wg;            /* cap on the persistent grid of the split-bf16 kernel (0 = one workgroup per CU, 256):
                               data-parallel runs leave CUs to the RCCL channel kernels this way; tests use it to make
                               every workgroup walk several (split-K slice, tile) items                       */
@@ -112,7 +113,8 @@ int pase_conv_gemm_stat_tiles(const PaseConvGemm* desc);
 /* the split-K factor the launch will actually use (after clamping) */
 int pase_conv_gemm_splitk(const PaseConvGemm* desc);
 /* which kernel family the launch described by desc runs on: 0 = exact-fp32 matrix pipe (v_mfma_f32_32x32x2_f32),
- * 2 = split-bf16 channel-minor kernel (conv_x6c.hip; needs desc->wx6).  For tests and bench reports. */
+ * 2 = split-bf16 channel-minor kernel (conv_x6c.hip; needs desc->wx6), 3 = the one-input-channel window-image split-bf16
+ * kernel (sinc_x6.hip: the SincNet layer).  For tests and bench reports. */
 int pase_conv_gemm_plan_kind(const PaseConvGemm* desc);
 /* bytes of the split-bf16 pack the launch described by desc (wx6 ignored) would read; 0 = this shape only runs on
  * the fp32 matrix pipe */
@@ -151,7 +153,8 @@ typedef struct PaseWgrad {
                               has a plan for the shape AND gx6 is given; else the fp32 matrix pipe.  Measurement / test
                               controls (the library reads no environment variables): bits 4-7 force an orientation
                               (pase_wgrad_plan_kind value, 0 = the library's routing); bit 8: 1x1 layers may take the split
-                              kernel in either orientation; bit 9: no row-coalesced staging                          */
+                              kernel in either orientation; bit 9: no row-coalesced staging; bit 10: keep the
+                              one-channel (SincNet) layer off its window-image kernel                               */
     void* gx6;             /* scratch for the split-bf16 operands: pase_wgrad_x6_bytes(desc) bytes, 16-B
                               aligned, caller-owned, written and read by this launch only; NULL = fp32 matrix pipe */
     int max_wg;            /* cap on the persistent grid (0 = 256), see PaseConvGemm::max_wg                      */
@@ -163,7 +166,8 @@ long pase_wgrad_x6_bytes(const PaseWgrad* desc);
  * 1 rows = g (packed), columns = (channel, tap) of z staged; 2 1x1 layer, rows = z channels (packed), columns = g staged;
  * 3 rows = (channel, tap) read from row-major bf16 planes of z, columns = g staged;
  * 4 rows = g (packed), columns = (channel, tap) COPIED out of pre-split phase-decomposed bf16 planes of z~ (no conversion
- *   in the GEMM: the default for every layer with taps) */
+ *   in the GEMM: the default for every layer with taps);
+ * 5 one input channel (SincNet): sinc_x6.hip, both operands converted while staged, window image of z */
 int pase_wgrad_plan_kind(const PaseWgrad* desc);
 
 /* ------------------------------------------------------------------------------------------

@@ -43,6 +43,7 @@
 #include "hip_compat.h"
 #include "pase_amd.h"
 #include "conv_x6c.h"
+#include "sinc_x6.h"
 
 namespace {
 
@@ -963,6 +964,8 @@ struct HostPlan {
     long x6_chunks;     // 16-byte chunks of the split-bf16 pack (0: fp32 plan)
     bool x6c;           // the launch runs on conv_x6c.hip (channel-minor split-bf16 kernel, two accumulators per tile)
     PaseX6cPlan c;
+    bool sinc;          // the launch runs on sinc_x6.hip (one input channel: window-image split-bf16 kernel)
+    PaseSincPlan sp;
 };
 
 unsigned magic_of(int d) {
@@ -976,6 +979,19 @@ HostPlan make_plan(const PaseConvGemm& p, bool want_x6) {
     HostPlan h;
     h.x6_chunks = 0;
     h.x6c = false;
+    h.sinc = false;
+    if (want_x6 && !(p.x6_ctl & 8) && pase_sinc_x6_plan(p, h.sp)) {      // (x6_ctl bit 3: A/B runs keep the layer on the fp32 pipe)
+        h.sinc = true;
+        h.pl = ConvPlan{};
+        h.pl.CB = 16;
+        h.pl.splitk = 1;
+        h.narrow = 1;
+        h.BN = 256;
+        h.n_col_tiles = p.S * h.sp.tiles_per_seq;
+        h.x6_chunks = h.sp.pack_bytes / 16;
+        h.blocks = h.n_col_tiles;
+        return h;
+    }
     if (want_x6) {
         if (pase_x6c_plan(p, h.c)) {
             h.x6c = true;
@@ -1108,7 +1124,7 @@ extern "C" int pase_conv_gemm(const PaseConvGemm* d, void* stream) {
     if (p.tapstep != 1 && p.tapstep != -1) return -5;
     const HostPlan h = make_plan(p, p.wx6 != nullptr);
     if (h.pl.CB < 1) return -6;
-    if (p.wx6 && (!h.pl.x6 || (((unsigned long long)(size_t)p.wx6) % 16) != 0)) return -11;
+    if (p.wx6 && ((!h.x6c && !h.sinc) || (((unsigned long long)(size_t)p.wx6) % 16) != 0)) return -11;
     if (h.pl.splitk > 1 && (p.stat_part || p.epilogue != PASE_EPI_STORE || p.post_op != PASE_POST_NONE)) return -7;
     if ((p.post_op == PASE_POST_POW || p.post_op == PASE_POST_LOGPOW || p.post_op == PASE_POST_MAG) &&
         (p.ps != 1 || p.stat_part || (p.M & 1))) return -9;
@@ -1123,6 +1139,7 @@ extern "C" int pase_conv_gemm(const PaseConvGemm* d, void* stream) {
     if (p.ps != 1 && (long)p.M * p.Cout_store >= 0xffffffffL) return -8;      // exact magic division
     if (p.epilogue == PASE_EPI_MSE_CTX && (long)p.M * p.r_ctx >= 0xffffffffL) return -8;
     hipStream_t st = (hipStream_t)stream;
+    if (h.sinc) return pase_sinc_x6_launch(p, h.sp, st);
     if (h.x6c) return pase_x6c_launch(p, h.c, st);
     const dim3 grid((unsigned)h.blocks), block(NTHREADS);
 #define PASE_CONV_LAUNCH(BM_, BN_)                                                                       \
@@ -1156,7 +1173,7 @@ extern "C" int pase_conv_gemm_splitk(const PaseConvGemm* d) {
 extern "C" int pase_conv_gemm_plan_kind(const PaseConvGemm* d) {
     if (d->M <= 0 || d->K <= 0 || d->S <= 0 || d->Ncols <= 0 || d->K != d->Cin * d->taps) return 0;
     const HostPlan h = make_plan(*d, d->wx6 != nullptr);
-    return h.x6c ? 2 : 0;
+    return h.sinc ? 3 : (h.x6c ? 2 : 0);
 }
 
 extern "C" long pase_conv_gemm_x6_bytes(const PaseConvGemm* d) {
@@ -1187,6 +1204,7 @@ extern "C" int pase_pack_x6(const PaseConvGemm* d, void* stream) {
     if (!p.wx6 || !p.wt || (((unsigned long long)(size_t)p.wx6) % 16) != 0) return -10;
     if (p.K != p.Cin * p.taps || p.ldwt < p.M) return -4;
     const HostPlan h = make_plan(p, true);
+    if (h.sinc) return pase_sinc_x6_pack(p, h.sp, (hipStream_t)stream);
     if (!h.x6c) return -11;
     return pase_x6c_pack(p, h.c, (hipStream_t)stream);
 }

@@ -155,6 +155,12 @@ __device__ __forceinline__ unsigned pase_cvt_pk_bf16(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, pase_bf16x2));
 }
 #endif
+// (Non-finite values: hi = bf16(Inf) = Inf and the remainders Inf - Inf are NaN, so an infinite operand makes every product
+//  it enters NaN where the fp32 pipe gives +-Inf.  Zeroing the lower pieces of a non-finite value does NOT restore +-Inf: the
+//  OTHER operand's mid / lo pieces have arbitrary signs (round-to-nearest remainders) and zeros, so mid * Inf is -+Inf or NaN
+//  and the six-term sum is NaN again for about half of all weights (tried in round 4, tests/test_conv_x6c.py
+//  ::test_infinite_activation_stays_non_finite_where_the_reference_is).  The contract is the footprint: exactly the outputs
+//  that are non-finite in fp32 arithmetic are non-finite here, every other output is unaffected.)
 __device__ __forceinline__ void pase_split_bf16x3_rne(const float (&x)[8], u32x4 (&out)[3]) {
     float r[8];
 #pragma unroll

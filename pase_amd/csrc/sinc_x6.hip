@@ -1,0 +1,393 @@
+// sinc_x6.hip -- the SincNet layer (ONE input channel, up to 256 taps, at most 64 filters) on the bf16 matrix pipe:
+//
+//   forward          y[s, m, q]  = sum_kk filt[m, kk] * x[s, q + kk - padL]                       (SincConv_fast's F.conv1d,
+//                                                                                                 pase/models/modules.py:932)
+//   weight gradient  dfilt[m, kk] += sum_{s,q} g[s, m, q] * x[s, q + kk - padL]                   (autograd's conv1d wgrad)
+//
+// Same arithmetic as conv_x6c.hip: every fp32 operand is the sum of three round-to-nearest bf16 pieces, a product is
+// hh + (mm + hl + lh + hm + mh) on v_mfma_f32_32x32x16_bf16 with the hh sum and the small terms in separate accumulators.
+//
+// Why its own kernels.  With one input channel the contraction index of the GEMM is the TAP, and an MFMA operand fragment
+// (eight consecutive k of one column) is eight consecutive SAMPLES x[u .. u + 7]: a sliding window.  The LDS image is the
+// "window image"  W[plane][w] = 16-byte chunk of the pieces of x[u0 + w .. u0 + w + 7]:  the fragment of (column c, tap
+// group g, half fk) is window c + 16 g + 8 fk -- one aligned, conflict-free ds_read_b128, consecutive lanes = consecutive
+// chunks -- and ONE staging pass (504 windows from 511 samples, each converted a handful of times) serves all 16 k-groups of
+// a 64 x 256 tile.  conv_x6c.hip's channel-minor image cannot express that (its k axis is channels), and its 128-row tile
+// would spend half of every MFMA on zero rows: the round-3 build ran both launches on the exact-fp32 pipe (98 / 107 TFLOP/s).
+//   Tile 64 x 256, 256 threads = 4 waves as 2 (rows) x 2 (column halves), wave tile 32 x 128 with two accumulators per B
+//   tile (128 VGPRs); two workgroups per CU so that one's staging / epilogue runs under the other's MFMAs.
+//   Weight gradient: BOTH operands are staged (g is converted on the fly: each element exactly once, the 64 x 256 tile is the
+//   whole problem), contraction over positions in stages of 64, split over the grid, fp32 atomics into dfilt.
+#include "sinc_x6.h"
+
+namespace {
+
+constexpr int SX_NT = 256;
+constexpr int SX_BN = 256;                    // columns (forward: positions; weight gradient: taps) per tile
+constexpr int SX_KGMAX = 16;                  // forward: k-groups of 16 taps
+constexpr int SX_NW = SX_BN + 16 * SX_KGMAX - 8;      // 504 windows of a forward tile
+constexpr int SW_POS = 64;                    // weight gradient: positions per stage (4 k-groups)
+constexpr int SW_NW = SX_BN + SW_POS;         // 320 windows of a weight-gradient stage
+constexpr int SW_ACH = (SW_POS / 8) * 64;     // chunks per plane of the g image: [8 position octets][64 rows]
+
+__device__ __forceinline__ int sx_reflect(int u, int T) {
+    u = max(u, -u);
+    return min(u, 2 * (T - 1) - u);
+}
+
+// nine consecutive samples -> the pieces of the two windows starting at sample 0 and sample 1:
+//   w0[pz] = pieces pz of v[0..7], w1[pz] = pieces pz of v[1..8]   (pase_split_bf16x3_rne's arithmetic on both pairings)
+__device__ __forceinline__ void sx_two_windows(const float (&v)[9], u32x4 (&w0)[3], u32x4 (&w1)[3]) {
+    float r[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r[i] = v[i];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        unsigned pe[4], po[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pe[i] = pase_cvt_pk_bf16(r[2 * i], r[2 * i + 1]);          // (0,1) (2,3) (4,5) (6,7)
+            po[i] = pase_cvt_pk_bf16(r[2 * i + 1], r[2 * i + 2]);      // (1,2) (3,4) (5,6) (7,8)
+            w0[s][i] = pe[i];
+            w1[s][i] = po[i];
+        }
+        if (s < 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                r[2 * i] -= __uint_as_float(pe[i] << 16);
+                r[2 * i + 1] -= __uint_as_float(pe[i] & 0xffff0000u);
+            }
+            r[8] -= __uint_as_float(po[3] & 0xffff0000u);
+        }
+    }
+}
+
+// ================================================================================================================
+// forward
+// ================================================================================================================
+__global__ void __launch_bounds__(SX_NT, 2) sinc_x6_fwd_kernel(PaseConvGemm p, PaseSincPlan pl) {
+    constexpr int RED_CHUNKS = (int)(sizeof(float) * 2 * 64 * 2 / 16);
+    __shared__ __attribute__((aligned(16))) u32x4 Ws[3 * SX_NW + RED_CHUNKS];
+    float (*red)[64][2] = reinterpret_cast<float (*)[64][2]>(&Ws[3 * SX_NW]);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = pase_uniform(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int fr = lane & 31, fk = lane >> 5;
+    const int tile = blockIdx.x;
+    const int s = tile / pl.tiles_per_seq;
+    const int q0 = (tile - s * pl.tiles_per_seq) * SX_BN;
+    const float* xrow = p.x + ((size_t)s * p.x_ctot + p.x_coff) * (size_t)p.Tin;
+
+    // ---- window image: thread -> windows 2 t, 2 t + 1 from the nine samples starting at q0 - padL + 2 t --------------
+    for (int t = tid; 2 * t < pl.nwin; t += SX_NT) {
+        float v[9];
+        const int u0 = q0 - p.padL + 2 * t;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) {
+            int u = u0 + e;
+            if (p.pad_mode == PASE_PAD_REFLECT) u = sx_reflect(u, p.Tin);
+            v[e] = (u >= 0 && u < p.Tin) ? xrow[u] : 0.f;
+        }
+        u32x4 w0[3], w1[3];
+        sx_two_windows(v, w0, w1);
+#pragma unroll
+        for (int pz = 0; pz < 3; ++pz) {
+            Ws[pz * SX_NW + 2 * t] = w0[pz];
+            if (2 * t + 1 < SX_NW) Ws[pz * SX_NW + 2 * t + 1] = w1[pz];
+        }
+    }
+
+    // ---- filters: fragment-ordered pack [32-row tile][k-group][plane][lane], prefetched two k-groups ahead --------------
+    const u32x4* ap = reinterpret_cast<const u32x4*>(p.wx6) + (size_t)wm * pl.n_kg * 192 + lane;
+    auto load_a = [&](u32x4 (&a)[3], int g) __attribute__((always_inline)) {
+        const int gg = min(g, pl.n_kg - 1);
+#pragma unroll
+        for (int pz = 0; pz < 3; ++pz) a[pz] = ap[(size_t)gg * 192 + pz * 64];
+    };
+    f32x16 accH[4], accS[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            accH[j][r] = 0.f;
+            accS[j][r] = 0.f;
+        }
+    u32x4 a0[3], a1[3], a2[3];
+    load_a(a0, 0);
+    load_a(a1, 1);
+    __syncthreads();
+
+    const int bcol = wn * 128 + fr + 8 * fk;
+    auto mfma_step = [&](const u32x4 (&a)[3], int g) __attribute__((always_inline)) {
+        constexpr int PZA[5] = {1, 0, 2, 0, 1}, PZB[5] = {1, 2, 0, 1, 0};       // mm, hl, lh, hm, mh -> accS; hh -> accH
+        const u32x4* xb = &Ws[bcol + 16 * g];
+#pragma unroll
+        for (int jp = 0; jp < 4; jp += 2) {
+            u32x4 b0[3], b1[3];
+#pragma unroll
+            for (int pz = 0; pz < 3; ++pz) {
+                b0[pz] = xb[pz * SX_NW + 32 * jp];
+                b1[pz] = xb[pz * SX_NW + 32 * (jp + 1)];
+            }
+#pragma unroll
+            for (int pi = 0; pi < 5; ++pi) {
+                accS[jp] = pase_mfma_bf16_32x32x16(a[PZA[pi]], b0[PZB[pi]], accS[jp]);
+                accS[jp + 1] = pase_mfma_bf16_32x32x16(a[PZA[pi]], b1[PZB[pi]], accS[jp + 1]);
+            }
+            accH[jp] = pase_mfma_bf16_32x32x16(a[0], b0[0], accH[jp]);
+            accH[jp + 1] = pase_mfma_bf16_32x32x16(a[0], b1[0], accH[jp + 1]);
+        }
+    };
+    for (int g = 0; g < pl.n_kg; g += 3) {
+        load_a(a2, g + 2);
+        mfma_step(a0, g);
+        if (g + 1 < pl.n_kg) {
+            load_a(a0, g + 3);
+            mfma_step(a1, g + 1);
+        }
+        if (g + 2 < pl.n_kg) {
+            load_a(a1, g + 4);
+            mfma_step(a2, g + 2);
+        }
+    }
+
+    // ---- epilogue: store, BatchNorm partial sums per (tile, row) ------------------------------------------------------
+    // D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int rbase = wm * 32 + 4 * fk;
+    int qcol[4];
+    bool cok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        qcol[j] = q0 + wn * 128 + j * 32 + fr;
+        cok[j] = qcol[j] < p.Ncols;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = rbase + (r & 3) + 8 * (r >> 2);
+        const bool mok = m < p.M;
+        const float bv = (p.bias && mok) ? p.bias[m] : 0.f;
+        float* yrow = p.y + ((size_t)s * p.y_ctot + p.y_coff + (mok ? m : 0)) * (size_t)p.Tout;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = accH[j][r] + accS[j][r] + bv;
+            if (mok && cok[j]) {
+                yrow[qcol[j]] = v;
+                s1 += v;
+                s2 += v * v;
+            }
+        }
+        if (p.stat_part) {      // uniform
+            s1 = pase_half_sum_lane31(s1);
+            s2 = pase_half_sum_lane31(s2);
+            if (fr == 31) {
+                red[wn][m][0] = s1;
+                red[wn][m][1] = s2;
+            }
+        }
+    }
+    if (p.stat_part) {
+        __syncthreads();
+        if (tid < 64 && tid < p.M) {
+            float* dst = p.stat_part + ((size_t)tile * p.M + tid) * 2;
+            dst[0] = red[0][tid][0] + red[1][tid][0];
+            dst[1] = red[0][tid][1] + red[1][tid][1];
+        }
+    }
+}
+
+// filt (K-major fp32 pack wt[kk * ldwt + m]) -> fragment-ordered bf16 planes [32-row tile (2)][k-group][plane][lane]:
+// lane = (fk, row): element e = tap 16 g + 8 fk + e of filter 32 rt + row; zero past the taps / past M
+__global__ void sinc_x6_pack_kernel(const float* __restrict__ wt, u32x4* __restrict__ out, int M, int ldwt, int taps, int n_kg) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 2 * n_kg * 64) return;
+    const int lane = idx & 63, g = (idx >> 6) % n_kg, rt = (idx >> 6) / n_kg;
+    const int fk = lane >> 5, m = rt * 32 + (lane & 31);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int kk = 16 * g + 8 * fk + e;
+        v[e] = (kk < taps && m < M) ? wt[(size_t)kk * ldwt + m] : 0.f;
+    }
+    u32x4 o[3];
+    pase_split_bf16x3_rne(v, o);
+#pragma unroll
+    for (int pz = 0; pz < 3; ++pz) out[((size_t)(rt * n_kg + g) * 3 + pz) * 64 + lane] = o[pz];
+}
+
+// ================================================================================================================
+// weight gradient
+// ================================================================================================================
+__global__ void __launch_bounds__(SX_NT, 2) sinc_x6_wgrad_kernel(PaseWgrad p, PaseSincPlan pl) {
+    // one LDS image per stage: g [plane][position octet c (8)][row (64)] and the window image of x [plane][320]
+    __shared__ __attribute__((aligned(16))) u32x4 Ws[3 * SW_ACH + 3 * SW_NW];
+    u32x4* As = Ws;
+    u32x4* Bs = Ws + 3 * SW_ACH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = pase_uniform(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int fr = lane & 31, fk = lane >> 5;
+    // this workgroup's stages: a contiguous range of the flattened (sequence, 64-position stage) index
+    const long total = (long)p.S * pl.tiles_per_seq;
+    const long per = (total + gridDim.x - 1) / gridDim.x;
+    const long st_begin = (long)blockIdx.x * per;
+    const long st_end = st_begin + per < total ? st_begin + per : total;
+    if (st_begin >= st_end) return;
+
+    // staging roles: g -- thread -> (row = tid >> 2, 16 positions 16 (tid & 3) ..);  x -- thread -> windows 2 tid, 2 tid + 1
+    const int grow = tid >> 2, gpart = tid & 3;
+    const bool grow_ok = grow < p.M;
+    const float g_al = (p.g_alpha && grow_ok) ? p.g_alpha[grow] : 1.f;
+    float gv[16], xv[9];
+    auto load_stage = [&](long st) __attribute__((always_inline)) {
+        const int s = (int)(st / pl.tiles_per_seq);
+        const int q0 = (int)(st - (long)s * pl.tiles_per_seq) * SW_POS;
+        const float* grw = p.g + ((size_t)s * p.g_ctot + p.g_coff + (grow_ok ? grow : 0)) * (size_t)p.Tg;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int q = q0 + 16 * gpart + e;
+            gv[e] = (grow_ok && q < p.Ncols) ? grw[q] : 0.f;
+        }
+        if (2 * tid < SW_NW) {
+            const float* xrow = p.z + ((size_t)s * p.z_ctot + p.z_coff) * (size_t)p.Tz;
+            const int u0 = q0 - p.padL + 2 * tid;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) {
+                int u = u0 + e;
+                if (p.pad_mode == PASE_PAD_REFLECT) u = sx_reflect(u, p.Tz);
+                xv[e] = (u >= 0 && u < p.Tz) ? xrow[u] : 0.f;
+            }
+        }
+    };
+    auto store_stage = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = gv[8 * h + e];
+                v[e] = (p.g_alpha && t < 0.f) ? t * g_al : t;
+            }
+            u32x4 o[3];
+            pase_split_bf16x3_rne(v, o);
+#pragma unroll
+            for (int pz = 0; pz < 3; ++pz) As[pz * SW_ACH + (2 * gpart + h) * 64 + grow] = o[pz];
+        }
+        if (2 * tid < SW_NW) {
+            u32x4 w0[3], w1[3];
+            sx_two_windows(xv, w0, w1);
+#pragma unroll
+            for (int pz = 0; pz < 3; ++pz) {
+                Bs[pz * SW_NW + 2 * tid] = w0[pz];
+                Bs[pz * SW_NW + 2 * tid + 1] = w1[pz];
+            }
+        }
+    };
+
+    f32x16 accH[4], accS[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            accH[j][r] = 0.f;
+            accS[j][r] = 0.f;
+        }
+    load_stage(st_begin);
+    for (long st = st_begin; st < st_end; ++st) {
+        store_stage();
+        __syncthreads();
+        if (st + 1 < st_end) load_stage(st + 1);          // in flight under this stage's MFMAs
+        constexpr int PZA[5] = {1, 0, 2, 0, 1}, PZB[5] = {1, 2, 0, 1, 0};
+#pragma unroll
+        for (int kg = 0; kg < SW_POS / 16; ++kg) {
+            u32x4 a[3];
+#pragma unroll
+            for (int pz = 0; pz < 3; ++pz) a[pz] = As[pz * SW_ACH + (2 * kg + fk) * 64 + wm * 32 + fr];
+            const u32x4* xb = &Bs[wn * 128 + fr + 16 * kg + 8 * fk];
+#pragma unroll
+            for (int jp = 0; jp < 4; jp += 2) {
+                u32x4 b0[3], b1[3];
+#pragma unroll
+                for (int pz = 0; pz < 3; ++pz) {
+                    b0[pz] = xb[pz * SW_NW + 32 * jp];
+                    b1[pz] = xb[pz * SW_NW + 32 * (jp + 1)];
+                }
+#pragma unroll
+                for (int pi = 0; pi < 5; ++pi) {
+                    accS[jp] = pase_mfma_bf16_32x32x16(a[PZA[pi]], b0[PZB[pi]], accS[jp]);
+                    accS[jp + 1] = pase_mfma_bf16_32x32x16(a[PZA[pi]], b1[PZB[pi]], accS[jp + 1]);
+                }
+                accH[jp] = pase_mfma_bf16_32x32x16(a[0], b0[0], accH[jp]);
+                accH[jp + 1] = pase_mfma_bf16_32x32x16(a[0], b1[0], accH[jp + 1]);
+            }
+        }
+        __syncthreads();                                    // every wave has read the image: the next stage may overwrite it
+    }
+
+    // ---- += into the caller-zeroed dfilt (other workgroups hold the other position ranges) ---------------------------
+    const int rbase = wm * 32 + 4 * fk;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int kk = wn * 128 + j * 32 + fr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = rbase + (r & 3) + 8 * (r >> 2);
+            if (m < p.M && kk < p.taps) atomicAdd(p.dw + (size_t)m * p.ldw + kk, accH[j][r] + accS[j][r]);
+        }
+    }
+}
+
+}  // namespace
+
+bool pase_sinc_x6_plan(const PaseConvGemm& p, PaseSincPlan& pl) {
+    if (p.Cin != 1 || p.x_ctot < 1 || p.taps < 32 || p.taps > 16 * SX_KGMAX || p.M > 64 || p.M < 1) return false;
+    if (p.stride != 1 || p.tapstep != 1 || p.tap_major || p.ps != 1 || p.poff != 0) return false;
+    if (p.epilogue != PASE_EPI_STORE || p.post_op != PASE_POST_NONE || p.splitk > 1) return false;
+    if (p.in_scale || p.in_alpha) return false;
+    if (p.pad_mode == PASE_PAD_REFLECT && p.padL >= p.Tin) return false;
+    if (p.Cout_store != p.M) return false;
+    pl.n_kg = (p.taps + 15) / 16;
+    pl.nwin = SX_BN + 16 * pl.n_kg - 8;
+    pl.tiles_per_seq = (p.Ncols + SX_BN - 1) / SX_BN;
+    pl.pack_bytes = (long)2 * pl.n_kg * 192 * 16;
+    if ((long)p.S * pl.tiles_per_seq >= 0x7fffffffL) return false;
+    return true;
+}
+
+int pase_sinc_x6_pack(const PaseConvGemm& p, const PaseSincPlan& pl, hipStream_t st) {
+    const int total = 2 * pl.n_kg * 64;
+    PASE_LAUNCH(sinc_x6_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), st, p.wt,
+                reinterpret_cast<u32x4*>(const_cast<void*>(p.wx6)), p.M, p.ldwt, p.taps, pl.n_kg);
+    PASE_CHECK_LAUNCH();
+    return 0;
+}
+
+int pase_sinc_x6_launch(const PaseConvGemm& p, const PaseSincPlan& pl, hipStream_t st) {
+    PASE_LAUNCH(sinc_x6_fwd_kernel, dim3((unsigned)(p.S * pl.tiles_per_seq)), dim3(SX_NT), st, p, pl);
+    PASE_CHECK_LAUNCH();
+    return 0;
+}
+
+bool pase_sinc_x6_wgrad_plan(const PaseWgrad& w, PaseSincPlan& pl) {
+    if (w.Cin != 1 || w.taps < 32 || w.taps > SX_BN || w.M > 64 || w.M < 1) return false;
+    if (w.stride != 1 || w.tapstep != 1 || w.tap_major || w.dbias) return false;
+    if (w.in_scale || w.in_alpha) return false;
+    if (w.pad_mode == PASE_PAD_REFLECT && w.padL >= w.Tz) return false;
+    pl.n_kg = SW_POS / 16;
+    pl.nwin = SW_NW;
+    pl.tiles_per_seq = (w.Ncols + SW_POS - 1) / SW_POS;       // stages per sequence
+    pl.pack_bytes = 16;                                         // no pack: both operands are converted while they are staged
+    return true;
+}
+
+int pase_sinc_x6_wgrad_launch(const PaseWgrad& w, const PaseSincPlan& pl, hipStream_t st) {
+    const long total = (long)w.S * pl.tiles_per_seq;
+    // two workgroups per CU; at least 8 stages per workgroup (the atomic flush of a 64 x 256 tile costs about two stages)
+    long nwg = w.max_wg > 0 ? 2L * w.max_wg : 512;
+    if (w.splitk > 0) nwg = w.splitk;
+    if (nwg > (total + 7) / 8) nwg = (total + 7) / 8;
+    if (nwg < 1) nwg = 1;
+    PASE_LAUNCH(sinc_x6_wgrad_kernel, dim3((unsigned)nwg), dim3(SX_NT), st, w, pl);
+    PASE_CHECK_LAUNCH();
+    return 0;
+}

@@ -24,6 +24,7 @@
 #include "hip_compat.h"
 #include "pase_amd.h"
 #include "conv_x6c.h"
+#include "sinc_x6.h"
 
 namespace {
 
@@ -650,12 +651,16 @@ __global__ void __launch_bounds__(NTHREADS, 2) wgrad_flat_kernel(PaseWgrad p, Wg
 
 extern "C" long pase_wgrad_x6_bytes(const PaseWgrad* d) {
     if (d->M <= 0 || d->Cin <= 0 || d->S <= 0 || d->Ncols <= 0) return 0;
+    PaseSincPlan sp;
+    if (!(d->x6 & 1024) && pase_sinc_x6_wgrad_plan(*d, sp)) return sp.pack_bytes;
     PaseX6cWgrad o;
     return pase_x6c_wgrad_plan(*d, o) ? o.pl.pack_bytes : 0;
 }
 
 extern "C" int pase_wgrad_plan_kind(const PaseWgrad* d) {
     if (d->M <= 0 || d->Cin <= 0 || d->S <= 0 || d->Ncols <= 0) return 0;
+    PaseSincPlan sp;
+    if (!(d->x6 & 1024) && pase_sinc_x6_wgrad_plan(*d, sp)) return 5;
     PaseX6cWgrad o;
     return pase_x6c_wgrad_plan(*d, o) ? (o.pl.zp ? 4 : o.pl.tmode) : 0;
 }
@@ -665,6 +670,8 @@ extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
     if (p.M <= 0 || p.Cin <= 0 || p.S <= 0 || p.Ncols <= 0) return 0;
     if (p.x6 && p.gx6) {
         if ((((unsigned long long)(size_t)p.gx6) % 16) != 0) return -10;
+        PaseSincPlan sp;
+        if (!(p.x6 & 1024) && pase_sinc_x6_wgrad_plan(p, sp)) return pase_sinc_x6_wgrad_launch(p, sp, (hipStream_t)stream);
         PaseX6cWgrad o;
         if (!pase_x6c_wgrad_plan(p, o)) return -11;        // a pack buffer on a launch without a plan is refused, not ignored
         return pase_x6c_wgrad_launch(p, o, (hipStream_t)stream);

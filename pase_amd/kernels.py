@@ -127,7 +127,8 @@ def _conv_desc(x, w, y, *, S, Cin, Tin, M, K, taps, Ncols, Tout, ldw=None, bias=
     d.tile_hint = tile_hint
     d.splitk = splitk
     # measurement / test controls travel in the descriptor (the C library reads no environment variables)
-    d.x6_ctl = (1 if os.environ.get("PASE_X6C_FORCE") else 0) | {"1": 2, "0": 4}.get(os.environ.get("PASE_X6C_XP", ""), 0)
+    d.x6_ctl = ((1 if os.environ.get("PASE_X6C_FORCE") else 0) | {"1": 2, "0": 4}.get(os.environ.get("PASE_X6C_XP", ""), 0)
+                | (8 if os.environ.get("PASE_SINC_X6", "1") == "0" else 0))
     d.max_wg = _max_wg()
     return d
 
@@ -375,6 +376,7 @@ def wgrad_gemm(g, z, dw, *, S, M, Tg, Ncols, Cin, Tz, taps, ldw=None, dbias=None
         d.x6 |= (int(os.environ.get("PASE_X6C_WGRAD_MODE", "0")) & 15) << 4
         d.x6 |= 256 if os.environ.get("PASE_X6C_WGRAD_FLAT") else 0
         d.x6 |= 512 if os.environ.get("PASE_X6C_NOVEC") else 0
+        d.x6 |= 1024 if os.environ.get("PASE_SINC_X6", "1") == "0" else 0
     d.max_wg = _max_wg()
     global LAST_WGRAD_X6, LAST_WGRAD_KIND
     LAST_WGRAD_X6 = False

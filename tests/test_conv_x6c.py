@@ -193,6 +193,28 @@ def test_presplit_activation_is_the_default_of_wide_1x1_and_2tap_launches(dev, m
     assert _rel(y2, ref2) < 1e-6
 
 
+def test_infinite_activation_stays_non_finite_where_the_reference_is(dev):
+    """+-Inf in the activation: exactly the outputs it reaches are non-finite (+-Inf in the reference and on the fp32 pipe;
+    NaN or +-Inf here: hi * Inf has the right sign, but the weight's mid / lo pieces times Inf have arbitrary signs and the sum
+    of the six terms is NaN about half of the time -- hip_compat.h), every other output is as accurate as ever."""
+    torch.manual_seed(15)
+    S, Cin, Cout, k, T = 1, 48, 70, 3, 200
+    x = torch.randn(S, Cin, T)
+    w = torch.randn(Cout, Cin, k) * 0.2
+    x[0, 5, 100] = float("inf")
+    x[0, 9, 30] = float("-inf")
+    ref = F.conv1d(F.pad(x.double(), (1, 1)), w.double())
+    y = torch.zeros(S, Cout, T, device=dev)
+    K.conv_gemm(x.to(dev), w.reshape(Cout, -1).contiguous().to(dev), y, S=S, Cin=Cin, Tin=T, M=Cout, K=Cin * k, taps=k,
+                Ncols=T, Tout=T, padL=1, pad_mode=K.PAD_ZERO)
+    assert K.LAST_PLAN_KIND == 2
+    yc = y.cpu().double()
+    bad_ref = ~torch.isfinite(ref)
+    assert int(bad_ref.sum()) == 2 * 3 * Cout
+    assert bool((~torch.isfinite(yc) == bad_ref).all())
+    assert _rel(torch.where(bad_ref, torch.zeros_like(yc), yc), torch.where(bad_ref, torch.zeros_like(ref), ref)) < 1e-6
+
+
 def test_channel_slice_in_and_out(dev):
     """x_coff / x_ctot (a slice of a wider input) and y_coff / y_ctot (a slice of a wider output)."""
     torch.manual_seed(5)
@@ -304,10 +326,15 @@ def test_plan_kind_and_pack_contract(dev):
     buf = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
     d.wx6 = buf.data_ptr()
     assert lib.pase_conv_gemm_plan_kind(C.byref(d)) == 2
-    # one input channel (the Sinc FIR): no k-group of 16 channels' -> no pack, fp32 pipe
+    # one input channel (the Sinc FIR): no k-group of 16 channels' -> not this kernel; its own window-image kernel
+    # (sinc_x6.hip, plan kind 3: pack = [2 row tiles][16 tap groups][3 planes][64 lanes] chunks), or the fp32 pipe on request
     d1 = K._conv_desc(torch.zeros(1, 1, 300, device=dev), None, torch.zeros(1, 8, 300, device=dev),
                       wt=torch.zeros(251, 8, device=dev), S=1, Cin=1, Tin=300, M=8, K=251, taps=251, Ncols=300, Tout=300,
                       padL=125)
+    assert lib.pase_conv_gemm_x6_bytes(C.byref(d1)) == 2 * 16 * 3 * 64 * 16
+    d1.wx6 = buf.data_ptr()
+    assert lib.pase_conv_gemm_plan_kind(C.byref(d1)) == 3
+    d1.x6_ctl = 8
     assert lib.pase_conv_gemm_x6_bytes(C.byref(d1)) == 0
 
 
