@@ -236,6 +236,8 @@ def conv_gemm(x, w, y, want_stats=False, **kw):
     d = _conv_desc(x, w, y, **kw)
     global LAST_XP
     LAST_XP = False
+    # (per-launch timing brackets the launch's own operand packs too: weight pack, pre-split activation)
+    ev0 = GEMM_TIMER.start() if GEMM_TIMER is not None else None
     if X6 and os.environ.get("PASE_X6_CONV", "1") != "0" and _x6_conv_ok(kw):
         # contraction on the bf16 matrix pipe with both operands split into three bf16 pieces (fp32-grade result,
         # see PaseConvGemm::wx6) for the launch shapes the library has a split-bf16 plan for
@@ -265,7 +267,6 @@ def conv_gemm(x, w, y, want_stats=False, **kw):
             y.zero_()
     global LAST_PLAN_KIND
     LAST_PLAN_KIND = _lib.lib().pase_conv_gemm_plan_kind(C.byref(d))
-    ev0 = GEMM_TIMER.start() if GEMM_TIMER is not None else None
     _check(_lib.lib().pase_conv_gemm(C.byref(d), _stream()), "pase_conv_gemm")
     if ev0 is not None:
         GEMM_TIMER.stop("conv_gemm", 2.0 * d.S * d.Ncols * d.M * d.K, ev0,
