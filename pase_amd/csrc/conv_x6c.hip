@@ -1420,30 +1420,37 @@ __global__ void pack_xcm_kernel(const float* __restrict__ x, u32x4* __restrict__
 // ZP (tmode 1 with pl.zp): z~ (on-load transform applied, padding materialised) as three phase-decomposed bf16 planes,
 //   out[plane][row = ci * st + b][s][i],  i in [0, lseg):  piece of z~[s][ci][st * (i + dmin) + b]   (reflected / zero outside
 //   [0, T)),  plus -- `ones` -- a last row of 1.0 (the bias column of the weight gradient).
-// Workgroup (s, ci): thread -> (8-position group gq, phase b) with b fastest, so that the eight loads of a wave walk a
-// contiguous stretch of the source row (every byte of a fetched line is used within the eight instructions) and each thread
-// writes one 16-byte chunk per plane into row ci * st + b.  grid = (S, Cin [+ 1]).
+// Flat work list, one thread per (sequence s, channel ci, 8-position group gq, phase b) with b fastest, then gq: the eight
+// loads of a wave walk a contiguous stretch of one source row (every byte of a fetched line is used within the eight
+// instructions) and each thread writes one 16-byte chunk per plane into row ci * st + b.  (A workgroup per (s, ci) row -- the
+// first form -- left most of its threads idle on the short rows of the upper layers: 54 work items per 256-thread block on
+// block 7, 1.8 ms per step in eight launches.)
 __global__ void pack_zph_kernel(const float* __restrict__ src, u32x4* __restrict__ out, int Cin, int S, int ctot, int coff,
                                 int T, int st, int lseg, int dmin, int pad_mode, long t_plane, const float* sc,
                                 const float* sh, const float* al, int ones) {
-    const int s_ = blockIdx.x;
-    const int ci = blockIdx.y;
     const int ngrp = lseg / 8;
+    const int per_row = ngrp * st;                             // work items of one (s, ci) source row
+    const long nrows = (long)S * (Cin + (ones ? 1 : 0));
+    const long total = nrows * per_row;
     const size_t pstride = (size_t)(t_plane / 8);
-    if (ones && ci == Cin) {
-        u32x4* orow = out + ((size_t)(Cin * st) * S + s_) * (size_t)ngrp;
-        const u32x4 one = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}, zero = {0u, 0u, 0u, 0u};
-        for (int gq = threadIdx.x; gq < ngrp; gq += blockDim.x) {
-            orow[gq] = one;
-            orow[pstride + gq] = zero;
-            orow[2 * pstride + gq] = zero;
-        }
-        return;
-    }
-    const float* row = src + ((size_t)s_ * ctot + coff + ci) * T;
-    const float a_sc = sc ? sc[ci] : 1.f, a_sh = sc ? sh[ci] : 0.f, a_al = al ? al[ci] : 1.f;
-    for (int idx = threadIdx.x; idx < ngrp * st; idx += blockDim.x) {
+    for (long w = (long)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (long)gridDim.x * blockDim.x) {
+        const long rowi = w / per_row;
+        const int idx = (int)(w - rowi * per_row);
+        const int C1 = Cin + (ones ? 1 : 0);
+        const int s_ = (int)(rowi / C1), ci = (int)(rowi - (long)s_ * C1);       // source rows in memory order
         const int gq = idx / st, b = idx - gq * st;
+        if (ci == Cin) {                                       // the ones row (bias column): 1.0 in hi, zero mid / lo
+            if (b == 0) {
+                u32x4* orow = out + ((size_t)(Cin * st) * S + s_) * (size_t)ngrp + gq;
+                const u32x4 one = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}, zero = {0u, 0u, 0u, 0u};
+                orow[0] = one;
+                orow[pstride] = zero;
+                orow[2 * pstride] = zero;
+            }
+            continue;
+        }
+        const float* row = src + ((size_t)s_ * ctot + coff + ci) * T;
+        const float a_sc = sc ? sc[ci] : 1.f, a_sh = sc ? sh[ci] : 0.f, a_al = al ? al[ci] : 1.f;
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -1775,8 +1782,10 @@ int pase_x6c_wgrad_launch(const PaseWgrad& w, const PaseX6cWgrad& o, hipStream_t
     }
     PASE_CHECK_LAUNCH();
     if (pl.zp) {
-        // one workgroup per (sequence, channel): all its phase rows; the ones row (bias column) is the last plane row
-        PASE_LAUNCH(pack_zph_kernel, dim3((unsigned)w.S, (unsigned)(w.Cin + (w.dbias ? 1 : 0))), dim3(256), st, w.z,
+        // one thread per (sequence, channel, 8-position group, phase); the ones row (bias column) is the last plane row
+        const long zitems = (long)w.S * (w.Cin + (w.dbias ? 1 : 0)) * (pl.t_lseg / 8) * w.stride;
+        const long zblocks = (zitems + 255) / 256;
+        PASE_LAUNCH(pack_zph_kernel, dim3((unsigned)(zblocks < 65536 ? zblocks : 65536)), dim3(256), st, w.z,
                     reinterpret_cast<u32x4*>(reinterpret_cast<char*>(w.gx6) + pl.zp_off), w.Cin, w.S, w.z_ctot, w.z_coff, w.Tz,
                     w.stride, pl.t_lseg, pl.t_dmin, w.pad_mode, pl.t_plane, w.in_scale, w.in_shift, w.in_alpha,
                     w.dbias ? 1 : 0);

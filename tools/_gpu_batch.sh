@@ -1,5 +1,6 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
-timeout 300 python tools/step_breakdown.py gpurun_out/gl_a.json > gpurun_out/gl_a.txt 2>&1; tail -1 gpurun_out/gl_a.txt
-PASE_X6C_XP=1 timeout 300 python tools/step_breakdown.py gpurun_out/gl_xpall.json > gpurun_out/gl_xpall.txt 2>&1; tail -1 gpurun_out/gl_xpall.txt
-PASE_X6C_XP=1 PASE_X6C_FORCE=1 timeout 300 python tools/step_breakdown.py gpurun_out/gl_xpforce.json > gpurun_out/gl_xpforce.txt 2>&1; tail -1 gpurun_out/gl_xpforce.txt
+timeout 600 python -m pytest tests/test_wgrad_x6c.py -m gpu -q > gpurun_out/g7_tests.log 2>&1; tail -2 gpurun_out/g7_tests.log | cut -c1-300
+timeout 300 python tools/step_breakdown.py gpurun_out/gl_b.json > gpurun_out/gl_b.txt 2>&1; tail -1 gpurun_out/gl_b.txt
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-h2d > gpurun_out/g7_bench.json 2> gpurun_out/g7_bench.err; python -c "
+import json; d=json.load(open('gpurun_out/g7_bench.json')); print(d['value'], d['ms_per_step'])"
