@@ -119,7 +119,8 @@ int pase_conv_gemm_plan_kind(const PaseConvGemm* desc);
 /* bytes of the split-bf16 pack the launch described by desc (wx6 ignored) would read; 0 = this shape only runs on
  * the fp32 matrix pipe */
 long pase_conv_gemm_x6_bytes(const PaseConvGemm* desc);
-/* desc->wx6 (pase_conv_gemm_x6_bytes(desc) bytes, 16-B aligned) <- desc->wt split into three bf16 planes in the
+/* desc->wx6 (pase_conv_gemm_x6_bytes(desc) bytes, 16-B aligned) <- desc->wt (or, when wt is NULL, desc->w in the reference's
+ * own layout: no K-major intermediate is needed on this pipe) split into three bf16 planes in the
  * fragment order of the launch desc describes (tile, stage and tap padding are functions of the descriptor: pack and
  * launch must see the same one).  Like pase_pack_wt it runs once per weight use. */
 int pase_pack_x6(const PaseConvGemm* desc, void* stream);

@@ -34,6 +34,12 @@ def device_type():
 def lib():
     global _lib
     if _lib is None:
+        ab = os.environ.get("PASE_LIB")
+        if ab:
+            # A/B MEASUREMENT builds of the same sources with another -D flag (tools/ab_build.sh); never set in production
+            _lib = ctypes.CDLL(ab)
+            _declare(_lib)
+            return _lib
         if not os.path.exists(HIP_SO):
             raise PaseLibraryError(
                 "pase_amd: %s is missing. Build it with `python -m pase_amd.build hip` "

@@ -1118,7 +1118,8 @@ extern "C" int pase_conv_gemm(const PaseConvGemm* d, void* stream) {
     const PaseConvGemm p = *d;
     if (p.M <= 0 || p.K <= 0 || p.S <= 0 || p.Ncols <= 0) return 0;
     if (p.K != p.Cin * p.taps) return -4;
-    if (!p.wt || p.ldwt < p.M || p.ldwt < 4 || (p.ldwt & 3) || (((unsigned long long)(size_t)p.wt) % 16) != 0) return -10;
+    // (a split-bf16 launch reads only its pack wx6: the K-major fp32 pack is the fp32-pipe kernels' operand)
+    if (!p.wx6 && (!p.wt || p.ldwt < p.M || p.ldwt < 4 || (p.ldwt & 3) || (((unsigned long long)(size_t)p.wt) % 16) != 0)) return -10;
     if (p.epilogue == PASE_EPI_MSE_CTX && (!p.label || !p.loss_acc || p.r_ctx < 1)) return -2;
     if (p.pad_mode == PASE_PAD_REFLECT && (p.padL >= p.Tin)) return -3;
     if (p.tapstep != 1 && p.tapstep != -1) return -5;
@@ -1201,8 +1202,8 @@ extern "C" int pase_pack_xp(const PaseConvGemm* d, void* stream) {
 
 extern "C" int pase_pack_x6(const PaseConvGemm* d, void* stream) {
     const PaseConvGemm p = *d;
-    if (!p.wx6 || !p.wt || (((unsigned long long)(size_t)p.wx6) % 16) != 0) return -10;
-    if (p.K != p.Cin * p.taps || p.ldwt < p.M) return -4;
+    if (!p.wx6 || (!p.wt && !p.w) || (((unsigned long long)(size_t)p.wx6) % 16) != 0) return -10;
+    if (p.K != p.Cin * p.taps || (p.wt && p.ldwt < p.M)) return -4;
     const HostPlan h = make_plan(p, true);
     if (h.sinc) return pase_sinc_x6_pack(p, h.sp, (hipStream_t)stream);
     if (!h.x6c) return -11;

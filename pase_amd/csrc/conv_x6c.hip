@@ -731,6 +731,9 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                     const int gi = gb + decltype(r)::value;                     // stage (relative) being multiplied
                     if (gi < nst) {
                         X6C_T0();
+#ifdef PASE_X6C_TRACE
+                        if (!(pl.prio & 128))      // ablation: the staging waves only keep the barriers (results are garbage)
+#endif
                         if (gi + 1 < nst) {
                             // in flight: stage gi + 1 (set rn, the older one) and stage gi + 2
                             {
@@ -745,6 +748,9 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                             }
                         }
                         // set r (stage gi, converted one window ago) is free: stage gi + 3
+#ifdef PASE_X6C_TRACE
+                        if (!(pl.prio & 128))
+#endif
                         if (gi + XR < nst) load_stage(r, g_begin + gi + XR);
                         if (wave == 4) X6C_TACC(8);
                         __syncthreads();
@@ -861,8 +867,10 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     auto load_a = [&](u32x4 (&a)[3]) __attribute__((always_inline)) {
         // unconditional (the steps past the end re-read the last fragments): a load behind a branch makes the compiler's
         // vmcnt bookkeeping fall back to vmcnt(0), which would wait for the fragments issued a moment ago
+#ifndef PASE_ABL_NOA      // (ablation builds of tools/trace_x6c.py: no A-fragment loads inside the loop)
 #pragma unroll
         for (int pz = 0; pz < 3; ++pz) a[pz] = x6c_load16u(reinterpret_cast<const unsigned short*>(ab[pz] + a_loff));
+#endif
         ++a_issued;
         const bool wrap = a_q16 + 1 == a_wrap;
         a_q16 = wrap ? 0 : a_q16 + 1;
@@ -870,6 +878,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
 #pragma unroll
         for (int pz = 0; pz < 3; ++pz) ab[pz] += adv;
     };
+#ifdef PASE_X6C_OLDLOOP      // A/B builds only (tools/ab_build.sh): round 3's step, fragments read right in front of their use
     // (Three hand-pinned schedules were measured against leaving the 12 ds_read_b128 + 24 MFMAs of a step to the compiler:
     //  (1) prefetching the next pair of B tiles before each block of 12 MFMAs, two tiles alternating: 4 ... 14 % SLOWER on
     //  every convolution of the PASE+ step;  (2) units of (planes m, l) / (plane h) with all four tiles rotating and the next
@@ -899,10 +908,67 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         }
     };
 
+#else
+    // The step's 12 B fragments are SOFTWARE-PIPELINED over its two halves (tiles {0, 1} and {2, 3}): the six ds_read_b128 of
+    // the next half -- the second half of this step, then the first half of the next step of the stage -- are issued one per
+    // two MFMAs of the current half, so a fragment has ~10 MFMAs (320+ cycles) to arrive.  Round 3 read a half's six fragments
+    // right in front of its 12 MFMAs: with ONE compute wave per SIMD nothing else covers the LDS latency, and a step took
+    // 1050-1100 ticks against 768 of pure MFMA issue.  tools/experiments/mfma_dep_probe.hip isolates it (ticks per 24-MFMA
+    // step, one wave per SIMD): bare MFMAs 788 in ANY accumulator order (dependent accumulators cost nothing); "6 reads, then
+    // 12 MFMAs" twice = 1040 (the old loop, to the tick); the next half's reads in front of this half's MFMAs 833; one read
+    // per two MFMAs 800.  (Round 3's hand schedules moved MFMAs and waits around but kept reads and their first use in the
+    // same half; its "prefetch the next pair" variant lost to register copies.)  Price: 24 VGPRs.  The first half of a
+    // stage's first step is read behind the stage barrier (the data is not there earlier): once per stage.
+    u32x4 bq[2][2][3];          // [half][tile of the pair][plane]
+    auto load_first = [&](const u32x4* xb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pz = 0; pz < 3; ++pz) bq[0][i][pz] = xb[pz * PLANE + bbase[i]];
+    };
+    // xn: the next step's fragments base in the same stage buffer (== xb when this is the stage's last step: a harmless re-read)
+    auto mfma_step = [&](const u32x4 (&a)[3], const u32x4* xb, const u32x4* xn) __attribute__((always_inline)) {
+        // plane pairs of the five small terms, smallest first: mm, hl, lh, hm, mh -> accS; hh -> accH
+        constexpr int PZA[6] = {1, 0, 2, 0, 1, 0}, PZB[6] = {1, 2, 0, 1, 0, 0};
+        // (the three A-fragment loads of load_a() first: left to itself the scheduler sinks them behind ~19 MFMAs -- their
+        //  address temporaries reuse the retiring fragment's registers -- and the "two steps ahead" prefetch becomes 160 cycles)
+        PASE_SGB(0x020, 3);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const u32x4* src = h == 0 ? xb : xn;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                // one fragment of the NEXT half ...
+#ifndef PASE_ABL_NOB      // (ablation builds: no B-fragment reads inside the steps)
+                bq[h ^ 1][i / 3][i % 3] = src[(i % 3) * PLANE + bbase[2 * (h ^ 1) + i / 3]];
+#endif
+                // ... per two products of this one
+                if (i < 5) {
+                    accS[2 * h] = pase_mfma_bf16_32x32x16(a[PZA[i]], bq[h][0][PZB[i]], accS[2 * h]);
+                    accS[2 * h + 1] = pase_mfma_bf16_32x32x16(a[PZA[i]], bq[h][1][PZB[i]], accS[2 * h + 1]);
+                } else {
+                    accH[2 * h] = pase_mfma_bf16_32x32x16(a[0], bq[h][0][0], accH[2 * h]);
+                    accH[2 * h + 1] = pase_mfma_bf16_32x32x16(a[0], bq[h][1][0], accH[2 * h + 1]);
+                }
+                PASE_SGB(0x100, 1);      // pin: one DS read, then two MFMAs
+                PASE_SGB(0x008, 2);
+            }
+        }
+    };
+
+#endif
     // ---- main loop: stage = KGS k-groups x A taps; step st = kg * A + t -------------------------------------
     u32x4 a0[3], a1[3], a2[3];
+#ifdef PASE_ABL_NOA
+#pragma unroll
+    for (int pz = 0; pz < 3; ++pz) {
+        a0[pz] = a1[pz] = a2[pz] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+        asm volatile("" : "+v"(a0[pz]), "+v"(a1[pz]), "+v"(a2[pz]));
+    }
+#endif
     load_a(a0);
     load_a(a1);
+#ifdef PASE_X6C_OLDLOOP
     __syncthreads();
     if (wave == 0) X6C_STAMP(1);
     int gi = 0, st = 0, kg = 0, t = 0;
@@ -929,6 +995,39 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         }
         done = last;
     };
+#else
+    __syncthreads();
+    if (wave == 0) X6C_STAMP(1);
+    int gi = 0, st = 0, kg = 0, t = 0;
+    bool done = false;
+    load_first(&Xs[bsel * BUF]);
+    auto step = [&](const u32x4 (&acur)[3], u32x4 (&anxt)[3]) __attribute__((always_inline)) {
+        const bool last = (gi == nst - 1) && (st == nsteps - 1);            // uniform
+        load_a(anxt);
+        const u32x4* xb = &Xs[bsel * BUF + kg * KGC + t];
+        ++st;
+        if (++t == pl.A) {
+            t = 0;
+            ++kg;
+        }
+        const bool stage_end = st == nsteps;                                  // uniform
+        mfma_step(acur, xb, stage_end ? xb : &Xs[bsel * BUF + kg * KGC + t]);
+        if (stage_end) {
+            st = 0;
+            kg = 0;
+            t = 0;
+            ++gi;
+            {
+                X6C_T0();
+                __syncthreads();
+                if (wave == 0) X6C_TACC(9);
+            }
+            bsel ^= 1;
+            load_first(&Xs[bsel * BUF]);          // (past the last stage: a harmless read of the other buffer)
+        }
+        done = last;
+    };
+#endif
     while (true) {
         step(a0, a2);
         if (done) break;
@@ -1269,9 +1368,12 @@ extern "C" int pase_x6c_trace_reset() {
 // weights (K-major fp32 pack wt[k * ldwt + m], k = ci * taps + kk) -> fragment-ordered bf16 planes:
 // out[((rt32 * steps + st) * 3 + plane) * 64 + lane], step st = g * A + a, lane = (fk, row): element e = channel'
 // 16 g + 8 fk + e at tap' a.  Zero for channels' past Cin * P, taps past the real count and rows past M.
+// (wt == NULL: straight from the weight as the reference stores it, w[m * ldw + (tap_major ? kk * Cin + ci : ci * taps + kk)] --
+//  the K-major intermediate is only needed by the fp32-pipe kernels; one launch less per split-bf16 convolution)
 __global__ void pack_x6c_kernel(const float* __restrict__ wt, u32x4* __restrict__ out, int M, int ldwt, int Cin, int taps,
                                 int P, int A, int CinP, int rev, int steps, long total, int perm_ps, int perm_cout,
-                                const float* in_scale, const float* in_shift, const float* in_alpha, float* prm, int prm_n) {
+                                const float* in_scale, const float* in_shift, const float* in_alpha, float* prm, int prm_n,
+                                const float* __restrict__ w, int ldw, int tap_major) {
     // the on-load parameters expanded per channel' behind the chunks (same launch: one pack launch per GEMM launch)
     for (long c = (long)blockIdx.x * blockDim.x + threadIdx.x; c < prm_n; c += (long)gridDim.x * blockDim.x) {
         const int ci = min((int)c / P, Cin - 1);
@@ -1295,7 +1397,9 @@ __global__ void pack_x6c_kernel(const float* __restrict__ wt, u32x4* __restrict_
             const int cp = g * 16 + fk * 8 + e;
             const int ci = cp / P, b = cp - ci * P;
             const int kk = rev ? taps - 1 - a : a * P + b;
-            v[e] = (cp < CinP && kk >= 0 && kk < taps && m < M) ? wt[((size_t)ci * taps + kk) * ldwt + msrc] : 0.f;
+            const bool ok = cp < CinP && kk >= 0 && kk < taps && m < M;
+            if (wt) v[e] = ok ? wt[((size_t)ci * taps + kk) * ldwt + msrc] : 0.f;
+            else v[e] = ok ? w[(size_t)msrc * ldw + (tap_major ? kk * Cin + ci : ci * taps + kk)] : 0.f;
         }
         u32x4 o[3];
         pase_split_bf16x3_rne(v, o);
@@ -1473,7 +1577,14 @@ __global__ void pack_zph_kernel(const float* __restrict__ src, u32x4* __restrict
 
 // (wave priorities: s_setprio of either role changed nothing on the PASE+ step -- DESIGN.md 3.0; the plan field stays for
 //  the trace build's ablations)
+#ifdef PASE_X6C_TRACE
+int x6c_prio() {      // trace builds only (tools/trace_x6c.py): ablation bits
+    const char* e = getenv("PASE_X6C_ABLATE");
+    return e ? atoi(e) : 0;
+}
+#else
 int x6c_prio() { return 0; }
+#endif
 
 unsigned magic_of(int d) {
     return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned long long)d);
@@ -1582,7 +1693,8 @@ int pase_x6c_pack(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st) 
     PASE_LAUNCH(pack_x6c_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), st, p.wt,
                 reinterpret_cast<u32x4*>(const_cast<void*>(p.wx6)), p.M, p.ldwt, p.Cin, p.taps, pl.P, pl.A, pl.CinP, pl.rev,
                 pl.steps_total, total, pl.xPerm ? p.ps : 1, p.Cout_store, p.in_scale, p.in_shift, p.in_alpha,
-                reinterpret_cast<float*>(reinterpret_cast<u32x4*>(const_cast<void*>(p.wx6)) + pl.pack_chunks), pl.prm_n);
+                reinterpret_cast<float*>(reinterpret_cast<u32x4*>(const_cast<void*>(p.wx6)) + pl.pack_chunks), pl.prm_n,
+                p.w, p.ldw, p.tap_major);
     PASE_CHECK_LAUNCH();
     return 0;
 }

@@ -198,7 +198,9 @@ __global__ void __launch_bounds__(SX_NT, 2) sinc_x6_fwd_kernel(PaseConvGemm p, P
 
 // filt (K-major fp32 pack wt[kk * ldwt + m]) -> fragment-ordered bf16 planes [32-row tile (2)][k-group][plane][lane]:
 // lane = (fk, row): element e = tap 16 g + 8 fk + e of filter 32 rt + row; zero past the taps / past M
-__global__ void sinc_x6_pack_kernel(const float* __restrict__ wt, u32x4* __restrict__ out, int M, int ldwt, int taps, int n_kg) {
+// (wt == NULL: straight from the filters as the reference stores them, w[m * ldw + kk])
+__global__ void sinc_x6_pack_kernel(const float* __restrict__ wt, u32x4* __restrict__ out, int M, int ldwt, int taps, int n_kg,
+                                    const float* __restrict__ w, int ldw) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 2 * n_kg * 64) return;
     const int lane = idx & 63, g = (idx >> 6) % n_kg, rt = (idx >> 6) / n_kg;
@@ -207,7 +209,7 @@ __global__ void sinc_x6_pack_kernel(const float* __restrict__ wt, u32x4* __restr
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int kk = 16 * g + 8 * fk + e;
-        v[e] = (kk < taps && m < M) ? wt[(size_t)kk * ldwt + m] : 0.f;
+        v[e] = (kk < taps && m < M) ? (wt ? wt[(size_t)kk * ldwt + m] : w[(size_t)m * ldw + kk]) : 0.f;
     }
     u32x4 o[3];
     pase_split_bf16x3_rne(v, o);
@@ -357,7 +359,7 @@ bool pase_sinc_x6_plan(const PaseConvGemm& p, PaseSincPlan& pl) {
 int pase_sinc_x6_pack(const PaseConvGemm& p, const PaseSincPlan& pl, hipStream_t st) {
     const int total = 2 * pl.n_kg * 64;
     PASE_LAUNCH(sinc_x6_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), st, p.wt,
-                reinterpret_cast<u32x4*>(const_cast<void*>(p.wx6)), p.M, p.ldwt, p.taps, pl.n_kg);
+                reinterpret_cast<u32x4*>(const_cast<void*>(p.wx6)), p.M, p.ldwt, p.taps, pl.n_kg, p.w, p.ldw);
     PASE_CHECK_LAUNCH();
     return 0;
 }

@@ -226,13 +226,11 @@ def _x6_conv_ok(kw):
 
 def conv_gemm(x, w, y, want_stats=False, **kw):
     """see include/pase_amd.h PaseConvGemm.  With splitk > 1 the output is zero-filled here first.
-    The kernel reads the K-major pack of the weight: pass it as wt= (e.g. straight from pack_dgrad, or a
-    weight that already is K-major) or it is produced here from `w`.
+    The fp32-pipe kernels read the K-major pack of the weight: pass it as wt= (e.g. straight from pack_dgrad, or a
+    weight that already is K-major) or it is produced here from `w`; a split-bf16 launch packs its operand from wt= if
+    given, else straight from `w`.
     want_stats=True: the (column tiles, M, 2) partial-sum buffer for pase_bn_finalize is allocated here (the tile count
     is a function of the plan the library picks for the COMPLETE descriptor, split-bf16 pack included) and returned."""
-    if kw.get("wt") is None:
-        kw["wt"] = pack_wt(w, M=kw["M"], K=kw["K"], Cin=kw["Cin"], taps=kw["taps"], ldw=kw.get("ldw"),
-                           tap_major=kw.get("tap_major", 0))
     d = _conv_desc(x, w, y, **kw)
     global LAST_XP
     LAST_XP = False
@@ -253,6 +251,10 @@ def conv_gemm(x, w, y, want_stats=False, **kw):
                 d.xp6 = xp6.data_ptr()
                 _check(_lib.lib().pase_pack_xp(C.byref(d), _stream()), "pase_pack_xp")
                 LAST_XP = True
+    if not d.wx6 and not d.wt:
+        # the fp32-pipe kernels read the K-major pack of the weight (a split-bf16 launch packs straight from `w`)
+        wt = pack_wt(w, M=kw["M"], K=kw["K"], Cin=kw["Cin"], taps=kw["taps"], ldw=kw.get("ldw"), tap_major=kw.get("tap_major", 0))
+        d.wt, d.ldwt = wt.data_ptr(), wt.shape[1]
     stat = None
     if want_stats:
         stat = torch.empty(_lib.lib().pase_conv_gemm_stat_tiles(C.byref(d)), d.M, 2, device=x.device, dtype=torch.float32)

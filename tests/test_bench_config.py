@@ -68,8 +68,8 @@ def _noise(variant, n):
     return is_noise_grad(n)
 
 
-@pytest.fixture(scope="module", params=[("pase+", True), ("pase+", False), ("pase", True), ("emb256", True)],
-                ids=["x6", "fp32pipe", "pase-cfg1-x6", "emb256-lnorm-2xqrnn-bs64-x6"])
+@pytest.fixture(scope="module", params=[("pase+", True), ("pase+", False), ("pase", True), ("pase", False), ("emb256", True)],
+                ids=["x6", "fp32pipe", "pase-cfg1-x6", "pase-cfg1-fp32pipe", "emb256-lnorm-2xqrnn-bs64-x6"])
 def setup(request):
     """The benchmark configuration is gated on both matrix pipes -- the split-bf16 contraction (the shipped default) and
     the exact-fp32 MFMA pipe (K.X6 False) run the same two tests against the same comparator -- the other two BASELINE
@@ -197,6 +197,7 @@ def test_bs32_embedding_losses_and_elementwise_grads(setup):
         worst = max(worst, (e_ours, n))
         per_channel = n.endswith(("norm.weight", "norm.bias", "act.weight", ".bias", "low_hz_", "band_hz_"))
         floor = 1.5e-3 if per_channel else 5e-4
+        setup.setdefault("eref", {})[n] = e_ref
         if e_ref >= 0.5:
             # the fp64 gradient of this tensor is (numerically) zero -- e.g. a worker whose hidden units are all dead at
             # this random state -- and BOTH fp32 evaluations are pure round-off relative to it: nothing to compare
@@ -249,18 +250,33 @@ def test_bs32_ten_adam_steps_track(setup):
     # round-off-sized (dense-skip and decoder weights early in training) moves by lr per step in a direction both
     # implementations pick by round-off -- a per-element bound says nothing there.  What must agree is the UPDATE as
     # a whole: its direction (cosine >= 0.95 per tensor; measured >= 0.98) and its length (within 5 %).
-    worst = (1.0, None)
+    # A tensor whose step-0 gradient the torch fp32 comparator itself only knows to a few per cent (relative L2 against fp64
+    # >= 2e-2: the cancellation-dominated SincNet vectors, workers whose hidden units are nearly all dead at this state) is
+    # noise-dominated -- Adam turns that into +-lr steps in round-off directions on both sides; measured on emb256: the cmi
+    # worker's hidden weight, cosine -0.006 between two fp32 evaluations -- and single-element tensors (a head's scalar bias)
+    # have no direction at all: both are reported, not gated.
+    # Gates = measured worst case minus a margin (round 4, both pipes, several boxes; atomics make the runs differ):
+    #   pase+ (benchmark)  cos >= 0.986, length within 3.8 %   -> 0.95, 5 %
+    #   pase (configs[1])  cos >= 0.951, length within 6.5 %   -> 0.92, 8 %   (half the samples per BatchNorm statistic)
+    #   emb256 (configs[4]) cos >= 0.895 (first dense-skip weight), length within 4.2 % -> 0.85, 8 %
+    COS = {"pase+": 0.95, "pase": 0.92, "emb256": 0.85}[variant]
+    LEN = {"pase+": 0.05, "pase": 0.08, "emb256": 0.08}[variant]
+    rows, ungated = [], []
+    eref = setup.get("eref", {})
     for n, p in tr.model.named_parameters():
         if _noise(variant, n) or n in setup.get("dead", ()):
             continue
         da, db = (p.detach() - p0[n]).double().flatten(), (P[n].detach() - p0[n]).double().flatten()
         cos = float((da * db).sum() / (da.norm() * db.norm()).clamp_min(1e-30))
-        worst = min(worst, (cos, n))
-        # (emb256: the first dense-skip weight measured 0.895 -- its gradients are round-off-sized for the first steps)
-        assert cos >= (0.95 if variant == "pase+" else 0.85), (n, cos)
         ratio = float(da.norm() / db.norm().clamp_min(1e-30))
-        assert 0.95 <= ratio <= 1.05, (n, ratio)
-    print("smallest cosine between the two 10-step updates:", worst)
+        (ungated if (eref.get(n, 0.0) >= 2e-2 or p.numel() == 1) else rows).append((cos, ratio, n))
+    print("smallest cosines between the two 10-step updates:", sorted(rows)[:6])
+    print("update-length ratios farthest from 1:", sorted(rows, key=lambda r: -abs(r[1] - 1.0))[:6])
+    print("not gated (noise-dominated step-0 gradient or a single element):", sorted(ungated)[:8])
+    assert len(ungated) <= 8, ungated
+    for cos, ratio, n in rows:
+        assert cos >= COS, (n, cos)
+        assert 1.0 - LEN <= ratio <= 1.0 + LEN, (n, ratio)
 
 
 def test_bs32_producer_mode_step(tmp_path):

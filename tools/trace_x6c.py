@@ -22,15 +22,17 @@ from pase_amd.engine import Act  # noqa: E402
 
 def build_trace_lib():
     # built in the CPU container (hipcc cross-compiles) so that no GPU minutes go into compiling: `python tools/trace_x6c.py build`
-    out = os.path.join(ROOT, "tools", "_trace", "libpase_trace.so")
+    # PASE_TRACE_FLAGS: extra -D flags of an A/B variant (e.g. -DPASE_X6C_OLDLOOP), PASE_TRACE_TAG: its file name suffix
+    extra = os.environ.get("PASE_TRACE_FLAGS", "").split()
+    out = os.path.join(ROOT, "tools", "_trace", "libpase_trace%s.so" % os.environ.get("PASE_TRACE_TAG", ""))
     stamp = out + ".digest"
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    if os.path.exists(out) and os.path.exists(stamp) and open(stamp).read() == build.hip_digest():
+    if os.path.exists(out) and (extra == ["x"] or (os.path.exists(stamp) and open(stamp).read() == build.hip_digest() + " ".join(extra))):
         return out
     srcs = build._sources()
-    flags = [f for f in build._hip_flags()] + ["-DPASE_X6C_TRACE"]
+    flags = [f for f in build._hip_flags()] + ["-DPASE_X6C_TRACE"] + extra
     subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + flags + ["-o", out] + srcs)
-    open(stamp, "w").write(build.hip_digest())
+    open(stamp, "w").write(build.hip_digest() + " ".join(extra))
     return out
 
 
