@@ -352,7 +352,13 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                     const int b = ob - db * p.stride;
                     const int row = ones ? pl.zp_rows - 1 : ci * p.stride + b;
                     const int sh = ones ? 0 : db;
-                    zp_col[par] = (unsigned)(row * p.S) * (unsigned)pl.t_lseg + (unsigned)(sh + fkL * 8);
+                    // (each plane holds its rows twice, the second copy one element later: an odd shift reads that copy one
+                    //  element earlier, so every chunk address is a multiple of 4 bytes -- tools/experiments/window_load_probe:
+                    //  a wave's 16-byte loads at 2-byte-aligned addresses take 256 ticks each, at 4-byte-aligned ones 64;
+                    //  in the kernel: 14 % fewer cycles per item)
+                    const int odd = sh & 1;
+                    zp_col[par] = (unsigned)odd * (unsigned)(pl.t_plane / 2) + (unsigned)(row * p.S) * (unsigned)pl.t_lseg +
+                                  (unsigned)(sh - odd + fkL * 8);
                     if (valid) pos_valid |= 1u << par;
                 }
                 live = 0u;
@@ -1547,17 +1553,20 @@ __global__ void pack_zph_kernel(const float* __restrict__ src, u32x4* __restrict
             if (b == 0) {
                 u32x4* orow = out + ((size_t)(Cin * st) * S + s_) * (size_t)ngrp + gq;
                 const u32x4 one = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}, zero = {0u, 0u, 0u, 0u};
-                orow[0] = one;
-                orow[pstride] = zero;
-                orow[2 * pstride] = zero;
+#pragma unroll
+                for (int cp = 0; cp < 2; ++cp) {
+                    orow[cp * (pstride / 2)] = one;
+                    orow[pstride + cp * (pstride / 2)] = zero;
+                    orow[2 * pstride + cp * (pstride / 2)] = zero;
+                }
             }
             continue;
         }
         const float* row = src + ((size_t)s_ * ctot + coff + ci) * T;
         const float a_sc = sc ? sc[ci] : 1.f, a_sh = sc ? sh[ci] : 0.f, a_al = al ? al[ci] : 1.f;
-        float v[8];
+        float v[9];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
+        for (int e = 0; e < 9; ++e) {
             int u = st * (gq * 8 + e + dmin) + b;
             if (pad_mode == PASE_PAD_REFLECT) u = x6c_reflect(u, T);
             float t = 0.f;
@@ -1567,11 +1576,14 @@ __global__ void pack_zph_kernel(const float* __restrict__ src, u32x4* __restrict
             }
             v[e] = t;
         }
-        u32x4 o[3];
-        pase_split_bf16x3_rne(v, o);
+        u32x4 o0[3], o1[3];
+        pase_split_two_windows(v, o0, o1);
         u32x4* orow = out + ((size_t)(ci * st + b) * S + s_) * (size_t)ngrp + gq;
 #pragma unroll
-        for (int pz = 0; pz < 3; ++pz) orow[pz * pstride] = o[pz];
+        for (int pz = 0; pz < 3; ++pz) {
+            orow[pz * pstride] = o0[pz];
+            orow[pz * pstride + pstride / 2] = o1[pz];          // second copy: elements one later
+        }
     }
 }
 
@@ -1794,7 +1806,7 @@ bool pase_x6c_wgrad_plan(const PaseWgrad& w, PaseX6cWgrad& o) {
             const long body = (long)pl.zp_rows * w.S * pl.t_lseg;
             if (body < (1L << 30) && (long)w.padL + w.taps < (1L << 20)) {
                 pl.zp = 1;
-                pl.t_plane = body;                                  // a multiple of 8 (lseg is)
+                pl.t_plane = 2 * body;                              // two copies (see the stager); body is a multiple of 8 (lseg is)
                 pl.ps_magic = magic_of(w.stride);
                 pl.t_stride = w.stride;
                 pl.zp_n = w.taps / w.stride;

@@ -179,6 +179,34 @@ __device__ __forceinline__ void pase_split_bf16x3_rne(const float (&x)[8], u32x4
     for (int i = 0; i < 4; ++i) out[2][i] = pase_cvt_pk_bf16(r[2 * i], r[2 * i + 1]);
 }
 
+// nine consecutive values -> the pieces of the two 8-element windows starting at element 0 and element 1:
+//   w0[pz] = pieces pz of v[0..7], w1[pz] = pieces pz of v[1..8]   (pase_split_bf16x3_rne's arithmetic on both pairings;
+//   used where a fragment must start at ANY element: the second window makes every start dword-aligned)
+__device__ __forceinline__ void pase_split_two_windows(const float (&v)[9], u32x4 (&w0)[3], u32x4 (&w1)[3]) {
+    float r[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) r[i] = v[i];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        unsigned pe[4], po[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pe[i] = pase_cvt_pk_bf16(r[2 * i], r[2 * i + 1]);          // (0,1) (2,3) (4,5) (6,7)
+            po[i] = pase_cvt_pk_bf16(r[2 * i + 1], r[2 * i + 2]);      // (1,2) (3,4) (5,6) (7,8)
+            w0[s][i] = pe[i];
+            w1[s][i] = po[i];
+        }
+        if (s < 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                r[2 * i] -= __uint_as_float(pe[i] << 16);
+                r[2 * i + 1] -= __uint_as_float(pe[i] & 0xffff0000u);
+            }
+            r[8] -= __uint_as_float(po[3] & 0xffff0000u);
+        }
+    }
+}
+
 // four values -> three pieces x two dwords (half a fragment)
 __device__ __forceinline__ void pase_split_bf16x3_quad(const float (&x)[4], unsigned (&out)[3][2]) {
     float r[4];

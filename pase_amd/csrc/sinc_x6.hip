@@ -35,33 +35,6 @@ __device__ __forceinline__ int sx_reflect(int u, int T) {
     return min(u, 2 * (T - 1) - u);
 }
 
-// nine consecutive samples -> the pieces of the two windows starting at sample 0 and sample 1:
-//   w0[pz] = pieces pz of v[0..7], w1[pz] = pieces pz of v[1..8]   (pase_split_bf16x3_rne's arithmetic on both pairings)
-__device__ __forceinline__ void sx_two_windows(const float (&v)[9], u32x4 (&w0)[3], u32x4 (&w1)[3]) {
-    float r[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) r[i] = v[i];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        unsigned pe[4], po[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            pe[i] = pase_cvt_pk_bf16(r[2 * i], r[2 * i + 1]);          // (0,1) (2,3) (4,5) (6,7)
-            po[i] = pase_cvt_pk_bf16(r[2 * i + 1], r[2 * i + 2]);      // (1,2) (3,4) (5,6) (7,8)
-            w0[s][i] = pe[i];
-            w1[s][i] = po[i];
-        }
-        if (s < 2) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                r[2 * i] -= __uint_as_float(pe[i] << 16);
-                r[2 * i + 1] -= __uint_as_float(pe[i] & 0xffff0000u);
-            }
-            r[8] -= __uint_as_float(po[3] & 0xffff0000u);
-        }
-    }
-}
-
 // ================================================================================================================
 // forward
 // ================================================================================================================
@@ -89,7 +62,7 @@ __global__ void __launch_bounds__(SX_NT, 2) sinc_x6_fwd_kernel(PaseConvGemm p, P
             v[e] = (u >= 0 && u < p.Tin) ? xrow[u] : 0.f;
         }
         u32x4 w0[3], w1[3];
-        sx_two_windows(v, w0, w1);
+        pase_split_two_windows(v, w0, w1);
 #pragma unroll
         for (int pz = 0; pz < 3; ++pz) {
             Ws[pz * SX_NW + 2 * t] = w0[pz];
@@ -277,7 +250,7 @@ __global__ void __launch_bounds__(SX_NT, 2) sinc_x6_wgrad_kernel(PaseWgrad p, Pa
         }
         if (2 * tid < SW_NW) {
             u32x4 w0[3], w1[3];
-            sx_two_windows(xv, w0, w1);
+            pase_split_two_windows(xv, w0, w1);
 #pragma unroll
             for (int pz = 0; pz < 3; ++pz) {
                 Bs[pz * SW_NW + 2 * tid] = w0[pz];
