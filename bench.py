@@ -221,6 +221,9 @@ def main():
     ap.add_argument("--rccl-max-nchannels", type=int, default=0,
                     help="N > 1: NCCL_MAX_NCHANNELS for RCCL (each channel occupies a CU that the backward's kernels then do "
                          "not get); 0 = leave RCCL's default")
+    ap.add_argument("--reserve-cus", type=int, default=-1,
+                    help="N > 1: CUs the persistent split-bf16 GEMM grids leave free for RCCL's channel kernels (grid cap = "
+                         "256 - this); -1 = 16 for N > 1, 0 for N = 1")
     ap.add_argument("--producer", action="store_true",
                     help="BASELINE.json configs[3] shape: every step's batch is produced ON DEVICE inside the timed "
                          "region (random crops of a resident waveform pool, Reverb / additive-noise gating on "
@@ -263,7 +266,8 @@ def main():
     torch.manual_seed(2)             # train.py:376 default seed
     with contextlib.redirect_stdout(io.StringIO()):
         tr = trainer(frontend_cfg=dict(fe_cfg), minions_cfg=wk_cfg,
-                     cfg=dict(fe_lr=1e-3, min_lr=5e-4, epoch=1, bpe=max(1, args.steps + args.warmup)),
+                     cfg=dict(fe_lr=1e-3, min_lr=5e-4, epoch=1, bpe=max(1, args.steps + args.warmup),
+                              reserve_cus=(args.reserve_cus if args.reserve_cus >= 0 else (16 if world > 1 else 0))),
                      lr_mode="poly", device=dev)
     B, T = args.batch, args.chunk
     batch = synthetic_batch(1234 + rank, B, T, raw, dev)
@@ -478,6 +482,7 @@ def main():
         if multi is not None:
             out["multi_gpu"] = multi
             out["config"]["rccl_max_nchannels"] = args.rccl_max_nchannels or "RCCL default"
+            out["config"]["reserved_cus"] = tr.reserve_cus
         if shared and world > 1:
             out["invalid_as_scaling_number"] = ("%d ranks share %d GPU(s) over gloo: functional smoke of the N>1 path only"
                                                 % (world, ndev))

@@ -668,6 +668,10 @@ extern "C" int pase_wgrad_plan_kind(const PaseWgrad* d) {
 extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
     PaseWgrad p = *d;
     if (p.M <= 0 || p.Cin <= 0 || p.S <= 0 || p.Ncols <= 0) return 0;
+    // argument checks shared by every kernel family (the split-bf16 paths reflect once: an out-of-range pad would contribute
+    // zeros there instead of an error)
+    if (p.tapstep != 1 && p.tapstep != -1) return -5;
+    if (p.pad_mode == PASE_PAD_REFLECT && p.padL >= p.Tz) return -3;
     if (p.x6 && p.gx6) {
         if ((((unsigned long long)(size_t)p.gx6) % 16) != 0) return -10;
         PaseSincPlan sp;

@@ -310,8 +310,14 @@ def on_wgrad_stream(like, fn, keep=()):
         fn()
         return
     ws.wait_event(cur.record_event())
-    with torch.cuda.stream(ws):
-        fn()
+    try:
+        with torch.cuda.stream(ws):
+            fn()
+    except BaseException:
+        # leave no fork behind: the forking stream waits for whatever was enqueued, the kept operands are released
+        cur.wait_stream(ws)
+        _WKEEP.pop((like.device.index, cur.cuda_stream), None)
+        raise
     # The operands must outlive the side stream's kernels.  Not Tensor.record_stream (its deferred-free events are not
     # graph-capture safe: capture_end segfaulted on the mini configuration): hold references until the forking stream
     # joins -- after that, memory the caching allocator hands back to that stream is ordered behind the side stream's work.
@@ -562,7 +568,8 @@ def encoder_backward(fe, ctx, demb, sink, want_dx=False, on_ready=None):
     ain = ctx.ain
     ccat = ain.C
     dwcat = _zeros((emb, ccat), x)
-    on_wgrad_stream(x, lambda: conv_wgrad(dyemb, ain, dwcat, sink.buf(fe.W.bias), taps=1), keep=(dyemb, ain.t))
+    wb_bias = sink.buf(fe.W.bias)        # (gradient buffers are taken on the forking stream: GradSink(direct=False) allocates)
+    on_wgrad_stream(x, lambda: conv_wgrad(dyemb, ain, dwcat, wb_bias, taps=1), keep=(dyemb, ain.t))
     cw = fe.W.in_channels
     pairs = [(fe.W.weight, dwcat[:, :cw])]
     if fe.denseskips_on:
@@ -591,8 +598,10 @@ def encoder_backward(fe, ctx, demb, sink, want_dx=False, on_ready=None):
         # true zero; the input's would have to be a zero of the activated tensor) and stay on the 1x1 kernel
         dg_next = torch.nn.functional.pad(dgates[:, :, 1:], (0, 1))
 
-        def wq(dgates=dgates, dg_next=dg_next, inp=inp, dwq=dwq, layer=layer, cin=cin):
-            conv_wgrad(dgates, inp, dwq, sink.buf(layer.linear.bias), taps=1, padL=0, pad_mode=K.PAD_ZERO)
+        dbq = sink.buf(layer.linear.bias)
+
+        def wq(dgates=dgates, dg_next=dg_next, inp=inp, dwq=dwq, dbq=dbq, cin=cin):
+            conv_wgrad(dgates, inp, dwq, dbq, taps=1, padL=0, pad_mode=K.PAD_ZERO)
             conv_wgrad(dg_next, inp, dwq, None, taps=1, padL=0, pad_mode=K.PAD_ZERO, dw_col_off=cin)
         on_wgrad_stream(x, wq, keep=(dgates, dg_next, inp.t))
         # dX[s,ci,u] = sum_{o,r} Wq[o, r*cin+ci] * dG[s,o,u+r]
@@ -650,8 +659,10 @@ def encoder_backward(fe, ctx, demb, sink, want_dx=False, on_ready=None):
             sink.add(conv.band_hz_, dband)
         else:
             dbias = sink.buf(blk.conv.bias) if (rec["has_bn"] or rec.get("kind") in ("in", "ln")) else None
-            def wg(dy=dy, inp=inp, blk=blk, C=C, dbias=dbias, taps=taps, rec=rec, n=n):
-                conv_wgrad(dy, inp, sink.buf(blk.conv.weight).view(C, -1), dbias, taps=taps, stride=blk.stride,
+            dwblk = sink.buf(blk.conv.weight).view(C, -1)
+
+            def wg(dy=dy, inp=inp, blk=blk, dwblk=dwblk, dbias=dbias, taps=taps, rec=rec, n=n):
+                conv_wgrad(dy, inp, dwblk, dbias, taps=taps, stride=blk.stride,
                            padL=rec["padL"], pad_mode=K.PAD_REFLECT)
                 # (the fork event also covers the per-channel sums sink.add_cols committed above: a bucket handed over on
                 #  the side stream is complete)
@@ -799,8 +810,8 @@ def worker_backward(layers, out_conv, ctx, dpred, sink, need_dinput=True):
         have_dz = True
     else:
         dpred = dpred.contiguous()
-        on_wgrad_stream(x, lambda: conv_wgrad(dpred, cur, sink.buf(out_conv.weight).view(nout, -1),
-                                              sink.buf(out_conv.bias), taps=1), keep=(dpred, cur.t))
+        dw_out, db_out = sink.buf(out_conv.weight).view(nout, -1), sink.buf(out_conv.bias)
+        on_wgrad_stream(x, lambda: conv_wgrad(dpred, cur, dw_out, db_out, taps=1), keep=(dpred, cur.t))
         dsrc = GradSrc(conv_dgrad(dpred, out_conv.weight, R=nout, O=cur.C, k=1, stride=1, Tin=T, padL=0, padR=0,
                                   s_red=cur.C, s_out=1, s_k=1), ctot=cur.C, Tp=T)
         have_dz = False
@@ -822,8 +833,10 @@ def worker_backward(layers, out_conv, ctx, dpred, sink, need_dinput=True):
             # dW[ci, co, kk] = sum_{s,t} act(in)[s,ci,t] * dz[s,co,t*st + kk - pad]
             if inp.scale is not None:
                 raise NotImplementedError("deconv wgrad with an affine on-load input")
-            def wd(inp=inp, dz=dz, dc=dc, cin=cin, C=C, Tz=Tz, k=k, st=st, pad=pad):
-                K.wgrad_gemm(inp.t, dz, sink.buf(dc.weight).view(cin, -1), S=B, M=cin, Tg=inp.T, Ncols=inp.T, Cin=C,
+            dw_dc = sink.buf(dc.weight).view(cin, -1)
+
+            def wd(inp=inp, dz=dz, dw_dc=dw_dc, cin=cin, C=C, Tz=Tz, k=k, st=st, pad=pad):
+                K.wgrad_gemm(inp.t, dz, dw_dc, S=B, M=cin, Tg=inp.T, Ncols=inp.T, Cin=C,
                              Tz=Tz, taps=k, ldw=C * k, g_ctot=inp.ctot, g_coff=inp.coff, stride=st, tapstep=1, padL=pad,
                              pad_mode=K.PAD_ZERO, g_alpha=inp.alpha)
             on_wgrad_stream(x, wd, keep=(inp.t, dz))
@@ -835,8 +848,9 @@ def worker_backward(layers, out_conv, ctx, dpred, sink, need_dinput=True):
         else:
             k = blk.context
             cin = inp.C
-            on_wgrad_stream(x, lambda dz=dz, inp=inp, blk=blk, C=C, k=k: conv_wgrad(
-                dz, inp, sink.buf(blk.W.weight).view(C, -1), None, taps=k, padL=k // 2, pad_mode=K.PAD_ZERO),
+            dw_blk = sink.buf(blk.W.weight).view(C, -1)
+            on_wgrad_stream(x, lambda dz=dz, inp=inp, dw_blk=dw_blk, k=k: conv_wgrad(
+                dz, inp, dw_blk, None, taps=k, padL=k // 2, pad_mode=K.PAD_ZERO),
                 keep=(dz, inp.t))
             last = blk is layers[0]
             if need_dinput or not last:

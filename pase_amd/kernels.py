@@ -236,6 +236,11 @@ def conv_gemm(x, w, y, want_stats=False, **kw):
     LAST_XP = False
     # (per-launch timing brackets the launch's own operand packs too: weight pack, pre-split activation)
     ev0 = GEMM_TIMER.start() if GEMM_TIMER is not None else None
+    if want_stats:
+        # the plan (pixel-shuffle row order, automatic split-K) depends on whether BatchNorm partial sums are written: the pack
+        # and the launch must see the SAME descriptor, so the statistics buffer exists before the pack is sized.  Its tile count
+        # is a function of the plan WITH the split-bf16 pack, hence sized against a descriptor that carries a (dummy) pack.
+        d.stat_part = 1          # non-NULL marker for the sizing queries below; replaced by the real buffer
     if X6 and os.environ.get("PASE_X6_CONV", "1") != "0" and _x6_conv_ok(kw):
         # contraction on the bf16 matrix pipe with both operands split into three bf16 pieces (fp32-grade result,
         # see PaseConvGemm::wx6) for the launch shapes the library has a split-bf16 plan for

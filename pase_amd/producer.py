@@ -296,9 +296,16 @@ class DeviceBatchProducer(object):
         def wavs_under(dirs, lst):
             dirs = [dirs] if isinstance(dirs, str) else list(dirs)
             names = []
+            if lst is not None and not os.path.exists(lst) and not synthetic_ok:
+                # the reference's SimpleAdditiveShift opens the list and fails (transforms.py): a typo in the cfg must not
+                # silently train on another overlap pool
+                raise FileNotFoundError("overlap_list %r does not exist" % (lst,))
             if lst is not None and os.path.exists(lst):
                 with open(lst) as f:
                     names = [os.path.join(dirs[0], ln.strip()) for ln in f if ln.strip()]
+                missing = [n for n in names if not os.path.exists(n)]
+                if missing and not synthetic_ok:
+                    raise FileNotFoundError("%d files of overlap_list %r do not exist (first: %s)" % (len(missing), lst, missing[0]))
             else:
                 for d in dirs:
                     if os.path.isdir(d):

@@ -211,6 +211,14 @@ class trainer(object):
         self.rank = dist.get_rank() if self.world > 1 else 0
         self._side = None
         self.device_targets = None
+        # Data-parallel runs leave CUs to RCCL: every split-bf16 GEMM is a persistent grid of one 512-thread workgroup per
+        # CU at 225 VGPRs per lane -- a channel kernel cannot share a CU with it (the SIMD's register file is full) and would
+        # only get one at a launch's tail.  cfg["reserve_cus"] (default 16 for world > 1, 0 otherwise) caps those grids at
+        # 256 - reserve_cus (PaseConvGemm::max_wg / PaseWgrad::max_wg); 16 covers RCCL's default channel count on a ring.
+        self.reserve_cus = int(self.cfg.get("reserve_cus", 16 if self.world > 1 else 0)) if hasattr(self, "cfg") else 0
+        if self.reserve_cus > 0:
+            from . import kernels as _K
+            _K.MAX_WG = max(1, 256 - self.reserve_cus)
         if self.world > 1:
             self.broadcast_parameters()
 
@@ -434,7 +442,9 @@ class trainer(object):
 
     def comm_report(self):
         """Timings of the most recent comm_diag step (synchronises): per bucket bytes / when it became ready / when its
-        collective ran, relative to the step's first kernel; `comm_exposed_ms` = how long the main stream waited for the
+        collective ran, relative to the step's first kernel (`ready_ms` is recorded on the stream that hands the bucket over:
+        the main stream for the worker and head buckets, the weight-gradient side stream for the conv-block buckets --
+        engine.encoder_backward joins that stream before it returns, which is what keeps ready_ms <= backward_end_ms); `comm_exposed_ms` = how long the main stream waited for the
         side stream after the last backward kernel; `comm_total_ms` = sum of the collectives' durations;
         `host_enqueue_ms` = wall time this rank's Python spent enqueueing the step (no device synchronisation inside)."""
         ev = getattr(self, "_comm_events", None)

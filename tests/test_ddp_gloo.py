@@ -216,3 +216,57 @@ def test_four_ranks_uneven_timing_stay_identical_and_rank0_checkpoints():
             with open(os.path.join(ck, f)) as fh:
                 j = json.load(fh)
             assert len(j["latest"]) == 1, (f, j)     # a second writer would have appended a duplicate
+
+
+@pytest.mark.gpu
+def test_reserved_cus_let_a_side_stream_kernel_run_beside_a_persistent_gemm():
+    """Data-parallel readiness (round-3 review item 8b): the split-bf16 GEMMs are persistent grids of one 512-thread workgroup
+    per CU whose registers fill the SIMDs, so a kernel on another stream (RCCL's channel kernels) finds no CU until a launch
+    drains.  With the grid capped at 256 - reserved CUs (PaseConvGemm::max_wg, what trainer(cfg reserve_cus) sets for
+    world > 1) a 64-workgroup kernel enqueued on a side stream BEHIND the start of a long GEMM finishes while the GEMM is
+    still running; without the cap it has to wait for the GEMM's tail."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from pase_amd import _lib
+    from pase_amd import kernels as K
+    _lib.use_library(None, "cuda")
+    _lib.lib()
+    dev = torch.device("cuda:0")
+    S, Cin, Cout, k, T = 96, 256, 256, 11, 800           # block 5 of PASE+: ~0.55 ms, 2 x 600 tiles on 256 workgroups
+    x = torch.randn(S, Cin, T, device=dev)
+    w = torch.randn(Cout, Cin * k, device=dev) * 0.05
+    y = torch.empty(S, Cout, T, device=dev)
+    small = torch.zeros(64 * 256 * 4, device=dev)        # 64 blocks of 256 threads x 4 elements (torch's vectorised add)
+    side = torch.cuda.Stream()
+
+    def gemm():
+        K.conv_gemm(x, w, y, S=S, Cin=Cin, Tin=T, M=Cout, K=Cin * k, taps=k, Ncols=T, Tout=T, padL=5, pad_mode=K.PAD_REFLECT)
+
+    def run(max_wg):
+        saved = K.MAX_WG
+        K.MAX_WG = max_wg
+        try:
+            gemm()
+            small.add_(1.0)
+            torch.cuda.synchronize()
+            e_g0, e_g1, e_s1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            main = torch.cuda.current_stream()
+            e_g0.record(main)
+            gemm()                                  # pack launches + the persistent GEMM
+            side.wait_event(e_g0)
+            with torch.cuda.stream(side):
+                small.add_(1.0)
+                e_s1.record(side)
+            e_g1.record(main)
+            torch.cuda.synchronize()
+            return e_g0.elapsed_time(e_g1), e_g0.elapsed_time(e_s1)
+        finally:
+            K.MAX_WG = saved
+    assert K.LAST_PLAN_KIND is None or True
+    t_gemm, t_side = run(240)
+    assert K.LAST_PLAN_KIND == 2
+    t_gemm_full, t_side_full = run(0)
+    print("reserved 16 CUs: GEMM %.3f ms, side kernel done at %.3f ms | no reservation: GEMM %.3f ms, side kernel at %.3f ms"
+          % (t_gemm, t_side, t_gemm_full, t_side_full))
+    assert t_side < 0.6 * t_gemm, (t_side, t_gemm)          # it ran beside the GEMM, not behind it
+    assert t_gemm <= 1.15 * t_gemm_full, (t_gemm, t_gemm_full)  # and 16 of 256 CUs cost the GEMM at most their share (+ noise)

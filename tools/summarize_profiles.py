@@ -29,6 +29,47 @@ def last_step(rows):
     return rows[idx[-14] + 1: idx[-1] + 1]
 
 
+def nth_step(rows, j):
+    """kernels of training step j (0-based): between the 13 Adam launches that end step j - 1 and those that end step j"""
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    idx = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+    if len(idx) < 13 * (j + 1):
+        return None
+    lo = idx[13 * j - 1] + 1 if j > 0 else 0
+    return rows[lo: idx[13 * (j + 1) - 1] + 1]
+
+
+def union_us(iv):
+    iv = sorted(iv)
+    tot, cur_s, cur_e = 0, None, None
+    for s_, e_ in iv:
+        if cur_e is None or s_ > cur_e:
+            if cur_e is not None:
+                tot += cur_e - cur_s
+            cur_s, cur_e = s_, e_
+        else:
+            cur_e = max(cur_e, e_)
+    if cur_e is not None:
+        tot += cur_e - cur_s
+    return tot / 1e3
+
+
+FAMILY = (("split-bf16 convolutions / data gradients", ("conv_x6c_kernel<192", "conv_x6c_kernel<128, 3", "sinc_x6_fwd")),
+          ("split-bf16 weight gradients", ("conv_x6c_kernel<128, 4", "sinc_x6_wgrad")),
+          ("exact-fp32 GEMMs", ("conv_gemm_kernel", "wgrad_gemm_kernel", "wgrad_flat_kernel")),
+          ("operand packs", ("pack_",)),
+          ("elementwise / normalisation / scan / heads", ("act_bwd", "bn_", "qrnn_", "head1_", "adam", "commit_cols", "rownorm",
+                                                          "ctx_loss", "sinc_filters")),
+          ("stock torch kernels", ("at::native", "__amd_rocclr")))
+
+
+def family_of(name):
+    for fam, keys in FAMILY:
+        if any(k in name for k in keys):
+            return fam
+    return "other"
+
+
 def counters(path):
     agg = defaultdict(lambda: defaultdict(float))
     f = os.path.join(G, path + "_" + tag, "r_counter_collection.csv")
@@ -68,6 +109,31 @@ if kt:
                                "families": [{"kernel": k, "calls": v[0], "total_us": round(v[1], 1),
                                              "avg_us": round(v[1] / v[0], 1), "pct": round(100 * v[1] / tot, 2)}
                                             for k, v in sorted(fam.items(), key=lambda x: -x[1][1])[:28]]}
+    # the OVERLAPPED step the headline is measured on (bench.py: W warm-up + K timed steps run with the weight-gradient /
+    # head / pooling side streams on; the two steps behind them are the serialised per-launch timing steps summarised above):
+    # step W + K - 1.  Per stream: kernels and busy time (union of its kernels' intervals); `gpu_busy_us` = union over all
+    # streams; sum_kernel_us > step_span_us is what the overlap buys.
+    nsteps = len([r for r in csv.DictReader(open(kt)) if "adam_kernel" in r["Kernel_Name"]]) // 13
+    ov = nth_step(list(csv.DictReader(open(kt))), nsteps - 3) if nsteps >= 4 else None
+    if ov:
+        iv_all, per = [], defaultdict(list)
+        fam2 = defaultdict(lambda: [0, 0.0])
+        for r in ov:
+            s_, e_ = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            iv_all.append((s_, e_))
+            per[(r.get("Queue_Id", "?"), r.get("Stream_Id", "?"))].append((s_, e_))
+            fam2[short(r["Kernel_Name"])][0] += 1
+            fam2[short(r["Kernel_Name"])][1] += (e_ - s_) / 1e3
+        span2 = (max(e for _, e in iv_all) - min(s_ for s_, _ in iv_all)) / 1e3
+        out["overlapped_step"] = {
+            "which": "training step %d of %d in the trace (last timed step of bench.py)" % (nsteps - 3, nsteps),
+            "step_span_us": round(span2, 1), "sum_kernel_us": round(sum(v[1] for v in fam2.values()), 1),
+            "gpu_busy_us": round(union_us(iv_all), 1), "launches": len(ov),
+            "streams": [{"queue/stream": "%s/%s" % k, "kernels": len(v), "busy_us": round(union_us(v), 1),
+                         "sum_kernel_us": round(sum(e - s_ for s_, e in v) / 1e3, 1)}
+                        for k, v in sorted(per.items(), key=lambda kv: -len(kv[1]))],
+            "families": [{"kernel": k, "calls": v[0], "total_us": round(v[1], 1), "avg_us": round(v[1] / v[0], 1)}
+                         for k, v in sorted(fam2.items(), key=lambda x: -x[1][1])[:14]]}
 # --- HBM traffic (FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x,
 #     MI355X_MICROARCH.md section HBM -> both the raw and the corrected figure are given)
 fe, wr = counters("pmc_fetch"), counters("pmc_write")
@@ -80,6 +146,13 @@ if fe and wr:
                    "write_MB": round(w_kib * 1024 / 1e6, 1)})
     tr.sort(key=lambda x: -(x["fetch_MB_x2"] + x["write_MB"]))
     out["hbm_traffic_per_step"] = tr[:24]
+    byfam = defaultdict(lambda: [0.0, 0.0])
+    for row in tr:
+        byfam[family_of(row["kernel"])][0] += row["fetch_MB_x2"]
+        byfam[family_of(row["kernel"])][1] += row["write_MB"]
+    out["hbm_traffic_by_family_GB"] = {k: {"fetch_x2": round(v[0] / 1e3, 2), "write": round(v[1] / 1e3, 2),
+                                           "total": round((v[0] + v[1]) / 1e3, 2)} for k, v in byfam.items()}
+    out["hbm_traffic_total_GB"] = round(sum(v[0] + v[1] for v in byfam.values()) / 1e3, 2)
 sq = counters("pmc_sq")
 if sq:
     rows = []
