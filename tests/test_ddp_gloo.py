@@ -223,8 +223,12 @@ def test_reserved_cus_let_a_side_stream_kernel_run_beside_a_persistent_gemm():
     """Data-parallel readiness (round-3 review item 8b): the split-bf16 GEMMs are persistent grids of one 512-thread workgroup
     per CU whose registers fill the SIMDs, so a kernel on another stream (RCCL's channel kernels) finds no CU until a launch
     drains.  With the grid capped at 256 - reserved CUs (PaseConvGemm::max_wg, what trainer(cfg reserve_cus) sets for
-    world > 1) a 64-workgroup kernel enqueued on a side stream BEHIND the start of a long GEMM finishes while the GEMM is
-    still running; without the cap it has to wait for the GEMM's tail."""
+    world > 1) a 64-workgroup kernel enqueued on a side stream WHILE a long GEMM runs finishes long before the GEMM does, and
+    the cap costs the GEMM no more than its share of the chip.  (Measured, round 4: a LIGHT kernel -- torch's vectorised add,
+    a few dozen VGPRs -- also gets in without the cap, 62 registers per lane are left beside the GEMM's two waves per SIMD;
+    RCCL's channel kernels are not light, and no multi-GPU node was available to measure them: the uncapped numbers are
+    printed, not asserted.)"""
+    import time
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from pase_amd import _lib
@@ -232,7 +236,7 @@ def test_reserved_cus_let_a_side_stream_kernel_run_beside_a_persistent_gemm():
     _lib.use_library(None, "cuda")
     _lib.lib()
     dev = torch.device("cuda:0")
-    S, Cin, Cout, k, T = 96, 256, 256, 11, 800           # block 5 of PASE+: ~0.55 ms, 2 x 600 tiles on 256 workgroups
+    S, Cin, Cout, k, T = 384, 256, 256, 11, 800          # block 5 of PASE+ at four times the batch: ~2.2 ms, 10 items per workgroup
     x = torch.randn(S, Cin, T, device=dev)
     w = torch.randn(Cout, Cin * k, device=dev) * 0.05
     y = torch.empty(S, Cout, T, device=dev)
@@ -247,26 +251,30 @@ def test_reserved_cus_let_a_side_stream_kernel_run_beside_a_persistent_gemm():
         K.MAX_WG = max_wg
         try:
             gemm()
-            small.add_(1.0)
+            with torch.cuda.stream(side):          # (first use of a stream creates its hardware queue: not inside the timing)
+                small.add_(1.0)
             torch.cuda.synchronize()
             e_g0, e_g1, e_s1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
             main = torch.cuda.current_stream()
             e_g0.record(main)
-            gemm()                                  # pack launches + the persistent GEMM
-            side.wait_event(e_g0)
+            gemm()                                  # pack launch + the persistent GEMM
+            e_g1.record(main)
+            time.sleep(0.0007)                      # the GEMM is on the CUs by now (its launch took ~0.1 ms of host time)
             with torch.cuda.stream(side):
                 small.add_(1.0)
                 e_s1.record(side)
-            e_g1.record(main)
             torch.cuda.synchronize()
             return e_g0.elapsed_time(e_g1), e_g0.elapsed_time(e_s1)
         finally:
             K.MAX_WG = saved
-    assert K.LAST_PLAN_KIND is None or True
-    t_gemm, t_side = run(240)
+    run(0)                                          # clocks / caches warm
+    r240 = [run(240), run(240)]
     assert K.LAST_PLAN_KIND == 2
-    t_gemm_full, t_side_full = run(0)
+    r0 = [run(0), run(0)]
+    t_gemm, t_side = min(r240)
+    t_gemm_full, t_side_full = min(r0)
     print("reserved 16 CUs: GEMM %.3f ms, side kernel done at %.3f ms | no reservation: GEMM %.3f ms, side kernel at %.3f ms"
           % (t_gemm, t_side, t_gemm_full, t_side_full))
-    assert t_side < 0.6 * t_gemm, (t_side, t_gemm)          # it ran beside the GEMM, not behind it
-    assert t_gemm <= 1.15 * t_gemm_full, (t_gemm, t_gemm_full)  # and 16 of 256 CUs cost the GEMM at most their share (+ noise)
+    assert t_gemm > 1.5, t_gemm                                  # long enough for the side kernel to arrive mid-flight
+    assert t_side < t_gemm - 0.4, (t_side, t_gemm)                # it ran beside the GEMM, not behind it
+    assert t_gemm <= 1.15 * t_gemm_full, (t_gemm, t_gemm_full)    # and 16 of 256 CUs cost the GEMM at most their share (+ noise)
