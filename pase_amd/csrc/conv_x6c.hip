@@ -874,15 +874,29 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         // unconditional (the steps past the end re-read the last fragments): a load behind a branch makes the compiler's
         // vmcnt bookkeeping fall back to vmcnt(0), which would wait for the fragments issued a moment ago
 #ifndef PASE_ABL_NOA      // (ablation builds of tools/trace_x6c.py: no A-fragment loads inside the loop)
+        if constexpr (!TM) {
+            // packs: the three planes of a step are 1 KB apart -- ONE pointer, the plane offset rides in the instruction's
+            // immediate field (a third of the address arithmetic of three independent pointers)
+            const X6cU16* a1 = reinterpret_cast<const X6cU16*>(ab[0] + a_loff);
 #pragma unroll
-        for (int pz = 0; pz < 3; ++pz) a[pz] = x6c_load16u(reinterpret_cast<const unsigned short*>(ab[pz] + a_loff));
+            for (int pz = 0; pz < 3; ++pz) a[pz] = a1[64 * pz].v;
+        } else {
+#pragma unroll
+            for (int pz = 0; pz < 3; ++pz) a[pz] = x6c_load16u(reinterpret_cast<const unsigned short*>(ab[pz] + a_loff));
+        }
 #endif
         ++a_issued;
-        const bool wrap = a_q16 + 1 == a_wrap;
-        a_q16 = wrap ? 0 : a_q16 + 1;
-        const int adv = (a_issued < nsteps_run) ? a_adv + (wrap ? a_hh2 : 0) : 0;
+        int adv = (a_issued < nsteps_run) ? a_adv : 0;
+        if constexpr (TM) {      // (mode 3 only: plane rows wrap at the sequence boundaries; the convolutions carry no such state)
+            const bool wrap = a_q16 + 1 == a_wrap;
+            a_q16 = wrap ? 0 : a_q16 + 1;
+            adv = (a_issued < nsteps_run) ? a_adv + (wrap ? a_hh2 : 0) : 0;
+        }
+        if constexpr (!TM) ab[0] += adv;
+        else {
 #pragma unroll
-        for (int pz = 0; pz < 3; ++pz) ab[pz] += adv;
+            for (int pz = 0; pz < 3; ++pz) ab[pz] += adv;
+        }
     };
 #ifdef PASE_X6C_OLDLOOP      // A/B builds only (tools/ab_build.sh): round 3's step, fragments read right in front of their use
     // (Three hand-pinned schedules were measured against leaving the 12 ds_read_b128 + 24 MFMAs of a step to the compiler:
@@ -1004,34 +1018,33 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
 #else
     __syncthreads();
     if (wave == 0) X6C_STAMP(1);
-    int gi = 0, st = 0, kg = 0, t = 0;
+    // step bookkeeping in increments (no multiplies, four scalar counters): chunk offset of the step's fragments inside Xs,
+    // taps left in the k-group, steps left in the stage, stages left in the item
+    int xoff = bsel * BUF, taps_left = pl.A, steps_left = nsteps, stages_left = nst;
     bool done = false;
-    load_first(&Xs[bsel * BUF]);
+    load_first(&Xs[xoff]);
     auto step = [&](const u32x4 (&acur)[3], u32x4 (&anxt)[3]) __attribute__((always_inline)) {
-        const bool last = (gi == nst - 1) && (st == nsteps - 1);            // uniform
         load_a(anxt);
-        const u32x4* xb = &Xs[bsel * BUF + kg * KGC + t];
-        ++st;
-        if (++t == pl.A) {
-            t = 0;
-            ++kg;
-        }
-        const bool stage_end = st == nsteps;                                  // uniform
-        mfma_step(acur, xb, stage_end ? xb : &Xs[bsel * BUF + kg * KGC + t]);
+        const u32x4* xb = &Xs[xoff];
+        const bool kg_end = --taps_left == 0;                                 // uniform
+        xoff += kg_end ? KGC - (pl.A - 1) : 1;
+        taps_left = kg_end ? pl.A : taps_left;
+        const bool stage_end = --steps_left == 0;                             // uniform
+        mfma_step(acur, xb, stage_end ? xb : &Xs[xoff]);
         if (stage_end) {
-            st = 0;
-            kg = 0;
-            t = 0;
-            ++gi;
             {
                 X6C_T0();
                 __syncthreads();
                 if (wave == 0) X6C_TACC(9);
             }
             bsel ^= 1;
-            load_first(&Xs[bsel * BUF]);          // (past the last stage: a harmless read of the other buffer)
+            xoff = bsel * BUF;
+            taps_left = pl.A;
+            steps_left = nsteps;
+            --stages_left;
+            load_first(&Xs[xoff]);                // (past the last stage: a harmless read of the other buffer)
         }
-        done = last;
+        done = stages_left == 0;
     };
 #endif
     while (true) {
