@@ -280,6 +280,12 @@ int pase_sinc_filters_bwd(const float* low_hz_, const float* band_hz_, const flo
  * AccumulateGrad does for those parameters in the reference) */
 int pase_commit_cols(const double* sums, int ld, int C, float* g0, int c0, float* g1, int c1, float* g2, int c2,
                      void* stream);
+/* dst_k[r, c] += src_k[r, c] for up to 16 row-major blocks (rows x width, leading dimensions src_ld / dst_ld) in one
+ * launch: staged weight gradients of concatenated / stacked GEMMs into their parameters' gradient buffers (what autograd's
+ * slicing backward of torch.cat does in the reference: frontend.py:244-266 dense-skip sum, one Conv1d per worker) */
+typedef struct PaseAddBlock { const float* src; float* dst; int rows, width, src_ld, dst_ld; } PaseAddBlock;
+typedef struct PaseAddBlocks { int n; PaseAddBlock seg[16]; } PaseAddBlocks;
+int pase_add_blocks(const PaseAddBlocks* desc, void* stream);
 int pase_pack_dgrad(const float* src, float* dst, int R, int O, int k, int st, long s_red, long s_out, long s_k,
                     void* stream);
 /* same pack written K-major for pase_conv_gemm's `wt` operand: dst ((R*ceil(k/st)), ldt),

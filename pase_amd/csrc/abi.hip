@@ -7,6 +7,7 @@ extern "C" int pase_abi_sizeof(int which) {
         case 0: return (int)sizeof(PaseConvGemm);
         case 1: return (int)sizeof(PaseWgrad);
         case 2: return (int)sizeof(PaseActBwd);
+        case 3: return (int)sizeof(PaseAddBlocks);
         default: return -1;
     }
 }

@@ -289,6 +289,18 @@ __global__ void __launch_bounds__(NT) commit_cols_kernel(const double* sums, int
     if (g2) g2[c] += (float)row[c2];
 }
 
+// Parameter-gradient commit of STAGED weight gradients: dst_k[r, c] += src_k[r, c] for up to 16 row-major blocks in ONE launch
+// (the concatenated W + dense-skip weight gradient -> its eight parameters' .grad buffers: column slices; the stacked first
+// layers of the MLP heads -> nine parameters: row slices).  torch's _foreach_add_ falls back to one strided add per slice.
+__global__ void __launch_bounds__(NT) add_blocks_kernel(PaseAddBlocks p) {
+    const PaseAddBlock b = p.seg[blockIdx.y];
+    const long n = (long)b.rows * b.width;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+        const int r = (int)(i / b.width), c = (int)(i - (long)r * b.width);
+        b.dst[(size_t)r * b.dst_ld + c] += b.src[(size_t)r * b.src_ld + c];
+    }
+}
+
 // ---- Adam (torch.optim.Adam defaults; WorkerScheduler/trainer.py:91,111,134) ----------------------
 // One launch per logical optimizer over its flat parameter / gradient / moment buffers.  `step` and
 // `lr` live in device memory so a captured hipGraph replays correctly as they change.
@@ -408,6 +420,24 @@ extern "C" int pase_commit_cols(const double* sums, int ld, int C, float* g0, in
     if (C <= 0) return 0;
     PASE_LAUNCH(commit_cols_kernel, dim3((unsigned)((C + NT - 1) / NT)), dim3(NT), (hipStream_t)stream, sums, ld, C, g0,
                 c0, g1, c1, g2, c2);
+    PASE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pase_add_blocks(const PaseAddBlocks* d, void* stream) {
+    if (d->n <= 0) return 0;
+    if (d->n > 16) return -2;
+    long nmax = 0;
+    for (int k = 0; k < d->n; ++k) {
+        const PaseAddBlock& b = d->seg[k];
+        if (b.rows < 0 || b.width < 0 || b.src_ld < b.width || b.dst_ld < b.width || !b.src || !b.dst) return -2;
+        const long n = (long)b.rows * b.width;
+        nmax = n > nmax ? n : nmax;
+    }
+    if (nmax == 0) return 0;
+    long gx = (nmax + NT - 1) / NT;
+    if (gx > 1024) gx = 1024;
+    PASE_LAUNCH(add_blocks_kernel, dim3((unsigned)gx, (unsigned)d->n), dim3(NT), (hipStream_t)stream, *d);
     PASE_CHECK_LAUNCH();
     return 0;
 }

@@ -54,7 +54,7 @@ class ZeroArena:
     current capacity falls back to torch.zeros for the overflow and the arena is regrown at the next begin_step.
     Views are only valid until the next begin_step()."""
 
-    LIMIT = 64 << 20      # larger requests keep their own allocation
+    LIMIT = 1 << 30       # larger requests keep their own allocation
 
     def __init__(self):
         self.buf = None
@@ -103,6 +103,9 @@ def _zeros(shape, like, dtype=torch.float32):
     return torch.zeros(shape, device=like.device, dtype=dtype)
 
 
+K.ZERO_ALLOC = _zeros
+
+
 # =========================================================================================
 # primitive layers
 # =========================================================================================
@@ -121,12 +124,13 @@ def conv_fwd(a: Act, w2d, bias, *, Cout, taps, stride=1, padL=0, padR=0, pad_mod
     S, Tin = a.S, a.T
     if Tout is None:
         Tout = (Tin + padL + padR - taps) // stride + 1
+    kw = dict(S=S, Cin=a.C, Tin=Tin, M=Cout, K=a.C * taps, taps=taps, Ncols=Tout, Tout=Tout, ldw=w2d.shape[1], bias=bias,
+              in_scale=a.scale, in_shift=a.shift, in_alpha=a.alpha, x_ctot=a.ctot, x_coff=a.coff, tap_major=tap_major,
+              stride=stride, tapstep=tapstep, padL=padL, pad_mode=pad_mode, Cout_store=Cout)
+    if out is None and not want_stats:
+        return K.conv_gemm_out(a.t, w2d, (S, Cout, Tout), y_ctot=Cout, y_coff=0, **kw), None
     y = out if out is not None else _new((S, Cout, Tout), a.t)
-    stat = K.conv_gemm(a.t, w2d, y, want_stats=want_stats, S=S, Cin=a.C, Tin=Tin, M=Cout, K=a.C * taps, taps=taps,
-                Ncols=Tout, Tout=Tout,
-                ldw=w2d.shape[1], bias=bias, in_scale=a.scale, in_shift=a.shift, in_alpha=a.alpha,
-                x_ctot=a.ctot, x_coff=a.coff, tap_major=tap_major, stride=stride, tapstep=tapstep, padL=padL,
-                pad_mode=pad_mode, y_ctot=y.shape[1], y_coff=out_coff, Cout_store=Cout)
+    stat = K.conv_gemm(a.t, w2d, y, want_stats=want_stats, y_ctot=y.shape[1], y_coff=out_coff, **kw)
     return y, stat
 
 
@@ -138,10 +142,10 @@ def conv_dgrad(dy, w_nat, *, R, O, k, stride, Tin, padL, padR, s_red, s_out, s_k
     wt = K.pack_dgrad_t(w_nat, R=R, O=O, k=k, st=stride, s_red=s_red, s_out=s_out, s_k=s_k)
     Tp = Tin + padL + padR
     Ncols = -(-Tp // stride)
-    dx = _new((S, O, Tp), dy)
-    K.conv_gemm(dy, None, dx, wt=wt, S=S, Cin=R, Tin=Tg, M=stride * O, K=R * taps_p, taps=taps_p, Ncols=Ncols, Tout=Tp,
-                stride=1, tapstep=-1, padL=0, pad_mode=K.PAD_ZERO, Cout_store=O, ps=stride, poff=0)
-    return dx
+    # (split-K launches -- the wide heads' data gradients, decoder layers whose tiles do not fill whole rounds -- add into a
+    #  zeroed output: it comes out of the step's zero arena, K.conv_gemm_out)
+    return K.conv_gemm_out(dy, None, (S, O, Tp), wt=wt, S=S, Cin=R, Tin=Tg, M=stride * O, K=R * taps_p, taps=taps_p, Ncols=Ncols,
+                           Tout=Tp, stride=1, tapstep=-1, padL=0, pad_mode=K.PAD_ZERO, Cout_store=O, ps=stride, poff=0)
 
 
 def conv_wgrad(dy, a: Act, dw2d, dbias, *, taps, stride=1, padL=0, pad_mode=K.PAD_ZERO, tap_major=0, tapstep=1,
@@ -162,12 +166,10 @@ def deconv_fwd(a: Act, w_nat, bias, *, Cout, k, stride):
     taps_p = -(-k // stride)
     wt = K.pack_dgrad_t(w_nat, R=a.C, O=Cout, k=k, st=stride, s_red=Cout * k, s_out=k, s_k=1)
     Tout = (Tin - 1) * stride - 2 * pad + k
-    y = _new((S, Cout, Tout), a.t)
-    K.conv_gemm(a.t, None, y, wt=wt, S=S, Cin=a.C, Tin=Tin, M=stride * Cout, K=a.C * taps_p, taps=taps_p,
-                Ncols=Tin + taps_p - 1, Tout=Tout, bias=bias, in_scale=a.scale, in_shift=a.shift, in_alpha=a.alpha,
-                x_ctot=a.ctot, x_coff=a.coff, stride=1, tapstep=-1, padL=0, pad_mode=K.PAD_ZERO, Cout_store=Cout,
-                ps=stride, poff=-pad)
-    return y
+    return K.conv_gemm_out(a.t, None, (S, Cout, Tout), wt=wt, S=S, Cin=a.C, Tin=Tin, M=stride * Cout, K=a.C * taps_p,
+                           taps=taps_p, Ncols=Tin + taps_p - 1, Tout=Tout, bias=bias, in_scale=a.scale, in_shift=a.shift,
+                           in_alpha=a.alpha, x_ctot=a.ctot, x_coff=a.coff, stride=1, tapstep=-1, padL=0, pad_mode=K.PAD_ZERO,
+                           Cout_store=Cout, ps=stride, poff=-pad)
 
 
 _NBT = None      # BatchNorm counters touched by the encoder forward in flight (one multi-tensor increment)
@@ -356,7 +358,21 @@ class GradSink:
         self.buf(p).add_(value.reshape(p.shape))
 
     def add_many(self, pairs):
-        """param.grad += value for several (param, value) pairs in ONE multi-tensor launch."""
+        """param.grad += value for several (param, value) pairs in ONE launch: pase_add_blocks takes 2-D row-major blocks with a
+        row stride on either side (column / row slices of a staged concatenated gradient); anything else goes to torch
+        (whose _foreach_add_ issues one strided add per non-contiguous slice)."""
+        if not pairs:
+            return
+        blocks = []
+        for p, v in pairs:
+            d = self.buf(p)
+            if v.dim() == 2 and d.is_contiguous() and d.numel() == v.numel() and v.shape[0] == p.shape[0]:
+                blocks.append((d.view(v.shape[0], -1), v))
+            else:
+                blocks = None
+                break
+        if blocks is not None and K.add_blocks(blocks):
+            return
         dst = [self.buf(p) for p, _ in pairs]
         src = [v.reshape(p.shape) for p, v in pairs]
         if len(dst) == 1:

@@ -224,7 +224,28 @@ def _x6_conv_ok(kw):
     return True
 
 
-def conv_gemm(x, w, y, want_stats=False, **kw):
+ZERO_ALLOC = None      # set by pase_amd.engine: (shape, like) -> zero-initialised tensor out of the step's zero arena
+
+
+def conv_gemm_out(x, w, y_shape, **kw):
+    """conv_gemm into a freshly allocated output.  A launch the library will split along K adds into a zeroed output: that
+    one comes out of the step's zero arena (ONE memset per step) instead of a torch.empty + a fill launch of its own."""
+    d = _conv_desc(x, w, None, **kw)
+    split = False
+    if d.splitk != 1:
+        if X6 and os.environ.get("PASE_X6_CONV", "1") != "0" and _x6_conv_ok(kw) and _lib.lib().pase_conv_gemm_x6_bytes(C.byref(d)) > 0:
+            d.wx6 = 1          # non-NULL marker: the split-K factor is the split-bf16 plan's
+        split = _lib.lib().pase_conv_gemm_splitk(C.byref(d)) > 1
+    if split and ZERO_ALLOC is not None:
+        y = ZERO_ALLOC(tuple(y_shape), x)
+        conv_gemm(x, w, y, y_zeroed=True, **kw)
+    else:
+        y = torch.empty(tuple(y_shape), device=x.device, dtype=torch.float32)
+        conv_gemm(x, w, y, **kw)
+    return y
+
+
+def conv_gemm(x, w, y, want_stats=False, y_zeroed=False, **kw):
     """see include/pase_amd.h PaseConvGemm.  With splitk > 1 the output is zero-filled here first.
     The fp32-pipe kernels read the K-major pack of the weight: pass it as wt= (e.g. straight from pack_dgrad, or a
     weight that already is K-major) or it is produced here from `w`; a split-bf16 launch packs its operand from wt= if
@@ -269,7 +290,7 @@ def conv_gemm(x, w, y, want_stats=False, **kw):
         if kw["stat_part"].shape[0] != need:
             raise ValueError("pase_conv_gemm: stat_part has %d tile rows, the launch writes %d (use want_stats=True)"
                              % (kw["stat_part"].shape[0], need))
-    if d.splitk != 1:
+    if d.splitk != 1 and not y_zeroed:
         if _lib.lib().pase_conv_gemm_splitk(C.byref(d)) > 1:
             y.zero_()
     global LAST_PLAN_KIND
@@ -311,6 +332,14 @@ class PaseActBwd(C.Structure):
     ]
 
 
+class PaseAddBlock(C.Structure):
+    _fields_ = [("src", _fp), ("dst", _fp), ("rows", C.c_int), ("width", C.c_int), ("src_ld", C.c_int), ("dst_ld", C.c_int)]
+
+
+class PaseAddBlocks(C.Structure):
+    _fields_ = [("n", C.c_int), ("seg", PaseAddBlock * 16)]
+
+
 _i, _f, _d, _l = C.c_int, C.c_float, C.c_double, C.c_long
 _SIMPLE.update({
     "pase_wgrad_gemm": [C.POINTER(PaseWgrad), _fp],
@@ -341,6 +370,7 @@ _SIMPLE.update({
     "pase_gammatone_blocks": [_fp, _fp, _fp, _i, _i, _i, _i, _fp],
     "pase_gammatone_frames": [_fp, _fp, _i, _i, _i, _i, _i, _i, _f, _fp],
     "pase_commit_cols": [_fp, _i, _i, _fp, _i, _fp, _i, _fp, _i, _fp],
+    "pase_add_blocks": [C.POINTER(PaseAddBlocks), _fp],
     "pase_pack_wt": [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp],
     "pase_adam_step": [_fp, _fp, _fp, _fp, _l, _fp, _fp, _f, _f, _f, _f, _fp],
     "pase_step_tick": [_fp, _fp],
@@ -361,6 +391,8 @@ def abi_check(l):
         raise _lib.PaseLibraryError("ABI mismatch: PaseWgrad")
     if l.pase_abi_sizeof(2) != C.sizeof(PaseActBwd):
         raise _lib.PaseLibraryError("ABI mismatch: PaseActBwd")
+    if l.pase_abi_sizeof(3) != C.sizeof(PaseAddBlocks):
+        raise _lib.PaseLibraryError("ABI mismatch: PaseAddBlocks")
 
 
 def wgrad_gemm(g, z, dw, *, S, M, Tg, Ncols, Cin, Tz, taps, ldw=None, dbias=None, g_ctot=None, g_coff=0,
@@ -622,6 +654,29 @@ def overlap_gather(pool, off, length, src, beg, shift, out, *, B, T):
 
 def zero_front(x, shift, *, B, T):
     _check(_lib.lib().pase_zero_front(_ptr(x), _ptr(shift, torch.int32), B, T, _stream()), "pase_zero_front")
+
+
+def add_blocks(pairs):
+    """dst += src for (dst, src) pairs of 2-D row-major blocks (unit inner stride; a row stride on either side) in ONE launch
+    per 16 pairs (pase_add_blocks).  Returns False when a pair does not have that form (the caller falls back to torch)."""
+    segs = []
+    for dst, src in pairs:
+        if dst.dim() != 2 or src.dim() != 2 or dst.shape != src.shape or dst.dtype != torch.float32 or src.dtype != torch.float32:
+            return False
+        if (dst.stride(1) != 1 and dst.shape[1] > 1) or (src.stride(1) != 1 and src.shape[1] > 1):
+            return False
+        if dst.device.type != _lib.device_type() or src.device.type != _lib.device_type():
+            return False
+        segs.append((src.data_ptr(), dst.data_ptr(), dst.shape[0], dst.shape[1], max(src.stride(0), src.shape[1]),
+                     max(dst.stride(0), dst.shape[1])))
+    for i in range(0, len(segs), 16):
+        d = PaseAddBlocks()
+        chunk = segs[i:i + 16]
+        d.n = len(chunk)
+        for k, (sp, dp, r, w_, sl, dl) in enumerate(chunk):
+            d.seg[k].src, d.seg[k].dst, d.seg[k].rows, d.seg[k].width, d.seg[k].src_ld, d.seg[k].dst_ld = sp, dp, r, w_, sl, dl
+        _check(_lib.lib().pase_add_blocks(C.byref(d), _stream()), "pase_add_blocks")
+    return True
 
 
 def commit_cols(sums, ld, C_, pairs):

@@ -343,3 +343,32 @@ def test_wgrad_split_bf16_is_fp32_grade(dev, Cin, Cout, k, st, T, S):
         K.X6 = saved
     assert err[True][0] < 1e-6 and err[True][1] < 1e-6, err
     assert err[True][0] < 2.0 * err[False][0] + 1e-8, err
+
+
+def test_add_blocks_commits_column_and_row_slices(dev):
+    """pase_add_blocks: dst_k += src_k for several row-major blocks in one launch -- column slices of a concatenated weight
+    gradient (row stride on the source) and row slices of a stacked one, into contiguous parameter-gradient buffers."""
+    from pase_amd import kernels as K
+    torch.manual_seed(3)
+    cat = torch.randn(12, 50, device=dev)
+    widths = [7, 20, 1, 22]
+    dsts = [torch.randn(12, w_, device=dev) for w_ in widths]
+    want = []
+    off = 0
+    pairs = []
+    for d_, w_ in zip(dsts, widths):
+        want.append(d_.clone() + cat[:, off:off + w_])
+        pairs.append((d_, cat[:, off:off + w_]))
+        off += w_
+    stacked = torch.randn(30, 9, device=dev)
+    rows = [torch.randn(10, 9, device=dev) for _ in range(3)]
+    for i, r_ in enumerate(rows):
+        want.append(r_.clone() + stacked[10 * i:10 * i + 10])
+        pairs.append((r_, stacked[10 * i:10 * i + 10]))
+    assert K.add_blocks(pairs)
+    for got, w_ in zip(dsts + rows, want):
+        torch.testing.assert_close(got, w_, rtol=0, atol=0)
+    # more than 16 blocks: several launches; a 3-D operand: refused (the caller falls back to torch)
+    many = [(torch.zeros(2, 3, device=dev), torch.ones(2, 3, device=dev)) for _ in range(20)]
+    assert K.add_blocks(many) and all(float(d_.sum()) == 6.0 for d_, _ in many)
+    assert not K.add_blocks([(torch.zeros(2, 3, 1, device=dev), torch.ones(2, 3, 1, device=dev))])
