@@ -95,8 +95,10 @@ typedef struct PaseConvGemm {
     int x6_ctl;            /* split-bf16 plan control (0 = the library's routing).  bit 0: take the split-bf16 kernel
                               wherever it has a plan, skipping the measured per-shape routing rules; bit 1: ask for the
                               pre-split activation on every stride-1 launch; bit 2: never; bit 3: keep the one-channel
-                              (SincNet) layer off its window-image kernel (A/B runs and tests; the library itself reads
-                              NO environment variables)                                                          */
+                              (SincNet) layer off its window-image kernel; bit 4: no 64 x 256 tile for launches of at
+                              most 64 rows; bit 5: the general epilogue on every tile (no lean store / MSE path); bits 8-15: start
+                              the persistent workgroups n x 512 clocks out of phase (A/B runs and tests; the library
+                              itself reads NO environment variables)                                             */
     int max_wg;            /* cap on the persistent grid of the split-bf16 kernel (0 = one workgroup per CU, 256):
                               data-parallel runs leave CUs to the RCCL channel kernels this way; tests use it to make
                               every workgroup walk several (split-K slice, tile) items                       */

@@ -17,6 +17,8 @@ struct PaseX6cPlan {
     int BM, BN;
     int n_row_tiles, n_col_tiles, splitk;
     int steps_total;    // stages * KGS * A MFMA steps (16 k each; k-groups past G are zero in the pack)
+    int epi32;          // output (and label) below 2 GiB: the lean epilogues address them with 32-bit byte offsets
+    int stagger;        // start phase spacing of the persistent workgroups (units of 512 clocks; 0 = none)
     int prio;           // s_setprio of the staging waves (bits 0-1) and of the compute waves (bits 2-3)
     int tmode;          // 0: convolution.  Weight gradients (contraction over positions): 1 rows = g (packed), columns =
                         // (channel, tap) of z (staged);  2 1x1 swapped: rows = z channels (packed), columns = g rows (staged);

@@ -75,24 +75,35 @@ __device__ __forceinline__ int zp_tap_of(int r, const PaseX6cPlan& pl) {
     return pl.zp_rem + q + pl.t_stride * (r2 - q * pl.zp_n);
 }
 
+#ifdef PASE_X6C_EARLYPRO    // A/B builds (tools/ab_build.sh): the next item's prologue BEFORE the last stage's barrier (see the staging loop)
+#define X6C_EARLY_PRO 1
+#else
+#define X6C_EARLY_PRO 0
+#endif
 #ifdef PASE_X6C_TRACE   // tools/trace_x6c.py only: per-item phase timestamps (shader clock) of workgroups 0 and 131
 #define X6C_TRACE_ITEMS 64
-__device__ unsigned long long g_x6c_trace[2 * X6C_TRACE_ITEMS * 12];
+__device__ unsigned long long g_x6c_trace[2 * X6C_TRACE_ITEMS * 20];
 #define X6C_STAMP(slot)                                                                                     \
     do {                                                                                                    \
         if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 131) && trace_n < X6C_TRACE_ITEMS)               \
-            g_x6c_trace[((blockIdx.x ? 1 : 0) * X6C_TRACE_ITEMS + trace_n) * 12 + (slot)] = clock64();      \
+            g_x6c_trace[((blockIdx.x ? 1 : 0) * X6C_TRACE_ITEMS + trace_n) * 20 + (slot)] = clock64();      \
     } while (0)
 #define X6C_TRACE_NEXT() ++trace_n
+#ifdef PASE_X6C_TRACE_FINE      // stamps inside the epilogue (each costs an s_memtime round trip: ~500 clocks)
+#define X6C_FSTAMP(slot) X6C_STAMP(slot)
+#else
+#define X6C_FSTAMP(slot)
+#endif
 // accumulate the cycles between X6C_T0() and X6C_TACC(slot) into a per-item sum
 #define X6C_T0() const unsigned long long t0_ = clock64()
 #define X6C_TACC(slot)                                                                                      \
     do {                                                                                                    \
         if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 131) && trace_n < X6C_TRACE_ITEMS)               \
-            g_x6c_trace[((blockIdx.x ? 1 : 0) * X6C_TRACE_ITEMS + trace_n) * 12 + (slot)] += clock64() - t0_; \
+            g_x6c_trace[((blockIdx.x ? 1 : 0) * X6C_TRACE_ITEMS + trace_n) * 20 + (slot)] += clock64() - t0_; \
     } while (0)
 #else
 #define X6C_STAMP(slot)
+#define X6C_FSTAMP(slot)
 #define X6C_TRACE_NEXT()
 #define X6C_T0()
 #define X6C_TACC(slot)
@@ -105,6 +116,9 @@ __device__ __forceinline__ void sload8(const float* q, float (&o)[8]) {
     for (int i = 0; i < 8; ++i) o[i] = q[i];
 }
 __device__ __forceinline__ float sload1(const float* q) { return *q; }
+__device__ __forceinline__ void sload32(const float* q, float (&o)[32]) {
+    for (int i = 0; i < 32; ++i) o[i] = q[i];
+}
 __device__ __forceinline__ void sload8x2(const float* q0, const float* q1, float (&o0)[8], float (&o1)[8]) {
     sload8(q0, o0);
     sload8(q1, o1);
@@ -121,6 +135,21 @@ __device__ __forceinline__ float sload1(const float* q) {
     float v;
     asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(q) : "memory");
     return v;
+}
+// 32 consecutive floats (the bias of a wave's 32 rows): the scalar cache answers in a few hundred clocks, while a vector load
+// issued at this point queues behind the staging waves' loads for the NEXT tile (3.7 k clocks measured, tools/trace_x6c.py)
+typedef float pase_f16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void sload32(const float* q, float (&o)[32]) {
+    pase_f16 v0, v1;
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(v0), "=&s"(v1)
+                 : "s"(q)
+                 : "memory");
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        o[i] = v0[i];
+        o[16 + i] = v1[i];
+    }
 }
 // two arrays, one wait
 __device__ __forceinline__ void sload8x2(const float* q0, const float* q1, float (&o0)[8], float (&o1)[8]) {
@@ -206,9 +235,13 @@ __device__ __forceinline__ void x6c_vmwait_slots(int nslots) {
 // chunks = 1 KB contiguous.  Worth it where every staged element used to be converted many times over -- a column tile is
 // re-staged by each of the M / 128 row tiles that need it (169 times on the 21 525-row heads) -- and the k-loop has one or
 // two taps to amortise the conversion over.
-template <int NPOS, int KGS_T, bool TM = false, bool ZP = false>
+// NARROW (convolutions of at most 64 rows: block 1 of the encoder): workgroup tile 64 x 256, compute waves 2 (rows) x 2 (column
+// halves) -- the 128-row tile would spend half of every MFMA on zero rows.  Same wave tile (32 x 128), same loop; the stage
+// holds 256 + 64 positions (<320, 2>).
+template <int NPOS, int KGS_T, bool TM = false, bool ZP = false, bool NARROW = false>
 __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6cPlan pl) {
-    constexpr int WM = 4, WN = 1, NBT = 4;
+    static_assert(!(NARROW && TM), "the 64 x 256 tile is a convolution tile");
+    constexpr int WM = NARROW ? 2 : 4, WN = NARROW ? 2 : 1, NBT = 4;
     constexpr int BM = 32 * WM, BN = 32 * NBT * WN;
     constexpr int NPS = (NPOS + 127) / 128;        // position slots per thread and k-group
     constexpr int NSLOT = NPS * KGS_T;
@@ -234,7 +267,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     // wave doing both cannot arrange; each role has its own vmcnt counter, so a staging wave waiting for activations from
     // HBM never holds back a weight fragment.  One barrier per stage joins them.
     const bool stager = wave >= 4;                 // uniform
-    const int wm = wave & 3, wn = 0;
+    const int wm = NARROW ? (wave & 1) : (wave & 3), wn = NARROW ? ((wave >> 1) & 1) : 0;
     const int fr = lane & 31, fk = lane >> 5;
     const int fkL = (wave >> 1) & 1;               // stager: octet of the k-group this wave stages (uniform)
     const int whalf = wave & 1;                    // stager: which 64 of a slot's 128 positions (uniform)
@@ -249,6 +282,9 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     const int g_per = (GS + pl.splitk - 1) / pl.splitk;
     const int nsteps = KGS * pl.A;                 // MFMA steps per stage
     const bool has_aff = p.in_scale != nullptr, has_alpha = p.in_alpha != nullptr;       // uniform
+    // convolutions whose bias index is the tile row (no pixel shuffle, no spectrum post-op): see the accumulator initialisation
+    const bool bias_init = !TM && p.bias != nullptr && p.ps == 1 && p.post_op != PASE_POST_POW &&
+                           p.post_op != PASE_POST_LOGPOW && p.post_op != PASE_POST_MAG;
     const float* xbase = p.x + (size_t)p.x_coff * p.Tin;
     const int prm_n = GS * KGS * 16;               // channels' incl. the zero groups that fill the last stage
     const float* prm = reinterpret_cast<const float*>(reinterpret_cast<const u32x4*>(p.wx6) + pl.pack_chunks);
@@ -256,6 +292,13 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
 #ifdef PASE_X6C_TRACE
     int trace_n = 0;
 #endif
+    // Start the workgroups out of phase (16 phases, `stagger` x 512 clocks apart): tiles of one launch take the same time, so
+    // 256 persistent workgroups started together reach their epilogues together and the store bursts queue up behind one
+    // another while the memory system idles during the main loops
+    if (pl.stagger > 0) {
+        const int ph = ((int)blockIdx.x >> 3) & 15;
+        for (int i = 0; i < ph * pl.stagger; ++i) PASE_SLEEP(8);
+    }
 
 #ifndef PASE_HIPEMU
     {   // wave priorities (uniform): the staging waves are the younger half of the workgroup and lose every VALU issue
@@ -735,7 +778,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 pase_static_for<XR>([&](auto r) __attribute__((always_inline)) {
                     constexpr int rn = (decltype(r)::value + 1) % XR;          // register set of stage gi + 1
                     const int gi = gb + decltype(r)::value;                     // stage (relative) being multiplied
-                    if (gi < nst) {
+                    if (gi < nst - X6C_EARLY_PRO) {
                         X6C_T0();
 #ifdef PASE_X6C_TRACE
                         if (!(pl.prio & 128))      // ablation: the staging waves only keep the barriers (results are garbage)
@@ -784,7 +827,23 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 }
             }
             item = next_item(item);
+#if X6C_EARLY_PRO
+            // Measured variant (round 4, NOT the default): the compute waves are multiplying the item's LAST stage and nothing
+            // is left to stage for it, so the next item's prologue (position arithmetic, first loads, first stage into the
+            // other buffer -- free since the barrier that ended the stage before) could run under that stage instead of
+            // beside the compute waves' epilogue.  It is slower (PASE+ bs32 step 29.9 -> 30.8 ms, same box): the prologue
+            // (7 ... 16 k clocks) is longer than the last stage of most launches, so the compute waves now wait for it at the
+            // stage's barrier and only then start an epilogue that is no faster alone than beside the prologue.
+            if (item < nitems) {
+                bsel ^= 1;
+                prologue(item);
+                bsel ^= 1;
+            }
+            __syncthreads();               // end of the last stage
+            bsel ^= 1;
+#else
             if (item < nitems) prologue(item);
+#endif
             // the barrier of the compute waves' epilogue (partial BatchNorm sums / loss partials go through LDS)
             if (epi_barrier) __syncthreads();
         }
@@ -823,14 +882,30 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         bbase[j] = fk * NPOS + i;
     }
 
+    // The bias is the accumulators' initial value (rows = output channels, no pixel shuffle: index = row): its loads are
+    // issued here, a barrier and two weight-fragment loads before they are needed.  In the epilogue the same 16 values cost
+    // 2.9 k clocks per tile -- a load there waits behind whatever the memory pipeline holds at that point, and the compute
+    // wave is alone on its SIMD: nothing hides it (tools/trace_x6c.py, `qrnn` against `qrnn_nb`).
     f32x16 accH[NBT], accS[NBT];
+    {
+        float binit[16];
 #pragma unroll
-    for (int j = 0; j < NBT; ++j)
+        for (int r = 0; r < 16; ++r) binit[r] = 0.f;
+        if (!TM && bias_init && split == 0) {      // uniform
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            accH[j][r] = 0.f;
-            accS[j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 32 + 4 * fk + (r & 3) + 8 * (r >> 2);
+                binit[r] = p.bias[min(m, p.M - 1)];
+            }
         }
+#pragma unroll
+        for (int j = 0; j < NBT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                accH[j][r] = binit[r];
+                accS[j][r] = 0.f;
+            }
+    }
 
     // ---- A fragments, TWO steps ahead: three uniform plane pointers + one per-lane byte offset ----------------------
     //   packs (convolutions, tmode 1 / 2): [32-row tile][step][plane][lane] 16-byte chunks, 3072 bytes per step
@@ -1147,6 +1222,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         cq[j] = cok[j] ? (int)n - s * pe.Ncols : 0;
     }
     const bool rows_full = m0 + wm * 32 + 32 <= pe.M;        // uniform
+    if (wave == 0) X6C_STAMP(12);
 
     if (pe.epilogue == PASE_EPI_STORE &&
         (pe.post_op == PASE_POST_POW || pe.post_op == PASE_POST_LOGPOW || pe.post_op == PASE_POST_MAG)) {
@@ -1168,8 +1244,9 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             }
         }
     } else if (pe.epilogue == PASE_EPI_STORE) {
+        if (wave == 0) X6C_FSTAMP(16);
         const bool pshuf = pe.ps != 1;
-        const float* biasp = (p.bias && split == 0) ? p.bias : nullptr;
+        const float* biasp = (p.bias && split == 0 && !bias_init) ? p.bias : nullptr;      // (else: already in the accumulators)
         int cbase[NBT], posb[NBT];
         bool colok[NBT];
         bool interior = true;
@@ -1183,16 +1260,18 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         float bvs[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) bvs[r] = 0.f;
-        if (biasp) {   // uniform
+        auto load_bias = [&]() __attribute__((always_inline)) {
+            if (biasp) {   // uniform
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = rbase + (r & 3) + 8 * (r >> 2);
-                int co = m;
-                if (pshuf) co = ple.xPerm ? (int)div_magic((unsigned)m, ple.ps_magic)
-                                         : m - (int)div_magic((unsigned)m, ple.cout_magic) * pe.Cout_store;
-                if (m < pe.M) bvs[r] = biasp[co];
+                for (int r = 0; r < 16; ++r) {
+                    const int m = rbase + (r & 3) + 8 * (r >> 2);
+                    int co = m;
+                    if (pshuf) co = ple.xPerm ? (int)div_magic((unsigned)m, ple.ps_magic)
+                                             : m - (int)div_magic((unsigned)m, ple.cout_magic) * pe.Cout_store;
+                    if (m < pe.M) bvs[r] = biasp[co];
+                }
             }
-        }
+        };
         auto store_rows = [&](auto fast_tag, auto atomic_tag) __attribute__((always_inline)) {
             constexpr bool FAST = decltype(fast_tag)::value;
             constexpr bool ATOMIC = decltype(atomic_tag)::value;
@@ -1276,6 +1355,60 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             }
         };
         const bool fast = rows_full && pe.post_op == PASE_POST_NONE && pase_wave_all(interior) != 0;
+        if (wave == 0) X6C_FSTAMP(17);
+        if (fast && !pshuf && ple.splitk == 1 && ple.epi32) {
+            // The common tile (whole rows, interior columns, plain store): the address arithmetic is the epilogue's cost --
+            // one compute wave per SIMD, so every VALU instruction here is an idle matrix core.  Row pointers are wave-uniform
+            // (scalar unit), the lane's part of the address is one 32-bit byte offset per column block (computed once): a
+            // store is `global_store_dword v_off, v_val, s[row]` and nothing else.
+            const unsigned to4 = (unsigned)pe.Tout * 4u;
+            const int mu0 = m0 + wm * 32;                                       // uniform
+            unsigned cb4[NBT];
+#pragma unroll
+            for (int j = 0; j < NBT; ++j) cb4[j] = (unsigned)(cbase[j] + 4 * fk * pe.Tout) * 4u;
+            char* ybase = reinterpret_cast<char*>(p.y);
+            if (wave == 0) X6C_FSTAMP(18);
+#ifdef PASE_ABL_EPI2      // trace ablation: the row pass twice (slot 13 = end of the first, cold, pass; slot 14 = end of the second)
+#pragma unroll 1
+            for (int rep = 0; rep < 2; ++rep) {
+            asm volatile("" : "+v"(cb4[0]));
+            if (rep == 1 && wave == 0) X6C_FSTAMP(14);
+#endif
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mu = mu0 + (r & 3) + 8 * (r >> 2);                    // uniform; this lane's row = mu + 4 * fk
+                char* yrow = ybase + (size_t)mu * to4;
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < NBT; ++j) {
+                    const float v = acc[j][r];               // (bias included: !pshuf, see bias_init)
+#ifdef PASE_ABL_NOSTORE      // trace ablation: everything but the store instructions
+                    asm volatile("" ::"v"(v), "v"(cb4[j]), "s"(yrow));
+#else
+                    *reinterpret_cast<float*>(yrow + cb4[j]) = v;
+#endif
+                    s1 += v;
+                    s2 += v * v;
+                }
+#ifndef PASE_ABL_EPI2
+                if (r == 0 && wave == 0) X6C_FSTAMP(14);
+                if (r == 7 && wave == 0) X6C_FSTAMP(15);
+#endif
+                if (p.stat_part) {   // uniform branch
+                    s1 = pase_half_sum_lane31(s1);
+                    s2 = pase_half_sum_lane31(s2);
+                    if (fr == 31) {
+                        const int ml = mu - m0 + 4 * fk;
+                        red[wn][ml][0] = s1;
+                        red[wn][ml][1] = s2;
+                    }
+                }
+            }
+#ifdef PASE_ABL_EPI2
+            }
+#endif
+        } else {
+        load_bias();
         if (ple.splitk > 1) {
             if (fast) store_rows(std::true_type{}, std::true_type{});
             else store_rows(std::false_type{}, std::true_type{});
@@ -1283,6 +1416,8 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             if (fast) store_rows(std::true_type{}, std::false_type{});
             else store_rows(std::false_type{}, std::false_type{});
         }
+        }
+        if (wave == 0) X6C_STAMP(13);
         if (p.stat_part) {
             __syncthreads();
             // one partial (sum, sumsq) per (column tile, output row); rows are channels here
@@ -1317,7 +1452,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 const bool mok = FAST || m < pe.M;
                 const int d = (int)div_magic((unsigned)m, ple.rctx_magic);
                 jj16[r] = m - d * pe.r_ctx;
-                bvs[r] = (mok && p.bias) ? p.bias[m] : 0.f;
+                bvs[r] = (mok && p.bias && !bias_init) ? p.bias[m] : 0.f;      // (bias_init: already in the accumulators)
                 lrow[r] = d * pe.Ncols + jj16[r];
             }
             // all 64 label loads of the tile first (one memory latency instead of four), then the arithmetic and stores
@@ -1353,11 +1488,87 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 }
             }
         };
+        // The common tile (whole rows, all columns valid), lean: wave-uniform row pointers + one 32-bit byte offset per column
+        // block for the stores, one add per label load, the context-window range check only in column blocks that touch a
+        // sequence edge (see the store epilogue: the address arithmetic was 3/4 of this epilogue's 19 k clocks per tile)
+        auto mse_lean = [&](auto y_tag, auto g_tag) __attribute__((always_inline)) {
+            constexpr bool HAS_Y = decltype(y_tag)::value;
+            constexpr bool HAS_G = decltype(g_tag)::value;
+            const unsigned nc4 = (unsigned)pe.Ncols * 4u;
+            const int mu0 = m0 + wm * 32;                                       // uniform
+            unsigned ooff[NBT], loff[NBT];
+            bool inner[NBT];
+#pragma unroll
+            for (int j = 0; j < NBT; ++j) {
+                ooff[j] = (unsigned)((cs[j] * pe.M + 4 * fk) * pe.Ncols + cq[j]) * 4u;
+                loff[j] = (unsigned)(cs[j] * pe.label_D * pe.Ncols + cq[j] - half) * 4u;
+                inner[j] = pase_wave_all(cq[j] >= half && cq[j] - half + pe.r_ctx <= pe.Ncols) != 0;
+            }
+            float bvs[16];
+            int jj16[16];
+            unsigned lrow4[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mu0 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                const int d = (int)div_magic((unsigned)m, ple.rctx_magic);
+                jj16[r] = m - d * pe.r_ctx;
+                lrow4[r] = (unsigned)(d * pe.Ncols + jj16[r]) * 4u;
+                bvs[r] = 0.f;
+            }
+            if (p.bias && !bias_init) {   // uniform: through the scalar cache (see sload32)
+                float bsc[32];
+                sload32(p.bias + mu0, bsc);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ri = (r & 3) + 8 * (r >> 2);
+                    bvs[r] = fk ? bsc[ri + 4] : bsc[ri];
+                }
+            }
+            const char* lab = reinterpret_cast<const char*>(p.label);
+            float tg[NBT][16];
+#pragma unroll
+            for (int j = 0; j < NBT; ++j) {
+                if (inner[j]) {   // uniform
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tg[j][r] = *reinterpret_cast<const float*>(lab + (unsigned)(loff[j] + lrow4[r]));
+                } else {
+                    const int tb = cq[j] - half;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        tg[j][r] = 0.f;
+                        if ((unsigned)(tb + jj16[r]) < (unsigned)pe.Ncols)
+                            tg[j][r] = *reinterpret_cast<const float*>(lab + (unsigned)(loff[j] + lrow4[r]));
+                    }
+                }
+            }
+            char* ybase = reinterpret_cast<char*>(p.y);
+            char* gbase = reinterpret_cast<char*>(p.grad_out);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const size_t rowb = (size_t)(mu0 + (r & 3) + 8 * (r >> 2)) * nc4;   // uniform
+#pragma unroll
+                for (int j = 0; j < NBT; ++j) {
+                    const float pred = acc[j][r] + bvs[r];
+                    const float diff = pred - tg[j][r];
+                    lsum += diff * diff;
+                    if constexpr (HAS_Y) *reinterpret_cast<float*>(ybase + rowb + ooff[j]) = pred;
+                    if constexpr (HAS_G) *reinterpret_cast<float*>(gbase + rowb + ooff[j]) = diff * pe.grad_scale;
+                }
+                if (r == 0 && wave == 0) X6C_FSTAMP(14);
+                if (r == 7 && wave == 0) X6C_FSTAMP(15);
+            }
+        };
         bool allc = true;
 #pragma unroll
         for (int j = 0; j < NBT; ++j) allc = allc && cok[j];
-        if (rows_full && pase_wave_all(allc) != 0) mse_rows(std::true_type{});
-        else mse_rows(std::false_type{});
+        if (rows_full && pase_wave_all(allc) != 0) {
+            if (!ple.epi32) mse_rows(std::true_type{});
+            else if (p.y && p.grad_out) mse_lean(std::true_type{}, std::true_type{});
+            else if (p.grad_out) mse_lean(std::false_type{}, std::true_type{});
+            else if (p.y) mse_lean(std::true_type{}, std::false_type{});
+            else mse_lean(std::false_type{}, std::false_type{});
+        } else mse_rows(std::false_type{});
+        if (wave == 0) X6C_STAMP(13);
         lsum = pase_wave_sum64(lsum);
         if (lane == 0) red[0][wave][0] = lsum;
         __syncthreads();
@@ -1375,10 +1586,10 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
 #ifdef PASE_X6C_TRACE
 extern "C" int pase_x6c_trace_read(unsigned long long* host) {
     hipDeviceSynchronize();
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_x6c_trace), sizeof(unsigned long long) * 2 * X6C_TRACE_ITEMS * 12);
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_x6c_trace), sizeof(unsigned long long) * 2 * X6C_TRACE_ITEMS * 20);
 }
 extern "C" int pase_x6c_trace_reset() {
-    static unsigned long long zeros[2 * X6C_TRACE_ITEMS * 12];
+    static unsigned long long zeros[2 * X6C_TRACE_ITEMS * 20];
     hipDeviceSynchronize();
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_x6c_trace), zeros, sizeof(zeros));
 }
@@ -1640,7 +1851,6 @@ bool pase_x6c_plan(const PaseConvGemm& p, PaseX6cPlan& pl) {
     // x A taps: launches of at most 64 rows with fewer than four taps' would spend more issue slots splitting than
     // multiplying -- they stay on the fp32 matrix pipe
     const bool force = (p.x6_ctl & 1) != 0;      // measurement runs: skip the routing rules below
-    if (!force && p.M <= 64 && pl.A < 4) return false;
     // ... and so do launches with fewer than 128 k (eight MFMA steps per tile): they are store-bound
     if (!force && (long)pl.CinP * pl.A < 128) return false;
     // Measured on the PASE+ bs32 step (profiles/gemm_launches_r03.json): 1x1 launches with K < 768 (the 256-channel worker
@@ -1652,23 +1862,40 @@ bool pase_x6c_plan(const PaseConvGemm& p, PaseX6cPlan& pl) {
     // it), which also lifts the K < 768 rule for them (the stacked 2304-row first layers of the MLP heads)
     const bool xp_ok = pl.P == 1 && (long)pl.G * 2 * p.S * (long)(p.Ncols + pl.A - 1) < (1L << 27);
     const bool xp_want = xp_ok && !(p.x6_ctl & 4) && ((p.x6_ctl & 2) || (pl.A <= 2 && p.M >= 1024));
+    // Round 4: launches of at most 64 rows get a 64 x 256 tile (NARROW) when they have taps' to walk and >= 512 k (block 1 of
+    // the encoder: 640 channels' x 2 taps'); the 1x1 launches of 64 rows have 8 ... 16 MFMA steps per tile and are store-bound
+    // on either pipe.  x6_ctl bit 4 forbids it (A/B measurements)
+    const bool narrow = p.M <= 64 && pl.A >= 2 && (long)pl.CinP * pl.A >= 512 && !xp_want && !(p.x6_ctl & 16);
+    if (!force && !narrow && p.M <= 64 && pl.A < 4) return false;
     if (!force && pl.A == 1 && pl.CinP < 768 && p.M < 8192 && (long)p.S * p.Ncols > 128 && !xp_want) return false;
     pl.NBT = 4;
     pl.WM = 4;
     pl.BM = 128;
     pl.BN = 128;
+    if (narrow) {          // 64 x 256 (conv_x6c_kernel<320, 2, ..., NARROW>)
+        pl.WM = 2;
+        pl.BM = 64;
+        pl.BN = 256;
+    }
     // every sequence a column tile touches carries its own halo of A - 1 positions
     const int nseg_max = (pl.BN - 2) / p.Ncols + 2;
     if ((long)nseg_max * (pl.A - 1) > HALO_MAX) return false;
     // k-groups per stage: three for 1x1 layers (no halo: 12 KB per k-group), two where a stage would otherwise be
     // shorter than four steps
     pl.KGS = pl.A == 1 ? (pl.G >= 3 ? 3 : pl.G) : ((pl.A < 4 && pl.G >= 2) ? 2 : 1);
+    if (narrow && pl.KGS > 2) pl.KGS = 2;
     const int GS = (pl.G + pl.KGS - 1) / pl.KGS;
     pl.steps_total = GS * pl.KGS * pl.A;
     const long ntot = (long)p.S * p.Ncols;
     pl.n_row_tiles = (p.M + pl.BM - 1) / pl.BM;
     pl.n_col_tiles = (int)((ntot + pl.BN - 1) / pl.BN);
     pl.prio = x6c_prio();
+    pl.stagger = (p.x6_ctl >> 8) & 255;
+    {   // the lean epilogues address the output with 32-bit BYTE offsets
+        const size_t out_elems = p.epilogue == PASE_EPI_STORE ? (size_t)p.S * p.y_ctot * p.Tout : (size_t)p.S * p.M * p.Ncols;
+        const size_t lab_elems = p.epilogue == PASE_EPI_STORE ? 0 : (size_t)p.S * p.label_D * p.Ncols;
+        pl.epi32 = (out_elems < (1u << 29) && lab_elems < (1u << 29) && !(p.x6_ctl & 32)) ? 1 : 0;
+    }
     pl.tmode = 0;
     pl.xp_tpad = p.Ncols + pl.A - 1;
     pl.xp_plane = xp_want ? (long)pl.G * 2 * p.S * pl.xp_tpad : 0;
@@ -1730,7 +1957,9 @@ int pase_x6c_launch(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st
     const long cap = p.max_wg > 0 ? p.max_wg : 256;      // data-parallel runs leave CUs to RCCL; tests force several items per workgroup
     if (nwg > cap) nwg = cap;
     const dim3 grid((unsigned)nwg), block(NT);
-    if (pl.xp) {
+    if (pl.WM == 2) {
+        PASE_LAUNCH((conv_x6c_kernel<320, 2, false, false, true>), grid, block, st, p, pl);
+    } else if (pl.xp) {
         if (pl.A == 1) PASE_LAUNCH((conv_x6c_kernel<128, 3, false, true>), grid, block, st, p, pl);
         else PASE_LAUNCH((conv_x6c_kernel<192, 2, false, true>), grid, block, st, p, pl);
     } else if (pl.A == 1) PASE_LAUNCH((conv_x6c_kernel<128, 3>), grid, block, st, p, pl);

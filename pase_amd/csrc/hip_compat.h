@@ -58,6 +58,11 @@ __device__ __forceinline__ int pase_uniform(int v) { return __builtin_amdgcn_rea
 // All lanes of this wave have executed everything before this point (LDS exchanged between the lanes of ONE wave needs no
 // workgroup barrier: a wave's LDS operations execute in order; the compiler just must not move them across)
 #ifdef PASE_HIPEMU
+#define PASE_SLEEP(n) ((void)0)
+#else
+#define PASE_SLEEP(n) __builtin_amdgcn_s_sleep(n)     // n x 64 clocks
+#endif
+#ifdef PASE_HIPEMU
 __device__ __forceinline__ void pase_wave_sync() { (void)__shfl_xor(0, 1); }
 #else
 __device__ __forceinline__ void pase_wave_sync() { __builtin_amdgcn_wave_barrier(); }

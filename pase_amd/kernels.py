@@ -128,7 +128,10 @@ def _conv_desc(x, w, y, *, S, Cin, Tin, M, K, taps, Ncols, Tout, ldw=None, bias=
     d.splitk = splitk
     # measurement / test controls travel in the descriptor (the C library reads no environment variables)
     d.x6_ctl = ((1 if os.environ.get("PASE_X6C_FORCE") else 0) | {"1": 2, "0": 4}.get(os.environ.get("PASE_X6C_XP", ""), 0)
-                | (8 if os.environ.get("PASE_SINC_X6", "1") == "0" else 0))
+                | (8 if os.environ.get("PASE_SINC_X6", "1") == "0" else 0)
+                | (16 if os.environ.get("PASE_X6C_NARROW", "1") == "0" else 0)
+                | (32 if os.environ.get("PASE_X6C_LEANEPI", "1") == "0" else 0)
+                | ((int(os.environ.get("PASE_X6C_STAGGER", "0")) & 255) << 8))
     d.max_wg = _max_wg()
     return d
 

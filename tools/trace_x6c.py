@@ -49,10 +49,10 @@ def run_shape(name, dev):
                 alpha=torch.full((Cin,), 0.1, device=dev))
         return lambda: E.conv_fwd(a, w.view(Cout, -1), b, Cout=Cout, taps=k, stride=st, padL=pL, padR=pR,
                                   pad_mode=K.PAD_REFLECT, want_stats=True)
-    if name == "qrnn":
+    if name in ("qrnn", "qrnn_nb"):
         x = torch.randn(S, 512, 200, device=dev)
         lin = torch.randn(1536, 1024, device=dev) * 0.05
-        b = torch.randn(1536, device=dev)
+        b = torch.randn(1536, device=dev) if name == "qrnn" else None
         y = torch.empty(S, 1536, 200, device=dev)
         return lambda: K.conv_gemm(x, lin, y, S=S, Cin=512, Tin=200, M=1536, K=1024, taps=2, Ncols=200, Tout=200, bias=b,
                                    tap_major=1, tapstep=-1)
@@ -117,7 +117,7 @@ def main():
     lib.pase_x6c_trace_reset.argtypes = []
     dev = torch.device("cuda:0")
     NI = 64
-    buf = (C.c_ulonglong * (2 * NI * 12))()
+    buf = (C.c_ulonglong * (2 * NI * 20))()
     for name in shapes:
         fn = run_shape(name, dev)
         fn()
@@ -135,7 +135,7 @@ def main():
         for wg in (0, 1):
             rows = []
             for i in range(NI):
-                t = [buf[(wg * NI + i) * 12 + s] for s in range(12)]
+                t = [buf[(wg * NI + i) * 20 + s] for s in range(20)]
                 if t[3] == 0 or t[3] < t[0]:
                     break
                 rows.append(t)
@@ -147,12 +147,23 @@ def main():
             def avg(f):
                 v = [f(r) for r in mid]
                 return sum(v) / len(v)
-            print("   workgroup %-3s items %2d | compute: wait %7.0f  mfma %7.0f (in barriers %7.0f)  epi %7.0f  item-to-item %7.0f"
+            print("   workgroup %-3s items %2d | compute: wait %7.0f  mfma %7.0f (in barriers %7.0f)  epi %7.0f (setup %5.0f, rows %6.0f, "
+                  "tail %6.0f)  item-to-item %7.0f"
                   " | staging: pro %7.0f  loop %7.0f (busy %7.0f: vmwait %7.0f, convert+store %7.0f)" % (
                       "0" if wg == 0 else "131", len(rows), avg(lambda r: r[1] - r[0]), avg(lambda r: r[2] - r[1]),
-                      avg(lambda r: r[9]), avg(lambda r: r[3] - r[2]), (rows[-1][0] - rows[0][0]) / max(1, len(rows) - 1),
+                      avg(lambda r: r[9]), avg(lambda r: r[3] - r[2]), avg(lambda r: r[12] - r[2]), avg(lambda r: r[13] - r[12]),
+                      avg(lambda r: r[3] - r[13]), (rows[-1][0] - rows[0][0]) / max(1, len(rows) - 1),
                       avg(lambda r: r[5] - r[4]), avg(lambda r: r[6] - r[5]), avg(lambda r: r[8]), avg(lambda r: r[10]),
                       avg(lambda r: r[11])))
+            if mid[0][14] and not mid[0][15]:     # -DPASE_ABL_EPI2: the row pass of the lean store epilogue ran twice
+                print("        rows: first pass %6.0f, second pass %6.0f" % (avg(lambda r: r[14] - r[12]), avg(lambda r: r[13] - r[14])))
+            elif mid[0][14]:                      # lean store epilogue: bias wait + first row / rows 1-7 / rows 8-15
+                print("        rows: first %6.0f, next seven %6.0f, last eight %6.0f" % (
+                    avg(lambda r: r[14] - r[12]), avg(lambda r: r[15] - r[14]), avg(lambda r: r[13] - r[15])))
+                if mid[0][18]:
+                    print("        first: to the store branch %5.0f, offsets + interior vote %5.0f, bias %5.0f, row 0 %5.0f" % (
+                        avg(lambda r: r[16] - r[12]), avg(lambda r: r[17] - r[16]), avg(lambda r: r[18] - r[17]),
+                        avg(lambda r: r[14] - r[18])))
 
 
 if __name__ == "__main__":
