@@ -157,7 +157,8 @@ typedef struct PaseWgrad {
                               controls (the library reads no environment variables): bits 4-7 force an orientation
                               (pase_wgrad_plan_kind value, 0 = the library's routing); bit 8: 1x1 layers may take the split
                               kernel in either orientation; bit 9: no row-coalesced staging; bit 10: keep the
-                              one-channel (SincNet) layer off its window-image kernel                               */
+                              one-channel (SincNet) layer off its window-image kernel; bits 12-14: k-groups per stage
+                              of the pre-split-planes kernel (0 = its capacity)                                     */
     void* gx6;             /* scratch for the split-bf16 operands: pase_wgrad_x6_bytes(desc) bytes, 16-B
                               aligned, caller-owned, written and read by this launch only; NULL = fp32 matrix pipe */
     int max_wg;            /* cap on the persistent grid (0 = 256), see PaseConvGemm::max_wg                      */

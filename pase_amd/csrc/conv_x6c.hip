@@ -45,6 +45,7 @@ namespace {
 constexpr int NT = 512;        // 4 compute waves (one per SIMD) + 4 staging waves
 constexpr int HALO_MAX = 64;      // extra positions a stage holds beyond its BN columns (halo of every sequence touched)
 constexpr int KGS_MAX = 2;
+constexpr int TMZ_KGS = 5;        // k-groups per stage buffer of the weight-gradient kernel on pre-split planes (<128, TMZ_KGS, true, true>)
 
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
     const int q = nwg / 8, r = nwg % 8;
@@ -198,6 +199,40 @@ __device__ __forceinline__ u32x4 x6c_load16u(const unsigned short* q) {
     return reinterpret_cast<const X6cU16*>(q)->v;
 #endif
 }
+// Buffer-descriptor loads (weight fragments): address = descriptor base (4 SGPRs) + per-lane byte offset (one VGPR that never
+// changes) + scalar byte offset (one SGPR, advanced per step) -- no vector address arithmetic inside the loop
+#ifdef PASE_HIPEMU
+struct X6cRsrc { const char* base; };
+__device__ __forceinline__ X6cRsrc x6c_make_rsrc(const void* base) { return X6cRsrc{reinterpret_cast<const char*>(base)}; }
+__device__ __forceinline__ u32x4 x6c_buffer_load16(const X6cRsrc& r, unsigned voff, unsigned soff) {
+    u32x4 v;
+    __builtin_memcpy(&v, r.base + (size_t)voff + (size_t)soff, 16);
+    return v;
+}
+#else
+typedef __amdgpu_buffer_rsrc_t X6cRsrc;
+__device__ __forceinline__ X6cRsrc x6c_make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)0xffffffffu, 0x00020000);
+}
+__device__ __forceinline__ u32x4 x6c_buffer_load16(X6cRsrc r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+#endif
+// One 16-byte chunk per lane straight from global memory into LDS (global_load_lds_dwordx4): destination = wave-uniform LDS
+// address + 16 * lane, no staging registers, no ds_write; complete once the wave's vmcnt has drained (x6c_vm_drain) AND a
+// barrier has passed before another wave reads it
+#ifdef PASE_HIPEMU
+__device__ __forceinline__ void x6c_load_lds16(const void* src, u32x4* lds_wave_base, int lane) {
+    __builtin_memcpy(&lds_wave_base[lane], src, 16);
+}
+__device__ __forceinline__ void x6c_vm_drain() {}
+#else
+__device__ __forceinline__ void x6c_load_lds16(const void* src, u32x4* lds_wave_base, int) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void x6c_vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
 struct alignas(16) X6cF4 { float x, y, z, w; };
 __device__ __forceinline__ void x6c_gload(float& dst, const float* base, unsigned voff_bytes) {
     dst = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + voff_bytes);
@@ -770,6 +805,70 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         };
         const bool spectrum = p.post_op == PASE_POST_POW || p.post_op == PASE_POST_LOGPOW || p.post_op == PASE_POST_MAG;
         const bool epi_barrier = TM ? false : (p.epilogue == PASE_EPI_STORE ? (!spectrum && p.stat_part != nullptr) : true);
+#ifndef PASE_X6C_NODL     // (A/B builds, tools/ab_build.sh: the pre-split operands through registers as until round 4)
+        if constexpr (ZP) {
+            // Pre-split operands (weight gradients on phase planes, convolutions on channel-minor planes): a stage is a COPY,
+            // and the stage buffers' chunk order is lane-linear -- global_load_lds_dwordx4 does it without registers, vector
+            // ALU work or LDS write instructions.  (Through registers the compiler's s_waitcnt bookkeeping had degraded to
+            // vmcnt(0) in front of every load group and every write: the per-slot branches and the address registers it
+            // allocated on top of the load destinations -- the staging waves ran one memory latency per slot, 90 % busy, and
+            // the weight gradients at 1290 clocks per step against 790 of MFMA work.)
+            auto direct_stage = [&](int g, int bs) __attribute__((always_inline)) {
+                pase_static_for<NSLOT>([&](auto sl_tag) __attribute__((always_inline)) {
+                    constexpr int sl = decltype(sl_tag)::value;
+                    constexpr int kg = sl / NPS, ps = sl % NPS, par = kg & (NPAR - 1);
+                    const int i0 = 128 * ps + 64 * (whalf ^ par);                  // uniform: first position of this wave
+                    if (slot_live(kg, ps) && (NPS * 128 == NPOS || i0 < NPOS)) {   // uniform
+                        u32x4* dst = &Xs[bs * BUF + kg * KGC + fkL * NPOS + i0];
+                        if constexpr (TM) {
+                            const int kgi = g * KGS + kg;
+                            const int s_ = (int)div_magic((unsigned)kgi, pl.seg_magic);
+                            const int q16 = kgi - s_ * pl.P;
+                            const unsigned off = zp_col[par] + (unsigned)(min(s_, p.S - 1) * pl.t_lseg + q16 * 16);
+#pragma unroll
+                            for (int pz = 0; pz < 3; ++pz)
+                                x6c_load_lds16(zpb + (size_t)pz * (size_t)pl.t_plane + off, dst + pz * PLANE, lane);
+                        } else {
+                            const int gidx = min(g * KGS + kg, pl.G - 1);
+                            const unsigned off = (unsigned)((gidx * 2 + fkL) * p.S) * (unsigned)pl.xp_tpad + pos_xoff[par][ps];
+#pragma unroll
+                            for (int pz = 0; pz < 3; ++pz)
+                                x6c_load_lds16(xpc + (size_t)pz * (size_t)pl.xp_plane + off, dst + pz * PLANE, lane);
+                        }
+                    }
+                });
+            };
+            auto prologue_dl = [&](int item) __attribute__((always_inline)) {
+                if (wave == 4) X6C_STAMP(4);
+                setup_item(item);
+                direct_stage(g_begin, bsel);
+                if (wave == 4) X6C_STAMP(5);
+            };
+            int item = next_item((int)blockIdx.x - (int)gridDim.x);
+            if (item < nitems) prologue_dl(item);
+            while (item < nitems) {
+                x6c_vm_drain();
+                __syncthreads();           // the item's first stage is visible to the compute waves
+                for (int gi = 0; gi < nst; ++gi) {
+                    X6C_T0();
+                    if (gi + 1 < nst) direct_stage(g_begin + gi + 1, bsel ^ 1);
+                    x6c_vm_drain();
+                    if (wave == 4) X6C_TACC(8);
+                    __syncthreads();
+                    bsel ^= 1;
+                }
+                if (wave == 4) X6C_STAMP(6);
+                X6C_TRACE_NEXT();
+                item = next_item(item);
+                if (item < nitems) prologue_dl(item);
+                if (epi_barrier) {
+                    x6c_vm_drain();
+                    __syncthreads();       // the barrier of the compute waves' epilogue
+                }
+            }
+            return;
+        }
+#endif
         int item = next_item((int)blockIdx.x - (int)gridDim.x);
         if (item < nitems) prologue(item);
         while (item < nitems) {
@@ -912,7 +1011,9 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     //   tmode 3: row (ci, kk) of the weight gradient = phase b / shift d of channel ci in row-major bf16 planes of z~
     //     (pack_zplanes_kernel: [plane][ci * stride + b][s][t_lseg]); the k-group (s, q0) of that row starts at element
     //     s * t_lseg + q0 + (d - dmin): consecutive k-groups are 16 elements apart, t_hh more across a sequence boundary
-    const char* ab[3];
+    // (scalar byte offsets from the scratch's start, p.wx6: the plans keep it below 4 GiB)
+    const X6cRsrc a_rs = x6c_make_rsrc(p.wx6);
+    unsigned ab[3];
     unsigned a_loff;
     int a_adv, a_q16 = 0, a_wrap = 0x7fffffff, a_hh2 = 0;
     if (TM && pl.tmode == 3) {
@@ -934,14 +1035,14 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         a_loff = 2u * (unsigned)(odd * (int)(pl.t_plane / 2) + ((ci * pl.t_stride + b) * p.S) * pl.t_lseg + sh - odd + fk * 8);
 #pragma unroll
         for (int pz = 0; pz < 3; ++pz)
-            ab[pz] = reinterpret_cast<const char*>(p.wx6) + 2 * ((size_t)pz * pl.t_plane + (size_t)sq * pl.t_lseg + (size_t)a_q16 * 16);
+            ab[pz] = (unsigned)(2 * ((size_t)pz * pl.t_plane + (size_t)sq * pl.t_lseg + (size_t)a_q16 * 16));
     } else {
         a_adv = 3072;
         a_loff = 16u * (unsigned)lane;
 #pragma unroll
         for (int pz = 0; pz < 3; ++pz)
-            ab[pz] = reinterpret_cast<const char*>(p.wx6) + 16 * (((size_t)(mt * WM + wm) * (unsigned)pl.steps_total +
-                                                                  (size_t)g_begin * (unsigned)nsteps) * 192u + 64u * pz);
+            ab[pz] = (unsigned)(16 * (((size_t)(mt * WM + wm) * (unsigned)pl.steps_total + (size_t)g_begin * (unsigned)nsteps) * 192u +
+                                      64u * pz));
     }
     const int nsteps_run = nst * nsteps;
     int a_issued = 0;
@@ -949,15 +1050,17 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         // unconditional (the steps past the end re-read the last fragments): a load behind a branch makes the compiler's
         // vmcnt bookkeeping fall back to vmcnt(0), which would wait for the fragments issued a moment ago
 #ifndef PASE_ABL_NOA      // (ablation builds of tools/trace_x6c.py: no A-fragment loads inside the loop)
-        if constexpr (!TM) {
-            // packs: the three planes of a step are 1 KB apart -- ONE pointer, the plane offset rides in the instruction's
-            // immediate field (a third of the address arithmetic of three independent pointers)
-            const X6cU16* a1 = reinterpret_cast<const X6cU16*>(ab[0] + a_loff);
+        // Buffer loads: descriptor + the lane's constant byte offset + a scalar offset.  (As plain global loads the compiler
+        // added base + lane offset into a VGPR pair per step, allocated on top of the destination registers; the
+        // write-after-write wait it then needs against the load that last filled them came out as s_waitcnt vmcnt(0) at the
+        // loop header: every fragment in flight had to land before the next one was requested -- prefetch distance 1, not 2.)
+        if constexpr (!TM || ZP) {
+            // packs: the three planes of a step are 1 KB apart -- ONE scalar offset
 #pragma unroll
-            for (int pz = 0; pz < 3; ++pz) a[pz] = a1[64 * pz].v;
+            for (int pz = 0; pz < 3; ++pz) a[pz] = x6c_buffer_load16(a_rs, a_loff + 1024u * pz, ab[0]);
         } else {
 #pragma unroll
-            for (int pz = 0; pz < 3; ++pz) a[pz] = x6c_load16u(reinterpret_cast<const unsigned short*>(ab[pz] + a_loff));
+            for (int pz = 0; pz < 3; ++pz) a[pz] = x6c_buffer_load16(a_rs, a_loff, ab[pz]);
         }
 #endif
         ++a_issued;
@@ -967,7 +1070,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             a_q16 = wrap ? 0 : a_q16 + 1;
             adv = (a_issued < nsteps_run) ? a_adv + (wrap ? a_hh2 : 0) : 0;
         }
-        if constexpr (!TM) ab[0] += adv;
+        if constexpr (!TM || ZP) ab[0] += adv;
         else {
 #pragma unroll
             for (int pz = 0; pz < 3; ++pz) ab[pz] += adv;
@@ -1063,6 +1166,13 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
 #endif
     load_a(a0);
     load_a(a1);
+#ifdef PASE_X6C_A3        // A/B builds: weight-gradient fragments THREE steps ahead (four register sets)
+    constexpr bool A3 = TM;
+#else
+    constexpr bool A3 = false;
+#endif
+    u32x4 a3[3];
+    if constexpr (A3) load_a(a2);
 #ifdef PASE_X6C_OLDLOOP
     __syncthreads();
     if (wave == 0) X6C_STAMP(1);
@@ -1122,6 +1232,18 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         done = stages_left == 0;
     };
 #endif
+    if constexpr (A3) {
+        while (true) {
+            step(a0, a3);
+            if (done) break;
+            step(a1, a0);
+            if (done) break;
+            step(a2, a1);
+            if (done) break;
+            step(a3, a2);
+            if (done) break;
+        }
+    } else {
     while (true) {
         step(a0, a2);
         if (done) break;
@@ -1129,6 +1251,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         if (done) break;
         step(a2, a1);
         if (done) break;
+    }
     }
 
     if (wave == 0) X6C_STAMP(2);
@@ -1903,6 +2026,7 @@ bool pase_x6c_plan(const PaseConvGemm& p, PaseX6cPlan& pl) {
     pl.pack_chunks = (long)pl.n_row_tiles * pl.WM * pl.steps_total * 192;
     pl.prm_n = GS * pl.KGS * 16;
     pl.pack_bytes = (pl.pack_chunks * 16 + 3L * pl.prm_n * 4 + 15) / 16 * 16;
+    if (pl.pack_bytes >= (1L << 32)) return false;      // the weight fragments are addressed with 32-bit scalar offsets
     pl.ncols_magic = magic_of(p.Ncols);
     pl.cout_magic = magic_of(p.Cout_store);
     pl.ps_magic = magic_of(p.ps);
@@ -2084,7 +2208,10 @@ bool pase_x6c_wgrad_plan(const PaseWgrad& w, PaseX6cWgrad& o) {
     const long Gk = (long)w.S * QP16;
     if (Gk * 16 >= LIM) return false;
     pl.P = QP16; pl.A = 1; pl.G = (int)Gk; pl.CinP = 0x7fffffff;
-    pl.KGS = Gk >= 4 ? 4 : (int)Gk;
+    // k-groups (16 positions) per stage.  A stage ends in a barrier and the first fragment reads of the next one, ~1.4 k clocks
+    // against 0.8 k per step: the pre-split planes' kernel holds TMZ_KGS of them (LDS: 2 x 12 KB per k-group)
+    const int kgs_cap = pl.zp ? ((w.x6 >> 12) & 7 ? (int)((w.x6 >> 12) & 7) : TMZ_KGS) : 4;
+    pl.KGS = Gk >= kgs_cap ? kgs_cap : (int)Gk;
     const int GS = (pl.G + pl.KGS - 1) / pl.KGS;
     pl.steps_total = GS * pl.KGS;
     pl.WM = 4; pl.NBT = 4; pl.BM = 128; pl.BN = 128;
@@ -2123,6 +2250,7 @@ bool pase_x6c_wgrad_plan(const PaseWgrad& w, PaseX6cWgrad& o) {
     pl.pack_chunks = (long)pl.n_row_tiles * 4 * pl.steps_total * 192;
     pl.prm_n = 0;
     pl.pack_bytes = pl.tmode == 3 ? 3 * pl.t_plane * 2 : pl.pack_chunks * 16;
+    if (pl.pack_bytes >= (1L << 32)) return false;      // (32-bit scalar offsets of the fragment loads)
     if (pl.zp) {
         pl.zp_off = pl.pack_bytes;
         pl.pack_bytes += 3 * pl.t_plane * 2;
@@ -2160,7 +2288,7 @@ int pase_x6c_wgrad_launch(const PaseWgrad& w, const PaseX6cWgrad& o, hipStream_t
     long nwg = (long)pl.n_row_tiles * pl.n_col_tiles * pl.splitk;
     const long cap = w.max_wg > 0 ? w.max_wg : 256;
     if (nwg > cap) nwg = cap;
-    if (pl.zp) PASE_LAUNCH((conv_x6c_kernel<128, 4, true, true>), dim3((unsigned)nwg), dim3(NT), st, c, pl);
+    if (pl.zp) PASE_LAUNCH((conv_x6c_kernel<128, TMZ_KGS, true, true>), dim3((unsigned)nwg), dim3(NT), st, c, pl);
     else PASE_LAUNCH((conv_x6c_kernel<128, 4, true>), dim3((unsigned)nwg), dim3(NT), st, c, pl);
     PASE_CHECK_LAUNCH();
     return 0;

@@ -420,6 +420,7 @@ def wgrad_gemm(g, z, dw, *, S, M, Tg, Ncols, Cin, Tz, taps, ldw=None, dbias=None
         d.x6 |= 256 if os.environ.get("PASE_X6C_WGRAD_FLAT") else 0
         d.x6 |= 512 if os.environ.get("PASE_X6C_NOVEC") else 0
         d.x6 |= 1024 if os.environ.get("PASE_SINC_X6", "1") == "0" else 0
+        d.x6 |= (int(os.environ.get("PASE_X6C_TMKGS", "0")) & 7) << 12
     d.max_wg = _max_wg()
     global LAST_WGRAD_X6, LAST_WGRAD_KIND
     LAST_WGRAD_X6 = False
