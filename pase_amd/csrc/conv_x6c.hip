@@ -1984,7 +1984,11 @@ bool pase_x6c_plan(const PaseConvGemm& p, PaseX6cPlan& pl) {
     // tiles; launches with >= 1024 rows and one or two taps take it (x6_ctl bit 1 forces it on any stride-1 launch, bit 2 forbids
     // it), which also lifts the K < 768 rule for them (the stacked 2304-row first layers of the MLP heads)
     const bool xp_ok = pl.P == 1 && (long)pl.G * 2 * p.S * (long)(p.Ncols + pl.A - 1) < (1L << 27);
-    const bool xp_want = xp_ok && !(p.x6_ctl & 4) && ((p.x6_ctl & 2) || (pl.A <= 2 && p.M >= 1024));
+    // (with the planes staged by global_load_lds the break-even moved: one or two taps from 512 rows, three taps from 1024 --
+    //  PASE+ bs32, same box: the decoder's 1280-row 3-tap layer 1.26 -> 1.10 ms, the 512-row QRNN projection 0.45 -> 0.41,
+    //  block 1's data gradient 0.58 -> 0.50; 6- and 11-tap layers and the 256-row launches lose 5 ... 15 % to the pack)
+    const bool xp_want = xp_ok && !(p.x6_ctl & 4) &&
+                         ((p.x6_ctl & 2) || (pl.A <= 2 && p.M >= 512) || (pl.A <= 3 && p.M >= 1024));
     // Round 4: launches of at most 64 rows get a 64 x 256 tile (NARROW) when they have taps' to walk and >= 512 k (block 1 of
     // the encoder: 640 channels' x 2 taps'); the 1x1 launches of 64 rows have 8 ... 16 MFMA steps per tile and are store-bound
     // on either pipe.  x6_ctl bit 4 forbids it (A/B measurements)

@@ -193,21 +193,28 @@ __global__ void __launch_bounds__(NT) act_bwd_reduce_kernel(PaseActBwd p, ActBwd
     const float dmul = p.has_bn == 2 ? a : 1.f;
     float f_dz[4] = {0.f, 0.f, 0.f, 0.f}, f_dzx[4] = {0.f, 0.f, 0.f, 0.f}, f_da[4] = {0.f, 0.f, 0.f, 0.f};
     if (live) {
+        // all eight loads of a round first (as in the apply pass), then the arithmetic: with the loads inside the per-element
+        // branch the pass ran one memory latency per element and thread -- 1.1 TB/s on the 786 MB SincNet output against the
+        // apply pass's 4.7 TB/s over the same two tensors (profiles/bench_r04_kernel_stats.csv).  Elements past the end read as
+        // y = 0, dA = 0: they add nothing to the three sums.
         for (int tb = t0 + lid; tb < t1; tb += 4 * nl) {
+            float yv[4], dA[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int t = tb + u * nl;
-                if (t < t1) {
-                    const float yv = yrow[t];
-                    const float z = yv * a + b;
-                    const float dA = grad_post_act(p, s, c, t, pmagic);
-                    const float dz = z > 0.f ? dA : dA * al;
-                    if (drow) drow[t] = dz * dmul;
-                    const float xhat = (yv - mean) * rstd;
-                    f_dz[u] += dz;
-                    f_dzx[u] = fmaf(dz, xhat, f_dzx[u]);
-                    if (!(z > 0.f)) f_da[u] = fmaf(dA, z, f_da[u]);
-                }
+                yv[u] = t < t1 ? yrow[t] : 0.f;
+                dA[u] = t < t1 ? grad_post_act(p, s, c, t, pmagic) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = tb + u * nl;
+                const float z = yv[u] * a + b;
+                const float dz = z > 0.f ? dA[u] : dA[u] * al;
+                if (drow && t < t1) drow[t] = dz * dmul;
+                const float xhat = (yv[u] - mean) * rstd;
+                f_dz[u] += dz;
+                f_dzx[u] = fmaf(dz, xhat, f_dzx[u]);
+                f_da[u] = fmaf(z > 0.f ? 0.f : dA[u], z, f_da[u]);
             }
         }
     }
