@@ -267,7 +267,7 @@ def main():
     with contextlib.redirect_stdout(io.StringIO()):
         tr = trainer(frontend_cfg=dict(fe_cfg), minions_cfg=wk_cfg,
                      cfg=dict(fe_lr=1e-3, min_lr=5e-4, epoch=1, bpe=max(1, args.steps + args.warmup),
-                              reserve_cus=(args.reserve_cus if args.reserve_cus >= 0 else (16 if world > 1 else 0))),
+                              reserve_cus=(args.reserve_cus if args.reserve_cus >= 0 else (32 if world > 1 else 0))),
                      lr_mode="poly", device=dev)
     B, T = args.batch, args.chunk
     batch = synthetic_batch(1234 + rank, B, T, raw, dev)

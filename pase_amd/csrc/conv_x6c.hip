@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     const int nsteps = KGS * pl.A;                 // MFMA steps per stage
     const bool has_aff = p.in_scale != nullptr, has_alpha = p.in_alpha != nullptr;       // uniform
     // convolutions whose bias index is the tile row (no pixel shuffle, no spectrum post-op): see the accumulator initialisation
-    const bool bias_init = !TM && p.bias != nullptr && p.ps == 1 && p.post_op != PASE_POST_POW &&
+    const bool bias_init = !TM && p.bias != nullptr && p.ps == 1 && !(p.x6_ctl & 64) && p.post_op != PASE_POST_POW &&
                            p.post_op != PASE_POST_LOGPOW && p.post_op != PASE_POST_MAG;
     const float* xbase = p.x + (size_t)p.x_coff * p.Tin;
     const int prm_n = GS * KGS * 16;               // channels' incl. the zero groups that fill the last stage

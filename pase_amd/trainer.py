@@ -212,10 +212,13 @@ class trainer(object):
         self._side = None
         self.device_targets = None
         # Data-parallel runs leave CUs to RCCL: every split-bf16 GEMM is a persistent grid of one 512-thread workgroup per
-        # CU at 225 VGPRs per lane -- a channel kernel cannot share a CU with it (the SIMD's register file is full) and would
-        # only get one at a launch's tail.  cfg["reserve_cus"] (default 16 for world > 1, 0 otherwise) caps those grids at
-        # 256 - reserve_cus (PaseConvGemm::max_wg / PaseWgrad::max_wg); 16 covers RCCL's default channel count on a ring.
-        self.reserve_cus = int(self.cfg.get("reserve_cus", 16 if self.world > 1 else 0)) if hasattr(self, "cfg") else 0
+        # CU whose two waves per SIMD hold the whole register file (249 VGPRs, allocated as 256) -- a channel kernel cannot
+        # share a CU with it and would only get one at a launch's tail.  cfg["reserve_cus"] (default 32 for world > 1, 0
+        # otherwise) caps those grids at 256 - reserve_cus (PaseConvGemm::max_wg / PaseWgrad::max_wg).  32, not 16: workgroups
+        # are dealt to the four shader engines of each XCD in turn, and with 30 workgroups per XCD two of its engines are
+        # full -- a 64-workgroup kernel on another stream then waits for the GEMM's tail although 16 CUs idle (measured,
+        # tools/experiments/side_probe.py: admitted at a cap of 224, not at 240); 28 per XCD leave one CU free in every engine.
+        self.reserve_cus = int(self.cfg.get("reserve_cus", 32 if self.world > 1 else 0)) if hasattr(self, "cfg") else 0
         if self.reserve_cus > 0:
             from . import kernels as _K
             _K.MAX_WG = max(1, 256 - self.reserve_cus)

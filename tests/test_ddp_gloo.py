@@ -222,12 +222,10 @@ def test_four_ranks_uneven_timing_stay_identical_and_rank0_checkpoints():
 def test_reserved_cus_let_a_side_stream_kernel_run_beside_a_persistent_gemm():
     """Data-parallel readiness (round-3 review item 8b): the split-bf16 GEMMs are persistent grids of one 512-thread workgroup
     per CU whose registers fill the SIMDs, so a kernel on another stream (RCCL's channel kernels) finds no CU until a launch
-    drains.  With the grid capped at 256 - reserved CUs (PaseConvGemm::max_wg, what trainer(cfg reserve_cus) sets for
-    world > 1) a 64-workgroup kernel enqueued on a side stream WHILE a long GEMM runs finishes long before the GEMM does, and
-    the cap costs the GEMM no more than its share of the chip.  (Measured, round 4: a LIGHT kernel -- torch's vectorised add,
-    a few dozen VGPRs -- also gets in without the cap, 62 registers per lane are left beside the GEMM's two waves per SIMD;
-    RCCL's channel kernels are not light, and no multi-GPU node was available to measure them: the uncapped numbers are
-    printed, not asserted.)"""
+    drains.  With the grid capped at 256 - 32 CUs (PaseConvGemm::max_wg, what trainer(cfg reserve_cus) sets for world > 1) a
+    64-workgroup kernel enqueued on a side stream WHILE a long GEMM runs finishes long before the GEMM does, and the cap costs
+    the GEMM no more than its share of the chip.  (32, not 16: workgroups go to the four shader engines of each XCD in turn;
+    30 per XCD fill two of them and the side kernel waits for the GEMM's tail although 16 CUs idle -- printed, not asserted.)"""
     import time
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -241,12 +239,33 @@ def test_reserved_cus_let_a_side_stream_kernel_run_beside_a_persistent_gemm():
     w = torch.randn(Cout, Cin * k, device=dev) * 0.05
     y = torch.empty(S, Cout, T, device=dev)
     small = torch.zeros(64 * 256 * 4, device=dev)        # 64 blocks of 256 threads x 4 elements (torch's vectorised add)
-    side = torch.cuda.Stream()
+    # (HIP multiplexes streams onto a few hardware queues; a side stream that shares the main stream's queue runs BEHIND it
+    #  whatever the CUs do -- seen in the full suite, where earlier tests have created streams.  Four candidates, best one counts.)
+    cands = [torch.cuda.Stream() for _ in range(4)]
+
+    def concurrent(side):      # control: does a kernel on `side` run beside a one-block spin kernel on the main stream at all?
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(side):
+            small.add_(1.0)
+        torch.cuda.synchronize()
+        e0.record(main)
+        torch.cuda._sleep(4_000_000)                # ~2 ms of one workgroup
+        e1.record(main)
+        time.sleep(0.0005)
+        with torch.cuda.stream(side):
+            small.add_(1.0)
+            e2.record(side)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e2) < e0.elapsed_time(e1) - 0.3
+    sides = [sd for sd in cands if concurrent(sd)]
+    if not sides:
+        pytest.skip("every candidate side stream shares the main stream's hardware queue in this process")
 
     def gemm():
         K.conv_gemm(x, w, y, S=S, Cin=Cin, Tin=T, M=Cout, K=Cin * k, taps=k, Ncols=T, Tout=T, padL=5, pad_mode=K.PAD_REFLECT)
 
-    def run(max_wg):
+    def run(max_wg, side):
         saved = K.MAX_WG
         K.MAX_WG = max_wg
         try:
@@ -267,14 +286,15 @@ def test_reserved_cus_let_a_side_stream_kernel_run_beside_a_persistent_gemm():
             return e_g0.elapsed_time(e_g1), e_g0.elapsed_time(e_s1)
         finally:
             K.MAX_WG = saved
-    run(0)                                          # clocks / caches warm
-    r240 = [run(240), run(240)]
+    run(0, sides[0])                                # clocks / caches warm
+    r224 = [run(224, sd) for sd in sides]
     assert K.LAST_PLAN_KIND == 2
-    r0 = [run(0), run(0)]
-    t_gemm, t_side = min(r240)
-    t_gemm_full, t_side_full = min(r0)
-    print("reserved 16 CUs: GEMM %.3f ms, side kernel done at %.3f ms | no reservation: GEMM %.3f ms, side kernel at %.3f ms"
-          % (t_gemm, t_side, t_gemm_full, t_side_full))
+    r240 = [run(240, sd) for sd in sides]
+    r0 = [run(0, sd) for sd in sides]
+    t_gemm, t_side = min(g for g, _ in r224), min(sd for _, sd in r224)
+    t_gemm_full, t_side_full = min(g for g, _ in r0), min(sd for _, sd in r0)
+    print("reserved 32 CUs: GEMM %.3f ms, side kernel done at %.3f ms | 16 CUs: %.3f / %.3f | no reservation: GEMM %.3f ms, side "
+          "kernel at %.3f ms" % (t_gemm, t_side, min(g for g, _ in r240), min(sd for _, sd in r240), t_gemm_full, t_side_full))
     assert t_gemm > 1.5, t_gemm                                  # long enough for the side kernel to arrive mid-flight
     assert t_side < t_gemm - 0.4, (t_side, t_gemm)                # it ran beside the GEMM, not behind it
-    assert t_gemm <= 1.15 * t_gemm_full, (t_gemm, t_gemm_full)    # and 16 of 256 CUs cost the GEMM at most their share (+ noise)
+    assert t_gemm <= 1.22 * t_gemm_full, (t_gemm, t_gemm_full)    # and 32 of 256 CUs cost the GEMM at most their share (+ noise)
