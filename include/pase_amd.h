@@ -96,7 +96,8 @@ typedef struct PaseConvGemm {
                               wherever it has a plan, skipping the measured per-shape routing rules; bit 1: ask for the
                               pre-split activation on every stride-1 launch; bit 2: never; bit 3: keep the one-channel
                               (SincNet) layer off its window-image kernel; bit 4: no 64 x 256 tile for launches of at
-                              most 64 rows; bit 5: the general epilogue on every tile (no lean store / MSE path); bits 8-15: start
+                              most 64 rows; bit 5: the general epilogue on every tile (no lean store / MSE path); bit 6: the bias
+                              added in the epilogue instead of being the accumulators' initial value; bits 8-15: start
                               the persistent workgroups n x 512 clocks out of phase (A/B runs and tests; the library
                               itself reads NO environment variables)                                             */
     int max_wg;            /* cap on the persistent grid of the split-bf16 kernel (0 = one workgroup per CU, 256):
