@@ -100,6 +100,23 @@ def test_conv_transpose_pixel_shuffle(dev, Cin, Cout, k, stride, T, S):
     assert _rel(y, ref) < 1e-6
 
 
+@pytest.mark.parametrize("splitk", [1, 3])
+def test_64_row_tile_with_and_without_splitk(dev, splitk):
+    """<= 64 rows, 11 taps, K = 704: the 64 x 256 tile (compute waves 2 x 2); split-K adds the slices' tiles atomically into the
+    zeroed output (two column halves per row block), only slice 0 carries the bias (the accumulators' initial value)."""
+    torch.manual_seed(21)
+    S, Cin, Cout, k, T = 2, 64, 56, 11, 300
+    x = torch.randn(S, Cin, T)
+    w = torch.randn(Cout, Cin, k) * 0.1
+    b = torch.randn(Cout)
+    ref = F.conv1d(F.pad(x.double(), (5, 5), mode="reflect"), w.double(), b.double())
+    y = torch.zeros(S, Cout, T, device=dev)
+    K.conv_gemm(x.to(dev), w.reshape(Cout, -1).contiguous().to(dev), y, y_zeroed=True, S=S, Cin=Cin, Tin=T, M=Cout, K=Cin * k,
+                taps=k, Ncols=T, Tout=T, bias=b.to(dev), padL=5, pad_mode=K.PAD_REFLECT, splitk=splitk)
+    assert K.LAST_PLAN_KIND == 2
+    assert _rel(y, ref) < 1e-6
+
+
 @pytest.mark.parametrize("splitk", [1, 0, 3])
 def test_strided_data_gradient_splitk(dev, splitk):
     """Data-gradient of a stride-2 conv in padded coordinates (engine.conv_dgrad): rows = (phase, input channel),
