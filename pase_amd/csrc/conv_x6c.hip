@@ -234,19 +234,68 @@ __device__ __forceinline__ void x6c_load_lds16(const void* src, u32x4* lds_wave_
 __device__ __forceinline__ void x6c_vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #endif
 struct alignas(16) X6cF4 { float x, y, z, w; };
-__device__ __forceinline__ void x6c_gload(float& dst, const float* base, unsigned voff_bytes) {
-    dst = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + voff_bytes);
+// Staging registers: eight fp32 values per slot as two 4-vectors (the row-coalesced weight-gradient path fills them with two
+// global_load_dwordx4, every other path with eight global_load_dword).
+#ifdef PASE_HIPEMU
+typedef float x6c_f4 __attribute__((vector_size(16)));
+#else
+typedef float x6c_f4 __attribute__((ext_vector_type(4)));
+#endif
+#if defined(PASE_HIPEMU) || defined(PASE_X6C_AUTOWAIT)
+// (emulator, and A/B builds with -DPASE_X6C_AUTOWAIT: plain loads, the compiler's own s_waitcnt bookkeeping)
+template <int E>
+__device__ __forceinline__ void x6c_gload(x6c_f4 (&q)[2], const float* base, unsigned voff_bytes) {
+    q[E >> 2][E & 3] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + voff_bytes);
+}
+__device__ __forceinline__ void x6c_gload_x8(x6c_f4 (&q)[2], const float* base, unsigned voff_bytes) {
+    const X6cF4* s4 = reinterpret_cast<const X6cF4*>(reinterpret_cast<const char*>(base) + voff_bytes);
+    const X6cF4 lo = s4[0], hi = s4[1];
+    q[0] = x6c_f4{lo.x, lo.y, lo.z, lo.w};
+    q[1] = x6c_f4{hi.x, hi.y, hi.z, hi.w};
 }
 template <int N>
 __device__ __forceinline__ void x6c_vmwait() {}
-__device__ __forceinline__ void x6c_claim(float (&)[8]) {}
-// wait until at most 8 * nslots of this wave's loads are outstanding (nslots: uniform, 0 .. 4)
-__device__ __forceinline__ void x6c_vmwait_slots(int nslots) {
-    if (nslots <= 0) x6c_vmwait<0>();
-    else if (nslots == 1) x6c_vmwait<8>();
-    else if (nslots == 2) x6c_vmwait<16>();
-    else if (nslots == 3) x6c_vmwait<24>();
-    else x6c_vmwait<32>();
+__device__ __forceinline__ void x6c_claim(x6c_f4 (&)[2]) {}
+#else
+// The staging waves' loads are HIDDEN from the compiler (cdna_hip_programming.md 5.7 form (ii)): issued as inline asm two
+// stages before their conversion, waited for with hand-counted s_waitcnt vmcnt(N) (every live slot issues the same number
+// of them and nothing else of a staging wave uses the vector memory path inside the stage loop), and tied to their first use
+// by x6c_claim.  Left to the compiler the pipeline was synchronous: the per-slot branches, the rotated register sets and
+// address temporaries allocated on top of the load destinations made it wait vmcnt(0) in front of every load group and
+// every conversion -- the compute waves of the 1x1 / stride-2 / swapped launches spent 11 ... 60 % of their loop in the stage
+// barrier (tools/trace_x6c.py: LPS data gradient 60 %, LPS weight gradient 47 %, blocks 6 / 7 11 %).
+template <int E>
+__device__ __forceinline__ void x6c_gload(x6c_f4 (&q)[2], const float* base, unsigned voff_bytes) {
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(q[E >> 2][E & 3]) : "v"(voff_bytes), "s"(base) : "memory");
+}
+__device__ __forceinline__ void x6c_gload_x8(x6c_f4 (&q)[2], const float* base, unsigned voff_bytes) {
+    asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:16"
+                 : "=&v"(q[0]), "=&v"(q[1])
+                 : "v"(voff_bytes), "s"(base)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void x6c_vmwait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void x6c_claim(x6c_f4 (&q)[2]) { asm volatile("" : "+v"(q[0]), "+v"(q[1])); }
+#endif
+// wait until at most `per_slot` * nslots of this wave's loads are outstanding (nslots: uniform, 0 .. 5; per_slot 8, or 2 on the
+// row-coalesced weight-gradient path)
+__device__ __forceinline__ void x6c_vmwait_slots(int nslots, bool two_per_slot) {
+    const int n = nslots <= 0 ? 0 : (two_per_slot ? 2 : 8) * (nslots > 5 ? 5 : nslots);
+    switch (n) {
+        case 0: x6c_vmwait<0>(); break;
+        case 2: x6c_vmwait<2>(); break;
+        case 4: x6c_vmwait<4>(); break;
+        case 6: x6c_vmwait<6>(); break;
+        case 8: x6c_vmwait<8>(); break;
+        case 10: x6c_vmwait<10>(); break;
+        case 16: x6c_vmwait<16>(); break;
+        case 24: x6c_vmwait<24>(); break;
+        case 32: x6c_vmwait<32>(); break;
+        default: x6c_vmwait<40>(); break;
+    }
 }
 
 // NPOS: positions (16-byte chunks) per (plane, fk) row of a k-group; KGS_T: k-groups a stage buffer holds.
@@ -535,7 +584,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     const bool has_aff = p.in_scale != nullptr, has_alpha = p.in_alpha != nullptr;       // uniform
     const float* xbase = p.x + (size_t)p.x_coff * p.Tin;
 
-    float xreg[XR][ZP ? 1 : NSLOT][8];
+    x6c_f4 xreg[XR][ZP ? 1 : NSLOT][2];
     unsigned xmask[XR][ZP ? 1 : NSLOT];         // bit e: element e of the slot is a real sample (else: zero AFTER the transform)
     u32x4 xpl[XR][ZP ? NSLOT : 1][3];           // ZP: the slot's three plane chunks as loaded
     const unsigned short* zpb = reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(p.wx6) + pl.zp_off);
@@ -588,10 +637,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
 #ifdef PASE_X6C_TRACE
                 if (pl.prio & 64) off = (unsigned)(lane & 15) * 8u;      // ablation: every load hits the same two cache lines
 #endif
-                const X6cF4* q4 = reinterpret_cast<const X6cF4*>(reinterpret_cast<const char*>(xbase) + (size_t)off * 4u);
-                const X6cF4 lo = q4[0], hi = q4[1];
-                xreg[rs][sl][0] = lo.x; xreg[rs][sl][1] = lo.y; xreg[rs][sl][2] = lo.z; xreg[rs][sl][3] = lo.w;
-                xreg[rs][sl][4] = hi.x; xreg[rs][sl][5] = hi.y; xreg[rs][sl][6] = hi.z; xreg[rs][sl][7] = hi.w;
+                x6c_gload_x8(xreg[rs][sl], xbase, off * 4u);
                 xmask[rs][sl] = ok ? 0xffu : 0u;
                 return;
             }
@@ -601,20 +647,21 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             const float* sb = xbase + (size_t)sq * p.x_ctot * p.Tin;
             const unsigned vbit = ((pos_valid & ~t_ones) >> par) & 1u;
             if (inter) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    x6c_gload(xreg[rs][sl][e], sb + ((qb0 + e) * p.stride + t_kmin), pos_voff[par][ps] * 4u);
+                pase_static_for<8>([&](auto et) __attribute__((always_inline)) {
+                    constexpr int e = decltype(et)::value;
+                    x6c_gload<e>(xreg[rs][sl], sb + ((qb0 + e) * p.stride + t_kmin), pos_voff[par][ps] * 4u);
+                });
                 xmask[rs][sl] = (0u - vbit) & 0xffu;
             } else {
                 unsigned mask = 0u;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
+                pase_static_for<8>([&](auto et) __attribute__((always_inline)) {
+                    constexpr int e = decltype(et)::value;
                     int u = (qb0 + e) * p.stride + t_koff[par][ps];
                     if (p.pad_mode == PASE_PAD_REFLECT) u = x6c_reflect(u, p.Tin);
                     const unsigned okb = (qb0 + e < p.Ncols ? vbit : 0u) & x6c_in_range(u, p.Tin);
-                    x6c_gload(xreg[rs][sl][e], sb, ((unsigned)(pos_u0[par][ps] + u) & (0u - okb)) * 4u);
+                    x6c_gload<e>(xreg[rs][sl], sb, ((unsigned)(pos_u0[par][ps] + u) & (0u - okb)) * 4u);
                     mask |= okb << e;
-                }
+                });
                 xmask[rs][sl] = mask;
             }
             return;
@@ -632,29 +679,29 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         const unsigned vbit = (pos_valid >> (par * NPS + ps)) & 1u;
         if (all_inter) {
             // interior: one load per element off a uniform base, no per-element address arithmetic
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            pase_static_for<8>([&](auto et) __attribute__((always_inline)) {
+                constexpr int e = decltype(et)::value;
                 int ci, b;
                 bool chok;
                 chan_of(g, kg, e, ci, b, chok);
-                x6c_gload(xreg[rs][sl][e], xbase + (size_t)ci * p.Tin + b, pos_voff[par][ps] * 4u);
-            }
+                x6c_gload<e>(xreg[rs][sl], xbase + (size_t)ci * p.Tin + b, pos_voff[par][ps] * 4u);
+            });
             xmask[rs][sl] = (0u - vbit) & 0xffu;
         } else {
             // padding arithmetic in integer lanes (no per-element lane-mask SGPR pairs: eight of them per slot, three
             // register sets deep, is what spilled): okb = 1 for a real sample, the offset is ANDed with 0 - okb
             unsigned mask = 0u;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            pase_static_for<8>([&](auto et) __attribute__((always_inline)) {
+                constexpr int e = decltype(et)::value;
                 int ci, b;
                 bool chok;
                 chan_of(g, kg, e, ci, b, chok);
                 int u = pos_u0[par][ps] + b;
                 if (p.pad_mode == PASE_PAD_REFLECT) u = x6c_reflect(u, p.Tin);
                 const unsigned okb = vbit & x6c_in_range(u, p.Tin);
-                x6c_gload(xreg[rs][sl][e], xbase + (size_t)ci * p.Tin, ((pos_sbase[par][ps] + (unsigned)u) & (0u - okb)) * 4u);
+                x6c_gload<e>(xreg[rs][sl], xbase + (size_t)ci * p.Tin, ((pos_sbase[par][ps] + (unsigned)u) & (0u - okb)) * 4u);
                 mask |= okb << e;
-            }
+            });
             xmask[rs][sl] = mask;
         }
         }
@@ -675,7 +722,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         x6c_claim(xreg[rs][sl]);
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = xreg[rs][sl][e];
+        for (int e = 0; e < 8; ++e) v[e] = xreg[rs][sl][e >> 2][e & 3];
         if constexpr (TM) {
             if (pl.t_vec) {
                 constexpr int h = (sl >> 1) & 1;
@@ -790,7 +837,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             });
             load_stage(std::integral_constant<int, 0>{}, g_begin);
             if (1 < nst) load_stage(std::integral_constant<int, 1>{}, g_begin + 1);
-            x6c_vmwait_slots(1 < nst ? nlive : 0);         // stage 0 has landed
+            x6c_vmwait_slots(1 < nst ? nlive : 0, TM && pl.t_vec);         // stage 0 has landed
             store_stage(std::integral_constant<int, 0>{}, g_begin, bsel);
             if (2 < nst) load_stage(std::integral_constant<int, 2>{}, g_begin + 2);
             if (wave == 4) X6C_STAMP(5);
@@ -886,7 +933,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                             // in flight: stage gi + 1 (set rn, the older one) and stage gi + 2
                             {
                                 X6C_T0();
-                                x6c_vmwait_slots(gi + 2 < nst ? nlive : 0);
+                                x6c_vmwait_slots(gi + 2 < nst ? nlive : 0, TM && pl.t_vec);
                                 if (wave == 4) X6C_TACC(10);
                             }
                             {
@@ -2196,7 +2243,8 @@ bool pase_x6c_wgrad_plan(const PaseWgrad& w, PaseX6cWgrad& o) {
     }
     // g staged (modes 2 / 3): 8-position chunks start on 16-byte boundaries when the rows do
     pl.t_vec = (pl.tmode >= 2 && w.Tg % 4 == 0 && w.Ncols % 8 == 0 && (long)w.S * QP16 >= 4 &&
-                (reinterpret_cast<uintptr_t>(w.g) & 15) == 0 && !(w.x6 & 512)) ? 1 : 0;
+                (reinterpret_cast<uintptr_t>(w.g) & 15) == 0 && !(w.x6 & 512) &&
+                (long)w.S * w.g_ctot * w.Tg * 4 < (1L << 32)) ? 1 : 0;        // (32-bit byte offsets of the staging loads)
     // the split is paid once per staged element and shared by the row tiles of the workgroup: at most 64 rows would leave
     // half of every MFMA multiplying zeros
     if (o.a_rows <= 64) return false;
