@@ -677,6 +677,35 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         } else {
         const bool all_inter = ((inter_slots >> (par * NPS + ps)) & 1u) != 0;      // uniform
         const unsigned vbit = (pos_valid >> (par * NPS + ps)) & 1u;
+        const int c0l = (g * KGS + kg) * 16 + fkL * 8;                             // first channel' of the octet (uniform)
+        if (all_inter && pl.P == 1 && c0l + 8 <= p.Cin) {
+            // interior, stride 1, eight real channels: ONE 64-bit base per slot and a scalar increment per element (the
+            // general form below spends a magic division, a clamp and a 64-bit multiply-add per element on the scalar
+            // unit -- the staging waves of the K = 21 525 data gradients were 2/3 address arithmetic)
+            const float* bp = xbase + (size_t)c0l * p.Tin;
+            pase_static_for<8>([&](auto et) __attribute__((always_inline)) {
+                constexpr int e = decltype(et)::value;
+                x6c_gload<e>(xreg[rs][sl], bp, pos_voff[par][ps] * 4u);
+                bp += p.Tin;
+            });
+            xmask[rs][sl] = (0u - vbit) & 0xffu;
+        } else
+        if (all_inter && c0l + 8 <= pl.CinP) {
+            // interior, eight real channels' of a strided launch: (channel, phase) of element 0 by one division, then the
+            // base pointer walks -- + 1 sample to the next phase, + Tin - (P - 1) to the next channel's phase 0
+            const int cq0 = (int)div_magic((unsigned)c0l, pl.p_magic);
+            int bph = c0l - cq0 * pl.P;
+            const float* bp = xbase + (size_t)cq0 * p.Tin + bph;
+            const int to_next = p.Tin - (pl.P - 1);
+            pase_static_for<8>([&](auto et) __attribute__((always_inline)) {
+                constexpr int e = decltype(et)::value;
+                x6c_gload<e>(xreg[rs][sl], bp, pos_voff[par][ps] * 4u);
+                const bool wrap = ++bph == pl.P;                                  // uniform
+                bp += wrap ? to_next : 1;
+                bph = wrap ? 0 : bph;
+            });
+            xmask[rs][sl] = (0u - vbit) & 0xffu;
+        } else
         if (all_inter) {
             // interior: one load per element off a uniform base, no per-element address arithmetic
             pase_static_for<8>([&](auto et) __attribute__((always_inline)) {
