@@ -26,15 +26,21 @@
 // next tap is the next chunk.  The operand split (and the on-load BatchNorm affine + PReLU, padding, two-sequence
 // logic) is done ONCE per staged element, by the staging threads, and shared by every tap, every row tile of the
 // workgroup and every wave -- the round-2 kernel redid it in each wave for every fragment it read.
-// The weight operand never touches LDS: pase_pack_x6 stores it in fragment order [32-row tile][step][plane][lane],
-// so a wave's A fragment is one coalesced 1 KB global_load_dwordx4 per plane, prefetched one step ahead, and each
-// of a workgroup's waves owns different rows (4 x 1 wave layout: no redundant loads).
+// The weight operand never touches LDS: pase_x6c_pack stores it in fragment order [32-row tile][step][plane][lane],
+// so a wave's A fragment is one coalesced 1 KB buffer_load_dwordx4 per plane (descriptor + constant lane offset + a scalar
+// offset that advances per step: no vector address arithmetic), prefetched two steps ahead, and each of a workgroup's
+// compute waves owns different rows (no redundant loads).
 //
-// Tile.  256 threads = 4 waves; wave tile 32 rows x 128 columns (4 B tiles x 2 accumulators = 128 VGPRs); workgroup
-// 128 x 128 (waves 4 x 1) or 64 x 256 (waves 2 x 2, for M <= 64).  LDS: double-buffered stages of KGS (1 or 2)
-// 16-channel' groups, 2 workgroups per CU.  One barrier per stage (KGS * taps' steps of 24 MFMAs per wave); the next
-// stage's global loads are issued a stage ahead into registers and converted into the other LDS buffer in slices
-// between the steps of the current stage.
+// Tile and roles.  512 threads = 8 waves, one workgroup per CU, persistent grid (<= 256 workgroups walk the (split-K slice,
+// tile) items).  Waves 0-3 only multiply: wave tile 32 rows x 128 columns (4 B tiles x 2 accumulators = 128 VGPRs), workgroup
+// tile 128 x 128 (waves 4 x 1) or 64 x 256 (waves 2 x 2, launches of at most 64 rows); the B fragments of the next half step
+// are read from LDS one per two MFMAs of the current one.  Waves 4-7 only stage, into two LDS buffers of KGS k-groups
+// (16 channels' each) x taps': activations that are split while they are staged travel through registers, loaded two stages
+// ahead by inline-asm loads with hand-counted s_waitcnt (x6c_gload / x6c_vmwait_slots / x6c_claim: the compiler's own
+// bookkeeping made that pipeline synchronous); pre-split operands (ZP weight-gradient planes, XP activation planes) are copied
+// by global_load_lds_dwordx4 without registers.  One barrier per stage (KGS * taps' steps of 24 MFMAs per compute wave).
+// Template instantiations: <NPOS, KGS_T> = positions per stage row / k-groups a stage buffer holds; TM = contraction over
+// positions (weight gradients); ZP = pre-split staged operand; NARROW = the 64 x 256 tile.
 #include <cstdlib>
 #include <type_traits>
 
@@ -44,7 +50,6 @@ namespace {
 
 constexpr int NT = 512;        // 4 compute waves (one per SIMD) + 4 staging waves
 constexpr int HALO_MAX = 64;      // extra positions a stage holds beyond its BN columns (halo of every sequence touched)
-constexpr int KGS_MAX = 2;
 constexpr int TMZ_KGS = 5;        // k-groups per stage buffer of the weight-gradient kernel on pre-split planes (<128, TMZ_KGS, true, true>)
 
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
@@ -167,10 +172,8 @@ __device__ __forceinline__ void sload8x2(const float* q0, const float* q1, float
 }
 #endif
 
-// Activation loads of the staging waves: plain loads off a uniform base + 32-bit per-lane byte offset, issued two stages
-// before they are consumed; hipcc counts its own s_waitcnt vmcnt(N) for them.  (Round 3 also tried hiding them from the
-// compiler -- inline-asm global_load + hand-counted waits, cdna_hip_programming.md 5.7 form (ii); no faster once the waves
-// were specialised, and one more thing the emulator cannot check.)
+// Activation loads of the staging waves: a uniform base (SGPR pair) + a 32-bit per-lane byte offset, issued two stages before
+// they are consumed (x6c_gload below; hidden from the compiler and waited for by hand, see there).
 // Padding: validity is carried as INTEGER bits (okb, xmask), never as bools -- a bool per element becomes a 64-bit lane
 // mask in an SGPR pair, 8 per slot x 4 slots x 3 register sets, i.e. > 100 spilled SGPRs and a select chain per element.
 __device__ __forceinline__ int x6c_reflect(int u, int T) {              // single reflection about 0 and T - 1
