@@ -149,6 +149,33 @@ def test_accumulates_into_dw_and_persistent_items(dev, monkeypatch):
     assert _rel(db, g.double().sum((0, 2)) - 1.0) < 1e-6
 
 
+@pytest.mark.parametrize("mode", ["4", "1"])
+def test_persistent_items_on_planes_and_on_registers(dev, monkeypatch, mode):
+    """Three workgroups walk all (split-K slice, tile) items of an 11-tap stride-2 weight gradient: every workgroup stages the
+    NEXT item's first stage (LDS DMA from the pre-split planes in mode 4, hand-waited register loads in mode 1) while its compute
+    waves flush the current item's tile."""
+    monkeypatch.setenv("PASE_X6C_WGRAD_MODE", mode)
+    monkeypatch.setenv("PASE_X6C_MAXWG", "3")
+    torch.manual_seed(11)
+    S, Cin, Cout, k, st, T = 3, 20, 150, 11, 2, 336
+    x = torch.randn(S, Cin, T)
+    sc, sh, al = torch.rand(Cin) + 0.5, torch.randn(Cin) * 0.1, torch.rand(Cin) * 0.5
+    P = (k // 2 - 1, k // 2)
+    w = torch.randn(Cout, Cin, k, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    y = F.conv1d(F.pad(_xf(x, sc, sh, al), P, mode="reflect"), w, b, stride=st)
+    g = torch.randn(y.shape)
+    (y * g.double()).sum().backward()
+    dw = torch.zeros(Cout, Cin * k, device=dev)
+    db = torch.zeros(Cout, device=dev)
+    K.wgrad_gemm(g.to(dev), x.to(dev), dw, S=S, M=Cout, Tg=y.shape[2], Ncols=y.shape[2], Cin=Cin, Tz=T, taps=k, dbias=db,
+                 in_scale=sc.to(dev), in_shift=sh.to(dev), in_alpha=al.to(dev), stride=st, padL=P[0], pad_mode=K.PAD_REFLECT,
+                 splitk=4)
+    assert K.LAST_WGRAD_X6 and K.LAST_WGRAD_KIND == int(mode)
+    assert _rel(dw.view(Cout, Cin, k), w.grad) < 1e-6
+    assert _rel(db, b.grad) < 1e-6
+
+
 def test_small_launches_stay_on_the_fp32_pipe(dev):
     """at most 64 rows on the packed side: no split-bf16 plan (pase_wgrad_x6_bytes == 0), exact-fp32 MFMA kernel."""
     torch.manual_seed(4)
