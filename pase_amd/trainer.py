@@ -218,8 +218,11 @@ class trainer(object):
         # are dealt to the four shader engines of each XCD in turn, and with 30 workgroups per XCD two of its engines are
         # full -- a 64-workgroup kernel on another stream then waits for the GEMM's tail although 16 CUs idle (measured,
         # tools/experiments/side_probe.py: admitted at a cap of 224, not at 240); 28 per XCD leave one CU free in every engine.
+        # The cap is in force only while collectives can be in flight -- from the hand-over of the first bucket (the workers'
+        # gradients, before the encoder backward) to the join at the end of the step (_step_ddp); the forward and the heads'
+        # backward run on all 256 CUs.  A single-process trainer with cfg reserve_cus > 0 keeps it on throughout.
         self.reserve_cus = int(self.cfg.get("reserve_cus", 32 if self.world > 1 else 0)) if hasattr(self, "cfg") else 0
-        if self.reserve_cus > 0:
+        if self.reserve_cus > 0 and self.world == 1:
             from . import kernels as _K
             _K.MAX_WG = max(1, 256 - self.reserve_cus)
         if self.world > 1:
@@ -410,9 +413,14 @@ class trainer(object):
         t_host0 = time.perf_counter()
         ev_begin = torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True)) if diag is not None else None
 
+        from . import kernels as _K
+        cap = max(1, 256 - self.reserve_cus) if (use_side and self.reserve_cus > 0) else 0
+
         def launch(tag, bufs):
             if not bufs:
                 return
+            if cap:
+                _K.MAX_WG = cap            # GEMMs enqueued from here on leave CUs to the collectives' kernels
             if use_side:
                 ready = torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=diag is not None))
                 side.wait_event(ready)
@@ -428,9 +436,13 @@ class trainer(object):
                 for b in bufs:
                     self._allreduce(b)
 
-        losses = model.loss_and_grads(
-            batch, sink, device, before_encoder_backward=lambda: launch("workers", [self._worker_grads]),
-            on_encoder_grads=lambda tag: launch(tag, [fg[b:e] for b, e in buckets.get(tag, [])]))
+        try:
+            losses = model.loss_and_grads(
+                batch, sink, device, before_encoder_backward=lambda: launch("workers", [self._worker_grads]),
+                on_encoder_grads=lambda tag: launch(tag, [fg[b:e] for b, e in buckets.get(tag, [])]))
+        finally:
+            if cap:
+                _K.MAX_WG = 0
         if use_side:
             if diag is not None:
                 ev_bwd_end = torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True))
