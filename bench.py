@@ -223,7 +223,9 @@ def main():
                          "not get); 0 = leave RCCL's default")
     ap.add_argument("--reserve-cus", type=int, default=-1,
                     help="N > 1: CUs the persistent split-bf16 GEMM grids leave free for RCCL's channel kernels (grid cap = "
-                         "256 - this); -1 = 16 for N > 1, 0 for N = 1")
+                         "CUs of the device - this); -1 = 32 for N > 1 (one CU per shader engine: DESIGN.md section 6), 0 for N = 1")
+    ap.add_argument("--no-capped-leg", action="store_true",
+                    help="N = 1: skip the extra K steps that price the data-parallel CU reservation (n_gt1_cap_cost)")
     ap.add_argument("--producer", action="store_true",
                     help="BASELINE.json configs[3] shape: every step's batch is produced ON DEVICE inside the timed "
                          "region (random crops of a resident waveform pool, Reverb / additive-noise gating on "
@@ -378,6 +380,30 @@ def main():
                "how": "pinned host ring -> copy stream -> double-buffered device slots, overlapped with the previous step"}
         del feeder, ring
 
+    # ---- N = 1: what the data-parallel step's CU reservation costs THIS GPU's step -- the same K steps with the encoder
+    # backward's persistent grids capped at (CUs - 32), exactly the launches trainer._step_ddp caps while collectives are in
+    # flight (no collective runs here: this is the price paid before a byte moves)
+    capped = None
+    if world == 1 and not args.producer and not args.graph and tr.reserve_cus == 0 and not args.no_capped_leg:
+        saved = (tr.reserve_cus, tr._grid_cap, tr.cfg.get("reserve_scope"))
+        ncu = int(torch.cuda.get_device_properties(dev).multi_processor_count)
+        tr.reserve_cus, tr._grid_cap = 32, ncu - 32
+        tr.cfg["reserve_scope"] = "encoder_backward"
+        try:
+            for _ in range(2):
+                tr.train_step(batch)
+            sync()
+            t0 = time.time()
+            for _ in range(args.steps):
+                tr.train_step(batch)
+            sync()
+            capped_ms = (time.time() - t0) / args.steps * 1e3
+        finally:
+            tr.reserve_cus, tr._grid_cap = saved[0], saved[1]
+            tr.cfg["reserve_scope"] = saved[2] or "step"
+        capped = {"ms_per_step_capped": round(capped_ms, 3), "reserve_cus": 32, "scope": "encoder backward (what N > 1 caps)",
+                  "cost_frac": round(capped_ms / ms_per_step - 1.0, 4)}
+
     # ---- dominant-kernel roofline, measured live: two extra steps with every MFMA-kernel launch
     # bracketed by HIP events on the launch stream (outside the timed region above)
     from pase_amd import kernels as K
@@ -394,11 +420,17 @@ def main():
         # HBM traffic cannot be counted from inside the run (PMC passes need rocprofv3): it comes from this round's
         # profile summary, and ONLY if that profile was taken of the very library that is loaded now (source digest)
         from pase_amd import build as _B
-        with open(os.path.join(ROOT, "profiles", "summary_r04.json")) as f:
-            prof = json.load(f)
-        if prof.get("lib_digest") != _B.hip_digest():
-            raise ValueError("profile is of another build")
-        traffic_src = "profiles/summary_r04.json"
+        prof = None
+        for tag in ("r05", "r04"):          # the newest profile summary taken of the very library loaded now
+            fn = os.path.join(ROOT, "profiles", "summary_%s.json" % tag)
+            if os.path.exists(fn):
+                with open(fn) as f:
+                    cand = json.load(f)
+                if cand.get("lib_digest") == _B.hip_digest():
+                    prof, traffic_src = cand, "profiles/summary_%s.json" % tag
+                    break
+        if prof is None:
+            raise ValueError("no profile of this build")
         # PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs) summed over every conv_gemm
         # instantiation, GB per launch; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B
         # requests as 64 B)
@@ -480,6 +512,13 @@ def main():
         }
         if h2d is not None:
             out["h2d"] = h2d
+        if capped is not None:
+            out["n_gt1_cap_cost"] = capped
+        za = getattr(tr, "_zero_arena", None) or getattr(tr, "_graph_arena", None)
+        if za is not None and za.buf is not None:
+            out["config"]["zero_arena_MB"] = round(za.buf.numel() / 1e6, 1)
+        if _lib.LIBRARY_OVERRIDE:
+            out["library_override"] = _lib.LIBRARY_OVERRIDE      # an A/B build (PASE_LIB), not the shipped library
         if multi is not None:
             out["multi_gpu"] = multi
             out["config"]["rccl_max_nchannels"] = args.rccl_max_nchannels or "RCCL default"

@@ -12,6 +12,7 @@ HIP_SO = os.path.join(_HERE, "libpase_hip.so")
 
 _lib = None
 _device_type = "cuda"
+LIBRARY_OVERRIDE = None      # path of a PASE_LIB A/B build when one was loaded instead of pase_amd/libpase_hip.so
 
 
 class PaseLibraryError(RuntimeError):
@@ -36,7 +37,13 @@ def lib():
     if _lib is None:
         ab = os.environ.get("PASE_LIB")
         if ab:
-            # A/B MEASUREMENT builds of the same sources with another -D flag (tools/ab_build.sh); never set in production
+            # A/B MEASUREMENT builds of the same sources with another -D flag (tools/ab_build.sh); never set in production.
+            # No source-digest check is possible (the flags differ by construction): the override is loud instead -- printed
+            # once, and bench.py records LIBRARY_OVERRIDE in its JSON line
+            global LIBRARY_OVERRIDE
+            LIBRARY_OVERRIDE = os.path.abspath(ab)
+            import sys
+            sys.stderr.write("pase_amd: PASE_LIB override, loading %s (A/B measurement build, no freshness check)\n" % LIBRARY_OVERRIDE)
             _lib = ctypes.CDLL(ab)
             _declare(_lib)
             return _lib

@@ -11,6 +11,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "pase_amd", "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 HIP_SO = os.path.join(ROOT, "pase_amd", "libpase_hip.so")
+# the same library with the staging waves' loads left to the compiler's own s_waitcnt bookkeeping (-DPASE_X6C_AUTOWAIT):
+# test infrastructure only -- tests/test_conv_x6c.py compares it bit for bit with the shipped hand-counted waits on the GPU
+AUTOWAIT_SO = os.path.join(ROOT, "tests", "libpase_hip_autowait.so")
+RESOURCES = os.path.join(ROOT, "pase_amd", "libpase_hip.resources.json")
 EMU_DIR = os.path.join(ROOT, "tests", "hipemu")
 EMU_SO = os.path.join(EMU_DIR, "libpase_emu.so")
 
@@ -59,30 +63,102 @@ def hip_digest():
     return _digest(_sources() + _deps(), " ".join(f for f in _hip_flags() if f not in (INCLUDE, CSRC)))
 
 
+def _kernel_resources(remarks):
+    """{mangled kernel name: {VGPRs, ScratchSize, VGPRs Spill, SGPRs Spill, LDS Size, ...}} from hipcc's
+    -Rpass-analysis=kernel-resource-usage remarks."""
+    import re
+    res, cur = {}, None
+    for line in remarks.splitlines():
+        m = re.search(r"remark:\s+Function Name: (\S+)", line)
+        if m:
+            cur = res.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\S+) \[-Rpass-analysis", line)
+        if m and cur is not None:
+            try:
+                cur[m.group(1).strip()] = int(m.group(2))
+            except ValueError:
+                cur[m.group(1).strip()] = m.group(2)
+    return res
+
+
+def check_x6c_resources(res):
+    """The staging waves of conv_x6c_kernel's register-staged instantiations (template argument ZP = false) issue their loads
+    as inline asm whose destination VGPRs the compiler believes defined at issue, waited for by hand-counted s_waitcnt and
+    tied to their first use by x6c_claim (conv_x6c.hip, x6c_gload).  A scratch spill or a register copy of those VGPRs before
+    the wait would read stale data silently, and the kernel sits at 249 of 256 VGPRs: a toolchain or flag change that makes
+    it spill must fail the BUILD, not a training run.  Raises on any private-segment use or spilled VGPR there."""
+    bad = []
+    seen = 0
+    for name, r in res.items():
+        if "conv_x6c_kernelILi" not in name:
+            continue
+        seen += 1
+        # conv_x6c_kernel<NPOS, KGS, TM, ZP, NARROW>: ...ILi<NPOS>ELi<KGS>ELb<TM>ELb<ZP>ELb<NARROW>EE...
+        import re
+        m = re.search(r"conv_x6c_kernelILi(\d+)ELi(\d+)ELb([01])ELb([01])ELb([01])E", name)
+        zp = bool(m and m.group(4) == "1")
+        if zp:
+            continue          # pre-split operands are staged by LDS DMA: no asm-loaded registers
+        if r.get("ScratchSize", 0) != 0 or r.get("VGPRs Spill", 0) != 0:
+            bad.append((name, r.get("ScratchSize"), r.get("VGPRs Spill")))
+    if seen == 0:
+        raise RuntimeError("build: no conv_x6c_kernel instantiation in the resource remarks (flag or name changed?)")
+    if bad:
+        raise RuntimeError("build: conv_x6c_kernel instantiations with hand-counted staging waits use scratch / spill VGPRs "
+                           "(stale-register hazard, see check_x6c_resources): %r" % (bad,))
+
+
 def build_hip(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
+    import json
     srcs = _sources()
     flags = _hip_flags()
     digest = hip_digest()
-    if not force and _up_to_date(HIP_SO, digest):
+    # PASE_BUILD_NO_AUTOWAIT=1 (development iterations): skip the second compile of conv_x6c.hip; the GPU test that needs
+    # tests/libpase_hip_autowait.so then refuses a stale one by its digest stamp
+    want_aw = os.environ.get("PASE_BUILD_NO_AUTOWAIT", "0") != "1"
+    if not force and _up_to_date(HIP_SO, digest) and (not want_aw or _up_to_date(AUTOWAIT_SO, digest)):
         return HIP_SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
+    cflags = [f for f in flags if f != "-shared"]
     for s in srcs:
         o = s[:-4] + ".o"
         objs.append(o)
-        procs.append(subprocess.Popen([hipcc, "-c", s, "-o", o] + [f for f in flags if f != "-shared"],
+        extra = ["-Rpass-analysis=kernel-resource-usage"] if s.endswith("conv_x6c.hip") else []
+        procs.append(subprocess.Popen([hipcc, "-c", s, "-o", o] + cflags + extra,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    # (in parallel: conv_x6c.hip once more with the compiler's own waits, for the bit-for-bit GPU test)
+    x6c = os.path.join(CSRC, "conv_x6c.hip")
+    aw_obj = os.path.join(CSRC, "conv_x6c.autowait.o")
+    aw = subprocess.Popen([hipcc, "-c", x6c, "-o", aw_obj, "-DPASE_X6C_AUTOWAIT"] + cflags,
+                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) if want_aw else None
     for pr, s in zip(procs, srcs):
         out, _ = pr.communicate()
         if pr.returncode != 0:
             sys.stderr.write(out)
             raise RuntimeError("hipcc failed on " + s)
-        if verbose and out:
+        if s.endswith("conv_x6c.hip"):
+            res = _kernel_resources(out)
+            check_x6c_resources(res)
+            with open(RESOURCES, "w") as f:
+                json.dump({k: v for k, v in sorted(res.items()) if "conv_x6c_kernel" in k}, f, indent=1)
+        elif verbose and out:
             print(out)
     _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_SO] + objs)
     with open(HIP_SO + ".sha256", "w") as f:
+        f.write(digest)
+    if aw is None:
+        return HIP_SO
+    out, _ = aw.communicate()
+    if aw.returncode != 0:
+        sys.stderr.write(out)
+        raise RuntimeError("hipcc failed on conv_x6c.hip (-DPASE_X6C_AUTOWAIT)")
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", AUTOWAIT_SO] +
+         [aw_obj if o.endswith("conv_x6c.o") else o for o in objs])
+    with open(AUTOWAIT_SO + ".sha256", "w") as f:
         f.write(digest)
     return HIP_SO
 

@@ -2024,6 +2024,22 @@ int x6c_prio() {      // trace builds only (tools/trace_x6c.py): ablation bits
 int x6c_prio() { return 0; }
 #endif
 
+// persistent grids: one workgroup per CU of the device the launch goes to (256 on an MI355X in SPX mode; a partitioned
+// device reports its own count).  The split-K models below are tuned for 256 and stay so.
+int x6c_cu_count() {
+#ifdef PASE_HIPEMU
+    return 256;
+#else
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        n = (hipGetDevice(&dev) == hipSuccess &&
+             hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    return n;
+#endif
+}
+
 unsigned magic_of(int d) {
     return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned long long)d);
 }
@@ -2161,7 +2177,7 @@ int pase_x6c_pack(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st) 
 int pase_x6c_launch(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st) {
     // persistent grid: one workgroup per CU (8 waves, 74 KB of LDS), items dealt round-robin
     long nwg = (long)pl.n_row_tiles * pl.n_col_tiles * pl.splitk;
-    const long cap = p.max_wg > 0 ? p.max_wg : 256;      // data-parallel runs leave CUs to RCCL; tests force several items per workgroup
+    const long cap = p.max_wg > 0 ? p.max_wg : x6c_cu_count();      // data-parallel runs leave CUs to RCCL; tests force several items per workgroup
     if (nwg > cap) nwg = cap;
     const dim3 grid((unsigned)nwg), block(NT);
     if (pl.WM == 2) {
@@ -2370,7 +2386,7 @@ int pase_x6c_wgrad_launch(const PaseWgrad& w, const PaseX6cWgrad& o, hipStream_t
         PASE_CHECK_LAUNCH();
     }
     long nwg = (long)pl.n_row_tiles * pl.n_col_tiles * pl.splitk;
-    const long cap = w.max_wg > 0 ? w.max_wg : 256;
+    const long cap = w.max_wg > 0 ? w.max_wg : x6c_cu_count();
     if (nwg > cap) nwg = cap;
     if (pl.zp) PASE_LAUNCH((conv_x6c_kernel<128, TMZ_KGS, true, true>), dim3((unsigned)nwg), dim3(NT), st, c, pl);
     else PASE_LAUNCH((conv_x6c_kernel<128, 4, true>), dim3((unsigned)nwg), dim3(NT), st, c, pl);

@@ -214,7 +214,9 @@ __global__ void __launch_bounds__(NT) act_bwd_reduce_kernel(PaseActBwd p, ActBwd
                 const float xhat = (yv[u] - mean) * rstd;
                 f_dz[u] += dz;
                 f_dzx[u] = fmaf(dz, xhat, f_dzx[u]);
-                f_da[u] = fmaf(z > 0.f ? 0.f : dA[u], z, f_da[u]);
+                // (select on the PRODUCT: 0 * z is NaN for z = +Inf, and the reference's prelu backward adds nothing there;
+                //  the padded tail has dA = 0 and a finite z = b)
+                f_da[u] += z > 0.f ? 0.f : dA[u] * z;
             }
         }
     }

@@ -651,6 +651,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) wgrad_flat_kernel(PaseWgrad p, Wg
 
 extern "C" long pase_wgrad_x6_bytes(const PaseWgrad* d) {
     if (d->M <= 0 || d->Cin <= 0 || d->S <= 0 || d->Ncols <= 0) return 0;
+    if (!(d->x6 & 1)) return 0;          // bit 0 enables the split-bf16 path; the bits above it are controls only
     PaseSincPlan sp;
     if (!(d->x6 & 1024) && pase_sinc_x6_wgrad_plan(*d, sp)) return sp.pack_bytes;
     PaseX6cWgrad o;
@@ -659,6 +660,7 @@ extern "C" long pase_wgrad_x6_bytes(const PaseWgrad* d) {
 
 extern "C" int pase_wgrad_plan_kind(const PaseWgrad* d) {
     if (d->M <= 0 || d->Cin <= 0 || d->S <= 0 || d->Ncols <= 0) return 0;
+    if (!(d->x6 & 1)) return 0;
     PaseSincPlan sp;
     if (!(d->x6 & 1024) && pase_sinc_x6_wgrad_plan(*d, sp)) return 5;
     PaseX6cWgrad o;
@@ -672,7 +674,7 @@ extern "C" int pase_wgrad_gemm(const PaseWgrad* d, void* stream) {
     // zeros there instead of an error)
     if (p.tapstep != 1 && p.tapstep != -1) return -5;
     if (p.pad_mode == PASE_PAD_REFLECT && p.padL >= p.Tz) return -3;
-    if (p.x6 && p.gx6) {
+    if ((p.x6 & 1) && p.gx6) {
         if ((((unsigned long long)(size_t)p.gx6) % 16) != 0) return -10;
         PaseSincPlan sp;
         if (!(p.x6 & 1024) && pase_sinc_x6_wgrad_plan(p, sp)) return pase_sinc_x6_wgrad_launch(p, sp, (hipStream_t)stream);

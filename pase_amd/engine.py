@@ -55,6 +55,9 @@ class ZeroArena:
     Views are only valid until the next begin_step()."""
 
     LIMIT = 1 << 30       # larger requests keep their own allocation
+    TOTAL = 4 << 30       # ... and so does everything past this much per step: arena regions are not recycled within a step
+                          # (split-K outputs live until their consumer has run), so the arena is as large as their SUM --
+                          # bounded here; bench.py reports the size (`zero_arena_MB`)
 
     def __init__(self):
         self.buf = None
@@ -81,6 +84,8 @@ class ZeroArena:
         if nbytes > self.LIMIT or nbytes == 0:
             return None
         off = (self.used + 255) // 256 * 256
+        if off + nbytes > self.TOTAL:
+            return None
         self.need = max(self.need, off + nbytes)
         if self.buf is None or off + nbytes > self.buf.numel():
             self.need = off + nbytes
@@ -119,7 +124,7 @@ def reflect_pads(k, stride):
 
 
 def conv_fwd(a: Act, w2d, bias, *, Cout, taps, stride=1, padL=0, padR=0, pad_mode=K.PAD_ZERO, want_stats=False,
-             tap_major=0, tapstep=1, out=None, out_coff=0, Tout=None):
+             tap_major=0, tapstep=1, out=None, out_coff=0, Tout=None, max_wg=0):
     """y[s,co,t] = b + sum w[co,(ci,kk)] * a~[s,ci,t*stride + kk*tapstep - padL]."""
     S, Tin = a.S, a.T
     if Tout is None:
@@ -128,13 +133,13 @@ def conv_fwd(a: Act, w2d, bias, *, Cout, taps, stride=1, padL=0, padR=0, pad_mod
               in_scale=a.scale, in_shift=a.shift, in_alpha=a.alpha, x_ctot=a.ctot, x_coff=a.coff, tap_major=tap_major,
               stride=stride, tapstep=tapstep, padL=padL, pad_mode=pad_mode, Cout_store=Cout)
     if out is None and not want_stats:
-        return K.conv_gemm_out(a.t, w2d, (S, Cout, Tout), y_ctot=Cout, y_coff=0, **kw), None
+        return K.conv_gemm_out(a.t, w2d, (S, Cout, Tout), y_ctot=Cout, y_coff=0, **kw, max_wg=max_wg), None
     y = out if out is not None else _new((S, Cout, Tout), a.t)
-    stat = K.conv_gemm(a.t, w2d, y, want_stats=want_stats, y_ctot=y.shape[1], y_coff=out_coff, **kw)
+    stat = K.conv_gemm(a.t, w2d, y, want_stats=want_stats, y_ctot=y.shape[1], y_coff=out_coff, **kw, max_wg=max_wg)
     return y, stat
 
 
-def conv_dgrad(dy, w_nat, *, R, O, k, stride, Tin, padL, padR, s_red, s_out, s_k):
+def conv_dgrad(dy, w_nat, *, R, O, k, stride, Tin, padL, padR, s_red, s_out, s_k, max_wg=0):
     """Data-gradient of a (strided) conv in *padded* coordinates: (S, O, Tin+padL+padR).
     dXpad[s,o,u] = sum_{red,kk} W[red,o,kk] * dy[s,red,(u-kk)/stride]  (phase decomposition)."""
     S, _, Tg = dy.shape
@@ -145,21 +150,21 @@ def conv_dgrad(dy, w_nat, *, R, O, k, stride, Tin, padL, padR, s_red, s_out, s_k
     # (split-K launches -- the wide heads' data gradients, decoder layers whose tiles do not fill whole rounds -- add into a
     #  zeroed output: it comes out of the step's zero arena, K.conv_gemm_out)
     return K.conv_gemm_out(dy, None, (S, O, Tp), wt=wt, S=S, Cin=R, Tin=Tg, M=stride * O, K=R * taps_p, taps=taps_p, Ncols=Ncols,
-                           Tout=Tp, stride=1, tapstep=-1, padL=0, pad_mode=K.PAD_ZERO, Cout_store=O, ps=stride, poff=0)
+                           Tout=Tp, stride=1, tapstep=-1, padL=0, pad_mode=K.PAD_ZERO, Cout_store=O, ps=stride, poff=0, max_wg=max_wg)
 
 
 def conv_wgrad(dy, a: Act, dw2d, dbias, *, taps, stride=1, padL=0, pad_mode=K.PAD_ZERO, tap_major=0, tapstep=1,
-               g_ctot=None, g_coff=0, M=None, Ncols=None, g_alpha=None, dw_col_off=0):
+               g_ctot=None, g_coff=0, M=None, Ncols=None, g_alpha=None, dw_col_off=0, max_wg=0):
     S = a.S
     M = dy.shape[1] if M is None else M
     K.wgrad_gemm(dy, a.t, dw2d, S=S, M=M, Tg=dy.shape[2], Ncols=dy.shape[2] if Ncols is None else Ncols, Cin=a.C,
                  Tz=a.T, taps=taps, ldw=dw2d.shape[1], dbias=dbias, g_ctot=dy.shape[1] if g_ctot is None else g_ctot,
                  g_coff=g_coff, z_ctot=a.ctot, z_coff=a.coff, in_scale=a.scale, in_shift=a.shift, in_alpha=a.alpha,
                  tap_major=tap_major, stride=stride, tapstep=tapstep, padL=padL, pad_mode=pad_mode,
-                 g_alpha=g_alpha, dw_col_off=dw_col_off)
+                 g_alpha=g_alpha, dw_col_off=dw_col_off, max_wg=max_wg)
 
 
-def deconv_fwd(a: Act, w_nat, bias, *, Cout, k, stride):
+def deconv_fwd(a: Act, w_nat, bias, *, Cout, k, stride, max_wg=0):
     """nn.ConvTranspose1d(Cin, Cout, k, stride, padding=max(0,(stride-k)//-2)) (modules.py:567-575)."""
     S, Tin = a.S, a.T
     pad = max(0, (stride - k) // -2)
@@ -169,7 +174,7 @@ def deconv_fwd(a: Act, w_nat, bias, *, Cout, k, stride):
     return K.conv_gemm_out(a.t, None, (S, Cout, Tout), wt=wt, S=S, Cin=a.C, Tin=Tin, M=stride * Cout, K=a.C * taps_p,
                            taps=taps_p, Ncols=Tin + taps_p - 1, Tout=Tout, bias=bias, in_scale=a.scale, in_shift=a.shift,
                            in_alpha=a.alpha, x_ctot=a.ctot, x_coff=a.coff, stride=1, tapstep=-1, padL=0, pad_mode=K.PAD_ZERO,
-                           Cout_store=Cout, ps=stride, poff=-pad)
+                           Cout_store=Cout, ps=stride, poff=-pad, max_wg=max_wg)
 
 
 _NBT = None      # BatchNorm counters touched by the encoder forward in flight (one multi-tensor increment)
@@ -395,7 +400,7 @@ class EncoderCtx:
     pass
 
 
-def encoder_forward(fe, x, training, need_ctx=True):
+def encoder_forward(fe, x, training, need_ctx=True, max_wg=0):
     """WaveFe.forward on a (S,1,T) tensor (pase/models/frontend.py:234-279 minus the dict plumbing).
     Returns (emb (S,emb_dim,F), ctx)."""
     assert x.dim() == 3 and x.shape[1] == fe.num_inputs, x.shape
@@ -404,14 +409,14 @@ def encoder_forward(fe, x, training, need_ctx=True):
     global _NBT
     _NBT = []
     try:
-        return _encoder_forward(fe, x, training, S)
+        return _encoder_forward(fe, x, training, S, max_wg)
     finally:
         if _NBT:
             torch._foreach_add_(_NBT, 1)
         _NBT = None
 
 
-def _encoder_forward(fe, x, training, S):
+def _encoder_forward(fe, x, training, S, max_wg=0):
     ctx = EncoderCtx()
     ctx.x = x
     ctx.training = bool(training)
@@ -441,7 +446,7 @@ def _encoder_forward(fe, x, training, S):
         kind = norm_kind(getattr(blk, "norm", None))
         has_bn = kind == "bn"
         y, stat = conv_fwd(cur, w2d, bias, Cout=blk.fmaps, taps=taps, stride=st, padL=pL, padR=pR,
-                           pad_mode=K.PAD_REFLECT, want_stats=has_bn and training)
+                           pad_mode=K.PAD_REFLECT, want_stats=has_bn and training, max_wg=max_wg)
         if has_bn:
             if training:
                 scale, shift, mean, rstd = bn_train(stat, blk.fmaps, S * y.shape[2], blk.norm, x)
@@ -506,7 +511,7 @@ def _encoder_forward(fe, x, training, S):
         for li, layer in enumerate(layers):
             H = layer.hidden_size
             gates, _ = conv_fwd(rnn_in, layer.linear.weight, layer.linear.bias, Cout=3 * H, taps=2, tap_major=1,
-                                tapstep=-1, padL=0, padR=0, pad_mode=K.PAD_ZERO, Tout=F_)
+                                tapstep=-1, padL=0, padR=0, pad_mode=K.PAD_ZERO, Tout=F_, max_wg=max_wg)
             last = li == len(layers) - 1
             if last and skips:
                 h_t, h_ctot = acat, ccat
@@ -535,7 +540,7 @@ def _encoder_forward(fe, x, training, S):
         ain = rnn_in
     norm_out = fe.norm_out_mod
     yemb, stat = conv_fwd(ain, wcat, fe.W.bias, Cout=emb, taps=1,
-                          want_stats=(norm_kind(norm_out) == "bn" and training), Tout=F_)
+                          want_stats=(norm_kind(norm_out) == "bn" and training), Tout=F_, max_wg=max_wg)
     ctx.out_kind = norm_kind(norm_out)
     if ctx.out_kind == "bn":
         if training:
@@ -555,7 +560,7 @@ def _encoder_forward(fe, x, training, S):
     return out, ctx
 
 
-def encoder_backward(fe, ctx, demb, sink, want_dx=False, on_ready=None):
+def encoder_backward(fe, ctx, demb, sink, want_dx=False, on_ready=None, max_wg=0):
     """Accumulates d(loss)/d(param) into `sink` given demb = d(loss)/d(emb); with want_dx also returns
     d(loss)/d(input waveform) (S, num_inputs, T).  on_ready(tag): called as soon as a group of parameter gradients
     is final ON THE CURRENT STREAM -- "head" (W, dense-skip projections, QRNN), then each conv block index from the
@@ -585,7 +590,7 @@ def encoder_backward(fe, ctx, demb, sink, want_dx=False, on_ready=None):
     ccat = ain.C
     dwcat = _zeros((emb, ccat), x)
     wb_bias = sink.buf(fe.W.bias)        # (gradient buffers are taken on the forking stream: GradSink(direct=False) allocates)
-    on_wgrad_stream(x, lambda: conv_wgrad(dyemb, ain, dwcat, wb_bias, taps=1), keep=(dyemb, ain.t))
+    on_wgrad_stream(x, lambda: conv_wgrad(dyemb, ain, dwcat, wb_bias, taps=1, max_wg=max_wg), keep=(dyemb, ain.t))
     cw = fe.W.in_channels
     pairs = [(fe.W.weight, dwcat[:, :cw])]
     if fe.denseskips_on:
@@ -596,7 +601,7 @@ def encoder_backward(fe, ctx, demb, sink, want_dx=False, on_ready=None):
             off += c
     on_wgrad_stream(x, lambda: sink.add_many(pairs), keep=(dwcat,))
     dacat = conv_dgrad(dyemb, ctx.wcat, R=emb, O=ccat, k=1, stride=1, Tin=F_, padL=0, padR=0, s_red=ccat, s_out=1,
-                       s_k=1)  # (S, ccat, F)
+                       s_k=1, max_wg=max_wg)  # (S, ccat, F)
     # gradient w.r.t. the last block's activation
     dsrc, dsrc_ctot, dsrc_coff = dacat, ccat, 0
     # ---- QRNN stack --------------------------------------------------------------------------------
@@ -617,14 +622,14 @@ def encoder_backward(fe, ctx, demb, sink, want_dx=False, on_ready=None):
         dbq = sink.buf(layer.linear.bias)
 
         def wq(dgates=dgates, dg_next=dg_next, inp=inp, dwq=dwq, dbq=dbq, cin=cin):
-            conv_wgrad(dgates, inp, dwq, dbq, taps=1, padL=0, pad_mode=K.PAD_ZERO)
-            conv_wgrad(dg_next, inp, dwq, None, taps=1, padL=0, pad_mode=K.PAD_ZERO, dw_col_off=cin)
+            conv_wgrad(dgates, inp, dwq, dbq, taps=1, padL=0, pad_mode=K.PAD_ZERO, max_wg=max_wg)
+            conv_wgrad(dg_next, inp, dwq, None, taps=1, padL=0, pad_mode=K.PAD_ZERO, dw_col_off=cin, max_wg=max_wg)
         on_wgrad_stream(x, wq, keep=(dgates, dg_next, inp.t))
         # dX[s,ci,u] = sum_{o,r} Wq[o, r*cin+ci] * dG[s,o,u+r]
         wt = K.pack_dgrad_t(layer.linear.weight, R=3 * H, O=cin, k=2, st=1, s_red=2 * cin, s_out=1, s_k=cin)
         dxl = _new((S, cin, F_), x)
         K.conv_gemm(dgates, None, dxl, wt=wt, S=S, Cin=3 * H, Tin=F_, M=cin, K=3 * H * 2, taps=2, Ncols=F_, Tout=F_,
-                    stride=1, tapstep=1, padL=0, pad_mode=K.PAD_ZERO)
+                    stride=1, tapstep=1, padL=0, pad_mode=K.PAD_ZERO, max_wg=max_wg)
         dsrc, dsrc_ctot, dsrc_coff = dxl, cin, 0
     if on_ready is not None:
         join_wgrad_stream(x)
@@ -666,7 +671,7 @@ def encoder_backward(fe, ctx, demb, sink, want_dx=False, on_ready=None):
         if blk.sincnet:
             conv = blk.conv
             dfilt = _zeros((C, taps), x)
-            conv_wgrad(dy, inp, dfilt, None, taps=taps, stride=blk.stride, padL=rec["padL"], pad_mode=K.PAD_REFLECT)
+            conv_wgrad(dy, inp, dfilt, None, taps=taps, stride=blk.stride, padL=rec["padL"], pad_mode=K.PAD_REFLECT, max_wg=max_wg)
             dlow, dband = _new((C,), x), _new((C,), x)
             K.sinc_filters_bwd(conv.low_hz_, conv.band_hz_, conv.n_, conv.window_, dfilt, dlow, dband, C_=C, Kw=taps,
                                min_low=float(conv.min_low_hz), min_band=float(conv.min_band_hz),
@@ -679,7 +684,7 @@ def encoder_backward(fe, ctx, demb, sink, want_dx=False, on_ready=None):
 
             def wg(dy=dy, inp=inp, blk=blk, dwblk=dwblk, dbias=dbias, taps=taps, rec=rec, n=n):
                 conv_wgrad(dy, inp, dwblk, dbias, taps=taps, stride=blk.stride,
-                           padL=rec["padL"], pad_mode=K.PAD_REFLECT)
+                           padL=rec["padL"], pad_mode=K.PAD_REFLECT, max_wg=max_wg)
                 # (the fork event also covers the per-channel sums sink.add_cols committed above: a bucket handed over on
                 #  the side stream is complete)
                 if on_ready is not None and wside is not None:
@@ -693,7 +698,7 @@ def encoder_backward(fe, ctx, demb, sink, want_dx=False, on_ready=None):
             cin = inp.C
             w_nat = rec["filt"] if blk.sincnet else blk.conv.weight
             dsrc = conv_dgrad(dy, w_nat, R=C, O=cin, k=taps, stride=blk.stride, Tin=inp.T,
-                              padL=rec["padL"], padR=rec["padR"], s_red=cin * taps, s_out=taps, s_k=1)
+                              padL=rec["padL"], padR=rec["padR"], s_red=cin * taps, s_out=taps, s_k=1, max_wg=max_wg)
             dsrc_ctot, dsrc_coff = cin, 0
             dsrc_Tp, dsrc_padL, dsrc_mode = dsrc.shape[2], rec["padL"], K.PAD_REFLECT
     join_wgrad_stream(x)
@@ -736,7 +741,7 @@ class WorkerCtx:
     pass
 
 
-def worker_forward(layers, out_conv, a: Act, *, loss=None, want_pred=True):
+def worker_forward(layers, out_conv, a: Act, *, loss=None, want_pred=True, max_wg=0):
     """Forward of a Minion.  layers: list of GDeconv1DBlock / MLPBlock containers; out_conv: the final
     nn.Conv1d(hidden, num_outputs*r, 1).  loss: None or dict(name=<nn loss name>, r=<int|None>,
     target=<tensor>, weight=<float>) -> fused loss + d(loss*weight)/d(pred).
@@ -748,13 +753,13 @@ def worker_forward(layers, out_conv, a: Act, *, loss=None, want_pred=True):
     for blk in layers:
         if hasattr(blk, "deconv"):
             dc = blk.deconv
-            z = deconv_fwd(cur, dc.weight, dc.bias, Cout=dc.out_channels, k=blk.kwidth, stride=blk.stride)
+            z = deconv_fwd(cur, dc.weight, dc.bias, Cout=dc.out_channels, k=blk.kwidth, stride=blk.stride, max_wg=max_wg)
             ctx.recs.append(("deconv", blk, cur, z))
             cur = Act(z, C=dc.out_channels, alpha=blk.act.weight)
         else:
             k = blk.context
             z, _ = conv_fwd(cur, blk.W.weight.view(blk.fmaps, -1), blk.W.bias, Cout=blk.fmaps, taps=k, padL=k // 2,
-                            padR=k // 2, pad_mode=K.PAD_ZERO)
+                            padR=k // 2, pad_mode=K.PAD_ZERO, max_wg=max_wg)
             ctx.recs.append(("conv", blk, cur, z))
             cur = Act(z, C=blk.fmaps, alpha=blk.act.weight)
     ctx.last = cur
@@ -797,9 +802,9 @@ def worker_forward(layers, out_conv, a: Act, *, loss=None, want_pred=True):
         K.conv_gemm(cur.t, w2d, ctx.pred, S=B, Cin=cur.C, Tin=T, M=nout, K=cur.C, taps=1, Ncols=T, Tout=T,
                     bias=out_conv.bias, in_scale=cur.scale, in_shift=cur.shift, in_alpha=cur.alpha,
                     x_ctot=cur.ctot, x_coff=cur.coff, epilogue=K.EPI_MSE_CTX, label=tgt, grad_out=ctx.dpred,
-                    loss_acc=ctx.loss_acc, grad_scale=2.0 * gscale, r_ctx=r, label_D=tgt.shape[1])
+                    loss_acc=ctx.loss_acc, grad_scale=2.0 * gscale, r_ctx=r, label_D=tgt.shape[1], max_wg=max_wg)
         return ctx
-    pred, _ = conv_fwd(cur, w2d, out_conv.bias, Cout=nout, taps=1, Tout=T)
+    pred, _ = conv_fwd(cur, w2d, out_conv.bias, Cout=nout, taps=1, Tout=T, max_wg=max_wg)
     ctx.pred = pred
     if loss is not None:
         tgt = loss["target"].contiguous()
@@ -809,7 +814,7 @@ def worker_forward(layers, out_conv, a: Act, *, loss=None, want_pred=True):
     return ctx
 
 
-def worker_backward(layers, out_conv, ctx, dpred, sink, need_dinput=True):
+def worker_backward(layers, out_conv, ctx, dpred, sink, need_dinput=True, max_wg=0):
     """Backward of a Minion from dpred = d(loss)/d(pred).  Returns GradSrc for the worker input."""
     cur = ctx.last
     B, T = cur.S, cur.T
@@ -827,9 +832,9 @@ def worker_backward(layers, out_conv, ctx, dpred, sink, need_dinput=True):
     else:
         dpred = dpred.contiguous()
         dw_out, db_out = sink.buf(out_conv.weight).view(nout, -1), sink.buf(out_conv.bias)
-        on_wgrad_stream(x, lambda: conv_wgrad(dpred, cur, dw_out, db_out, taps=1), keep=(dpred, cur.t))
+        on_wgrad_stream(x, lambda: conv_wgrad(dpred, cur, dw_out, db_out, taps=1, max_wg=max_wg), keep=(dpred, cur.t))
         dsrc = GradSrc(conv_dgrad(dpred, out_conv.weight, R=nout, O=cur.C, k=1, stride=1, Tin=T, padL=0, padR=0,
-                                  s_red=cur.C, s_out=1, s_k=1), ctot=cur.C, Tp=T)
+                                  s_red=cur.C, s_out=1, s_k=1, max_wg=max_wg), ctot=cur.C, Tp=T)
         have_dz = False
     for kind, blk, inp, z in reversed(ctx.recs):
         C, Tz = z.shape[1], z.shape[2]
@@ -854,24 +859,24 @@ def worker_backward(layers, out_conv, ctx, dpred, sink, need_dinput=True):
             def wd(inp=inp, dz=dz, dw_dc=dw_dc, cin=cin, C=C, Tz=Tz, k=k, st=st, pad=pad):
                 K.wgrad_gemm(inp.t, dz, dw_dc, S=B, M=cin, Tg=inp.T, Ncols=inp.T, Cin=C,
                              Tz=Tz, taps=k, ldw=C * k, g_ctot=inp.ctot, g_coff=inp.coff, stride=st, tapstep=1, padL=pad,
-                             pad_mode=K.PAD_ZERO, g_alpha=inp.alpha)
+                             pad_mode=K.PAD_ZERO, g_alpha=inp.alpha, max_wg=max_wg)
             on_wgrad_stream(x, wd, keep=(inp.t, dz))
             last = blk is layers[0]
             if need_dinput or not last:
                 din, _ = conv_fwd(Act(dz, C=C), dc.weight.view(cin, -1), None, Cout=cin, taps=k, stride=st, padL=pad,
-                                  padR=pad, pad_mode=K.PAD_ZERO, Tout=inp.T)
+                                  padR=pad, pad_mode=K.PAD_ZERO, Tout=inp.T, max_wg=max_wg)
                 dsrc = GradSrc(din, ctot=cin, Tp=inp.T)
         else:
             k = blk.context
             cin = inp.C
             dw_blk = sink.buf(blk.W.weight).view(C, -1)
             on_wgrad_stream(x, lambda dz=dz, inp=inp, dw_blk=dw_blk, k=k: conv_wgrad(
-                dz, inp, dw_blk, None, taps=k, padL=k // 2, pad_mode=K.PAD_ZERO),
+                dz, inp, dw_blk, None, taps=k, padL=k // 2, pad_mode=K.PAD_ZERO, max_wg=max_wg),
                 keep=(dz, inp.t))
             last = blk is layers[0]
             if need_dinput or not last:
                 din = conv_dgrad(dz, blk.W.weight, R=C, O=cin, k=k, stride=1, Tin=inp.T, padL=k // 2, padR=k // 2,
-                                 s_red=cin * k, s_out=k, s_k=1)
+                                 s_red=cin * k, s_out=k, s_k=1, max_wg=max_wg)
                 dsrc = GradSrc(din, ctot=cin, Tp=din.shape[2], padL=k // 2)
     if len(ctx.recs) == 0 and ctx.head1:
         raise NotImplementedError("1-output worker without hidden layers")
@@ -879,7 +884,7 @@ def worker_backward(layers, out_conv, ctx, dpred, sink, need_dinput=True):
     return dsrc if need_dinput else None
 
 
-def mlp_group_step(workers, a: Act, targets, sink, accs=None):
+def mlp_group_step(workers, a: Act, targets, sink, accs=None, max_wg=0):
     """Forward + loss + backward of several one-hidden-layer MLP regression workers that read the
     SAME input (the chunk embedding): their first layers run as ONE stacked GEMM (9 x (256->256) ->
     one 2304-row launch instead of nine 100-workgroup launches), their input gradient as ONE dgrad,
@@ -893,7 +898,7 @@ def mlp_group_step(workers, a: Act, targets, sink, accs=None):
     htot = sum(hs)
     w1cat = torch.cat([w.blocks[0].W.weight.view(h, -1) for w, h in zip(workers, hs)], dim=0)
     b1cat = torch.cat([w.blocks[0].W.bias for w in workers], dim=0)
-    z_all, _ = conv_fwd(a, w1cat, b1cat, Cout=htot, taps=1, Tout=F_)
+    z_all, _ = conv_fwd(a, w1cat, b1cat, Cout=htot, taps=1, Tout=F_, max_wg=max_wg)
     dz_all = _new((B, htot, F_), x)
     out = {}
 
@@ -913,16 +918,16 @@ def mlp_group_step(workers, a: Act, targets, sink, accs=None):
         if loss.loss_name == "MSELoss" and r not in (None, 1):
             K.conv_gemm(z_all, w2d, None, S=B, Cin=h, Tin=F_, M=nout, K=h, taps=1, Ncols=F_, Tout=F_, bias=oc.bias,
                         in_alpha=cur.alpha, x_ctot=htot, x_coff=off, epilogue=K.EPI_MSE_CTX, label=tgt,
-                        grad_out=dpred, loss_acc=acc, grad_scale=2.0 * gscale, r_ctx=r, label_D=tgt.shape[1])
+                        grad_out=dpred, loss_acc=acc, grad_scale=2.0 * gscale, r_ctx=r, label_D=tgt.shape[1], max_wg=max_wg)
         else:
-            pred, _ = conv_fwd(cur, w2d, oc.bias, Cout=nout, taps=1, Tout=F_)
+            pred, _ = conv_fwd(cur, w2d, oc.bias, Cout=nout, taps=1, Tout=F_, max_wg=max_wg)
             K.ctx_loss(pred, tgt, dpred, acc, B=B, M=nout, F=F_, r_ctx=(r if r not in (None, 1) else 0),
                        label_D=tgt.shape[1], loss_type=LOSS_TYPES[loss.loss_name], grad_scale=gscale)
         out[w.name] = (acc, numel)
         # head backward (in line: forking the wide heads' weight gradients to the weight-gradient stream measured +0.9 ms per
         # step -- the narrow heads already run underneath the wide ones)
-        conv_wgrad(dpred, cur, sink.buf(oc.weight).view(nout, -1), sink.buf(oc.bias), taps=1)
-        dA = conv_dgrad(dpred, oc.weight, R=nout, O=h, k=1, stride=1, Tin=F_, padL=0, padR=0, s_red=h, s_out=1, s_k=1)
+        conv_wgrad(dpred, cur, sink.buf(oc.weight).view(nout, -1), sink.buf(oc.bias), taps=1, max_wg=max_wg)
+        dA = conv_dgrad(dpred, oc.weight, R=nout, O=h, k=1, stride=1, Tin=F_, padL=0, padR=0, s_red=h, s_out=1, s_k=1, max_wg=max_wg)
         _, sums = act_backward(z_all, C=h, T=F_, S=B, has_bn=False, alpha=blk.act.weight, dsrc=dA, dsrc_ctot=h, Tp=F_,
                                y_ctot=htot, y_coff=off, dy_out=dz_all)
         sink.add_cols(sums, 3, h, [(blk.act.weight, 2), (blk.W.bias, 0)])
@@ -954,7 +959,7 @@ def mlp_group_step(workers, a: Act, targets, sink, accs=None):
     # stacked first layer: one wgrad, one dgrad
     dw1 = _zeros((htot, cin), x)
 
-    conv_wgrad(dz_all, a, dw1, None, taps=1)
+    conv_wgrad(dz_all, a, dw1, None, taps=1, max_wg=max_wg)
     sink.add_many([(w.blocks[0].W.weight, dw1[off:off + h]) for w, h, off in zip(workers, hs, offs)])
-    dx = conv_dgrad(dz_all, w1cat, R=htot, O=cin, k=1, stride=1, Tin=F_, padL=0, padR=0, s_red=cin, s_out=1, s_k=1)
+    dx = conv_dgrad(dz_all, w1cat, R=htot, O=cin, k=1, stride=1, Tin=F_, padL=0, padR=0, s_red=cin, s_out=1, s_k=1, max_wg=max_wg)
     return out, dx

@@ -104,7 +104,7 @@ def _conv_desc(x, w, y, *, S, Cin, Tin, M, K, taps, Ncols, Tout, ldw=None, bias=
                x_ctot=None, x_coff=0, tap_major=0, stride=1, tapstep=1, padL=0, pad_mode=PAD_ZERO,
                y_ctot=None, y_coff=0, Cout_store=None, ps=1, poff=0,
                epilogue=EPI_STORE, label=None, grad_out=None, loss_acc=None, grad_scale=0.0,
-               r_ctx=0, label_D=0, tile_hint=0, splitk=0, post_op=0, post_scale=1.0, post_eps=0.0, wt=None):
+               r_ctx=0, label_D=0, tile_hint=0, splitk=0, post_op=0, post_scale=1.0, post_eps=0.0, wt=None, max_wg=0):
     d = PaseConvGemm()
     if wt is not None:
         d.wt, d.ldwt = _ptr(wt), wt.shape[1]
@@ -133,17 +133,17 @@ def _conv_desc(x, w, y, *, S, Cin, Tin, M, K, taps, Ncols, Tout, ldw=None, bias=
                 | (32 if os.environ.get("PASE_X6C_LEANEPI", "1") == "0" else 0)
                 | (64 if os.environ.get("PASE_X6C_BIASINIT", "1") == "0" else 0)
                 | ((int(os.environ.get("PASE_X6C_STAGGER", "0")) & 255) << 8))
-    d.max_wg = _max_wg()
+    d.max_wg = _max_wg(max_wg)
     return d
 
 
-MAX_WG = 0      # cap on the persistent grids of the split-bf16 kernels (0 = one workgroup per CU); the data-parallel trainer sets
-                # it to 256 - reserved CUs so that RCCL's channel kernels find free CUs beside the GEMMs
-
-
-def _max_wg():
+def _max_wg(max_wg):
+    """Cap on the persistent grid of a split-bf16 launch (PaseConvGemm::max_wg / PaseWgrad::max_wg; 0 = one workgroup per
+    CU).  It travels with the CALL -- the data-parallel trainer passes 256 - reserved CUs down the encoder backward so that
+    RCCL's channel kernels find free CUs beside the GEMMs -- never through module state.  PASE_X6C_MAXWG (tests: several items
+    per workgroup on small shapes) overrides it."""
     e = os.environ.get("PASE_X6C_MAXWG")
-    return int(e) if e else MAX_WG
+    return int(e) if e else int(max_wg or 0)
 
 
 def stat_tiles(*, M, S, Ncols, Cin, taps, stride=1, padL=0, tapstep=1, tile_hint=0):
@@ -401,7 +401,7 @@ def abi_check(l):
 
 def wgrad_gemm(g, z, dw, *, S, M, Tg, Ncols, Cin, Tz, taps, ldw=None, dbias=None, g_ctot=None, g_coff=0,
                z_ctot=None, z_coff=0, in_scale=None, in_shift=None, in_alpha=None, tap_major=0, stride=1,
-               tapstep=1, padL=0, pad_mode=PAD_ZERO, splitk=0, g_alpha=None, dw_col_off=0):
+               tapstep=1, padL=0, pad_mode=PAD_ZERO, splitk=0, g_alpha=None, dw_col_off=0, max_wg=0):
     d = PaseWgrad()
     d.g_alpha = _ptr(g_alpha)
     d.g, d.z, d.dw, d.dbias = _ptr(g), _ptr(z), _ptr(dw) + 4 * dw_col_off, _ptr(dbias)
@@ -422,7 +422,7 @@ def wgrad_gemm(g, z, dw, *, S, M, Tg, Ncols, Cin, Tz, taps, ldw=None, dbias=None
         d.x6 |= 512 if os.environ.get("PASE_X6C_NOVEC") else 0
         d.x6 |= 1024 if os.environ.get("PASE_SINC_X6", "1") == "0" else 0
         d.x6 |= (int(os.environ.get("PASE_X6C_TMKGS", "0")) & 7) << 12
-    d.max_wg = _max_wg()
+    d.max_wg = _max_wg(max_wg)
     global LAST_WGRAD_X6, LAST_WGRAD_KIND
     LAST_WGRAD_X6 = False
     LAST_WGRAD_KIND = 0

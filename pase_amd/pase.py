@@ -101,7 +101,7 @@ class pase(Model):
             labels[worker.name] = label
         return h, chunk, preds, labels
 
-    def _cls_step(self, emb, B, demb, sink, book):
+    def _cls_step(self, emb, B, demb, sink, book, max_wg=0):
         """Forward + loss + backward of the contrastive / classification workers (pase.py:345-354); their
         gradient w.r.t. the embeddings is accumulated into `demb`, their loss sums into `book`."""
         E, F_ = emb.shape[1], emb.shape[2]
@@ -122,8 +122,8 @@ class pase(Model):
                 wctx = engine.worker_forward(list(mn.blocks), mn.W, Act(xin, C=xin.shape[1]),
                                              loss=dict(name=loss.loss_name, r=loss.r, target=label,
                                                        weight=worker.loss_weight, acc=book.slot(worker.name)),
-                                             want_pred=False)
-                dsrc = engine.worker_backward(list(mn.blocks), mn.W, wctx, wctx.dpred, sink)
+                                             want_pred=False, max_wg=max_wg)
+                dsrc = engine.worker_backward(list(mn.blocks), mn.W, wctx, wctx.dpred, sink, max_wg=max_wg)
                 dx = dsrc.dense(xin.shape[1], 1)[:, :, 0]
                 pos, neg = dx[:B], dx[B:]
                 demb[:B, :, t] += pos[:, :E] + neg[:, :E]
@@ -140,8 +140,8 @@ class pase(Model):
                 wctx = engine.worker_forward(list(mn.blocks), mn.W, Act(xin, C=xin.shape[1]),
                                              loss=dict(name=loss.loss_name, r=loss.r, target=label,
                                                        weight=worker.loss_weight, acc=book.slot(worker.name)),
-                                             want_pred=False)
-                dsrc = engine.worker_backward(list(mn.blocks), mn.W, wctx, wctx.dpred, sink)
+                                             want_pred=False, max_wg=max_wg)
+                dsrc = engine.worker_backward(list(mn.blocks), mn.W, wctx, wctx.dpred, sink, max_wg=max_wg)
                 dx = dsrc.dense(xin.shape[1], 1)[:, :, 0]
                 ar = torch.arange(B, device=emb.device)
                 dv = demb[:B]          # (i, :, a_i) is unique per item; a_i == b_i is handled by the two statements
@@ -166,8 +166,8 @@ class pase(Model):
             wctx = engine.worker_forward(list(mn.blocks), mn.W, Act(win, C=2 * E),
                                          loss=dict(name=loss.loss_name, r=loss.r, target=label,
                                                    weight=worker.loss_weight, acc=book.slot(worker.name)),
-                                         want_pred=False)
-            dsrc = engine.worker_backward(list(mn.blocks), mn.W, wctx, wctx.dpred, sink)
+                                         want_pred=False, max_wg=max_wg)
+            dsrc = engine.worker_backward(list(mn.blocks), mn.W, wctx, wctx.dpred, sink, max_wg=max_wg)
             dx = dsrc.dense(2 * E, Tw)
             if worker.time_mean:
                 dx = (dx / F_).expand(nb, 2 * E, F_)
@@ -192,9 +192,14 @@ class pase(Model):
     # (what trainer.train_ -> model.forward -> backprop_scheduler._base_scheduler do through
     # autograd in the reference: trainer.py:229-232, worker_scheduler.py:43-75)
     # ------------------------------------------------------------------------------------------
-    def loss_and_grads(self, batch, sink=None, device=None, before_encoder_backward=None, on_encoder_grads=None):
+    def loss_and_grads(self, batch, sink=None, device=None, before_encoder_backward=None, on_encoder_grads=None,
+                       max_wg=0, encoder_backward_max_wg=None):
         """Returns {worker: loss_weight*loss, 'total': sum} (0-dim float64 device tensors) and
-        accumulates every parameter gradient into `sink` (default: param.grad)."""
+        accumulates every parameter gradient into `sink` (default: param.grad).
+        max_wg: cap on the persistent grids of the step's split-bf16 GEMM launches (0 = one workgroup per CU);
+        encoder_backward_max_wg: the cap for the encoder backward alone -- the data-parallel trainer leaves CUs to the
+        collectives that are in flight from `before_encoder_backward` on.  Both travel down the call path into each launch
+        descriptor (PaseConvGemm::max_wg / PaseWgrad::max_wg); there is no process-wide setting."""
         if sink is None:
             sink = engine.GradSink(direct=True)
         fe = self.frontend
@@ -204,7 +209,7 @@ class pase(Model):
         x = torch.cat([batch[k] for k in keys], dim=0)
         if device is not None:
             x = x.to(device)
-        emb, ectx = engine.encoder_forward(fe, x, training=fe.training)
+        emb, ectx = engine.encoder_forward(fe, x, training=fe.training, max_wg=max_wg)
         B = batch["chunk"].shape[0]
         E, F_ = emb.shape[1], emb.shape[2]
         demb = torch.zeros_like(emb)
@@ -229,11 +234,12 @@ class pase(Model):
             cls_stream.wait_event(main.record_event())
             with torch.cuda.stream(cls_stream):
                 demb_cls = torch.zeros_like(emb)
-                self._cls_step(emb, B, demb_cls, sink, book)
+                self._cls_step(emb, B, demb_cls, sink, book, max_wg)
         # one-hidden-layer MLP workers share their input: run their first layers stacked
         if group:
             tg = {w.name: (batch[w.name].to(device) if device is not None else batch[w.name]) for w in group}
-            res, dx = engine.mlp_group_step(group, Act(chunk, C=E), tg, sink, accs={w.name: book.slot(w.name) for w in group})
+            res, dx = engine.mlp_group_step(group, Act(chunk, C=E), tg, sink, accs={w.name: book.slot(w.name) for w in group},
+                                             max_wg=max_wg)
             demb[:B] += dx
             for w in group:
                 book.scale(w.name, w.loss_weight / res[w.name][1])
@@ -245,8 +251,8 @@ class pase(Model):
             wctx = engine.worker_forward(list(worker.blocks), worker.W, Act(chunk, C=E),
                                          loss=dict(name=loss.loss_name, r=loss.r, target=tgt,
                                                    weight=worker.loss_weight, acc=book.slot(worker.name)),
-                                         want_pred=False)
-            dsrc = engine.worker_backward(list(worker.blocks), worker.W, wctx, wctx.dpred, sink)
+                                         want_pred=False, max_wg=max_wg)
+            dsrc = engine.worker_backward(list(worker.blocks), worker.W, wctx, wctx.dpred, sink, max_wg=max_wg)
             demb[:B] += dsrc.dense(E, F_)
             book.scale(worker.name, worker.loss_weight / wctx.numel)
             del wctx, dsrc
@@ -254,9 +260,10 @@ class pase(Model):
             main.wait_event(cls_stream.record_event())
             demb += demb_cls
         else:
-            self._cls_step(emb, B, demb, sink, book)
+            self._cls_step(emb, B, demb, sink, book, max_wg)
         losses = book.finalize()
         if before_encoder_backward is not None:
             before_encoder_backward()   # all worker-head gradients are final here (DDP overlap point)
-        engine.encoder_backward(fe, ectx, demb, sink, on_ready=on_encoder_grads)
+        engine.encoder_backward(fe, ectx, demb, sink, on_ready=on_encoder_grads,
+                                max_wg=max_wg if encoder_backward_max_wg is None else encoder_backward_max_wg)
         return losses

@@ -222,9 +222,12 @@ class trainer(object):
         # gradients, before the encoder backward) to the join at the end of the step (_step_ddp); the forward and the heads'
         # backward run on all 256 CUs.  A single-process trainer with cfg reserve_cus > 0 keeps it on throughout.
         self.reserve_cus = int(self.cfg.get("reserve_cus", 32 if self.world > 1 else 0)) if hasattr(self, "cfg") else 0
-        if self.reserve_cus > 0 and self.world == 1:
-            from . import kernels as _K
-            _K.MAX_WG = max(1, 256 - self.reserve_cus)
+        ncu = 256
+        if pdev.type == "cuda":
+            ncu = int(torch.cuda.get_device_properties(pdev).multi_processor_count)
+        # the cap (workgroups) handed to the launches, 0 = none; it is an argument of loss_and_grads -> engine -> descriptor,
+        # not process state: two trainers in one process, or an exception in a step, cannot leak it into other launches
+        self._grid_cap = max(1, ncu - self.reserve_cus) if self.reserve_cus > 0 else 0
         if self.world > 1:
             self.broadcast_parameters()
 
@@ -350,7 +353,11 @@ class trainer(object):
             if self.world > 1 and not local_only:
                 losses = self._step_ddp(batch, sink, device)
             else:
-                losses = self.model.loss_and_grads(batch, sink, device)
+                # (single process with cfg reserve_cus > 0: capped throughout, or -- cfg reserve_scope = "encoder_backward" --
+                #  only where the data-parallel step caps it: what the reservation costs a step, measurable on one GPU)
+                bwd_only = self.cfg.get("reserve_scope", "step") == "encoder_backward"
+                losses = self.model.loss_and_grads(batch, sink, device, max_wg=0 if bwd_only else self._grid_cap,
+                                                   encoder_backward_max_wg=self._grid_cap if bwd_only else None)
                 self._step_all(1.0)
         finally:
             engine._ARENA = None
@@ -413,14 +420,13 @@ class trainer(object):
         t_host0 = time.perf_counter()
         ev_begin = torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True)) if diag is not None else None
 
-        from . import kernels as _K
-        cap = max(1, 256 - self.reserve_cus) if (use_side and self.reserve_cus > 0) else 0
+        # GEMMs of the encoder backward -- everything enqueued after the workers' bucket is handed over -- leave CUs to the
+        # collectives' kernels; the forward and the heads' backward keep the whole chip
+        cap = self._grid_cap if use_side else 0
 
         def launch(tag, bufs):
             if not bufs:
                 return
-            if cap:
-                _K.MAX_WG = cap            # GEMMs enqueued from here on leave CUs to the collectives' kernels
             if use_side:
                 ready = torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=diag is not None))
                 side.wait_event(ready)
@@ -436,13 +442,10 @@ class trainer(object):
                 for b in bufs:
                     self._allreduce(b)
 
-        try:
-            losses = model.loss_and_grads(
-                batch, sink, device, before_encoder_backward=lambda: launch("workers", [self._worker_grads]),
-                on_encoder_grads=lambda tag: launch(tag, [fg[b:e] for b, e in buckets.get(tag, [])]))
-        finally:
-            if cap:
-                _K.MAX_WG = 0
+        losses = model.loss_and_grads(
+            batch, sink, device, before_encoder_backward=lambda: launch("workers", [self._worker_grads]),
+            on_encoder_grads=lambda tag: launch(tag, [fg[b:e] for b, e in buckets.get(tag, [])]),
+            encoder_backward_max_wg=cap)
         if use_side:
             if diag is not None:
                 ev_bwd_end = torch.cuda.current_stream().record_event(torch.cuda.Event(enable_timing=True))

@@ -305,19 +305,43 @@ def test_bs32_ten_adam_steps_track(setup):
         assert 1.0 - LEN <= ratio <= 1.0 + LEN, (n, ratio)
 
 
+def _voiced_pool(rs, n, T):
+    """harmonic complexes with gliding f0 (70-280 Hz) + noise floor, an unvoiced noise stretch and a silent stretch each: signals
+    on which SWIPE' decides voiced AND unvoiced frames (white noise alone is unvoiced throughout: the prosody target would be a
+    constant row and its gate empty)"""
+    import numpy as np
+    t = np.arange(T) / 16000.0
+    out = []
+    for _ in range(n):
+        fa, fb = rs.uniform(70, 280, size=2)
+        f0 = fa + (fb - fa) * t / t[-1]
+        ph = 2 * np.pi * np.cumsum(f0) / 16000.0
+        x = 0.1 * sum(np.sin(k * ph) / k for k in range(1, 12)) + 0.003 * rs.standard_normal(T)
+        g0 = rs.randint(T // 4, T // 2)
+        x[g0:g0 + T // 8] = 0.02 * rs.standard_normal(T // 8)
+        x[:T // 40] = 0.0
+        out.append(x.clip(-1, 1).astype(np.float32))
+    return out
+
+
 def test_bs32_producer_mode_step(tmp_path):
     """BASELINE.json configs[3], the part one GPU can check: a bs32 step whose batch comes from the on-device producer
     (pase_amd/producer.py: crops + reverb / additive-noise chain + DSP regression targets, the data side of
     /root/reference/pase/dataset.py:430-520 + train.py:37-136) instead of given tensors.  Comparator: the SAME crops
-    through the numpy / scipy restatement of the target transforms (oracle/dsp_oracle.py; the f0 contour that feeds the
-    prosody target is the device tracker's -- its agreement with the SWIPE' restatement is tests/test_dsp.py's subject)
-    and the torch restatement of the step (oracle/pase_oracle.py).  Bar: every regression target within 2e-3 of its
-    range, all 13 losses within 2e-3 relative (the targets carry the DSP kernels' 1e-4-level differences into the
-    losses), total-loss gradient of every encoder block's conv weight within 1 % relative L2."""
+    through the numpy / scipy restatement of the target transforms (oracle/dsp_oracle.py) -- the prosody target from the
+    ORACLE's own SWIPE' contour (oracle/swipe_oracle.py, fp64), not from the device tracker's -- and the torch restatement of
+    the step (oracle/pase_oracle.py).  Three gates:
+      (a) targets: every regression target within 2e-3 of its range; prosody on the frames whose 9-frame delta window has
+          the same voicing decisions on both sides (agreement rate asserted inline), log-f0 rows within the 1.5 % f0
+          tolerance of tests/test_dsp.py, the f0-independent rows (voiced flag, energy, zero crossings) as tight as the others;
+      (b) losses: the HIP step on the producer's own batch against the comparator on the oracle's targets;
+      (c) gradients of EVERY parameter tensor, both sides on the same (oracle) labels, judged against an fp64 evaluation of
+          the step like the other full-size gates: ours <= 1.5 x torch-fp32 + floor."""
     import numpy as np
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from oracle import dsp_oracle as D
+    from oracle import swipe_oracle as SW
     from pase_amd import _lib, dsp, producer as PR
     from pase_amd.trainer import trainer
     _lib.use_library(None, "cuda")
@@ -326,7 +350,7 @@ def test_bs32_producer_mode_step(tmp_path):
     fe, wk, raw = _cfgs("pase+")
     Bp, Tp = 32, 32000
     rs = np.random.RandomState(77)
-    pool = PR.WavPool([(0.1 * rs.standard_normal(16000 * 5)).clip(-1, 1).astype(np.float32) for _ in range(40)], dev)
+    pool = PR.WavPool(_voiced_pool(rs, 40, 16000 * 5), dev)
     irs = [np.r_[np.zeros(40), 1.0, 0.3 * rs.standard_normal(7959) * np.exp(-np.arange(7959) / 1500.0)] for _ in range(4)]
     noises = [0.05 * rs.standard_normal(16000 * 6) for _ in range(4)]
     tg = dsp.DeviceTargets(raw, device=dev)
@@ -339,7 +363,7 @@ def test_bs32_producer_mode_step(tmp_path):
                                   PR.DeviceAdditive(noises, device=dev), 0.5, tg, rng=rs)
     batch = prod(Bp)
     assert batch["chunk"].shape == (Bp, 1, Tp) and not torch.equal(batch["chunk"], batch["cchunk"])
-    # ---- regression targets of the same clean crops on the CPU ------------------------------------------------------
+    # ---- (a) regression targets of the same clean crops on the CPU ---------------------------------------------------
     f0_dev = tg.feats["prosody"].tracker(batch["cchunk"]).cpu().numpy()
     fns = {"lps": D.lps, "fbank": D.fbanks, "gtn": D.gammatone, "mfcc": D.mfcc}
     clean = batch["cchunk"][:, 0].cpu().numpy()
@@ -349,20 +373,56 @@ def test_bs32_producer_mode_step(tmp_path):
         if name == "cchunk":
             continue
         kw = dict(w.get("transform", {}))
-        rows = []
+        rows, f0_or = [], []
         for b in range(Bp):
             if "prosody" in name:
-                X = D.prosody(clean[b], f0_dev[b], **kw)
+                f0_or.append(SW.swipe(clean[b].astype(np.float64))[:f0_dev.shape[1]])
+                X = D.prosody(clean[b], f0_or[-1], **kw)
             else:
                 X = next(fn for k_, fn in fns.items() if k_ in name)(clean[b], **kw)
             rows.append(D.znorm(np.asarray(X, dtype=np.float64), stats[name][0], stats[name][1]))
         ref = torch.from_numpy(np.stack(rows)).float().to(dev)
         assert ref.shape == batch[name].shape, (name, ref.shape, batch[name].shape)
-        span = float(ref.max() - ref.min())
-        bad = float(((batch[name] - ref).abs() > 2e-3 * span).float().mean())
-        # (log-power features of near-silent bins amplify round-off: a handful of elements may leave the band)
-        assert bad <= 1e-4, (name, bad, float((batch[name] - ref).abs().max()), span)
         ref_batch[name] = ref
+        span = float(ref.max() - ref.min())
+        err = (batch[name] - ref).abs()
+        if "prosody" not in name:
+            bad = float((err > 2e-3 * span).float().mean())
+            # (log-power features of near-silent bins amplify round-off: a handful of elements may leave the band)
+            assert bad <= 1e-4, (name, bad, float(err.max()), span)
+            continue
+        # prosody: the device SWIPE' against the oracle's, then the target on the frames both decide alike
+        f0_or = np.stack(f0_or)
+        Fp = ref.shape[2]
+        v_o, v_d = f0_or > 0, f0_dev > 0
+        agree = float((v_o == v_d).mean())
+        both = v_o & v_d
+        rel = np.abs(f0_dev[both] - f0_or[both]) / f0_or[both]
+        print("prosody: voicing agreement %.4f, voiced on both %.3f of the frames, f0 within 1.5 %% on %.4f of those, "
+              "median rel err %.2e" % (agree, float(both.mean()), float((rel <= 0.015).mean()), float(np.median(rel))))
+        assert both.mean() > 0.3 and (~v_o).mean() > 0.1, "the crops must have voiced AND unvoiced frames"
+        assert agree >= 0.99, agree
+        assert (rel <= 0.015).mean() >= 0.99 and np.median(rel) < 1e-3
+        # frames whose 9-frame Savitzky-Golay window (deltas) sees the same voicing decisions on both sides
+        same = (v_o == v_d)[:, :Fp].astype(np.float64)
+        win = np.stack([np.convolve(r_, np.ones(9), mode="same") for r_ in same]) >= 9 - 1e-9
+        win[:, :4] = False
+        win[:, -4:] = False        # (the 'interp' edge fit uses the first / last 9 frames)
+        for b in range(Bp):
+            win[b, :4] = win[b, -4:] = bool(same[b, :9].all()) and bool(same[b, -9:].all())
+        wmask = torch.from_numpy(win).to(dev)
+        assert float(wmask.float().mean()) >= 0.9
+        nrow = ref.shape[1] // 3                            # [lf0, voiced, energy, zcr] x (static, delta, delta-delta)
+        istd = torch.from_numpy(1.0 / stats[name][1]).to(dev)
+        for r_ in range(ref.shape[1]):
+            e = err[:, r_][wmask]
+            if r_ % nrow == 0:
+                # log-f0 (interpolated across unvoiced stretches from the neighbouring voiced frames): |d log f0| <= log(1.015)
+                # on >= 99 % of the compared frames, in z-normalised units
+                tol = float(np.log(1.015)) * float(istd[r_]) * (1.0 if r_ == 0 else 0.6)
+                assert float((e <= tol).float().mean()) >= 0.99, (r_, float(e.max()), tol)
+            else:
+                assert float((e > 2e-3 * span).float().mean()) <= 1e-3, (r_, float(e.max()), span)
     # ---- one step on both sides -------------------------------------------------------------------------------------
     torch.manual_seed(2)
     with contextlib.redirect_stdout(io.StringIO()):
@@ -371,18 +431,54 @@ def test_bs32_producer_mode_step(tmp_path):
     m = tr.model
     m.train()
     P = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
     names = [n for n, _ in m.named_parameters()]
     for n in names:
         P[n].requires_grad_(True)
+    # (b) losses: the producer's own batch (device targets) against the comparator on the oracle's targets
     for opt in tr.optimizers():
         opt.zero_grad()
     lf = {k: float(v) for k, v in m.loss_and_grads(batch).items()}
+    P0 = {k: v.detach().clone() for k, v in P.items()}
     lo, _ = _oracle_step(P, fe, raw, ref_batch)
     assert len(lo) == 13
-    for k, v in lo.items():
-        assert abs(lf[k] - v) <= 2e-3 * max(1.0, abs(v)), (k, lf[k], v)
+    rel_l = {k: abs(lf[k] - v) / max(1.0, abs(v)) for k, v in lo.items()}
+    print("producer-mode losses, relative difference:", {k: "%.1e" % v for k, v in rel_l.items()})
+    for k, v in rel_l.items():
+        # (the targets carry the DSP kernels' 1e-4-level differences into the losses; prosody additionally the frames on
+        #  which the two SWIPE' evaluations decide differently: <= 1 % of them, each worth O(1) in the voiced-flag row)
+        assert v <= (3e-2 if k in ("prosody", "total") else 1e-3), (k, lf[k], lo[k])
+    assert rel_l["total"] <= 2e-3, rel_l["total"]
+    # (c) gradients of every tensor on the SAME labels, judged against fp64 (as test_bs32_embedding_losses_and_elementwise_grads)
+    with torch.no_grad():
+        for k, v in m.state_dict().items():
+            v.copy_(sd0[k])
+    for opt in tr.optimizers():
+        opt.zero_grad()
+    m.loss_and_grads(ref_batch)
+    ref32 = {n: P[n].grad.detach().double().clone() for n in names}
+    P64 = {k: (v.detach().double() if v.is_floating_point() else v.detach().clone()) for k, v in P0.items()}
+    for n in names:
+        P64[n].requires_grad_(True)
+    _oracle_step(P64, fe, raw, {k: v.double() for k, v in ref_batch.items()})
+    bad, checked, skipped, stats_ = [], 0, [], []
     for n, p in m.named_parameters():
-        if n.startswith("frontend.blocks.") and n.endswith("conv.weight"):
-            ref = P[n].grad
-            rel2 = float((p.grad - ref).double().norm() / ref.double().norm())
-            assert rel2 <= 1e-2, (n, rel2)
+        if is_noise_grad(n):
+            continue
+        t64 = P64[n].grad
+        den = max(1e-300, float(t64.norm()))
+        e_ours = float((p.grad.double() - t64).norm()) / den
+        e_ref = float((ref32[n] - t64).norm()) / den
+        if e_ref >= 0.5:
+            skipped.append(n)
+            continue
+        per_channel = n.endswith(("norm.weight", "norm.bias", "act.weight", ".bias", "low_hz_", "band_hz_"))
+        floor = 1.5e-3 if per_channel else 5e-4
+        stats_.append((e_ours, n, e_ref))
+        if not e_ours <= 1.5 * e_ref + floor:
+            bad.append((n, "relL2 vs fp64: ours %.3e, torch fp32 %.3e" % (e_ours, e_ref)))
+        checked += 1
+    for r, n, rr in sorted(stats_, reverse=True)[:8]:
+        print("   relL2 vs fp64: ours %.3e  torch fp32 %.3e  %s" % (r, rr, n))
+    assert not bad, "%d tensors out of tolerance, first: %r" % (len(bad), bad[:3])
+    assert checked >= 100 and len(skipped) <= 4, (checked, skipped)

@@ -69,3 +69,68 @@ def test_encoder_block_launches_agree_between_the_pipes(gpu, name, Cin, Cout, k,
     Td = dx6.shape[-1]
     for sl in (slice(0, 16), slice(Td - 16, Td)):
         assert _rel(dx6[:, :, sl], dx32[:, :, sl]) < 3e-6, (name, "data-gradient edge", sl)
+
+
+def test_prelu_negative_slope_path_at_full_layer_size_vs_fp64(gpu):
+    """The PReLU negative-slope path with slopes != 1 at the size of the step's largest layer (block 0's output, 96 x 64 x
+    32 000), judged against fp64: the kink-free live-reference goldens (tests/test_pase_step.py `smooth`) set every slope to
+    1, so this is where a != 1 gets its tight gate.  Three consumers of a = PReLU(BN_train(y)) (modules.py:1073-1077):
+      * backward (pase_act_bwd_reduce / _apply): d/dy of  <g1, reflect-pad(a)> + <g2, mean-pool_160(a)>  -- block 1's data
+        gradient in padded coordinates (pads 9 / 10) folded back, merged with the pooled dense-skip gradient
+        (frontend.py:213-232) -- plus the three per-channel sums (d beta, d gamma, d alpha);
+      * forward on-load (conv_x6c staging: affine + PReLU applied while the operand is split): block 1's convolution;
+      * forward pooled (pase_bn_act_pool).
+    relative L2 <= 1e-6 against the fp64 evaluation of the same expressions (torch autograd in double on the same GPU)."""
+    import torch.nn.functional as F
+    torch.manual_seed(11)
+    C, T, pL, pR, d = 64, 32000, 9, 10, 160
+    gen = torch.Generator(device=gpu).manual_seed(5)
+    y = torch.randn(S, C, T, device=gpu, generator=gen)
+    gamma = torch.rand(C, device=gpu, generator=gen) * 0.6 + 0.7
+    beta = torch.randn(C, device=gpu, generator=gen) * 0.3
+    al = torch.rand(C, device=gpu, generator=gen) * 0.45 + 0.02          # slopes in (0.02, 0.47): a kink in every channel
+    g1 = torch.randn(S, C, T + pL + pR, device=gpu, generator=gen)
+    g2 = torch.randn(S, C, T // d, device=gpu, generator=gen)
+    # ---- fp64 truth -------------------------------------------------------------------------------------------------
+    y64 = y.double().requires_grad_(True)
+    ga64, be64, al64 = (t.double().requires_grad_(True) for t in (gamma, beta, al))
+    z = F.batch_norm(y64, None, None, ga64, be64, True, 0.1, 1e-5)
+    a64 = F.prelu(z, al64)
+    loss = (F.pad(a64, (pL, pR), mode="reflect") * g1.double()).sum() + (a64.view(S, C, T // d, d).mean(3) * g2.double()).sum()
+    loss.backward()
+    want_dy, want_db, want_dg, want_da = y64.grad, be64.grad, ga64.grad, al64.grad
+    pooled64 = a64.detach().view(S, C, T // d, d).mean(3)
+    w = torch.randn(64, C, 20, device=gpu, generator=gen) * 0.05
+    bias = torch.randn(64, device=gpu, generator=gen)
+    conv64 = F.conv1d(F.pad(a64.detach(), (pL, pR), mode="reflect"), w.double(), bias.double(), stride=10)
+    del z, a64, loss, y64
+    # ---- statistics the forward would have produced (fp64 -> fp32, as pase_bn_finalize hands them on) ----------------
+    mean = y.double().mean((0, 2))
+    var = y.double().var((0, 2), unbiased=False)
+    rstd = torch.rsqrt(var + 1e-5)
+    scale = (gamma.double() * rstd).float()
+    shift = (beta.double() - mean * gamma.double() * rstd).float()
+    mean, rstd = mean.float(), rstd.float()
+    # ---- backward ----------------------------------------------------------------------------------------------------
+    sums = torch.zeros(C, 3, dtype=torch.float64, device=gpu)
+    dy = torch.empty(S, C, T, device=gpu)
+    kw = dict(S=S, C_=C, T=T, dsrc=g1, Tp=T + pL + pR, padL=pL, pad_mode=K.PAD_REFLECT, dpool=g2, dpool_ctot=C, dpool_coff=0,
+              pool_F=T // d, pool_d=d, scale=scale, shift=shift, alpha=al, mean=mean, rstd=rstd, sums=sums, dy=dy, has_bn=1)
+    K.act_bwd_reduce(y, **kw)
+    K.act_bwd_apply(y, **kw)
+    torch.cuda.synchronize()
+    errs = dict(dy=_rel(dy, want_dy), dbeta=_rel(sums[:, 0], want_db), dgamma=_rel(sums[:, 1], want_dg),
+                dalpha=_rel(sums[:, 2], want_da))
+    del dy, want_dy
+    # ---- forward: on-load in the convolution's staging, and in the pooling pass --------------------------------------
+    a = Act(y, C=C, scale=scale, shift=shift, alpha=al)
+    for mode in (True, False):
+        K.X6 = mode
+        out, _ = E.conv_fwd(a, w.view(64, -1), bias, Cout=64, taps=20, stride=10, padL=pL, padR=pR, pad_mode=K.PAD_REFLECT)
+        errs["conv_onload_%s" % ("x6" if mode else "fp32pipe")] = _rel(out, conv64)
+    pooled = torch.empty(S, C, T // d, device=gpu)
+    K.bn_act_pool(y, pooled, scale, shift, al, S=S, C_=C, T=T, F=T // d, d=d, o_ctot=C, o_coff=0)
+    errs["pool"] = _rel(pooled, pooled64)
+    print("PReLU negative-slope path, relative L2 vs fp64:", {k: "%.2e" % v for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v <= 1e-6, (k, v)

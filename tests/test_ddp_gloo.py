@@ -262,13 +262,11 @@ def test_reserved_cus_let_a_side_stream_kernel_run_beside_a_persistent_gemm():
     if not sides:
         pytest.skip("every candidate side stream shares the main stream's hardware queue in this process")
 
-    def gemm():
-        K.conv_gemm(x, w, y, S=S, Cin=Cin, Tin=T, M=Cout, K=Cin * k, taps=k, Ncols=T, Tout=T, padL=5, pad_mode=K.PAD_REFLECT)
-
     def run(max_wg, side):
-        saved = K.MAX_WG
-        K.MAX_WG = max_wg
-        try:
+        def gemm():      # (the cap is an argument of the launch -- PaseConvGemm::max_wg -- not process state)
+            K.conv_gemm(x, w, y, S=S, Cin=Cin, Tin=T, M=Cout, K=Cin * k, taps=k, Ncols=T, Tout=T, padL=5, pad_mode=K.PAD_REFLECT,
+                        max_wg=max_wg)
+        if True:
             gemm()
             with torch.cuda.stream(side):          # (first use of a stream creates its hardware queue: not inside the timing)
                 small.add_(1.0)
@@ -284,8 +282,6 @@ def test_reserved_cus_let_a_side_stream_kernel_run_beside_a_persistent_gemm():
                 e_s1.record(side)
             torch.cuda.synchronize()
             return e_g0.elapsed_time(e_g1), e_g0.elapsed_time(e_s1)
-        finally:
-            K.MAX_WG = saved
     run(0, sides[0])                                # clocks / caches warm
     r224 = [run(224, sd) for sd in sides]
     assert K.LAST_PLAN_KIND == 2
