@@ -1177,6 +1177,14 @@ extern "C" int pase_conv_gemm_plan_kind(const PaseConvGemm* d) {
     return h.sinc ? 3 : (h.x6c ? 2 : 0);
 }
 
+// 1 when the descriptor's launch runs the STREAMED form of the split-bf16 convolution kernel (continuous stage stream across
+// a workgroup's items, accumulator tile drained from LDS by the staging waves: conv_x6c.hip, STREAM); reporting / tests only
+extern "C" int pase_conv_gemm_streamed(const PaseConvGemm* d) {
+    if (d->M <= 0 || d->K <= 0 || d->S <= 0 || d->Ncols <= 0 || d->K != d->Cin * d->taps) return 0;
+    const HostPlan h = make_plan(*d, d->wx6 != nullptr);
+    return (h.x6c && !h.sinc && h.c.stream) ? 1 : 0;
+}
+
 extern "C" long pase_conv_gemm_x6_bytes(const PaseConvGemm* d) {
     if (d->M <= 0 || d->K <= 0 || d->S <= 0 || d->Ncols <= 0 || d->K != d->Cin * d->taps) return 0;
     if (d->tapstep != 1 && d->tapstep != -1) return 0;

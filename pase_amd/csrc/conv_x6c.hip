@@ -325,9 +325,21 @@ __device__ __forceinline__ void x6c_vmwait_slots(int nslots, bool two_per_slot) 
 // NARROW (convolutions of at most 64 rows: block 1 of the encoder): workgroup tile 64 x 256, compute waves 2 (rows) x 2 (column
 // halves) -- the 128-row tile would spend half of every MFMA on zero rows.  Same wave tile (32 x 128), same loop; the stage
 // holds 256 + 64 positions (<320, 2>).
-template <int NPOS, int KGS_T, bool TM = false, bool ZP = false, bool NARROW = false>
+// STREAM (round 5; convolutions with a plain-store / BatchNorm-statistics or fused-MSE epilogue, no split-K, no pixel shuffle,
+// at least two stages per item): the two gaps of the persistent loop are closed.  (1) The staging waves run ONE continuous
+// stage stream across the items of the workgroup -- the next item's first stages are loaded / converted while the current item's
+// last stages are multiplied (geometry of the item being loaded and of the item being stored are separate state), so no item
+// starts with a prologue of 7 ... 16 k clocks during which the matrix core idles.  (2) The compute waves end an item by adding
+// their two accumulator sets and DUMPING the 128 x 128 fp32 tile into LDS (64 ds_write_b32 per lane) and go straight on to the
+// next item; the staging waves drain the tile to HBM one stage later -- bias, BatchNorm partial sums or the r-context MSE and
+// its gradient included -- beside the next item's MFMAs.  No barrier is added: the dump is published by the barrier that ends
+// the next item's first stage, the drain runs in that item's second stage, and the tile is free again before the item's last
+// barrier.  (tools/trace_x6c.py, round 4: the compute waves spent 8 ... 19 k clocks per item between the last MFMA of one tile
+// and the first of the next -- 13.6 k of a 38 k-clock item on the LPS heads.)
+template <int NPOS, int KGS_T, bool TM = false, bool ZP = false, bool NARROW = false, bool STREAM = false>
 __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6cPlan pl) {
     static_assert(!(NARROW && TM), "the 64 x 256 tile is a convolution tile");
+    static_assert(!(STREAM && (TM || NARROW)), "the streamed form is a 128 x 128 convolution tile");
     constexpr int WM = NARROW ? 2 : 4, WN = NARROW ? 2 : 1, NBT = 4;
     constexpr int BM = 32 * WM, BN = 32 * NBT * WN;
     constexpr int NPS = (NPOS + 127) / 128;        // position slots per thread and k-group
@@ -342,8 +354,13 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     constexpr int TR_FLOATS = 64 * 33;
     constexpr int TR_CHUNKS = TM ? (4 * TR_FLOATS * 4 + 15) / 16 : 0;
     // two stage buffers + the epilogue scratch (its own region: the next item's first stage is staged during the epilogue)
-    __shared__ __attribute__((aligned(16))) u32x4 Xs[2 * BUF + RED_CHUNKS + TR_CHUNKS];
+    // STREAM: the accumulator tile, [row][column] fp32 with a pitch of 136 floats (the two 32-lane halves of a compute wave
+    // write rows 4 apart: 4 * 136 floats = 32 banks apart; a drain lane reads 16 contiguous bytes of a row)
+    constexpr int TILE_P = 136;
+    constexpr int TILE_CHUNKS = STREAM ? BM * TILE_P * 4 / 16 : 0;
+    __shared__ __attribute__((aligned(16))) u32x4 Xs[2 * BUF + RED_CHUNKS + TR_CHUNKS + TILE_CHUNKS];
     float (*red)[BM][2] = reinterpret_cast<float (*)[BM][2]>(&Xs[2 * BUF]);
+    float* const acc_tile = reinterpret_cast<float*>(&Xs[2 * BUF + RED_CHUNKS + TR_CHUNKS]);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -413,6 +430,9 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     unsigned pos_valid = 0u, pos_inter = 0u;       // bit par * NPS + ps
     unsigned live = 0u, full = 0u;
     unsigned inter_slots = 0u;     // slots whose 64 positions (of this wave) are all in-range samples: no padding arithmetic
+    // STREAM: the loads run two stages ahead of the conversion ACROSS item boundaries -- the three wave-uniform masks above
+    // describe the item whose stages are being LOADED; these are the ones of the item whose stages are being CONVERTED
+    unsigned liveS = 0u, fullS = 0u, interS = 0u;
     // TM: per column (lane): channel row offset + tap offset (relative to the smallest tap offset), the tap offset itself,
     // on-load parameters, "all-ones column" flag (bias gradient); running column sums of the staged values (tmode 2)
     int t_koff[NPAR][NPS];
@@ -603,6 +623,9 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     };
     auto slot_live = [&](int kg, int ps) __attribute__((always_inline)) {
         return kg < KGS && ((live >> ((kg & (NPAR - 1)) * NPS + ps)) & 1u) != 0;
+    };
+    auto slot_live_s = [&](int kg, int ps) __attribute__((always_inline)) {      // ... of the item being converted
+        return kg < KGS && (((STREAM ? liveS : live) >> ((kg & (NPAR - 1)) * NPS + ps)) & 1u) != 0;
     };
     // TM: k-group (g, kg) -> sequence s, first position of this wave's octet; is every sample of the octet, for every tap,
     // an in-range sample of a real sequence (uniform)
@@ -826,8 +849,8 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * al[e];
         }
         // zero padding applies AFTER the transform (skipped when every lane of the wave holds real samples)
-        const bool all_inter = ((inter_slots >> (par * NPS + ps)) & 1u) != 0;             // uniform (as in load_slot)
-        const bool pos_full = ((full >> (par * NPS + ps)) & 1u) != 0;                     // uniform
+        const bool all_inter = (((STREAM ? interS : inter_slots) >> (par * NPS + ps)) & 1u) != 0;     // uniform (as in load_slot)
+        const bool pos_full = (((STREAM ? fullS : full) >> (par * NPS + ps)) & 1u) != 0;              // uniform
         if (!(all_inter && pos_full && chan_full)) {
             const int nch = pl.CinP - c0;                                                 // uniform
             const unsigned m = xmask[rs][sl] & (nch >= 8 ? 0xffu : nch > 0 ? (1u << nch) - 1u : 0u);
@@ -856,7 +879,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         };
         auto store_stage = [&](auto r_tag, int g, int bs) __attribute__((always_inline)) {
             pase_static_for<NSLOT>([&](auto sl) __attribute__((always_inline)) {
-                if (slot_live(decltype(sl)::value / NPS, decltype(sl)::value % NPS)) store_slot(r_tag, sl, g, bs);
+                if (slot_live_s(decltype(sl)::value / NPS, decltype(sl)::value % NPS)) store_slot(r_tag, sl, g, bs);
             });
         };
         int nlive = 0;                 // live slots of this wave for the current item: 8 * nlive loads per stage
@@ -882,6 +905,265 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             }
             return item;
         };
+
+        // ---- STREAM: the accumulator tile of a finished item, LDS -> HBM with the epilogue arithmetic, by the staging waves.
+        // Wave w (0 .. 3) takes tile rows 32 w .. 32 w + 31, two rows per pass: lanes 0-31 / 32-63 read 16 bytes each of one
+        // row (columns 4 (lane & 31) ..) -- a 512-byte contiguous run per row in LDS and, for interior tiles, in HBM.
+        //   PASE_EPI_STORE:   y = tile + bias, BatchNorm partial sums (sum, sum of squares over the valid columns of the
+        //                     row) straight into stat_part[column tile][row] -- a row lives in ONE half wave: no LDS, no barrier
+        //   PASE_EPI_MSE_CTX: rows m = d * r + j, target = label[b, d, t + j - r / 2] (zero outside the sequence), loss
+        //                     partial per wave -> one fp64 atomic, prediction and / or gradient stored
+        // (reference ops: nn.BatchNorm1d statistics of FeBlock modules.py:1073-1075; ContextualizedLoss losses.py:6-37)
+        float drain_lsum = 0.f;          // MSE: this lane's loss partial of the tile being drained (summed over its row chunks)
+        // rows [4 * c0, 4 * c1) of each wave's 32 (two rows per pass: `it` = 2 c .. ): the drain of a tile is spread over up to
+        // four ticks; `last`: the tile's final chunk (loss partial -> atomic)
+        auto drain_tile = [&](int item, int c0, int c1, bool last) __attribute__((always_inline)) {
+            if constexpr (STREAM) {
+            const int tl = xcd_swizzle(item, ntiles);
+            const int nt_ = tl / pl.n_row_tiles, mt_ = tl - nt_ * pl.n_row_tiles;
+            const int m0 = mt_ * BM, n0 = nt_ * BN;
+            const int cl = 4 * (lane & 31);
+            const int n = n0 + cl;                                    // first of this lane's four columns
+            // (sequence, position) of the four columns; `run`: all four are real columns of ONE sequence
+            int sq[4], qq[4];
+            bool okc[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                okc[e] = n + e < ntot;
+                const unsigned ne = (unsigned)(okc[e] ? n + e : 0);
+                sq[e] = (int)div_magic(ne, pl.ncols_magic);
+                qq[e] = (int)ne - sq[e] * p.Ncols;
+            }
+            const bool run = okc[3] && sq[3] == sq[0];
+            const float* tl_rows = acc_tile + (32 * (wave - 4) + (lane >> 5)) * TILE_P + cl;
+            const int mrow0 = m0 + 32 * (wave - 4) + (lane >> 5);
+            if (p.epilogue == PASE_EPI_STORE) {      // uniform
+                // output element offsets of the four columns (ps == 1): (s * y_ctot + y_coff) * Tout + q + poff, + m * Tout per row
+                size_t ob[4];
+                bool oko[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int pos = qq[e] + p.poff;
+                    oko[e] = okc[e] && pos >= 0 && pos < p.Tout;
+                    ob[e] = ((size_t)sq[e] * p.y_ctot + p.y_coff) * (size_t)p.Tout + (size_t)(oko[e] ? pos : 0);
+                }
+                const bool run_o = run && oko[0] && oko[3];
+                for (int c = c0; c < c1; ++c) {
+                    // four passes (eight rows of the wave) per group: their bias loads and LDS reads first
+                    float bv[4];
+                    X6cF4 t4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int it = 4 * c + i;
+                        const int m = mrow0 + 2 * it;
+                        bv[i] = (p.bias != nullptr && m < p.M) ? p.bias[m] : 0.f;
+                        t4[i] = *reinterpret_cast<const X6cF4*>(tl_rows + 2 * it * TILE_P);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int m = mrow0 + 2 * (4 * c + i);
+                        const bool mok = m < p.M;
+                        float v[4] = {t4[i].x + bv[i], t4[i].y + bv[i], t4[i].z + bv[i], t4[i].w + bv[i]};
+                        float* yr = p.y + (size_t)(mok ? m : 0) * (size_t)p.Tout;
+                        float s1 = 0.f, s2 = 0.f;
+                        if (mok) {
+                            if (run_o) {
+                                pase_store_run4(yr + ob[0], v);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    s1 += v[e];
+                                    s2 += v[e] * v[e];
+                                }
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (oko[e]) {
+                                        yr[ob[e]] = v[e];
+                                        s1 += v[e];
+                                        s2 += v[e] * v[e];
+                                    }
+                            }
+                        }
+                        if (p.stat_part != nullptr) {      // uniform
+                            s1 = pase_half_sum_lane31(s1);
+                            s2 = pase_half_sum_lane31(s2);
+                            if ((lane & 31) == 31 && mok) {
+                                float* dst = p.stat_part + ((size_t)nt_ * p.M + m) * 2;
+                                dst[0] = s1;
+                                dst[1] = s2;
+                            }
+                        }
+                    }
+                }
+            } else {      // PASE_EPI_MSE_CTX
+                const int half = p.r_ctx / 2;
+                size_t ob[4], lb[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ob[e] = (size_t)sq[e] * p.M * (size_t)p.Ncols + (size_t)qq[e];
+                    lb[e] = (size_t)sq[e] * p.label_D * (size_t)p.Ncols;
+                }
+                for (int c = c0; c < c1; ++c) {
+                    // the sixteen label loads, four bias loads and four LDS reads of the group first (one memory latency)
+                    float bv[4], tg[4][4];
+                    X6cF4 t4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int it = 4 * c + i;
+                        const int m = mrow0 + 2 * it;
+                        const bool mok = m < p.M;
+                        const int mm = mok ? m : 0;
+                        bv[i] = (p.bias != nullptr && mok) ? p.bias[mm] : 0.f;
+                        t4[i] = *reinterpret_cast<const X6cF4*>(tl_rows + 2 * it * TILE_P);
+                        const int d = (int)div_magic((unsigned)mm, pl.rctx_magic);
+                        const int jj = mm - d * p.r_ctx;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int tb = qq[e] - half + jj;
+                            tg[i][e] = 0.f;
+                            if (mok && okc[e] && (unsigned)tb < (unsigned)p.Ncols) tg[i][e] = p.label[lb[e] + (size_t)d * p.Ncols + tb];
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int m = mrow0 + 2 * (4 * c + i);
+                        const bool mok = m < p.M;
+                        const float tv[4] = {t4[i].x, t4[i].y, t4[i].z, t4[i].w};
+                        float pr[4], df[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            pr[e] = tv[e] + bv[i];
+                            df[e] = pr[e] - tg[i][e];
+                            if (mok && okc[e]) drain_lsum += df[e] * df[e];
+                            df[e] *= p.grad_scale;
+                        }
+                        const size_t ro = (size_t)(mok ? m : 0) * (size_t)p.Ncols;
+                        if (mok) {
+                            if (run) {
+                                if (p.y) pase_store_run4(p.y + ro + ob[0], pr);
+                                if (p.grad_out) pase_store_run4(p.grad_out + ro + ob[0], df);
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (okc[e]) {
+                                        if (p.y) p.y[ro + ob[e]] = pr[e];
+                                        if (p.grad_out) p.grad_out[ro + ob[e]] = df[e];
+                                    }
+                            }
+                        }
+                    }
+                }
+                if (last) {
+                    const float ls = pase_wave_sum64(drain_lsum);
+                    drain_lsum = 0.f;
+                    if (lane == 0) atomicAdd(p.loss_acc, (double)ls);
+                }
+            }
+            }
+        };
+        // a tile is drained in NCH chunks during the ticks 1 .. NCH of the item that follows it (NCH <= stages - 1: the tile is
+        // free again before the barrier that ends that item's last stage)
+        const int drain_nch = GS - 1 >= 4 ? 4 : (GS - 1 >= 2 ? 2 : 1);
+        const int drain_per = 4 / drain_nch;          // groups of eight rows per chunk
+
+        if constexpr (STREAM && !ZP) {
+            // ---- STREAM, operands split while they are staged (registers).  One stage per tick, three cursors along the
+            // workgroup's stage stream (items blockIdx.x, + gridDim.x, ...; every item has GS >= 2 stages, no split-K):
+            //   C  the stage the compute waves multiply during this tick (LDS buffer bsel),
+            //   S  = C + 1: waited for, converted and written to the other LDS buffer (register set (stream stage) mod 3),
+            //   L  = C + 3: its loads are issued into the register set C's stage left free one tick ago.
+            // Ticks -3 .. -1 fill the pipeline (the barrier that ends tick -1 is the compute waves' first barrier); an item
+            // boundary is nothing special for S and L except that each takes the next item's geometry when it crosses one --
+            // L by setup_item (live / full / inter_slots and the per-lane position arrays), S by copying the three uniform
+            // masks L holds at that moment (L entered the item two ticks earlier and, with >= 2 stages per item, has not left it).
+            const int NST = GS;
+            int itemL = (int)blockIdx.x - (int)gridDim.x, itemG = -1, giL = NST, nliveL = 0;
+            bool L_has = true;
+            int itemS = -1, giS = NST;
+            bool S_has = true;
+            int itemC = (int)blockIdx.x, giC = 0;
+            int setL = 0, setS = 0, c_last = 0, tile_item = -1;
+            bool finishing = false;
+            for (int v = -3;; ++v) {
+                if (!finishing) {
+                    // ---- S: stream stage v + 1
+                    if (v >= -1 && S_has) {
+                        if (giS == NST) {
+                            if (itemG != itemS) {
+                                itemS = itemG;
+                                giS = 0;
+                                liveS = live;
+                                fullS = full;
+                                interS = inter_slots;
+                            } else {
+                                S_has = false;
+                            }
+                        }
+                        if (S_has) {
+                            X6C_T0();
+                            x6c_vmwait_slots(c_last, false);       // everything but the loads of stream stage v + 2 has landed
+                            const int bs = v >= 0 ? (bsel ^ 1) : bsel;
+                            if (setS == 0) store_stage(std::integral_constant<int, 0>{}, giS, bs);
+                            else if (setS == 1) store_stage(std::integral_constant<int, 1>{}, giS, bs);
+                            else store_stage(std::integral_constant<int, 2>{}, giS, bs);
+                            setS = setS == 2 ? 0 : setS + 1;
+                            ++giS;
+                            if (wave == 4) X6C_TACC(11);
+                        }
+                    }
+                    // ---- L: stream stage v + 3
+                    if (L_has && giL == NST) {
+                        itemL += (int)gridDim.x;
+                        if (itemL < nitems) {
+                            setup_item(itemL);
+                            itemG = itemL;
+                            giL = 0;
+                            nliveL = 0;
+                            pase_static_for<NSLOT>([&](auto sl) __attribute__((always_inline)) {
+                                if (slot_live(decltype(sl)::value / NPS, decltype(sl)::value % NPS)) ++nliveL;
+                            });
+                        } else {
+                            L_has = false;
+                        }
+                    }
+                    if (L_has) {
+                        if (setL == 0) load_stage(std::integral_constant<int, 0>{}, giL);
+                        else if (setL == 1) load_stage(std::integral_constant<int, 1>{}, giL);
+                        else load_stage(std::integral_constant<int, 2>{}, giL);
+                        setL = setL == 2 ? 0 : setL + 1;
+                        ++giL;
+                        c_last = nliveL;
+                    } else {
+                        c_last = 0;
+                    }
+                }
+                // ---- the previous item's accumulator tile: published by the barrier that ended this item's first stage
+                if (tile_item >= 0 && (finishing || (v >= 0 && giC >= 1 && giC <= drain_nch))) {
+                    X6C_T0();
+                    const int c0 = finishing ? 0 : (giC - 1) * drain_per, c1 = finishing ? 4 : giC * drain_per;
+                    drain_tile(tile_item, c0, c1, c1 == 4);
+                    if (c1 == 4) tile_item = -1;
+                    if (wave == 4) X6C_TACC(8);
+                }
+                if (finishing) break;
+                if (v >= -1) __syncthreads();
+                if (v >= 0) {
+                    bsel ^= 1;
+                    if (++giC == NST) {
+                        if (wave == 4) X6C_STAMP(6);
+                        X6C_TRACE_NEXT();
+                        tile_item = itemC;
+                        itemC += (int)gridDim.x;
+                        giC = 0;
+                        if (itemC >= nitems) {
+                            finishing = true;
+                            __syncthreads();       // the compute waves have dumped the last item's accumulators
+                        }
+                    }
+                }
+            }
+            return;
+        }
         const bool spectrum = p.post_op == PASE_POST_POW || p.post_op == PASE_POST_LOGPOW || p.post_op == PASE_POST_MAG;
         const bool epi_barrier = TM ? false : (p.epilogue == PASE_EPI_STORE ? (!spectrum && p.stat_part != nullptr) : true);
 #ifndef PASE_X6C_NODL     // (A/B builds, tools/ab_build.sh: the pre-split operands through registers as until round 4)
@@ -917,6 +1199,58 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                     }
                 });
             };
+
+            if constexpr (STREAM) {
+                // ---- STREAM, pre-split activation copied by LDS DMA: one cursor N = C + 1 (the stage published by this tick's
+                // barrier), same tick / drain structure as the register form above
+                const int NST = GS;
+                int itemN = (int)blockIdx.x - (int)gridDim.x, giN = NST;
+                bool N_has = true;
+                int itemC = (int)blockIdx.x, giC = 0, tile_item = -1;
+                bool finishing = false;
+                for (int v = -1;; ++v) {
+                    if (!finishing) {
+                        if (N_has && giN == NST) {
+                            itemN += (int)gridDim.x;
+                            if (itemN < nitems) {
+                                setup_item(itemN);
+                                giN = 0;
+                            } else {
+                                N_has = false;
+                            }
+                        }
+                        if (N_has) {
+                            direct_stage(giN, v >= 0 ? (bsel ^ 1) : bsel);
+                            ++giN;
+                        }
+                    }
+                    if (tile_item >= 0 && (finishing || (v >= 0 && giC >= 1 && giC <= drain_nch))) {
+                        X6C_T0();
+                        const int c0 = finishing ? 0 : (giC - 1) * drain_per, c1 = finishing ? 4 : giC * drain_per;
+                        drain_tile(tile_item, c0, c1, c1 == 4);
+                        if (c1 == 4) tile_item = -1;
+                        if (wave == 4) X6C_TACC(8);
+                    }
+                    if (finishing) break;
+                    x6c_vm_drain();
+                    __syncthreads();
+                    if (v >= 0) {
+                        bsel ^= 1;
+                        if (++giC == NST) {
+                            if (wave == 4) X6C_STAMP(6);
+                            X6C_TRACE_NEXT();
+                            tile_item = itemC;
+                            itemC += (int)gridDim.x;
+                            giC = 0;
+                            if (itemC >= nitems) {
+                                finishing = true;
+                                __syncthreads();
+                            }
+                        }
+                    }
+                }
+                return;
+            }
             auto prologue_dl = [&](int item) __attribute__((always_inline)) {
                 if (wave == 4) X6C_STAMP(4);
                 setup_item(item);
@@ -1028,6 +1362,21 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         return;
     }
 
+  // (accumulators live across the item loop: STREAM dumps an item's sums at the START of the next item's turn, behind that
+  //  item's first two weight-fragment loads, so that those have landed when its first MFMA step wants them)
+  f32x16 accH[4], accS[4];
+  bool have_prev = false;
+  auto dump_tile = [&]() __attribute__((always_inline)) {
+      // STREAM: hh + (the five small terms) -> the LDS tile (D layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4
+      // (lane >> 5)); the staging waves drain it during the next item's second stage (drain_tile).  The tile is free: its
+      // previous content was drained before the barrier that ended the dumped item's last stage.
+      float* const td = acc_tile + (wm * 32 + 4 * fk) * TILE_P + fr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+              td[((r & 3) + 8 * (r >> 2)) * TILE_P + 32 * j] = accH[j][r] + accS[j][r];
+  };
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     // ---- tile decode -----------------------------------------------------------------------
     const int split = item / ntiles;
@@ -1064,12 +1413,12 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     // issued here, a barrier and two weight-fragment loads before they are needed.  In the epilogue the same 16 values cost
     // 2.9 k clocks per tile -- a load there waits behind whatever the memory pipeline holds at that point, and the compute
     // wave is alone on its SIMD: nothing hides it (tools/trace_x6c.py, `qrnn` against `qrnn_nb`).
-    f32x16 accH[NBT], accS[NBT];
-    {
+    static_assert(NBT == 4, "accumulators are declared for four B tiles");
+    if constexpr (!STREAM) {
         float binit[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) binit[r] = 0.f;
-        if (!TM && bias_init && split == 0) {      // uniform
+        if (!TM && !STREAM && bias_init && split == 0) {      // uniform (STREAM: the drain adds the bias)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 32 + 4 * fk + (r & 3) + 8 * (r >> 2);
@@ -1245,6 +1594,20 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
 #endif
     load_a(a0);
     load_a(a1);
+    if constexpr (STREAM) {
+        // the previous item's accumulators -> LDS tile, then zero (the drain adds the bias)
+        if (have_prev) {
+            dump_tile();
+            if (wave == 0) X6C_STAMP(3);
+        }
+#pragma unroll
+        for (int j = 0; j < NBT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                accH[j][r] = 0.f;
+                accS[j][r] = 0.f;
+            }
+    }
 #ifdef PASE_X6C_A3        // A/B builds: weight-gradient fragments THREE steps ahead (four register sets)
     constexpr bool A3 = TM;
 #else
@@ -1280,7 +1643,9 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         done = last;
     };
 #else
-    __syncthreads();
+    // (STREAM: only the workgroup's first item starts behind a barrier -- every later item's first stage was published by the
+    //  barrier that ended the previous item's last stage)
+    if (!STREAM || item == (int)blockIdx.x) __syncthreads();
     if (wave == 0) X6C_STAMP(1);
     // step bookkeeping in increments (no multiplies, four scalar counters): chunk offset of the step's fragments inside Xs,
     // taps left in the k-group, steps left in the stage, stages left in the item
@@ -1334,6 +1699,11 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     }
 
     if (wave == 0) X6C_STAMP(2);
+    if constexpr (STREAM) {
+        have_prev = true;        // dumped at the start of the next item's turn, or behind the loop
+        X6C_TRACE_NEXT();
+        continue;
+    }
     // ---- accumulators: hh + (the five small terms) -------------------------------------------------------
     // From here on the descriptor is read through the kernel-argument segment again (`p` is the first argument): the two
     // dozen fields only the epilogue needs then do not occupy scalar registers during the main loop (the compiler loads
@@ -1783,6 +2153,10 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     if (wave == 0) X6C_STAMP(3);
     X6C_TRACE_NEXT();
   }   // items
+  if constexpr (STREAM) {
+      if (have_prev) dump_tile();
+      __syncthreads();      // the staging waves drain the last item's tile behind this barrier
+  }
 }
 
 #ifdef PASE_X6C_TRACE
@@ -2159,6 +2533,19 @@ bool pase_x6c_plan(const PaseConvGemm& p, PaseX6cPlan& pl) {
         splitk = (GS + g_per - 1) / g_per;
     }
     pl.splitk = splitk;
+    // The streamed form (conv_x6c_kernel<..., STREAM>): 128 x 128 tiles, one split, at least two stages per item (the
+    // staging waves' load and store cursors then never span more than two items), and an epilogue the drain implements --
+    // plain stores (+ BatchNorm partial sums) without pixel shuffle or post-op, or the r-context MSE.  x6_ctl bit 7 forbids
+    // it (A/B measurements, tests of the unstreamed form).
+    {
+        const bool epi_ok = p.epilogue == PASE_EPI_MSE_CTX ||
+                            (p.epilogue == PASE_EPI_STORE && p.ps == 1 && p.post_op == PASE_POST_NONE);
+        bool ok = !narrow && epi_ok && splitk == 1 && GS >= 2 && !(p.x6_ctl & 128);
+#if defined(PASE_X6C_NODL) || defined(PASE_X6C_OLDLOOP) || defined(PASE_X6C_EARLYPRO)
+        ok = false;      // A/B builds of the unstreamed loop's variants
+#endif
+        pl.stream = ok ? 1 : 0;
+    }
     return true;
 }
 
@@ -2182,6 +2569,12 @@ int pase_x6c_launch(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st
     const dim3 grid((unsigned)nwg), block(NT);
     if (pl.WM == 2) {
         PASE_LAUNCH((conv_x6c_kernel<320, 2, false, false, true>), grid, block, st, p, pl);
+    } else if (pl.stream) {
+        if (pl.xp) {
+            if (pl.A == 1) PASE_LAUNCH((conv_x6c_kernel<128, 3, false, true, false, true>), grid, block, st, p, pl);
+            else PASE_LAUNCH((conv_x6c_kernel<192, 2, false, true, false, true>), grid, block, st, p, pl);
+        } else if (pl.A == 1) PASE_LAUNCH((conv_x6c_kernel<128, 3, false, false, false, true>), grid, block, st, p, pl);
+        else PASE_LAUNCH((conv_x6c_kernel<192, 2, false, false, false, true>), grid, block, st, p, pl);
     } else if (pl.xp) {
         if (pl.A == 1) PASE_LAUNCH((conv_x6c_kernel<128, 3, false, true>), grid, block, st, p, pl);
         else PASE_LAUNCH((conv_x6c_kernel<192, 2, false, true>), grid, block, st, p, pl);

@@ -49,6 +49,8 @@ def declare(l):
     l.pase_conv_gemm_x6_bytes.restype = C.c_long
     l.pase_conv_gemm_plan_kind.argtypes = [C.POINTER(PaseConvGemm)]
     l.pase_conv_gemm_plan_kind.restype = C.c_int
+    l.pase_conv_gemm_streamed.argtypes = [C.POINTER(PaseConvGemm)]
+    l.pase_conv_gemm_streamed.restype = C.c_int
     l.pase_pack_x6.argtypes = [C.POINTER(PaseConvGemm), C.c_void_p]
     l.pase_pack_x6.restype = C.c_int
     l.pase_conv_gemm_xp_bytes.argtypes = [C.POINTER(PaseConvGemm)]
@@ -132,6 +134,7 @@ def _conv_desc(x, w, y, *, S, Cin, Tin, M, K, taps, Ncols, Tout, ldw=None, bias=
                 | (16 if os.environ.get("PASE_X6C_NARROW", "1") == "0" else 0)
                 | (32 if os.environ.get("PASE_X6C_LEANEPI", "1") == "0" else 0)
                 | (64 if os.environ.get("PASE_X6C_BIASINIT", "1") == "0" else 0)
+                | (128 if os.environ.get("PASE_X6C_STREAM", "1") == "0" else 0)
                 | ((int(os.environ.get("PASE_X6C_STAGGER", "0")) & 255) << 8))
     d.max_wg = _max_wg(max_wg)
     return d
@@ -199,6 +202,7 @@ LAST_WGRAD_X6 = None       # did the most recent wgrad_gemm launch run on the sp
 LAST_WGRAD_KIND = None     # ... and in which orientation (pase_wgrad_plan_kind: 0 fp32 pipe, 1 / 2 / 3)
 LAST_XP = None             # did the most recent conv_gemm launch stage a pre-split activation (pase_pack_xp)
 LAST_PLAN_KIND = None      # plan kind of the most recent conv_gemm launch (0 fp32 pipe, 2 split-bf16 x6c): tests / reports
+LAST_STREAMED = None       # ... and whether it ran the streamed form of that kernel (pase_conv_gemm_streamed)
 
 
 def pack_wt(w, *, M, K, Cin, taps, ldw=None, tap_major=0):
@@ -297,8 +301,9 @@ def conv_gemm(x, w, y, want_stats=False, y_zeroed=False, **kw):
     if d.splitk != 1 and not y_zeroed:
         if _lib.lib().pase_conv_gemm_splitk(C.byref(d)) > 1:
             y.zero_()
-    global LAST_PLAN_KIND
+    global LAST_PLAN_KIND, LAST_STREAMED
     LAST_PLAN_KIND = _lib.lib().pase_conv_gemm_plan_kind(C.byref(d))
+    LAST_STREAMED = bool(_lib.lib().pase_conv_gemm_streamed(C.byref(d)))
     _check(_lib.lib().pase_conv_gemm(C.byref(d), _stream()), "pase_conv_gemm")
     if ev0 is not None:
         GEMM_TIMER.stop("conv_gemm", 2.0 * d.S * d.Ncols * d.M * d.K, ev0,

@@ -426,3 +426,89 @@ def test_zero_padded_data_gradient_with_interior_and_edge_lanes(dev, S, Cin, Cou
                       s_out=k, s_k=1)
     assert K.LAST_PLAN_KIND == 2
     assert _rel(dx, xp.grad) < 1e-6
+
+
+# ---- the streamed form (conv_x6c_kernel<..., STREAM>): continuous stage stream + accumulator tile drained by the staging waves ----
+def _stream_case(dev, case):
+    """(reference fp64 output, callable that launches and returns (y, stat or None, extra))"""
+    torch.manual_seed(31)
+    if case in ("two-stages", "stride2", "one-by-one-ragged-cols", "slice-of-wider-output"):
+        Cin, Cout, k, stride, T, S = {"two-stages": (32, 130, 11, 1, 250, 3), "stride2": (24, 200, 11, 2, 420, 3),
+                                      "one-by-one-ragged-cols": (96, 200, 1, 1, 90, 5),
+                                      "slice-of-wider-output": (48, 70, 3, 1, 131, 4)}[case]
+        x = torch.randn(S, Cin, T)
+        w = torch.randn(Cout, Cin, k) * 0.2
+        b = torch.randn(Cout)
+        sc, sh, al = torch.rand(Cin) + 0.5, torch.randn(Cin) * 0.1, torch.rand(Cin) * 0.5
+        P = (0, 0) if k == 1 else ((k // 2 - 1, k // 2) if (stride > 1 or k % 2 == 0) else (k // 2, k // 2))
+        xin = _xf(x, sc, sh, al)
+        ref = F.conv1d(F.pad(xin, P, mode="reflect") if k > 1 else xin, w.double(), b.double(), stride=stride)
+        Tout = ref.shape[2]
+        wide = case == "slice-of-wider-output"
+
+        def run():
+            y = torch.full((S, Cout + (5 if wide else 0), Tout), 7.0, device=dev)
+            stat = K.conv_gemm(x.to(dev), w.reshape(Cout, -1).contiguous().to(dev), y, want_stats=not wide, S=S, Cin=Cin, Tin=T,
+                               M=Cout, K=Cin * k, taps=k, Ncols=Tout, Tout=Tout, bias=b.to(dev), stride=stride, padL=P[0],
+                               pad_mode=K.PAD_REFLECT if k > 1 else K.PAD_ZERO, in_scale=sc.to(dev), in_shift=sh.to(dev),
+                               in_alpha=al.to(dev), y_ctot=Cout + (5 if wide else 0), y_coff=3 if wide else 0, Cout_store=Cout)
+            if wide:
+                assert float((y[:, :3] - 7.0).abs().max()) == 0.0 and float((y[:, 3 + Cout:] - 7.0).abs().max()) == 0.0
+                return y[:, 3:3 + Cout], None, None
+            return y, stat, None
+        return ref, run
+    # fused r-context MSE: ragged last row tile (D * r = 623 rows), 90 columns per sequence (column quads straddle
+    # sequences), prediction AND gradient stored
+    B, D, r, Fr, Ck = 3, 89, 7, 90, 768
+    M = D * r
+    h = torch.randn(B, Ck, Fr)
+    w3 = torch.randn(M, Ck) * 0.1
+    b3 = torch.randn(M)
+    lab = torch.randn(B, D, Fr)
+    pred = torch.einsum("mk,bkt->bmt", w3.double(), h.double()) + b3.double()[None, :, None]
+    padded = F.pad(lab.double(), (r // 2, r // 2))
+    tgt = torch.stack([padded[:, :, t:t + r].reshape(B, -1) for t in range(Fr)], 2)
+
+    def run():
+        g = torch.zeros(B, M, Fr, device=dev)
+        yp = torch.zeros(B, M, Fr, device=dev)
+        acc = torch.zeros(1, dtype=torch.float64, device=dev)
+        K.conv_gemm(h.to(dev), w3.to(dev), yp, S=B, Cin=Ck, Tin=Fr, M=M, K=Ck, taps=1, Ncols=Fr, Tout=Fr, bias=b3.to(dev),
+                    epilogue=K.EPI_MSE_CTX, label=lab.to(dev), grad_out=g, loss_acc=acc, grad_scale=0.5, r_ctx=r, label_D=D)
+        return yp, None, (g, acc)
+    return (pred, tgt), run
+
+
+@pytest.mark.parametrize("maxwg", [1, 2, 3, 0])
+@pytest.mark.parametrize("case", ["two-stages", "stride2", "one-by-one-ragged-cols", "slice-of-wider-output", "mse-ragged"])
+def test_streamed_form_matches_fp64_and_the_unstreamed_form(dev, monkeypatch, case, maxwg):
+    """Every eligible launch runs the streamed form by default; here with 1, 2, 3 workgroups (every workgroup walks several
+    items: the load / store / compute cursors cross item boundaries, the tile is drained one stage later, uneven item
+    counts) and uncapped (one item per workgroup: first item = last item).  Shapes: exactly two stages per item (the
+    minimum), a strided layer, a 1x1 layer whose column quads straddle sequences (90 columns per sequence), a channel slice
+    of a wider output, and the fused MSE epilogue with a ragged row tile.  Checked against fp64 AND against the unstreamed
+    form (PaseConvGemm::x6_ctl bit 7) of the same library."""
+    if maxwg:
+        monkeypatch.setenv("PASE_X6C_MAXWG", str(maxwg))
+    ref, run = _stream_case(dev, case)
+    got = {}
+    for streamed in (True, False):
+        monkeypatch.setenv("PASE_X6C_STREAM", "1" if streamed else "0")
+        y, stat, extra = run()
+        assert K.LAST_PLAN_KIND == 2 and K.LAST_STREAMED == streamed
+        got[streamed] = (y.cpu(), None if stat is None else stat.cpu().double().sum(0), extra)
+    if case == "mse-ragged":
+        pred, tgt = ref
+        for streamed in (True, False):
+            y, _, (g, acc) = got[streamed]
+            want = float(((pred - tgt) ** 2).sum())
+            assert abs(float(acc) - want) <= 1e-6 * want, (streamed, float(acc), want)
+            assert _rel(y, pred) < 1e-6 and _rel(g, 0.5 * (pred - tgt)) < 2e-6, streamed
+        return
+    for streamed in (True, False):
+        y, st, _ = got[streamed]
+        assert _rel(y, ref) < 1e-6, (streamed, _rel(y, ref))
+        if st is not None:
+            torch.testing.assert_close(st[:, 0], ref.sum((0, 2)), rtol=1e-5, atol=1e-4)
+            torch.testing.assert_close(st[:, 1], (ref ** 2).sum((0, 2)), rtol=1e-5, atol=1e-4)
+    assert _rel(got[True][0], got[False][0].double()) < 5e-7
