@@ -490,6 +490,7 @@ def test_streamed_form_matches_fp64_and_the_unstreamed_form(dev, monkeypatch, ca
     form (PaseConvGemm::x6_ctl bit 7) of the same library."""
     if maxwg:
         monkeypatch.setenv("PASE_X6C_MAXWG", str(maxwg))
+    monkeypatch.setenv("PASE_X6C_FORCE", "1")       # (the 96-channel 1x1 case is routed to the fp32 pipe otherwise)
     ref, run = _stream_case(dev, case)
     got = {}
     for streamed in (True, False):
