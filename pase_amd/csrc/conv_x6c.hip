@@ -1111,21 +1111,41 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                             if (wave == 4) X6C_TACC(11);
                         }
                     }
-                    // ---- L: stream stage v + 3
-                    if (L_has && giL == NST) {
-                        itemL += (int)gridDim.x;
-                        if (itemL < nitems) {
-                            setup_item(itemL);
-                            itemG = itemL;
-                            giL = 0;
-                            nliveL = 0;
-                            pase_static_for<NSLOT>([&](auto sl) __attribute__((always_inline)) {
-                                if (slot_live(decltype(sl)::value / NPS, decltype(sl)::value % NPS)) ++nliveL;
-                            });
-                        } else {
-                            L_has = false;
-                        }
+                }
+                // ---- position arithmetic of the next item / the drain of the previous item's tile: big straight-line code with
+                // many live values.  NOTHING hidden may be in flight across it: the compiler believes the staging registers
+                // defined when their asm load was ISSUED, and where register pressure is high it splits live ranges with
+                // copies -- a copy of a register whose load has not landed keeps the old content (seen on the GPU in the first
+                // form of this loop: non-finite outputs at item boundaries while the emulator passed).  So: wait for
+                // everything (the loads of stream stage v + 2 were issued a whole tick ago), THEN run that code, and issue
+                // this tick's loads last.
+                const bool crossing = !finishing && L_has && giL == NST;
+                const bool drain_now = tile_item >= 0 && (finishing || (v >= 0 && giC >= 1 && giC <= drain_nch));
+                if (crossing || drain_now) x6c_vmwait<0>();
+                if (crossing) {
+                    itemL += (int)gridDim.x;
+                    if (itemL < nitems) {
+                        setup_item(itemL);
+                        itemG = itemL;
+                        giL = 0;
+                        nliveL = 0;
+                        pase_static_for<NSLOT>([&](auto sl) __attribute__((always_inline)) {
+                            if (slot_live(decltype(sl)::value / NPS, decltype(sl)::value % NPS)) ++nliveL;
+                        });
+                    } else {
+                        L_has = false;
                     }
+                }
+                // ---- the previous item's accumulator tile: published by the barrier that ended this item's first stage
+                if (drain_now) {
+                    X6C_T0();
+                    const int c0 = finishing ? 0 : (giC - 1) * drain_per, c1 = finishing ? 4 : giC * drain_per;
+                    drain_tile(tile_item, c0, c1, c1 == 4);
+                    if (c1 == 4) tile_item = -1;
+                    if (wave == 4) X6C_TACC(8);
+                }
+                // ---- L: stream stage v + 3
+                if (!finishing) {
                     if (L_has) {
                         if (setL == 0) load_stage(std::integral_constant<int, 0>{}, giL);
                         else if (setL == 1) load_stage(std::integral_constant<int, 1>{}, giL);
@@ -1136,14 +1156,6 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                     } else {
                         c_last = 0;
                     }
-                }
-                // ---- the previous item's accumulator tile: published by the barrier that ended this item's first stage
-                if (tile_item >= 0 && (finishing || (v >= 0 && giC >= 1 && giC <= drain_nch))) {
-                    X6C_T0();
-                    const int c0 = finishing ? 0 : (giC - 1) * drain_per, c1 = finishing ? 4 : giC * drain_per;
-                    drain_tile(tile_item, c0, c1, c1 == 4);
-                    if (c1 == 4) tile_item = -1;
-                    if (wave == 4) X6C_TACC(8);
                 }
                 if (finishing) break;
                 if (v >= -1) __syncthreads();
