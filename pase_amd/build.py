@@ -109,6 +109,50 @@ def check_x6c_resources(res):
                            "(stale-register hazard, see check_x6c_resources): %r" % (bad,))
 
 
+def check_x6c_staging_isa(asm_text):
+    """ISA lint of conv_x6c.hip's hidden staging loads (x6c_gload: inline asm, destination considered defined at issue,
+    waited for by hand-counted s_waitcnt).  Every such load carries its register set in the asm text (`; staging set N`).
+    Each destination VGPR must belong to exactly ONE set in every kernel, and every set must have the same number of
+    destination registers: a load that lands in a temporary -- to be copied into its home register before the wait, i.e.
+    while the data is still in flight -- shows up as a destination shared between sets or as extra destinations.  (Round 5:
+    three identical asm statements in sibling branches were merged by the optimiser into one load + copies; the emulator
+    passed, the GPU returned stale registers.)"""
+    import re
+    kern, cur = {}, None
+    for line in asm_text.splitlines():
+        m = re.match(r"\s*\.type\s+(\S*conv_x6c_kernel\S*),@function", line)
+        if m:
+            cur = kern.setdefault(m.group(1), {})
+            continue
+        if cur is None:
+            continue
+        m = re.match(r"\s*global_load_dword(x4)?\s+v(\[)?(\d+)(?::(\d+)\])?,.*; staging set (\d+)", line)
+        if m:
+            lo = int(m.group(3))
+            hi = int(m.group(4)) if m.group(4) else lo
+            for r in range(lo, hi + 1):
+                cur.setdefault(r, set()).add(int(m.group(5)))
+    bad = []
+    checked = 0
+    for name, regs in kern.items():
+        if not regs:
+            continue
+        checked += 1
+        shared = sorted(r for r, sets in regs.items() if len(sets) > 1)
+        per_set = {}
+        for r, sets in regs.items():
+            for st in sets:
+                per_set[st] = per_set.get(st, 0) + 1
+        if shared or len(set(per_set.values())) > 1:
+            bad.append((name, "registers shared between sets: %r" % shared[:8], "destinations per set: %r" % per_set))
+    if checked == 0:
+        raise RuntimeError("build: no hidden staging load found in the conv_x6c assembly (asm text changed?)")
+    if bad:
+        raise RuntimeError("build: conv_x6c staging loads do not land in per-set home registers "
+                           "(stale-register hazard, see check_x6c_staging_isa): %r" % (bad,))
+    return checked
+
+
 def build_hip(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
     import json
@@ -135,6 +179,10 @@ def build_hip(force=False, verbose=False):
     aw_obj = os.path.join(CSRC, "conv_x6c.autowait.o")
     aw = subprocess.Popen([hipcc, "-c", x6c, "-o", aw_obj, "-DPASE_X6C_AUTOWAIT"] + cflags,
                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) if want_aw else None
+    # (in parallel as well: the device assembly of conv_x6c.hip for the staging-load lint; skipped with the autowait build)
+    lint_s = os.path.join(CSRC, "conv_x6c.lint.s")
+    lint = subprocess.Popen([hipcc, "-S", "--cuda-device-only", x6c, "-o", lint_s] + [f for f in cflags if f != "-fPIC"],
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) if want_aw else None
     for pr, s in zip(procs, srcs):
         out, _ = pr.communicate()
         if pr.returncode != 0:
@@ -152,6 +200,13 @@ def build_hip(force=False, verbose=False):
         f.write(digest)
     if aw is None:
         return HIP_SO
+    out, _ = lint.communicate()
+    if lint.returncode != 0:
+        sys.stderr.write(out)
+        raise RuntimeError("hipcc -S failed on conv_x6c.hip")
+    with open(lint_s) as f:
+        check_x6c_staging_isa(f.read())
+    os.remove(lint_s)
     out, _ = aw.communicate()
     if aw.returncode != 0:
         sys.stderr.write(out)

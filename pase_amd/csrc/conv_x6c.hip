@@ -246,10 +246,11 @@ typedef float x6c_f4 __attribute__((ext_vector_type(4)));
 #endif
 #if defined(PASE_HIPEMU) || defined(PASE_X6C_AUTOWAIT)
 // (emulator, and A/B builds with -DPASE_X6C_AUTOWAIT: plain loads, the compiler's own s_waitcnt bookkeeping)
-template <int E>
+template <int E, int RS>
 __device__ __forceinline__ void x6c_gload(x6c_f4 (&q)[2], const float* base, unsigned voff_bytes) {
     q[E >> 2][E & 3] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + voff_bytes);
 }
+template <int RS>
 __device__ __forceinline__ void x6c_gload_x8(x6c_f4 (&q)[2], const float* base, unsigned voff_bytes) {
     const X6cF4* s4 = reinterpret_cast<const X6cF4*>(reinterpret_cast<const char*>(base) + voff_bytes);
     const X6cF4 lo = s4[0], hi = s4[1];
@@ -258,6 +259,7 @@ __device__ __forceinline__ void x6c_gload_x8(x6c_f4 (&q)[2], const float* base, 
 }
 template <int N>
 __device__ __forceinline__ void x6c_vmwait() {}
+template <int RS>
 __device__ __forceinline__ void x6c_claim(x6c_f4 (&)[2]) {}
 #else
 // The staging waves' loads are HIDDEN from the compiler (cdna_hip_programming.md 5.7 form (ii)): issued as inline asm two
@@ -267,21 +269,31 @@ __device__ __forceinline__ void x6c_claim(x6c_f4 (&)[2]) {}
 // address temporaries allocated on top of the load destinations made it wait vmcnt(0) in front of every load group and
 // every conversion -- the compute waves of the 1x1 / stride-2 / swapped launches spent 11 ... 60 % of their loop in the stage
 // barrier (tools/trace_x6c.py: LPS data gradient 60 %, LPS weight gradient 47 %, blocks 6 / 7 11 %).
-template <int E>
+// RS = the register set the load belongs to, spelled into the asm text.  The STREAM form selects the set at run time
+// (`if (set == 0) load_stage<0> else if (set == 1) ...`): with IDENTICAL asm statements in the three branches the optimiser
+// merged them into one load whose result was then copied into the chosen set -- a copy of a register whose load had not
+// landed (seen in the ISA: destinations v32 ... v43 reused as scratch two instructions later; non-finite outputs on the GPU,
+// while the emulator passed).  Distinct asm strings cannot be merged: every load writes its home register.
+template <int E, int RS>
 __device__ __forceinline__ void x6c_gload(x6c_f4 (&q)[2], const float* base, unsigned voff_bytes) {
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(q[E >> 2][E & 3]) : "v"(voff_bytes), "s"(base) : "memory");
+    asm volatile("global_load_dword %0, %1, %2 ; staging set %3"
+                 : "=v"(q[E >> 2][E & 3])
+                 : "v"(voff_bytes), "s"(base), "n"(RS)
+                 : "memory");
 }
+template <int RS>
 __device__ __forceinline__ void x6c_gload_x8(x6c_f4 (&q)[2], const float* base, unsigned voff_bytes) {
-    asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:16"
+    asm volatile("global_load_dwordx4 %0, %2, %3 ; staging set %4\n\tglobal_load_dwordx4 %1, %2, %3 offset:16"
                  : "=&v"(q[0]), "=&v"(q[1])
-                 : "v"(voff_bytes), "s"(base)
+                 : "v"(voff_bytes), "s"(base), "n"(RS)
                  : "memory");
 }
 template <int N>
 __device__ __forceinline__ void x6c_vmwait() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-__device__ __forceinline__ void x6c_claim(x6c_f4 (&q)[2]) { asm volatile("" : "+v"(q[0]), "+v"(q[1])); }
+template <int RS>
+__device__ __forceinline__ void x6c_claim(x6c_f4 (&q)[2]) { asm volatile("; claim staging set %2" : "+v"(q[0]), "+v"(q[1]) : "n"(RS)); }
 #endif
 // wait until at most `per_slot` * nslots of this wave's loads are outstanding (nslots: uniform, 0 .. 5; per_slot 8, or 2 on the
 // row-coalesced weight-gradient path)
@@ -663,7 +675,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
 #ifdef PASE_X6C_TRACE
                 if (pl.prio & 64) off = (unsigned)(lane & 15) * 8u;      // ablation: every load hits the same two cache lines
 #endif
-                x6c_gload_x8(xreg[rs][sl], xbase, off * 4u);
+                x6c_gload_x8<rs>(xreg[rs][sl], xbase, off * 4u);
                 xmask[rs][sl] = ok ? 0xffu : 0u;
                 return;
             }
@@ -675,7 +687,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             if (inter) {
                 pase_static_for<8>([&](auto et) __attribute__((always_inline)) {
                     constexpr int e = decltype(et)::value;
-                    x6c_gload<e>(xreg[rs][sl], sb + ((qb0 + e) * p.stride + t_kmin), pos_voff[par][ps] * 4u);
+                    x6c_gload<e, rs>(xreg[rs][sl], sb + ((qb0 + e) * p.stride + t_kmin), pos_voff[par][ps] * 4u);
                 });
                 xmask[rs][sl] = (0u - vbit) & 0xffu;
             } else {
@@ -685,7 +697,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                     int u = (qb0 + e) * p.stride + t_koff[par][ps];
                     if (p.pad_mode == PASE_PAD_REFLECT) u = x6c_reflect(u, p.Tin);
                     const unsigned okb = (qb0 + e < p.Ncols ? vbit : 0u) & x6c_in_range(u, p.Tin);
-                    x6c_gload<e>(xreg[rs][sl], sb, ((unsigned)(pos_u0[par][ps] + u) & (0u - okb)) * 4u);
+                    x6c_gload<e, rs>(xreg[rs][sl], sb, ((unsigned)(pos_u0[par][ps] + u) & (0u - okb)) * 4u);
                     mask |= okb << e;
                 });
                 xmask[rs][sl] = mask;
@@ -711,7 +723,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             const float* bp = xbase + (size_t)c0l * p.Tin;
             pase_static_for<8>([&](auto et) __attribute__((always_inline)) {
                 constexpr int e = decltype(et)::value;
-                x6c_gload<e>(xreg[rs][sl], bp, pos_voff[par][ps] * 4u);
+                x6c_gload<e, rs>(xreg[rs][sl], bp, pos_voff[par][ps] * 4u);
                 bp += p.Tin;
             });
             xmask[rs][sl] = (0u - vbit) & 0xffu;
@@ -725,7 +737,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             const int to_next = p.Tin - (pl.P - 1);
             pase_static_for<8>([&](auto et) __attribute__((always_inline)) {
                 constexpr int e = decltype(et)::value;
-                x6c_gload<e>(xreg[rs][sl], bp, pos_voff[par][ps] * 4u);
+                x6c_gload<e, rs>(xreg[rs][sl], bp, pos_voff[par][ps] * 4u);
                 const bool wrap = ++bph == pl.P;                                  // uniform
                 bp += wrap ? to_next : 1;
                 bph = wrap ? 0 : bph;
@@ -739,7 +751,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 int ci, b;
                 bool chok;
                 chan_of(g, kg, e, ci, b, chok);
-                x6c_gload<e>(xreg[rs][sl], xbase + (size_t)ci * p.Tin + b, pos_voff[par][ps] * 4u);
+                x6c_gload<e, rs>(xreg[rs][sl], xbase + (size_t)ci * p.Tin + b, pos_voff[par][ps] * 4u);
             });
             xmask[rs][sl] = (0u - vbit) & 0xffu;
         } else {
@@ -754,7 +766,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 int u = pos_u0[par][ps] + b;
                 if (p.pad_mode == PASE_PAD_REFLECT) u = x6c_reflect(u, p.Tin);
                 const unsigned okb = vbit & x6c_in_range(u, p.Tin);
-                x6c_gload<e>(xreg[rs][sl], xbase + (size_t)ci * p.Tin, ((pos_sbase[par][ps] + (unsigned)u) & (0u - okb)) * 4u);
+                x6c_gload<e, rs>(xreg[rs][sl], xbase + (size_t)ci * p.Tin, ((pos_sbase[par][ps] + (unsigned)u) & (0u - okb)) * 4u);
                 mask |= okb << e;
             });
             xmask[rs][sl] = mask;
@@ -774,7 +786,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             }
             return;
         } else {
-        x6c_claim(xreg[rs][sl]);
+        x6c_claim<rs>(xreg[rs][sl]);
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = xreg[rs][sl][e >> 2][e & 3];
