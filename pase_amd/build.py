@@ -111,44 +111,63 @@ def check_x6c_resources(res):
 
 def check_x6c_staging_isa(asm_text):
     """ISA lint of conv_x6c.hip's hidden staging loads (x6c_gload: inline asm, destination considered defined at issue,
-    waited for by hand-counted s_waitcnt).  Every such load carries its register set in the asm text (`; staging set N`).
-    Each destination VGPR must belong to exactly ONE set in every kernel, and every set must have the same number of
-    destination registers: a load that lands in a temporary -- to be copied into its home register before the wait, i.e.
-    while the data is still in flight -- shows up as a destination shared between sets or as extra destinations.  (Round 5:
-    three identical asm statements in sibling branches were merged by the optimiser into one load + copies; the emulator
-    passed, the GPU returned stale registers.)"""
+    waited for by hand-counted s_waitcnt, handed to the conversion by x6c_claim).  Loads and claims carry their register
+    set -- and the claims their operand registers -- in the asm text.  Per kernel:
+      * every load destination belongs to exactly ONE set and every set has the same number of destinations (a load that
+        lands in a temporary shows up as a destination shared between sets or as extra destinations);
+      * the registers a set's claims hand to the conversion are exactly the registers its loads were issued into (a value
+        that was copied between issue and claim -- vector assembly, live-range split, merged sibling branches -- is read
+        from a register the load never wrote: STALE on the hardware, invisible to the emulator).
+    Round 5 found both failure classes in the first forms of the streamed loop; this is the build-time tripwire."""
     import re
+
+    def regs_of(tok):
+        m = re.match(r"v\[(\d+):(\d+)\]$", tok)
+        if m:
+            return list(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.match(r"v(\d+)$", tok)
+        return [int(m.group(1))] if m else []
     kern, cur = {}, None
     for line in asm_text.splitlines():
         m = re.match(r"\s*\.type\s+(\S*conv_x6c_kernel\S*),@function", line)
         if m:
-            cur = kern.setdefault(m.group(1), {})
+            cur = kern.setdefault(m.group(1), dict(load={}, claim={}))
             continue
         if cur is None:
             continue
-        m = re.match(r"\s*global_load_dword(x4)?\s+v(\[)?(\d+)(?::(\d+)\])?,.*; staging set (\d+)", line)
+        m = re.match(r"\s*global_load_dword(?:x4)?\s+(v\[\d+:\d+\]|v\d+),.*; staging set (\d+)", line)
         if m:
-            lo = int(m.group(3))
-            hi = int(m.group(4)) if m.group(4) else lo
-            for r in range(lo, hi + 1):
-                cur.setdefault(r, set()).add(int(m.group(5)))
+            for r in regs_of(m.group(1)):
+                cur["load"].setdefault(r, set()).add(int(m.group(2)))
+            continue
+        m = re.match(r"\s*; claim staging set (\d+) regs (.*)$", line)
+        if m:
+            for tok in m.group(2).split():
+                for r in regs_of(tok):
+                    cur["claim"].setdefault(int(m.group(1)), set()).add(r)
     bad = []
     checked = 0
-    for name, regs in kern.items():
-        if not regs:
+    for name, k in kern.items():
+        if not k["load"]:
             continue
         checked += 1
-        shared = sorted(r for r, sets in regs.items() if len(sets) > 1)
+        shared = sorted(r for r, sets in k["load"].items() if len(sets) > 1)
         per_set = {}
-        for r, sets in regs.items():
+        for r, sets in k["load"].items():
             for st in sets:
-                per_set[st] = per_set.get(st, 0) + 1
-        if shared or len(set(per_set.values())) > 1:
-            bad.append((name, "registers shared between sets: %r" % shared[:8], "destinations per set: %r" % per_set))
+                per_set.setdefault(st, set()).add(r)
+        if shared or len(set(len(v) for v in per_set.values())) > 1:
+            bad.append((name, "load destinations shared between sets %r, per set %r"
+                        % (shared[:8], {st: len(v) for st, v in per_set.items()})))
+        for st, regs in per_set.items():
+            cl = k["claim"].get(st, set())
+            if cl != regs:
+                bad.append((name, "set %d: loaded into %r but claimed from %r"
+                            % (st, sorted(regs - cl)[:12], sorted(cl - regs)[:12])))
     if checked == 0:
         raise RuntimeError("build: no hidden staging load found in the conv_x6c assembly (asm text changed?)")
     if bad:
-        raise RuntimeError("build: conv_x6c staging loads do not land in per-set home registers "
+        raise RuntimeError("build: conv_x6c staging loads are not claimed from the registers they were issued into "
                            "(stale-register hazard, see check_x6c_staging_isa): %r" % (bad,))
     return checked
 

@@ -257,10 +257,16 @@ __device__ __forceinline__ void x6c_gload_x8(x6c_f4 (&q)[2], const float* base, 
     q[0] = x6c_f4{lo.x, lo.y, lo.z, lo.w};
     q[1] = x6c_f4{hi.x, hi.y, hi.z, hi.w};
 }
+template <int E, int RS>
+__device__ __forceinline__ void x6c_gload(float (&q)[8], const float* base, unsigned voff_bytes) {
+    q[E] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + voff_bytes);
+}
 template <int N>
 __device__ __forceinline__ void x6c_vmwait() {}
 template <int RS>
 __device__ __forceinline__ void x6c_claim(x6c_f4 (&)[2]) {}
+template <int RS>
+__device__ __forceinline__ void x6c_claim(float (&)[8]) {}
 #else
 // The staging waves' loads are HIDDEN from the compiler (cdna_hip_programming.md 5.7 form (ii)): issued as inline asm two
 // stages before their conversion, waited for with hand-counted s_waitcnt vmcnt(N) (every live slot issues the same number
@@ -281,6 +287,17 @@ __device__ __forceinline__ void x6c_gload(x6c_f4 (&q)[2], const float* base, uns
                  : "v"(voff_bytes), "s"(base), "n"(RS)
                  : "memory");
 }
+// STREAM: eight SCALAR destinations per slot.  An element of a 4-vector as asm output makes the compiler assemble the vector
+// (REG_SEQUENCE) when it is claimed -- in the streamed loop it placed the four loads of a vector in non-consecutive registers
+// and copied them together at the claim, i.e. while the loads were in flight (ISA: set 1 loaded into v32-35 / v40-43 / ...,
+// claimed as v[32:39]).  A scalar needs no assembling: it stays where its load put it.
+template <int E, int RS>
+__device__ __forceinline__ void x6c_gload(float (&q)[8], const float* base, unsigned voff_bytes) {
+    asm volatile("global_load_dword %0, %1, %2 ; staging set %3"
+                 : "=v"(q[E])
+                 : "v"(voff_bytes), "s"(base), "n"(RS)
+                 : "memory");
+}
 template <int RS>
 __device__ __forceinline__ void x6c_gload_x8(x6c_f4 (&q)[2], const float* base, unsigned voff_bytes) {
     asm volatile("global_load_dwordx4 %0, %2, %3 ; staging set %4\n\tglobal_load_dwordx4 %1, %2, %3 offset:16"
@@ -293,7 +310,17 @@ __device__ __forceinline__ void x6c_vmwait() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 template <int RS>
-__device__ __forceinline__ void x6c_claim(x6c_f4 (&q)[2]) { asm volatile("; claim staging set %2" : "+v"(q[0]), "+v"(q[1]) : "n"(RS)); }
+__device__ __forceinline__ void x6c_claim(x6c_f4 (&q)[2]) {
+    // (the operands are spelled into the text: pase_amd/build.py's ISA lint checks that the registers the compiler hands to the
+    //  conversion are the very registers the set's loads were issued into -- a value that was copied while in flight is stale)
+    asm volatile("; claim staging set %2 regs %0 %1" : "+v"(q[0]), "+v"(q[1]) : "n"(RS));
+}
+template <int RS>
+__device__ __forceinline__ void x6c_claim(float (&q)[8]) {
+    asm volatile("; claim staging set %8 regs %0 %1 %2 %3 %4 %5 %6 %7"
+                 : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7])
+                 : "n"(RS));
+}
 #endif
 // wait until at most `per_slot` * nslots of this wave's loads are outstanding (nslots: uniform, 0 .. 5; per_slot 8, or 2 on the
 // row-coalesced weight-gradient path)
@@ -619,7 +646,12 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     const bool has_aff = p.in_scale != nullptr, has_alpha = p.in_alpha != nullptr;       // uniform
     const float* xbase = p.x + (size_t)p.x_coff * p.Tin;
 
-    x6c_f4 xreg[XR][ZP ? 1 : NSLOT][2];
+    x6c_f4 xreg[XR][(ZP || STREAM) ? 1 : NSLOT][2];
+    float xsc[XR][(STREAM && !ZP) ? NSLOT : 1][8];      // STREAM: the same staging registers as scalars (see x6c_gload)
+    auto xr_of = [&](auto rs_tag, auto sl_tag) -> decltype(auto) {
+        if constexpr (STREAM && !ZP) return (xsc[decltype(rs_tag)::value][decltype(sl_tag)::value]);
+        else return (xreg[decltype(rs_tag)::value][decltype(sl_tag)::value]);
+    };
     unsigned xmask[XR][ZP ? 1 : NSLOT];         // bit e: element e of the slot is a real sample (else: zero AFTER the transform)
     u32x4 xpl[XR][ZP ? NSLOT : 1][3];           // ZP: the slot's three plane chunks as loaded
     const unsigned short* zpb = reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(p.wx6) + pl.zp_off);
@@ -723,7 +755,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             const float* bp = xbase + (size_t)c0l * p.Tin;
             pase_static_for<8>([&](auto et) __attribute__((always_inline)) {
                 constexpr int e = decltype(et)::value;
-                x6c_gload<e, rs>(xreg[rs][sl], bp, pos_voff[par][ps] * 4u);
+                x6c_gload<e, rs>(xr_of(r_tag, sl_tag), bp, pos_voff[par][ps] * 4u);
                 bp += p.Tin;
             });
             xmask[rs][sl] = (0u - vbit) & 0xffu;
@@ -737,7 +769,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             const int to_next = p.Tin - (pl.P - 1);
             pase_static_for<8>([&](auto et) __attribute__((always_inline)) {
                 constexpr int e = decltype(et)::value;
-                x6c_gload<e, rs>(xreg[rs][sl], bp, pos_voff[par][ps] * 4u);
+                x6c_gload<e, rs>(xr_of(r_tag, sl_tag), bp, pos_voff[par][ps] * 4u);
                 const bool wrap = ++bph == pl.P;                                  // uniform
                 bp += wrap ? to_next : 1;
                 bph = wrap ? 0 : bph;
@@ -751,7 +783,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 int ci, b;
                 bool chok;
                 chan_of(g, kg, e, ci, b, chok);
-                x6c_gload<e, rs>(xreg[rs][sl], xbase + (size_t)ci * p.Tin + b, pos_voff[par][ps] * 4u);
+                x6c_gload<e, rs>(xr_of(r_tag, sl_tag), xbase + (size_t)ci * p.Tin + b, pos_voff[par][ps] * 4u);
             });
             xmask[rs][sl] = (0u - vbit) & 0xffu;
         } else {
@@ -766,7 +798,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 int u = pos_u0[par][ps] + b;
                 if (p.pad_mode == PASE_PAD_REFLECT) u = x6c_reflect(u, p.Tin);
                 const unsigned okb = vbit & x6c_in_range(u, p.Tin);
-                x6c_gload<e, rs>(xreg[rs][sl], xbase + (size_t)ci * p.Tin, ((pos_sbase[par][ps] + (unsigned)u) & (0u - okb)) * 4u);
+                x6c_gload<e, rs>(xr_of(r_tag, sl_tag), xbase + (size_t)ci * p.Tin, ((pos_sbase[par][ps] + (unsigned)u) & (0u - okb)) * 4u);
                 mask |= okb << e;
             });
             xmask[rs][sl] = mask;
@@ -786,10 +818,15 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             }
             return;
         } else {
-        x6c_claim<rs>(xreg[rs][sl]);
+        x6c_claim<rs>(xr_of(r_tag, sl_tag));
         float v[8];
+        if constexpr (STREAM && !ZP) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = xreg[rs][sl][e >> 2][e & 3];
+            for (int e = 0; e < 8; ++e) v[e] = xsc[rs][sl][e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = xreg[rs][sl][e >> 2][e & 3];
+        }
         if constexpr (TM) {
             if (pl.t_vec) {
                 constexpr int h = (sl >> 1) & 1;
@@ -1094,9 +1131,16 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             int itemS = -1, giS = NST;
             bool S_has = true;
             int itemC = (int)blockIdx.x, giC = 0;
-            int setL = 0, setS = 0, c_last = 0, tile_item = -1;
+            int c_last = 0, tile_item = -1;
             bool finishing = false;
-            for (int v = -3;; ++v) {
+            // (the tick is unrolled three times with STATIC register sets, as in the unstreamed loop: a set chosen at run time makes
+            //  the staging registers loop-carried values that cross if-chains, and the compiler then moves them between
+            //  registers while their loads are in flight -- pase_amd/build.py's ISA lint rejects such a build)
+            int v = -3;
+            bool done = false;
+            auto tick = [&](auto r_tag) __attribute__((always_inline)) {
+                constexpr int r = decltype(r_tag)::value;           // register set of stream stage v + 3 (and of stage v)
+                constexpr int rn = (r + 1) % XR;                     // ... of stream stage v + 1
                 if (!finishing) {
                     // ---- S: stream stage v + 1
                     if (v >= -1 && S_has) {
@@ -1115,10 +1159,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                             X6C_T0();
                             x6c_vmwait_slots(c_last, false);       // everything but the loads of stream stage v + 2 has landed
                             const int bs = v >= 0 ? (bsel ^ 1) : bsel;
-                            if (setS == 0) store_stage(std::integral_constant<int, 0>{}, giS, bs);
-                            else if (setS == 1) store_stage(std::integral_constant<int, 1>{}, giS, bs);
-                            else store_stage(std::integral_constant<int, 2>{}, giS, bs);
-                            setS = setS == 2 ? 0 : setS + 1;
+                            store_stage(std::integral_constant<int, rn>{}, giS, bs);
                             ++giS;
                             if (wave == 4) X6C_TACC(11);
                         }
@@ -1159,17 +1200,17 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 // ---- L: stream stage v + 3
                 if (!finishing) {
                     if (L_has) {
-                        if (setL == 0) load_stage(std::integral_constant<int, 0>{}, giL);
-                        else if (setL == 1) load_stage(std::integral_constant<int, 1>{}, giL);
-                        else load_stage(std::integral_constant<int, 2>{}, giL);
-                        setL = setL == 2 ? 0 : setL + 1;
+                        load_stage(r_tag, giL);
                         ++giL;
                         c_last = nliveL;
                     } else {
                         c_last = 0;
                     }
                 }
-                if (finishing) break;
+                if (finishing) {
+                    done = true;
+                    return;
+                }
                 if (v >= -1) __syncthreads();
                 if (v >= 0) {
                     bsel ^= 1;
@@ -1185,6 +1226,15 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                         }
                     }
                 }
+                ++v;
+            };
+            while (true) {
+                tick(std::integral_constant<int, 0>{});
+                if (done) break;
+                tick(std::integral_constant<int, 1>{});
+                if (done) break;
+                tick(std::integral_constant<int, 2>{});
+                if (done) break;
             }
             return;
         }
