@@ -145,7 +145,46 @@ def check_x6c_staging_isa(asm_text):
             for tok in m.group(2).split():
                 for r in regs_of(tok):
                     cur["claim"].setdefault(int(m.group(1)), set()).add(r)
+    # third rule: no COMPILER-inserted `s_waitcnt vmcnt` inside a hidden load sequence (within six lines of a hidden load and not
+    # itself inline asm).  The compiler knows nothing of the hidden loads: such a wait protects a register of some pending
+    # VISIBLE load -- e.g. never-consumed weight-fragment prefetches of the compute waves, whose exit path the compiler merged
+    # with the role branch, or per-column parameters loaded in setup_item -- and in doing so drains the hidden pipeline on
+    # every tick (round 5: 14 ... 80 % on the strided / 1x1 launches).  The kernels close those books with visible waits.
+    lines = asm_text.splitlines()
+    sync_waits = {}
+    cur_name = None
+    hidden_at = []
+    for i, line in enumerate(lines):
+        m = re.match(r"\s*\.type\s+(\S*conv_x6c_kernel\S*),@function", line)
+        if m:
+            cur_name = m.group(1)
+            hidden_at = []
+            continue
+        if cur_name is None:
+            continue
+        if "; staging set" in line and "global_load" in line:
+            hidden_at.append(i)
+        elif re.match(r"\s*s_waitcnt vmcnt", line) and "#ASMSTART" not in lines[i - 1]:
+            sync_waits.setdefault(cur_name, []).append(i)
+    hidden_by_kernel = {}
+    cur_name = None
+    for i, line in enumerate(lines):
+        m = re.match(r"\s*\.type\s+(\S*conv_x6c_kernel\S*),@function", line)
+        if m:
+            cur_name = m.group(1)
+        elif cur_name is not None and "; staging set" in line and "global_load" in line:
+            hidden_by_kernel.setdefault(cur_name, []).append(i)
     bad = []
+    for name, waits in sync_waits.items():
+        hid = hidden_by_kernel.get(name, [])
+        import bisect
+        n = 0
+        for w in waits:
+            j = bisect.bisect_left(hid, w)
+            if any(0 <= jj < len(hid) and abs(hid[jj] - w) <= 6 for jj in (j - 1, j)):
+                n += 1
+        if n:
+            bad.append((name, "%d compiler-inserted s_waitcnt vmcnt inside hidden load sequences" % n))
     checked = 0
     for name, k in kern.items():
         if not k["load"]:

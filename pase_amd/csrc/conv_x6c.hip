@@ -935,6 +935,12 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         auto prologue = [&](int item) __attribute__((always_inline)) {
             if (wave == 4) X6C_STAMP(4);
             setup_item(item);
+#if !defined(PASE_HIPEMU)
+            // (weight gradients: setup_item loads per-column PReLU slopes with ordinary loads.  Left pending in the compiler's
+            //  bookkeeping until their first use inside the stage loop, they made it put s_waitcnt vmcnt(0) in front of every
+            //  hidden load group of the row-coalesced path -- a synchronous pipeline.  Nothing hidden is in flight here.)
+            if constexpr (TM) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+#endif
             nlive = 0;
             pase_static_for<NSLOT>([&](auto sl) __attribute__((always_inline)) {
                 if (slot_live(decltype(sl)::value / NPS, decltype(sl)::value % NPS)) ++nlive;
@@ -1157,7 +1163,11 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                         }
                         if (S_has) {
                             X6C_T0();
-                            x6c_vmwait_slots(c_last, false);       // everything but the loads of stream stage v + 2 has landed
+                            {
+                                X6C_T0();
+                                x6c_vmwait_slots(c_last, false);   // everything but the loads of stream stage v + 2 has landed
+                                if (wave == 4) X6C_TACC(10);
+                            }
                             const int bs = v >= 0 ? (bsel ^ 1) : bsel;
                             store_stage(std::integral_constant<int, rn>{}, giS, bs);
                             ++giS;
@@ -1174,8 +1184,13 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 // this tick's loads last.
                 const bool crossing = !finishing && L_has && giL == NST;
                 const bool drain_now = tile_item >= 0 && (finishing || (v >= 0 && giC >= 1 && giC <= drain_nch));
-                if (crossing || drain_now) x6c_vmwait<0>();
+                if (crossing || drain_now) {
+                    X6C_T0();
+                    x6c_vmwait<0>();
+                    if (wave == 4) X6C_TACC(15);
+                }
                 if (crossing) {
+                    X6C_T0();
                     itemL += (int)gridDim.x;
                     if (itemL < nitems) {
                         setup_item(itemL);
@@ -1188,6 +1203,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                     } else {
                         L_has = false;
                     }
+                    if (wave == 4) X6C_TACC(12);
                 }
                 // ---- the previous item's accumulator tile: published by the barrier that ended this item's first stage
                 if (drain_now) {
@@ -1200,9 +1216,11 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 // ---- L: stream stage v + 3
                 if (!finishing) {
                     if (L_has) {
+                        X6C_T0();
                         load_stage(r_tag, giL);
                         ++giL;
                         c_last = nliveL;
+                        if (wave == 4) X6C_TACC(13);
                     } else {
                         c_last = 0;
                     }
@@ -1211,7 +1229,11 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                     done = true;
                     return;
                 }
-                if (v >= -1) __syncthreads();
+                if (v >= -1) {
+                    X6C_T0();
+                    __syncthreads();
+                    if (wave == 4) X6C_TACC(14);
+                }
                 if (v >= 0) {
                     bsel ^= 1;
                     if (++giC == NST) {
@@ -1294,8 +1316,10 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                             }
                         }
                         if (N_has) {
+                            X6C_T0();
                             direct_stage(giN, v >= 0 ? (bsel ^ 1) : bsel);
                             ++giN;
+                            if (wave == 4) X6C_TACC(13);
                         }
                     }
                     if (tile_item >= 0 && (finishing || (v >= 0 && giC >= 1 && giC <= drain_nch))) {
@@ -1306,8 +1330,16 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                         if (wave == 4) X6C_TACC(8);
                     }
                     if (finishing) break;
-                    x6c_vm_drain();
-                    __syncthreads();
+                    {
+                        X6C_T0();
+                        x6c_vm_drain();
+                        if (wave == 4) X6C_TACC(10);
+                    }
+                    {
+                        X6C_T0();
+                        __syncthreads();
+                        if (wave == 4) X6C_TACC(14);
+                    }
                     if (v >= 0) {
                         bsel ^= 1;
                         if (++giC == NST) {
@@ -1328,6 +1360,9 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             auto prologue_dl = [&](int item) __attribute__((always_inline)) {
                 if (wave == 4) X6C_STAMP(4);
                 setup_item(item);
+#if !defined(PASE_HIPEMU)
+                if constexpr (TM) __builtin_amdgcn_s_waitcnt(0x0F70);      // (see prologue)
+#endif
                 direct_stage(g_begin, bsel);
                 if (wave == 4) X6C_STAMP(5);
             };
@@ -2227,8 +2262,23 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     if (wave == 0) X6C_STAMP(3);
     X6C_TRACE_NEXT();
   }   // items
+#if !defined(PASE_HIPEMU)
+  if constexpr (!STREAM) {
+      // (every instantiation: see the STREAM branch below -- the unstreamed 1x1 and weight-gradient kernels carried the same
+      //  compiler-inserted waits inside their hidden load sequences)
+      __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+  }
+#endif
   if constexpr (STREAM) {
       if (have_prev) dump_tile();
+#if !defined(PASE_HIPEMU)
+      // Close the compiler's vector-memory books before this path joins the staging waves' code in the control-flow graph (the
+      // compiler lays the role branch and this exit through one block): the weight-fragment prefetches past the last step are
+      // never consumed, hence never waited for, and -- reaching the staging loop as "pending loads" of v[130:137] -- they made
+      // the compiler put s_waitcnt vmcnt(1 .. 2) into every hidden load sequence of the staging waves: a synchronous pipeline
+      // (seen in the ISA; the strided and 1x1 launches ran 14 ... 80 % slower than unstreamed).
+      __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+#endif
       __syncthreads();      // the staging waves drain the last item's tile behind this barrier
   }
 }

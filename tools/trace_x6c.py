@@ -49,6 +49,16 @@ def run_shape(name, dev):
                 alpha=torch.full((Cin,), 0.1, device=dev))
         return lambda: E.conv_fwd(a, w.view(Cout, -1), b, Cout=Cout, taps=k, stride=st, padL=pL, padR=pR,
                                   pad_mode=K.PAD_REFLECT, want_stats=True)
+    if name == "cat":        # dense-skip + W projection: (96, 1920, 200) -> 256 rows, 1x1, BatchNorm statistics
+        x = torch.randn(S, 1920, 200, device=dev)
+        w = torch.randn(256, 1920, device=dev) * 0.05
+        b = torch.randn(256, device=dev)
+        return lambda: E.conv_fwd(Act(x, C=1920), w, b, Cout=256, taps=1, want_stats=True, Tout=200)
+    if name == "dec3d":      # decoder output layer's data gradient: Conv1d(128 -> 256, k 30, stride 10) over 32 x 32000
+        x = torch.randn(32, 128, 32000, device=dev)
+        w = torch.randn(256, 128 * 30, device=dev) * 0.05
+        return lambda: E.conv_fwd(Act(x, C=128), w, None, Cout=256, taps=30, stride=10, padL=10, padR=10, pad_mode=K.PAD_ZERO,
+                                  Tout=3200)
     if name in ("qrnn", "qrnn_nb"):
         x = torch.randn(S, 512, 200, device=dev)
         lin = torch.randn(1536, 1024, device=dev) * 0.05
@@ -118,7 +128,8 @@ def main():
     dev = torch.device("cuda:0")
     NI = 64
     buf = (C.c_ulonglong * (2 * NI * 20))()
-    for name in shapes:
+    for name, mode in [(n_, m_) for n_ in shapes for m_ in ("1", "0")]:
+        os.environ["PASE_X6C_STREAM"] = mode
         fn = run_shape(name, dev)
         fn()
         fn()
@@ -131,18 +142,30 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)
         assert lib.pase_x6c_trace_read(buf) == 0
-        print("== %s: %.3f ms per call (pack launches included), plan kind %s" % (name, ms, K.LAST_PLAN_KIND))
+        print("== %s [stream=%s]: %.3f ms per call (pack launches included), plan kind %s streamed %s" % (name, mode, ms, K.LAST_PLAN_KIND, K.LAST_STREAMED))
         for wg in (0, 1):
             rows = []
             for i in range(NI):
                 t = [buf[(wg * NI + i) * 20 + s] for s in range(20)]
-                if t[3] == 0 or t[3] < t[0]:
+                if (t[2] if K.LAST_STREAMED else t[3]) == 0 or (not K.LAST_STREAMED and t[3] < t[0]):
                     break
                 rows.append(t)
             if len(rows) < 1:
                 print("   workgroup %s: no items traced" % ("0" if wg == 0 else "131"))
                 continue
             mid = rows[1:-1] if len(rows) >= 3 else rows
+            if K.LAST_STREAMED:
+                def avg(f):
+                    v = [f(r) for r in mid]
+                    return sum(v) / len(v)
+                print("   workgroup %-3s items %2d STREAMED | compute: turn-over (decode, A loads, dump) %6.0f  mfma %7.0f (in barriers %7.0f)  "
+                      "item-to-item %7.0f | staging per item: S wait %6.0f  S wait+convert %7.0f  L issue %6.0f  setup %6.0f  "
+                      "pre-drain wait %6.0f  drain %6.0f  in barriers %7.0f" % (
+                          "0" if wg == 0 else "131", len(rows), avg(lambda r: r[1] - r[0]), avg(lambda r: r[2] - r[1]),
+                          avg(lambda r: r[9]), (rows[-1][0] - rows[0][0]) / max(1, len(rows) - 1), avg(lambda r: r[10]),
+                          avg(lambda r: r[11]), avg(lambda r: r[13]), avg(lambda r: r[12]), avg(lambda r: r[15]), avg(lambda r: r[8]),
+                          avg(lambda r: r[14])))
+                continue
 
             def avg(f):
                 v = [f(r) for r in mid]
