@@ -98,7 +98,8 @@ typedef struct PaseConvGemm {
                               (SincNet) layer off its window-image kernel; bit 4: no 64 x 256 tile for launches of at
                               most 64 rows; bit 5: the general epilogue on every tile (no lean store / MSE path); bit 6: the bias
                               added in the epilogue instead of being the accumulators' initial value; bit 7: never the
-                              streamed form (per-item prologue and epilogue on the multiplying waves, as until round 4); bits 8-15: start
+                              streamed form (per-item prologue and epilogue on the multiplying waves, as until round 4), bit 16: the
+                              streamed form on every launch it can run (not only where it measured faster); bits 8-15: start
                               the persistent workgroups n x 512 clocks out of phase (A/B runs and tests; the library
                               itself reads NO environment variables)                                             */
     int max_wg;            /* cap on the persistent grid of the split-bf16 kernel (0 = one workgroup per CU, 256):

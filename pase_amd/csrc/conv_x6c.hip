@@ -970,10 +970,19 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         //                     partial per wave -> one fp64 atomic, prediction and / or gradient stored
         // (reference ops: nn.BatchNorm1d statistics of FeBlock modules.py:1073-1075; ContextualizedLoss losses.py:6-37)
         float drain_lsum = 0.f;          // MSE: this lane's loss partial of the tile being drained (summed over its row chunks)
-        // rows [4 * c0, 4 * c1) of each wave's 32 (two rows per pass: `it` = 2 c .. ): the drain of a tile is spread over up to
-        // four ticks; `last`: the tile's final chunk (loss partial -> atomic)
+        // Who drains.  Operands split while staged (registers): all four staging waves, 32 tile rows each.  Pre-split operands
+        // (LDS DMA): waves 6 / 7 drain, 64 rows each, and waves 4 / 5 issue ALL the DMA -- a wave that waits for its DMA with
+        // vmcnt(0) in front of every barrier would wait for the drain's label loads and store acknowledgements as well (one
+        // counter per wave, in order): with the roles apart the drain never sits on the stage's critical path.
+        constexpr int DW = ZP ? 2 : 4;                  // draining waves
+        constexpr int RPW = BM / DW;                    // tile rows per draining wave
+        constexpr int NGRP = RPW / 8;                   // groups of eight rows (four passes of two rows) per draining wave
+        const int dwi = wave - (ZP ? 6 : 4);            // index among the draining waves (negative: not one of them)
+        // groups [c0, c1) of each draining wave's NGRP: the drain of a tile is spread over several ticks; `last`: the tile's
+        // final chunk (BatchNorm partial sums of the whole tile / loss partial -> atomic)
         auto drain_tile = [&](int item, int c0, int c1, bool last) __attribute__((always_inline)) {
             if constexpr (STREAM) {
+            if (dwi < 0) return;                          // uniform
             const int tl = xcd_swizzle(item, ntiles);
             const int nt_ = tl / pl.n_row_tiles, mt_ = tl - nt_ * pl.n_row_tiles;
             const int m0 = mt_ * BM, n0 = nt_ * BN;
@@ -990,8 +999,10 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 qq[e] = (int)ne - sq[e] * p.Ncols;
             }
             const bool run = okc[3] && sq[3] == sq[0];
-            const float* tl_rows = acc_tile + (32 * (wave - 4) + (lane >> 5)) * TILE_P + cl;
-            const int mrow0 = m0 + 32 * (wave - 4) + (lane >> 5);
+            const int rw0 = RPW * dwi;                                 // this wave's first tile row
+            const float* tl_rows = acc_tile + (rw0 + (lane >> 5)) * TILE_P + cl;
+            const int mrow0 = m0 + rw0 + (lane >> 5);
+            const bool rows_full = m0 + rw0 + RPW <= p.M;             // uniform
             if (p.epilogue == PASE_EPI_STORE) {      // uniform
                 // output element offsets of the four columns (ps == 1): (s * y_ctot + y_coff) * Tout + q + poff, + m * Tout per row
                 size_t ob[4];
@@ -1003,6 +1014,31 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                     ob[e] = ((size_t)sq[e] * p.y_ctot + p.y_coff) * (size_t)p.Tout + (size_t)(oko[e] ? pos : 0);
                 }
                 const bool run_o = run && oko[0] && oko[3];
+                const bool lean = pl.epi32 && rows_full && pase_wave_all(run_o) != 0;      // uniform
+                if (lean) {
+                    // The common tile (whole rows, every column quad one contiguous run): every vector-ALU instruction of a
+                    // staging wave issues between the compute wave's MFMAs at ~10 cycles apiece, so the pass is pared down to
+                    // LDS read, bias add, one 16-byte store -- row pointer wave-uniform (scalar unit), the lane's part of the
+                    // address one 32-bit byte offset -- and the BatchNorm sums are taken in a pass of their own below.
+                    const unsigned cb4 = (unsigned)(ob[0] + (size_t)(lane >> 5) * (size_t)p.Tout) * 4u;
+                    const unsigned to8 = (unsigned)p.Tout * 8u;
+                    char* yrow = reinterpret_cast<char*>(p.y) + (size_t)(m0 + rw0 + 8 * c0) * (size_t)p.Tout * 4u;
+                    for (int c = c0; c < c1; ++c) {
+                        float bv[4];
+                        X6cF4 t4[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            bv[i] = p.bias != nullptr ? p.bias[mrow0 + 2 * (4 * c + i)] : 0.f;
+                            t4[i] = *reinterpret_cast<const X6cF4*>(tl_rows + 2 * (4 * c + i) * TILE_P);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float v[4] = {t4[i].x + bv[i], t4[i].y + bv[i], t4[i].z + bv[i], t4[i].w + bv[i]};
+                            pase_store_run4(reinterpret_cast<float*>(yrow + cb4), v);
+                            yrow += to8;
+                        }
+                    }
+                } else {
                 for (int c = c0; c < c1; ++c) {
                     // four passes (eight rows of the wave) per group: their bias loads and LDS reads first
                     float bv[4];
@@ -1020,38 +1056,132 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                         const bool mok = m < p.M;
                         float v[4] = {t4[i].x + bv[i], t4[i].y + bv[i], t4[i].z + bv[i], t4[i].w + bv[i]};
                         float* yr = p.y + (size_t)(mok ? m : 0) * (size_t)p.Tout;
-                        float s1 = 0.f, s2 = 0.f;
                         if (mok) {
                             if (run_o) {
                                 pase_store_run4(yr + ob[0], v);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    s1 += v[e];
-                                    s2 += v[e] * v[e];
-                                }
                             } else {
 #pragma unroll
                                 for (int e = 0; e < 4; ++e)
-                                    if (oko[e]) {
-                                        yr[ob[e]] = v[e];
-                                        s1 += v[e];
-                                        s2 += v[e] * v[e];
-                                    }
-                            }
-                        }
-                        if (p.stat_part != nullptr) {      // uniform
-                            s1 = pase_half_sum_lane31(s1);
-                            s2 = pase_half_sum_lane31(s2);
-                            if ((lane & 31) == 31 && mok) {
-                                float* dst = p.stat_part + ((size_t)nt_ * p.M + m) * 2;
-                                dst[0] = s1;
-                                dst[1] = s2;
+                                    if (oko[e]) yr[ob[e]] = v[e];
                             }
                         }
                     }
                 }
+                }
+                if (last && p.stat_part != nullptr) {      // uniform
+                    // BatchNorm partial sums of the tile (sum, sum of squares of y = tile + bias over the row's valid output
+                    // columns): a lane owns one row (and, with four draining waves, one half of its columns), reads it from
+                    // the LDS tile 16 bytes at a time and accumulates in registers -- no cross-lane reduction per pass.
+                    constexpr int NPART = 64 / RPW;                    // lanes per row: 2 (32 rows per wave) or 1 (64)
+                    constexpr int NQ = BN / 4 / NPART;                 // column quads per lane
+                    const int rl = lane & (RPW - 1), part = lane / RPW;
+                    const int m = m0 + rw0 + rl;
+                    const float b = (p.bias != nullptr && m < p.M) ? p.bias[m] : 0.f;
+                    const float* trow = acc_tile + (rw0 + rl) * TILE_P + part * (BN / NPART);
+                    float s1 = 0.f, s2 = 0.f;
+                    const int ncol_t = min(BN, ntot - n0);            // real columns of the tile (uniform)
+                    const bool cols_plain = ncol_t == BN && p.poff == 0 && p.Tout >= p.Ncols;      // uniform: every column is stored
+#pragma unroll 4
+                    for (int k = 0; k < NQ; ++k) {
+                        const X6cF4 t = *reinterpret_cast<const X6cF4*>(trow + 4 * k);
+                        const float v[4] = {t.x + b, t.y + b, t.z + b, t.w + b};
+                        if (cols_plain) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                s1 += v[e];
+                                s2 = fmaf(v[e], v[e], s2);
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int ce = part * (BN / NPART) + 4 * k + e;
+                                bool ok = ce < ncol_t;
+                                if (ok) {
+                                    const unsigned ne = (unsigned)(n0 + ce);
+                                    const int se = (int)div_magic(ne, pl.ncols_magic);
+                                    const int pos = (int)ne - se * p.Ncols + p.poff;
+                                    ok = pos >= 0 && pos < p.Tout;
+                                }
+                                if (ok) {
+                                    s1 += v[e];
+                                    s2 = fmaf(v[e], v[e], s2);
+                                }
+                            }
+                        }
+                    }
+                    if constexpr (NPART == 2) {
+                        s1 += __shfl_xor(s1, 32);
+                        s2 += __shfl_xor(s2, 32);
+                    }
+                    if (part == 0 && m < p.M) {
+                        float* dst = p.stat_part + ((size_t)nt_ * p.M + m) * 2;
+                        dst[0] = s1;
+                        dst[1] = s2;
+                    }
+                }
             } else {      // PASE_EPI_MSE_CTX
                 const int half = p.r_ctx / 2;
+                const bool lean = pl.epi32 && rows_full && pase_wave_all(run) != 0;          // uniform
+                if (lean) {
+                    // lean form (see the store branch): 32-bit byte offsets off wave-uniform row pointers; the four targets of a
+                    // column quad are four consecutive label samples -- one unaligned 16-byte load where the context window
+                    // stays inside the sequence, four predicated loads at its edges
+                    const unsigned nc4 = (unsigned)p.Ncols * 4u;
+                    const unsigned ooff = (unsigned)(((size_t)sq[0] * p.M + (size_t)(lane >> 5)) * (size_t)p.Ncols + (size_t)qq[0]) * 4u;
+                    const unsigned loff = (unsigned)(sq[0] * p.label_D * p.Ncols + qq[0] - half) * 4u;
+                    const int tb0 = qq[0] - half;
+                    const size_t rowb0 = (size_t)(m0 + rw0 + 8 * c0) * (size_t)nc4;
+                    char* yrow = p.y ? reinterpret_cast<char*>(p.y) + rowb0 : nullptr;
+                    char* grow = p.grad_out ? reinterpret_cast<char*>(p.grad_out) + rowb0 : nullptr;
+                    const char* lab = reinterpret_cast<const char*>(p.label);
+                    for (int c = c0; c < c1; ++c) {
+                        float bv[4], tg[4][4];
+                        X6cF4 t4[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int m = mrow0 + 2 * (4 * c + i);
+                            bv[i] = p.bias != nullptr ? p.bias[m] : 0.f;
+                            t4[i] = *reinterpret_cast<const X6cF4*>(tl_rows + 2 * (4 * c + i) * TILE_P);
+                            const int d = (int)div_magic((unsigned)m, pl.rctx_magic);
+                            const int jj = m - d * p.r_ctx;
+                            const unsigned la = loff + (unsigned)(d * p.Ncols + jj) * 4u;
+                            const int tb = tb0 + jj;
+                            if (tb >= 0 && tb + 3 < p.Ncols) {
+                                const pase_f4u t = *reinterpret_cast<const pase_f4u*>(lab + la);
+                                tg[i][0] = t.x;
+                                tg[i][1] = t.y;
+                                tg[i][2] = t.z;
+                                tg[i][3] = t.w;
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    tg[i][e] = 0.f;
+                                    if ((unsigned)(tb + e) < (unsigned)p.Ncols) tg[i][e] = *reinterpret_cast<const float*>(lab + (la + 4u * e));
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float tv[4] = {t4[i].x, t4[i].y, t4[i].z, t4[i].w};
+                            float pr[4], df[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                pr[e] = tv[e] + bv[i];
+                                df[e] = pr[e] - tg[i][e];
+                                drain_lsum = fmaf(df[e], df[e], drain_lsum);
+                                df[e] *= p.grad_scale;
+                            }
+                            if (yrow) {
+                                pase_store_run4(reinterpret_cast<float*>(yrow + ooff), pr);
+                                yrow += 2 * nc4;
+                            }
+                            if (grow) {
+                                pase_store_run4(reinterpret_cast<float*>(grow + ooff), df);
+                                grow += 2 * nc4;
+                            }
+                        }
+                    }
+                } else {
                 size_t ob[4], lb[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -1108,6 +1238,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                         }
                     }
                 }
+                }
                 if (last) {
                     const float ls = pase_wave_sum64(drain_lsum);
                     drain_lsum = 0.f;
@@ -1116,10 +1247,11 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             }
             }
         };
-        // a tile is drained in NCH chunks during the ticks 1 .. NCH of the item that follows it (NCH <= stages - 1: the tile is
-        // free again before the barrier that ends that item's last stage)
-        const int drain_nch = GS - 1 >= 4 ? 4 : (GS - 1 >= 2 ? 2 : 1);
-        const int drain_per = 4 / drain_nch;          // groups of eight rows per chunk
+        // a tile is drained in drain_nch chunks during the ticks 1 .. drain_nch of the item that follows it (drain_nch <= stages - 1:
+        // the tile is free again before the barrier that ends that item's last stage)
+        int drain_nch = 1;
+        while (drain_nch * 2 <= NGRP && drain_nch * 2 <= GS - 1) drain_nch *= 2;
+        const int drain_per = NGRP / drain_nch;          // groups of eight rows per chunk
 
         if constexpr (STREAM && !ZP) {
             // ---- STREAM, operands split while they are staged (registers).  One stage per tick, three cursors along the
@@ -1208,9 +1340,9 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 // ---- the previous item's accumulator tile: published by the barrier that ended this item's first stage
                 if (drain_now) {
                     X6C_T0();
-                    const int c0 = finishing ? 0 : (giC - 1) * drain_per, c1 = finishing ? 4 : giC * drain_per;
-                    drain_tile(tile_item, c0, c1, c1 == 4);
-                    if (c1 == 4) tile_item = -1;
+                    const int c0 = finishing ? 0 : (giC - 1) * drain_per, c1 = finishing ? NGRP : giC * drain_per;
+                    drain_tile(tile_item, c0, c1, c1 == NGRP);
+                    if (c1 == NGRP) tile_item = -1;
                     if (wave == 4) X6C_TACC(8);
                 }
                 // ---- L: stream stage v + 3
@@ -1270,13 +1402,13 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             // vmcnt(0) in front of every load group and every write: the per-slot branches and the address registers it
             // allocated on top of the load destinations -- the staging waves ran one memory latency per slot, 90 % busy, and
             // the weight gradients at 1290 clocks per step against 790 of MFMA work.)
-            auto direct_stage = [&](int g, int bs) __attribute__((always_inline)) {
+            auto direct_stage = [&](int g, int bs, int fk) __attribute__((always_inline)) {      // fk: octet of the k-groups (0 / 1)
                 pase_static_for<NSLOT>([&](auto sl_tag) __attribute__((always_inline)) {
                     constexpr int sl = decltype(sl_tag)::value;
                     constexpr int kg = sl / NPS, ps = sl % NPS, par = kg & (NPAR - 1);
                     const int i0 = 128 * ps + 64 * (whalf ^ par);                  // uniform: first position of this wave
                     if (slot_live(kg, ps) && (NPS * 128 == NPOS || i0 < NPOS)) {   // uniform
-                        u32x4* dst = &Xs[bs * BUF + kg * KGC + fkL * NPOS + i0];
+                        u32x4* dst = &Xs[bs * BUF + kg * KGC + fk * NPOS + i0];
                         if constexpr (TM) {
                             const int kgi = g * KGS + kg;
                             const int s_ = (int)div_magic((unsigned)kgi, pl.seg_magic);
@@ -1287,7 +1419,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                                 x6c_load_lds16(zpb + (size_t)pz * (size_t)pl.t_plane + off, dst + pz * PLANE, lane);
                         } else {
                             const int gidx = min(g * KGS + kg, pl.G - 1);
-                            const unsigned off = (unsigned)((gidx * 2 + fkL) * p.S) * (unsigned)pl.xp_tpad + pos_xoff[par][ps];
+                            const unsigned off = (unsigned)((gidx * 2 + fk) * p.S) * (unsigned)pl.xp_tpad + pos_xoff[par][ps];
 #pragma unroll
                             for (int pz = 0; pz < 3; ++pz)
                                 x6c_load_lds16(xpc + (size_t)pz * (size_t)pl.xp_plane + off, dst + pz * PLANE, lane);
@@ -1304,8 +1436,10 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 bool N_has = true;
                 int itemC = (int)blockIdx.x, giC = 0, tile_item = -1;
                 bool finishing = false;
+                // (roles: waves 4 / 5 copy -- both octets of every k-group, their own half of the positions --, waves 6 / 7 drain)
+                const bool copier = wave < 6;      // uniform
                 for (int v = -1;; ++v) {
-                    if (!finishing) {
+                    if (!finishing && copier) {
                         if (N_has && giN == NST) {
                             itemN += (int)gridDim.x;
                             if (itemN < nitems) {
@@ -1317,20 +1451,22 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                         }
                         if (N_has) {
                             X6C_T0();
-                            direct_stage(giN, v >= 0 ? (bsel ^ 1) : bsel);
+                            const int bs = v >= 0 ? (bsel ^ 1) : bsel;
+                            direct_stage(giN, bs, 0);
+                            direct_stage(giN, bs, 1);
                             ++giN;
                             if (wave == 4) X6C_TACC(13);
                         }
                     }
                     if (tile_item >= 0 && (finishing || (v >= 0 && giC >= 1 && giC <= drain_nch))) {
                         X6C_T0();
-                        const int c0 = finishing ? 0 : (giC - 1) * drain_per, c1 = finishing ? 4 : giC * drain_per;
-                        drain_tile(tile_item, c0, c1, c1 == 4);
-                        if (c1 == 4) tile_item = -1;
-                        if (wave == 4) X6C_TACC(8);
+                        const int c0 = finishing ? 0 : (giC - 1) * drain_per, c1 = finishing ? NGRP : giC * drain_per;
+                        drain_tile(tile_item, c0, c1, c1 == NGRP);
+                        if (c1 == NGRP) tile_item = -1;
+                        if (dwi == 0) X6C_TACC(8);
                     }
                     if (finishing) break;
-                    {
+                    if (copier) {
                         X6C_T0();
                         x6c_vm_drain();
                         if (wave == 4) X6C_TACC(10);
@@ -1363,7 +1499,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
 #if !defined(PASE_HIPEMU)
                 if constexpr (TM) __builtin_amdgcn_s_waitcnt(0x0F70);      // (see prologue)
 #endif
-                direct_stage(g_begin, bsel);
+                direct_stage(g_begin, bsel, fkL);
                 if (wave == 4) X6C_STAMP(5);
             };
             int item = next_item((int)blockIdx.x - (int)gridDim.x);
@@ -1373,7 +1509,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 __syncthreads();           // the item's first stage is visible to the compute waves
                 for (int gi = 0; gi < nst; ++gi) {
                     X6C_T0();
-                    if (gi + 1 < nst) direct_stage(g_begin + gi + 1, bsel ^ 1);
+                    if (gi + 1 < nst) direct_stage(g_begin + gi + 1, bsel ^ 1, fkL);
                     x6c_vm_drain();
                     if (wave == 4) X6C_TACC(8);
                     __syncthreads();
@@ -2665,6 +2801,12 @@ bool pase_x6c_plan(const PaseConvGemm& p, PaseX6cPlan& pl) {
         const bool epi_ok = p.epilogue == PASE_EPI_MSE_CTX ||
                             (p.epilogue == PASE_EPI_STORE && p.ps == 1 && p.post_op == PASE_POST_NONE);
         bool ok = !narrow && epi_ok && splitk == 1 && GS >= 2 && !(p.x6_ctl & 128);
+        // Measured on the PASE+ bs32 step (same-box A/B, round 5): the streamed form wins where the staging waves have slack --
+        // pre-split operands (LDS DMA: they are idle) and stride-1 layers with >= 8 taps (a converted element feeds >= 32 MFMAs)
+        // -- and loses 8 ... 25 % where they are the bottleneck already (strided layers: 6 taps' per conversion; 1x1 and
+        // stride-10 layers split while staged), because the drain and the next item's position arithmetic land on them.
+        // x6_ctl bit 0 (tests, A/B runs) skips this rule like the other routing rules.
+        if (!force && !(p.x6_ctl & 0x10000) && !(xp_want && p.xp6 != nullptr) && !(pl.P == 1 && pl.A >= 8)) ok = false;      // (bit 16: A/B runs stream every eligible launch)
 #if defined(PASE_X6C_NODL) || defined(PASE_X6C_OLDLOOP) || defined(PASE_X6C_EARLYPRO)
         ok = false;      // A/B builds of the unstreamed loop's variants
 #endif
