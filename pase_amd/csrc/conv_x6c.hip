@@ -978,8 +978,80 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         constexpr int RPW = BM / DW;                    // tile rows per draining wave
         constexpr int NGRP = RPW / 8;                   // groups of eight rows (four passes of two rows) per draining wave
         const int dwi = wave - (ZP ? 6 : 4);            // index among the draining waves (negative: not one of them)
-        // groups [c0, c1) of each draining wave's NGRP: the drain of a tile is spread over several ticks; `last`: the tile's
-        // final chunk (BatchNorm partial sums of the whole tile / loss partial -> atomic)
+        // Labels and bias of the NEXT chunk (at most two groups) are loaded one tick ahead: a draining wave is alone with its
+        // memory latencies -- loads issued and consumed inside one chunk cost a round trip per group (measured: the LPS heads
+        // 0.59 -> 0.91 ms with the drain latency-bound on two waves) -- whereas a tick later they have simply arrived.
+        // (pre-split operands only -- there the draining waves hold nothing else; the waves that convert operands keep three
+        //  register sets of staged activations and have no room for 40 more registers: the build's spill guard fired)
+        constexpr int PFG = ZP ? 2 : 0;                 // groups a prefetch holds
+        constexpr int MAXG = ZP ? 2 : 1;                // groups one drain_tile call takes (register budget of the converting waves)
+        float pf_tg[PFG ? PFG : 1][4][4], pf_bv[PFG ? PFG : 1][4];
+        int pf_c0 = -1, pf_n = 0;                       // groups [pf_c0, pf_c0 + pf_n) of the tile are prefetched (lean tiles only)
+        auto drain_prefetch = [&](int item, int c0, int c1) __attribute__((always_inline)) {
+            if constexpr (STREAM) {
+            pf_c0 = -1;
+            pf_n = 0;
+            if constexpr (PFG == 0) return;
+            if (dwi < 0 || c1 - c0 > 2 || c1 <= c0) return;          // uniform
+            const int tl = xcd_swizzle(item, ntiles);
+            const int nt_ = tl / pl.n_row_tiles, mt_ = tl - nt_ * pl.n_row_tiles;
+            const int m0 = mt_ * BM, n0 = nt_ * BN;
+            const int n = n0 + 4 * (lane & 31);
+            const bool ok3 = n + 3 < ntot;
+            const unsigned n0u = (unsigned)(n < ntot ? n : 0), n3u = (unsigned)(ok3 ? n + 3 : 0);
+            const int s0_ = (int)div_magic(n0u, pl.ncols_magic), s3_ = (int)div_magic(n3u, pl.ncols_magic);
+            const int q0_ = (int)n0u - s0_ * p.Ncols;
+            const bool run = ok3 && s3_ == s0_;
+            const int rw0 = RPW * dwi;
+            const int mrow0 = m0 + rw0 + (lane >> 5);
+            const bool rows_full = m0 + rw0 + RPW <= p.M;
+            bool lean = pl.epi32 && rows_full;
+            if (p.epilogue == PASE_EPI_STORE) {
+                const int pos0 = q0_ + p.poff;
+                lean = lean && pase_wave_all(run && pos0 >= 0 && pos0 + 3 < p.Tout) != 0;
+            } else {
+                lean = lean && pase_wave_all(run) != 0;
+            }
+            if (!lean) return;                                        // uniform
+            const int half = p.r_ctx / 2;
+            const unsigned loff = (unsigned)(s0_ * p.label_D * p.Ncols + q0_ - half) * 4u;
+            const int tb0 = q0_ - half;
+            const char* lab = reinterpret_cast<const char*>(p.label);
+            pase_static_for<2>([&](auto g_tag) __attribute__((always_inline)) {
+                constexpr int g = decltype(g_tag)::value;
+                if (c0 + g < c1) {                                    // uniform
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int m = mrow0 + 2 * (4 * (c0 + g) + i);
+                        pf_bv[g < PFG ? g : 0][i] = p.bias != nullptr ? p.bias[m] : 0.f;
+                        if (p.epilogue != PASE_EPI_STORE) {          // uniform
+                            const int d = (int)div_magic((unsigned)m, pl.rctx_magic);
+                            const int jj = m - d * p.r_ctx;
+                            const unsigned la = loff + (unsigned)(d * p.Ncols + jj) * 4u;
+                            const int tb = tb0 + jj;
+                            if (tb >= 0 && tb + 3 < p.Ncols) {
+                                const pase_f4u t = *reinterpret_cast<const pase_f4u*>(lab + la);
+                                pf_tg[g < PFG ? g : 0][i][0] = t.x;
+                                pf_tg[g < PFG ? g : 0][i][1] = t.y;
+                                pf_tg[g < PFG ? g : 0][i][2] = t.z;
+                                pf_tg[g < PFG ? g : 0][i][3] = t.w;
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    pf_tg[g < PFG ? g : 0][i][e] = 0.f;
+                                    if ((unsigned)(tb + e) < (unsigned)p.Ncols) pf_tg[g < PFG ? g : 0][i][e] = *reinterpret_cast<const float*>(lab + (la + 4u * e));
+                                }
+                            }
+                        }
+                    }
+                }
+            });
+            pf_c0 = c0;
+            pf_n = c1 - c0;
+            }
+        };
+        // groups [c0, c1), c1 - c0 <= MAXG, of each draining wave's NGRP: the drain of a tile is spread over several ticks; `last`:
+        // the tile's final chunk (BatchNorm partial sums of the whole tile / loss partial -> atomic)
         auto drain_tile = [&](int item, int c0, int c1, bool last) __attribute__((always_inline)) {
             if constexpr (STREAM) {
             if (dwi < 0) return;                          // uniform
@@ -1023,47 +1095,45 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                     const unsigned cb4 = (unsigned)(ob[0] + (size_t)(lane >> 5) * (size_t)p.Tout) * 4u;
                     const unsigned to8 = (unsigned)p.Tout * 8u;
                     char* yrow = reinterpret_cast<char*>(p.y) + (size_t)(m0 + rw0 + 8 * c0) * (size_t)p.Tout * 4u;
-                    for (int c = c0; c < c1; ++c) {
-                        float bv[4];
-                        X6cF4 t4[4];
+                    const bool use_pf = pf_c0 == c0 && pf_n >= c1 - c0;          // uniform
+                    pase_static_for<MAXG>([&](auto g_tag) __attribute__((always_inline)) {
+                        constexpr int g = decltype(g_tag)::value;
+                        const int c = c0 + g;
+                        if (c < c1) {                                            // uniform
+                            float bv[4];
+                            X6cF4 t4[4];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            bv[i] = p.bias != nullptr ? p.bias[mrow0 + 2 * (4 * c + i)] : 0.f;
-                            t4[i] = *reinterpret_cast<const X6cF4*>(tl_rows + 2 * (4 * c + i) * TILE_P);
-                        }
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float v[4] = {t4[i].x + bv[i], t4[i].y + bv[i], t4[i].z + bv[i], t4[i].w + bv[i]};
-                            pase_store_run4(reinterpret_cast<float*>(yrow + cb4), v);
-                            yrow += to8;
-                        }
-                    }
-                } else {
-                for (int c = c0; c < c1; ++c) {
-                    // four passes (eight rows of the wave) per group: their bias loads and LDS reads first
-                    float bv[4];
-                    X6cF4 t4[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int it = 4 * c + i;
-                        const int m = mrow0 + 2 * it;
-                        bv[i] = (p.bias != nullptr && m < p.M) ? p.bias[m] : 0.f;
-                        t4[i] = *reinterpret_cast<const X6cF4*>(tl_rows + 2 * it * TILE_P);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int m = mrow0 + 2 * (4 * c + i);
-                        const bool mok = m < p.M;
-                        float v[4] = {t4[i].x + bv[i], t4[i].y + bv[i], t4[i].z + bv[i], t4[i].w + bv[i]};
-                        float* yr = p.y + (size_t)(mok ? m : 0) * (size_t)p.Tout;
-                        if (mok) {
-                            if (run_o) {
-                                pase_store_run4(yr + ob[0], v);
-                            } else {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e)
-                                    if (oko[e]) yr[ob[e]] = v[e];
+                            for (int i = 0; i < 4; ++i) {
+                                if (PFG > 0 && use_pf) bv[i] = pf_bv[g < PFG ? g : 0][i];
+                                else bv[i] = p.bias != nullptr ? p.bias[mrow0 + 2 * (4 * c + i)] : 0.f;
+                                t4[i] = *reinterpret_cast<const X6cF4*>(tl_rows + 2 * (4 * c + i) * TILE_P);
                             }
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float v[4] = {t4[i].x + bv[i], t4[i].y + bv[i], t4[i].z + bv[i], t4[i].w + bv[i]};
+                                pase_store_run4(reinterpret_cast<float*>(yrow + cb4), v);
+                                yrow += to8;
+                            }
+                        }
+                    });
+                } else {
+                // edge tiles (ragged rows / columns, a quad across two sequences): one pass of two rows at a time, plainly --
+                // rare, and the converting waves have no registers to spare for a wider form
+#pragma unroll 1
+                for (int it = 4 * c0; it < 4 * c1; ++it) {
+                    const int m = mrow0 + 2 * it;
+                    const bool mok = m < p.M;
+                    const float bvv = (p.bias != nullptr && mok) ? p.bias[m] : 0.f;
+                    const X6cF4 t4 = *reinterpret_cast<const X6cF4*>(tl_rows + 2 * it * TILE_P);
+                    float v[4] = {t4.x + bvv, t4.y + bvv, t4.z + bvv, t4.w + bvv};
+                    float* yr = p.y + (size_t)(mok ? m : 0) * (size_t)p.Tout;
+                    if (mok) {
+                        if (run_o) {
+                            pase_store_run4(yr + ob[0], v);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (oko[e]) yr[ob[e]] = v[e];
                         }
                     }
                 }
@@ -1134,53 +1204,64 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                     char* yrow = p.y ? reinterpret_cast<char*>(p.y) + rowb0 : nullptr;
                     char* grow = p.grad_out ? reinterpret_cast<char*>(p.grad_out) + rowb0 : nullptr;
                     const char* lab = reinterpret_cast<const char*>(p.label);
-                    for (int c = c0; c < c1; ++c) {
-                        float bv[4], tg[4][4];
-                        X6cF4 t4[4];
+                    const bool use_pf = pf_c0 == c0 && pf_n >= c1 - c0;          // uniform
+                    pase_static_for<MAXG>([&](auto g_tag) __attribute__((always_inline)) {
+                        constexpr int g = decltype(g_tag)::value;
+                        const int c = c0 + g;
+                        if (c < c1) {                                            // uniform
+                            float bv[4], tg[4][4];
+                            X6cF4 t4[4];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int m = mrow0 + 2 * (4 * c + i);
-                            bv[i] = p.bias != nullptr ? p.bias[m] : 0.f;
-                            t4[i] = *reinterpret_cast<const X6cF4*>(tl_rows + 2 * (4 * c + i) * TILE_P);
-                            const int d = (int)div_magic((unsigned)m, pl.rctx_magic);
-                            const int jj = m - d * p.r_ctx;
-                            const unsigned la = loff + (unsigned)(d * p.Ncols + jj) * 4u;
-                            const int tb = tb0 + jj;
-                            if (tb >= 0 && tb + 3 < p.Ncols) {
-                                const pase_f4u t = *reinterpret_cast<const pase_f4u*>(lab + la);
-                                tg[i][0] = t.x;
-                                tg[i][1] = t.y;
-                                tg[i][2] = t.z;
-                                tg[i][3] = t.w;
-                            } else {
+                            for (int i = 0; i < 4; ++i) {
+                                const int m = mrow0 + 2 * (4 * c + i);
+                                t4[i] = *reinterpret_cast<const X6cF4*>(tl_rows + 2 * (4 * c + i) * TILE_P);
+                                if (PFG > 0 && use_pf) {
+                                    bv[i] = pf_bv[g < PFG ? g : 0][i];
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) tg[i][e] = pf_tg[g < PFG ? g : 0][i][e];
+                                } else {
+                                    bv[i] = p.bias != nullptr ? p.bias[m] : 0.f;
+                                    const int d = (int)div_magic((unsigned)m, pl.rctx_magic);
+                                    const int jj = m - d * p.r_ctx;
+                                    const unsigned la = loff + (unsigned)(d * p.Ncols + jj) * 4u;
+                                    const int tb = tb0 + jj;
+                                    if (tb >= 0 && tb + 3 < p.Ncols) {
+                                        const pase_f4u t = *reinterpret_cast<const pase_f4u*>(lab + la);
+                                        tg[i][0] = t.x;
+                                        tg[i][1] = t.y;
+                                        tg[i][2] = t.z;
+                                        tg[i][3] = t.w;
+                                    } else {
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) {
+                                            tg[i][e] = 0.f;
+                                            if ((unsigned)(tb + e) < (unsigned)p.Ncols) tg[i][e] = *reinterpret_cast<const float*>(lab + (la + 4u * e));
+                                        }
+                                    }
+                                }
+                            }
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float tv[4] = {t4[i].x, t4[i].y, t4[i].z, t4[i].w};
+                                float pr[4], df[4];
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
-                                    tg[i][e] = 0.f;
-                                    if ((unsigned)(tb + e) < (unsigned)p.Ncols) tg[i][e] = *reinterpret_cast<const float*>(lab + (la + 4u * e));
+                                    pr[e] = tv[e] + bv[i];
+                                    df[e] = pr[e] - tg[i][e];
+                                    drain_lsum = fmaf(df[e], df[e], drain_lsum);
+                                    df[e] *= p.grad_scale;
+                                }
+                                if (yrow) {
+                                    pase_store_run4(reinterpret_cast<float*>(yrow + ooff), pr);
+                                    yrow += 2 * nc4;
+                                }
+                                if (grow) {
+                                    pase_store_run4(reinterpret_cast<float*>(grow + ooff), df);
+                                    grow += 2 * nc4;
                                 }
                             }
                         }
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float tv[4] = {t4[i].x, t4[i].y, t4[i].z, t4[i].w};
-                            float pr[4], df[4];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                pr[e] = tv[e] + bv[i];
-                                df[e] = pr[e] - tg[i][e];
-                                drain_lsum = fmaf(df[e], df[e], drain_lsum);
-                                df[e] *= p.grad_scale;
-                            }
-                            if (yrow) {
-                                pase_store_run4(reinterpret_cast<float*>(yrow + ooff), pr);
-                                yrow += 2 * nc4;
-                            }
-                            if (grow) {
-                                pase_store_run4(reinterpret_cast<float*>(grow + ooff), df);
-                                grow += 2 * nc4;
-                            }
-                        }
-                    }
+                    });
                 } else {
                 size_t ob[4], lb[4];
 #pragma unroll
@@ -1188,53 +1269,39 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                     ob[e] = (size_t)sq[e] * p.M * (size_t)p.Ncols + (size_t)qq[e];
                     lb[e] = (size_t)sq[e] * p.label_D * (size_t)p.Ncols;
                 }
-                for (int c = c0; c < c1; ++c) {
-                    // the sixteen label loads, four bias loads and four LDS reads of the group first (one memory latency)
-                    float bv[4], tg[4][4];
-                    X6cF4 t4[4];
+#pragma unroll 1
+                for (int it = 4 * c0; it < 4 * c1; ++it) {
+                    const int m = mrow0 + 2 * it;
+                    const bool mok = m < p.M;
+                    const int mm = mok ? m : 0;
+                    const float bvv = (p.bias != nullptr && mok) ? p.bias[mm] : 0.f;
+                    const X6cF4 t4 = *reinterpret_cast<const X6cF4*>(tl_rows + 2 * it * TILE_P);
+                    const int d = (int)div_magic((unsigned)mm, pl.rctx_magic);
+                    const int jj = mm - d * p.r_ctx;
+                    const float tv[4] = {t4.x, t4.y, t4.z, t4.w};
+                    float pr[4], df[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int it = 4 * c + i;
-                        const int m = mrow0 + 2 * it;
-                        const bool mok = m < p.M;
-                        const int mm = mok ? m : 0;
-                        bv[i] = (p.bias != nullptr && mok) ? p.bias[mm] : 0.f;
-                        t4[i] = *reinterpret_cast<const X6cF4*>(tl_rows + 2 * it * TILE_P);
-                        const int d = (int)div_magic((unsigned)mm, pl.rctx_magic);
-                        const int jj = mm - d * p.r_ctx;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int tb = qq[e] - half + jj;
-                            tg[i][e] = 0.f;
-                            if (mok && okc[e] && (unsigned)tb < (unsigned)p.Ncols) tg[i][e] = p.label[lb[e] + (size_t)d * p.Ncols + tb];
-                        }
+                    for (int e = 0; e < 4; ++e) {
+                        const int tb = qq[e] - half + jj;
+                        float tg = 0.f;
+                        if (mok && okc[e] && (unsigned)tb < (unsigned)p.Ncols) tg = p.label[lb[e] + (size_t)d * p.Ncols + tb];
+                        pr[e] = tv[e] + bvv;
+                        df[e] = pr[e] - tg;
+                        if (mok && okc[e]) drain_lsum += df[e] * df[e];
+                        df[e] *= p.grad_scale;
                     }
+                    const size_t ro = (size_t)mm * (size_t)p.Ncols;
+                    if (mok) {
+                        if (run) {
+                            if (p.y) pase_store_run4(p.y + ro + ob[0], pr);
+                            if (p.grad_out) pase_store_run4(p.grad_out + ro + ob[0], df);
+                        } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int m = mrow0 + 2 * (4 * c + i);
-                        const bool mok = m < p.M;
-                        const float tv[4] = {t4[i].x, t4[i].y, t4[i].z, t4[i].w};
-                        float pr[4], df[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            pr[e] = tv[e] + bv[i];
-                            df[e] = pr[e] - tg[i][e];
-                            if (mok && okc[e]) drain_lsum += df[e] * df[e];
-                            df[e] *= p.grad_scale;
-                        }
-                        const size_t ro = (size_t)(mok ? m : 0) * (size_t)p.Ncols;
-                        if (mok) {
-                            if (run) {
-                                if (p.y) pase_store_run4(p.y + ro + ob[0], pr);
-                                if (p.grad_out) pase_store_run4(p.grad_out + ro + ob[0], df);
-                            } else {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e)
-                                    if (okc[e]) {
-                                        if (p.y) p.y[ro + ob[e]] = pr[e];
-                                        if (p.grad_out) p.grad_out[ro + ob[e]] = df[e];
-                                    }
-                            }
+                            for (int e = 0; e < 4; ++e)
+                                if (okc[e]) {
+                                    if (p.y) p.y[ro + ob[e]] = pr[e];
+                                    if (p.grad_out) p.grad_out[ro + ob[e]] = df[e];
+                                }
                         }
                     }
                 }
@@ -1247,11 +1314,24 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             }
             }
         };
-        // a tile is drained in drain_nch chunks during the ticks 1 .. drain_nch of the item that follows it (drain_nch <= stages - 1:
-        // the tile is free again before the barrier that ends that item's last stage)
-        int drain_nch = 1;
-        while (drain_nch * 2 <= NGRP && drain_nch * 2 <= GS - 1) drain_nch *= 2;
-        const int drain_per = NGRP / drain_nch;          // groups of eight rows per chunk
+        // A tile is drained during the ticks 1 .. stages - 1 of the item that follows it, `drain_gpt` groups per tick (the tile is
+        // free again before the barrier that ends that item's last stage); tick 0 prefetches the first chunk.  drain_tile takes
+        // at most two groups per call.
+        const int drain_gpt = (NGRP + (GS - 1) - 1) / (GS - 1);
+        int drain_pos = 0;                            // groups of the pending tile already drained
+        auto drain_step = [&](int item, int gi_c, bool fin) __attribute__((always_inline)) {      // -> true: the tile is done
+            // (ONE call site of drain_tile and one of drain_prefetch: every inlined copy costs the converting waves registers)
+            const int target = fin ? NGRP : min(NGRP, gi_c * drain_gpt);                      // gi_c == 0: nothing yet
+            for (int cc = drain_pos; cc < target; cc += MAXG)
+                drain_tile(item, cc, min(cc + MAXG, target), min(cc + MAXG, target) == NGRP);
+            drain_pos = target;
+            if (target < NGRP) {
+                drain_prefetch(item, target, min(target + 2, min(NGRP, (gi_c + 1) * drain_gpt)));
+                return false;
+            }
+            drain_pos = 0;
+            return true;
+        };
 
         if constexpr (STREAM && !ZP) {
             // ---- STREAM, operands split while they are staged (registers).  One stage per tick, three cursors along the
@@ -1315,7 +1395,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 // everything (the loads of stream stage v + 2 were issued a whole tick ago), THEN run that code, and issue
                 // this tick's loads last.
                 const bool crossing = !finishing && L_has && giL == NST;
-                const bool drain_now = tile_item >= 0 && (finishing || (v >= 0 && giC >= 1 && giC <= drain_nch));
+                const bool drain_now = tile_item >= 0 && (finishing || v >= 0);
                 if (crossing || drain_now) {
                     X6C_T0();
                     x6c_vmwait<0>();
@@ -1340,9 +1420,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 // ---- the previous item's accumulator tile: published by the barrier that ended this item's first stage
                 if (drain_now) {
                     X6C_T0();
-                    const int c0 = finishing ? 0 : (giC - 1) * drain_per, c1 = finishing ? NGRP : giC * drain_per;
-                    drain_tile(tile_item, c0, c1, c1 == NGRP);
-                    if (c1 == NGRP) tile_item = -1;
+                    if (drain_step(tile_item, giC, finishing)) tile_item = -1;
                     if (wave == 4) X6C_TACC(8);
                 }
                 // ---- L: stream stage v + 3
@@ -1458,11 +1536,9 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                             if (wave == 4) X6C_TACC(13);
                         }
                     }
-                    if (tile_item >= 0 && (finishing || (v >= 0 && giC >= 1 && giC <= drain_nch))) {
+                    if (tile_item >= 0 && (finishing || v >= 0)) {
                         X6C_T0();
-                        const int c0 = finishing ? 0 : (giC - 1) * drain_per, c1 = finishing ? NGRP : giC * drain_per;
-                        drain_tile(tile_item, c0, c1, c1 == NGRP);
-                        if (c1 == NGRP) tile_item = -1;
+                        if (drain_step(tile_item, giC, finishing)) tile_item = -1;
                         if (dwi == 0) X6C_TACC(8);
                     }
                     if (finishing) break;
@@ -2806,7 +2882,15 @@ bool pase_x6c_plan(const PaseConvGemm& p, PaseX6cPlan& pl) {
         // -- and loses 8 ... 25 % where they are the bottleneck already (strided layers: 6 taps' per conversion; 1x1 and
         // stride-10 layers split while staged), because the drain and the next item's position arithmetic land on them.
         // x6_ctl bit 0 (tests, A/B runs) skips this rule like the other routing rules.
+#ifdef PASE_X6C_STREAM_REG
         if (!force && !(p.x6_ctl & 0x10000) && !(xp_want && p.xp6 != nullptr) && !(pl.P == 1 && pl.A >= 8)) ok = false;      // (bit 16: A/B runs stream every eligible launch)
+#else
+        // The shipped library streams the pre-split launches only.  The form that converts while it stages is correct (GPU:
+        // bit-identical to the compiler-waited build) but buys 0 ... 3 % on the stride-1 11-tap layers, loses everywhere else,
+        // and its converting waves sit at the register limit (the lean drain + prefetch made them spill: the build's guard
+        // fires); it is compiled with -DPASE_X6C_STREAM_REG for A/B runs.
+        if (!(xp_want && p.xp6 != nullptr)) ok = false;
+#endif
 #if defined(PASE_X6C_NODL) || defined(PASE_X6C_OLDLOOP) || defined(PASE_X6C_EARLYPRO)
         ok = false;      // A/B builds of the unstreamed loop's variants
 #endif
@@ -2839,8 +2923,13 @@ int pase_x6c_launch(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st
         if (pl.xp) {
             if (pl.A == 1) PASE_LAUNCH((conv_x6c_kernel<128, 3, false, true, false, true>), grid, block, st, p, pl);
             else PASE_LAUNCH((conv_x6c_kernel<192, 2, false, true, false, true>), grid, block, st, p, pl);
-        } else if (pl.A == 1) PASE_LAUNCH((conv_x6c_kernel<128, 3, false, false, false, true>), grid, block, st, p, pl);
+        }
+#ifdef PASE_X6C_STREAM_REG
+        else if (pl.A == 1) PASE_LAUNCH((conv_x6c_kernel<128, 3, false, false, false, true>), grid, block, st, p, pl);
         else PASE_LAUNCH((conv_x6c_kernel<192, 2, false, false, false, true>), grid, block, st, p, pl);
+#else
+        else return -12;
+#endif
     } else if (pl.xp) {
         if (pl.A == 1) PASE_LAUNCH((conv_x6c_kernel<128, 3, false, true>), grid, block, st, p, pl);
         else PASE_LAUNCH((conv_x6c_kernel<192, 2, false, true>), grid, block, st, p, pl);

@@ -496,7 +496,9 @@ def test_streamed_form_matches_fp64_and_the_unstreamed_form(dev, monkeypatch, ca
     for streamed in (True, False):
         monkeypatch.setenv("PASE_X6C_STREAM", "1" if streamed else "0")
         y, stat, extra = run()
-        assert K.LAST_PLAN_KIND == 2 and K.LAST_STREAMED == streamed
+        # (the shipped library streams launches whose activation is pre-split -- the `presplit` pass of this file, stride-1
+        #  shapes only; the other pass checks that everything else is routed to the unstreamed form)
+        assert K.LAST_PLAN_KIND == 2 and K.LAST_STREAMED == (streamed and K.LAST_XP)
         got[streamed] = (y.cpu(), None if stat is None else stat.cpu().double().sum(0), extra)
     if case == "mse-ragged":
         pred, tgt = ref
