@@ -236,6 +236,17 @@ __device__ __forceinline__ void x6c_load_lds16(const void* src, u32x4* lds_wave_
 }
 __device__ __forceinline__ void x6c_vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #endif
+// ... and one dword per lane (global_load_lds_dword): destination = wave-uniform LDS address + 4 * lane, for the active lanes
+#ifdef PASE_HIPEMU
+__device__ __forceinline__ void x6c_load_lds4(const void* src, float* lds_wave_base, int lane) {
+    __builtin_memcpy(&lds_wave_base[lane], src, 4);
+}
+#else
+__device__ __forceinline__ void x6c_load_lds4(const void* src, float* lds_wave_base, int) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+#endif
 struct alignas(16) X6cF4 { float x, y, z, w; };
 // Staging registers: eight fp32 values per slot as two 4-vectors (the row-coalesced weight-gradient path fills them with two
 // global_load_dwordx4, every other path with eight global_load_dword).
@@ -340,6 +351,30 @@ __device__ __forceinline__ void x6c_vmwait_slots(int nslots, bool two_per_slot) 
     }
 }
 
+// at most n (rounded DOWN to a multiple of four, at most 32) of this wave's vector memory operations outstanding (real in every
+// hardware build, like x6c_vm_drain: it guards LDS DMA)
+#ifdef PASE_HIPEMU
+__device__ __forceinline__ void x6c_vmwait_le(int) {}
+#else
+template <int N>
+__device__ __forceinline__ void x6c_vm_wait_imm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void x6c_vmwait_le(int n) {
+    switch (n < 0 ? 0 : (n > 32 ? 8 : n >> 2)) {
+        case 0: x6c_vm_wait_imm<0>(); break;
+        case 1: x6c_vm_wait_imm<4>(); break;
+        case 2: x6c_vm_wait_imm<8>(); break;
+        case 3: x6c_vm_wait_imm<12>(); break;
+        case 4: x6c_vm_wait_imm<16>(); break;
+        case 5: x6c_vm_wait_imm<20>(); break;
+        case 6: x6c_vm_wait_imm<24>(); break;
+        case 7: x6c_vm_wait_imm<28>(); break;
+        default: x6c_vm_wait_imm<32>(); break;
+    }
+}
+#endif
+
 // NPOS: positions (16-byte chunks) per (plane, fk) row of a k-group; KGS_T: k-groups a stage buffer holds.
 //   <192, 2>: convolutions (128 columns + up to 64 halo positions)      <128, 3>: 1x1 layers (no halo)
 // The grid is PERSISTENT: workgroup b works through the items b, b + gridDim.x, ... (item = (split-K slice, tile)); the
@@ -397,9 +432,17 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     // write rows 4 apart: 4 * 136 floats = 32 banks apart; a drain lane reads 16 contiguous bytes of a row)
     constexpr int TILE_P = 136;
     constexpr int TILE_CHUNKS = STREAM ? BM * TILE_P * 4 / 16 : 0;
-    __shared__ __attribute__((aligned(16))) u32x4 Xs[2 * BUF + RED_CHUNKS + TR_CHUNKS + TILE_CHUNKS];
+    // STREAM on pre-split operands: what the drain reads besides the tile -- the bias of the tile's rows and, for the fused MSE,
+    // the slab of labels the tile's rows and columns touch ([label channel][column + context halo], SLAB_ROWS x SLAB_P floats)
+    // -- is copied into LDS by DMA a tick ahead: the draining waves then issue NO load from global memory, so neither they
+    // nor the compiler ever wait on the vector memory counter except for the operand DMA itself (see the tick below).
+    constexpr int SLAB_ROWS = 20, SLAB_P = 136;
+    constexpr int AUX_CHUNKS = (STREAM && ZP) ? (SLAB_ROWS * SLAB_P * 4 + BM * 4) / 16 : 0;
+    __shared__ __attribute__((aligned(16))) u32x4 Xs[2 * BUF + RED_CHUNKS + TR_CHUNKS + TILE_CHUNKS + AUX_CHUNKS];
     float (*red)[BM][2] = reinterpret_cast<float (*)[BM][2]>(&Xs[2 * BUF]);
     float* const acc_tile = reinterpret_cast<float*>(&Xs[2 * BUF + RED_CHUNKS + TR_CHUNKS]);
+    float* const aux_slab = reinterpret_cast<float*>(&Xs[2 * BUF + RED_CHUNKS + TR_CHUNKS + TILE_CHUNKS]);
+    float* const aux_bias = aux_slab + SLAB_ROWS * SLAB_P;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -970,20 +1013,23 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         //                     partial per wave -> one fp64 atomic, prediction and / or gradient stored
         // (reference ops: nn.BatchNorm1d statistics of FeBlock modules.py:1073-1075; ContextualizedLoss losses.py:6-37)
         float drain_lsum = 0.f;          // MSE: this lane's loss partial of the tile being drained (summed over its row chunks)
+        int drain_vm_ops = 0;            // vector memory operations the drain issued this tick -- a LOWER bound (lean tiles count
+                                         // their stores exactly; anything else sets it negative = unknown)
         // Who drains.  Operands split while staged (registers): all four staging waves, 32 tile rows each.  Pre-split operands
         // (LDS DMA): waves 6 / 7 drain, 64 rows each, and waves 4 / 5 issue ALL the DMA -- a wave that waits for its DMA with
         // vmcnt(0) in front of every barrier would wait for the drain's label loads and store acknowledgements as well (one
         // counter per wave, in order): with the roles apart the drain never sits on the stage's critical path.
-        constexpr int DW = ZP ? 2 : 4;                  // draining waves
+        constexpr int DW = 4;                           // draining waves (all four staging waves, 32 tile rows each)
         constexpr int RPW = BM / DW;                    // tile rows per draining wave
         constexpr int NGRP = RPW / 8;                   // groups of eight rows (four passes of two rows) per draining wave
-        const int dwi = wave - (ZP ? 6 : 4);            // index among the draining waves (negative: not one of them)
+        const int dwi = wave - 4;                       // index among the draining waves
         // Labels and bias of the NEXT chunk (at most two groups) are loaded one tick ahead: a draining wave is alone with its
         // memory latencies -- loads issued and consumed inside one chunk cost a round trip per group (measured: the LPS heads
         // 0.59 -> 0.91 ms with the drain latency-bound on two waves) -- whereas a tick later they have simply arrived.
         // (pre-split operands only -- there the draining waves hold nothing else; the waves that convert operands keep three
         //  register sets of staged activations and have no room for 40 more registers: the build's spill guard fired)
-        constexpr int PFG = ZP ? 2 : 0;                 // groups a prefetch holds
+        constexpr int PFG = 0;                          // groups a prefetch holds (0: prefetch off -- superseded for the pre-split form by
+                                                        // the LDS copies of bias and labels, see AUX_CHUNKS; kept for A/B builds)
         constexpr int MAXG = ZP ? 2 : 1;                // groups one drain_tile call takes (register budget of the converting waves)
         float pf_tg[PFG ? PFG : 1][4][4], pf_bv[PFG ? PFG : 1][4];
         int pf_c0 = -1, pf_n = 0;                       // groups [pf_c0, pf_c0 + pf_n) of the tile are prefetched (lean tiles only)
@@ -1105,6 +1151,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
                                 if (PFG > 0 && use_pf) bv[i] = pf_bv[g < PFG ? g : 0][i];
+                                else if (ZP) bv[i] = p.bias != nullptr ? aux_bias[rw0 + (lane >> 5) + 2 * (4 * c + i)] : 0.f;
                                 else bv[i] = p.bias != nullptr ? p.bias[mrow0 + 2 * (4 * c + i)] : 0.f;
                                 t4[i] = *reinterpret_cast<const X6cF4*>(tl_rows + 2 * (4 * c + i) * TILE_P);
                             }
@@ -1114,9 +1161,11 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                                 pase_store_run4(reinterpret_cast<float*>(yrow + cb4), v);
                                 yrow += to8;
                             }
+                            drain_vm_ops += 4;
                         }
                     });
                 } else {
+                drain_vm_ops = -1000;
                 // edge tiles (ragged rows / columns, a quad across two sequences): one pass of two rows at a time, plainly --
                 // rare, and the converting waves have no registers to spare for a wider form
 #pragma unroll 1
@@ -1146,7 +1195,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                     constexpr int NQ = BN / 4 / NPART;                 // column quads per lane
                     const int rl = lane & (RPW - 1), part = lane / RPW;
                     const int m = m0 + rw0 + rl;
-                    const float b = (p.bias != nullptr && m < p.M) ? p.bias[m] : 0.f;
+                    const float b = p.bias == nullptr ? 0.f : (ZP ? aux_bias[rw0 + rl] : (m < p.M ? p.bias[m] : 0.f));
                     const float* trow = acc_tile + (rw0 + rl) * TILE_P + part * (BN / NPART);
                     float s1 = 0.f, s2 = 0.f;
                     const int ncol_t = min(BN, ntot - n0);            // real columns of the tile (uniform)
@@ -1200,6 +1249,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                     const unsigned ooff = (unsigned)(((size_t)sq[0] * p.M + (size_t)(lane >> 5)) * (size_t)p.Ncols + (size_t)qq[0]) * 4u;
                     const unsigned loff = (unsigned)(sq[0] * p.label_D * p.Ncols + qq[0] - half) * 4u;
                     const int tb0 = qq[0] - half;
+                    const int d_first = (int)div_magic((unsigned)m0, pl.rctx_magic);
                     const size_t rowb0 = (size_t)(m0 + rw0 + 8 * c0) * (size_t)nc4;
                     char* yrow = p.y ? reinterpret_cast<char*>(p.y) + rowb0 : nullptr;
                     char* grow = p.grad_out ? reinterpret_cast<char*>(p.grad_out) + rowb0 : nullptr;
@@ -1219,6 +1269,19 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                                     bv[i] = pf_bv[g < PFG ? g : 0][i];
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) tg[i][e] = pf_tg[g < PFG ? g : 0][i][e];
+                                } else if (ZP) {
+                                    // bias and labels out of LDS (copied there a tick ago: stage_aux): slab row = label channel
+                                    // d - d_first, slab column = tile column + context index
+                                    bv[i] = p.bias != nullptr ? aux_bias[rw0 + (lane >> 5) + 2 * (4 * c + i)] : 0.f;
+                                    const int d = (int)div_magic((unsigned)m, pl.rctx_magic);
+                                    const int jj = m - d * p.r_ctx;
+                                    const float* sl = aux_slab + (d - d_first) * SLAB_P + cl + jj;
+                                    const int tb = tb0 + jj;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        const float t = sl[e];
+                                        tg[i][e] = (unsigned)(tb + e) < (unsigned)p.Ncols ? t : 0.f;
+                                    }
                                 } else {
                                     bv[i] = p.bias != nullptr ? p.bias[m] : 0.f;
                                     const int d = (int)div_magic((unsigned)m, pl.rctx_magic);
@@ -1260,9 +1323,11 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                                     grow += 2 * nc4;
                                 }
                             }
+                            drain_vm_ops += 4 * ((yrow ? 1 : 0) + (grow ? 1 : 0));
                         }
                     });
                 } else {
+                drain_vm_ops = -1000;
                 size_t ob[4], lb[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -1317,7 +1382,10 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         // A tile is drained during the ticks 1 .. stages - 1 of the item that follows it, `drain_gpt` groups per tick (the tile is
         // free again before the barrier that ends that item's last stage); tick 0 prefetches the first chunk.  drain_tile takes
         // at most two groups per call.
-        const int drain_gpt = (NGRP + (GS - 1) - 1) / (GS - 1);
+        // (pre-split form: the item's LAST tick copies the tile's bias / labels into LDS -- stage_aux -- so the drain of the
+        //  previous tile must be over one tick earlier)
+        const int drain_ticks = ZP ? GS - 2 : GS - 1;
+        const int drain_gpt = (NGRP + drain_ticks - 1) / drain_ticks;
         int drain_pos = 0;                            // groups of the pending tile already drained
         auto drain_step = [&](int item, int gi_c, bool fin) __attribute__((always_inline)) {      // -> true: the tile is done
             // (ONE call site of drain_tile and one of drain_prefetch: every inlined copy costs the converting waves registers)
@@ -1514,10 +1582,50 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 bool N_has = true;
                 int itemC = (int)blockIdx.x, giC = 0, tile_item = -1;
                 bool finishing = false;
-                // (roles: waves 4 / 5 copy -- both octets of every k-group, their own half of the positions --, waves 6 / 7 drain)
-                const bool copier = wave < 6;      // uniform
+                // bias and label slab of a tile -> LDS, by DMA, shared out over the four staging waves (wave w: slab rows w - 4,
+                // w, ... ; wave 4 also the bias).  Slab row dl = label channel d_first + dl, slab column cc = tile column + context
+                // index, i.e. flattened output column n0 + cc - r / 2 (columns outside the data are not copied: the drain's
+                // range check zeroes what it reads there).
+                auto stage_aux = [&](int item) __attribute__((always_inline)) {
+                    const int tl = xcd_swizzle(item, ntiles);
+                    const int nt_ = tl / pl.n_row_tiles, mt_ = tl - nt_ * pl.n_row_tiles;
+                    const int m0 = mt_ * BM, n0 = nt_ * BN;
+                    if (p.bias != nullptr && wave == 4) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            if (m0 + 64 * h + lane < p.M) x6c_load_lds4(p.bias + m0 + 64 * h + lane, aux_bias + 64 * h, lane);
+                    }
+                    if (p.epilogue == PASE_EPI_MSE_CTX) {      // uniform
+                        const int half = p.r_ctx / 2;
+                        const int d_first = (int)div_magic((unsigned)m0, pl.rctx_magic);
+                        const int d_last = (int)div_magic((unsigned)min(m0 + BM - 1, p.M - 1), pl.rctx_magic);
+                        unsigned csrc[3];
+                        bool cval[3];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const int cc = 64 * k + lane;
+                            const int nn = n0 + cc - half;
+                            cval[k] = cc < SLAB_P && nn >= 0 && nn < ntot;
+                            const unsigned nu = (unsigned)(cval[k] ? nn : 0);
+                            const int s_ = (int)div_magic(nu, pl.ncols_magic);
+                            csrc[k] = (unsigned)(s_ * p.label_D * p.Ncols + ((int)nu - s_ * p.Ncols));
+                        }
+                        for (int dl = wave - 4; dl <= d_last - d_first && dl < SLAB_ROWS; dl += 4) {
+                            const float* lrow = p.label + (size_t)(d_first + dl) * (size_t)p.Ncols;
+#pragma unroll
+                            for (int k = 0; k < 3; ++k)
+                                if (cval[k]) x6c_load_lds4(lrow + csrc[k], aux_slab + dl * SLAB_P + 64 * k, lane);
+                        }
+                    }
+                };
+                // One tick of a staging wave: (1) operand DMA of the stage this tick's barrier publishes; at the item's last
+                // tick also the tile's bias / labels (the drain that needs them starts a tick later, or behind the final
+                // barrier); (2) its share of the previous tile's drain: LDS reads and global STORES only; (3) wait until at
+                // most (number of those stores) vector memory operations are outstanding -- the counter retires in order, so
+                // that is exactly "the DMA has landed", and nobody waits for a store acknowledgement -- then the barrier.
                 for (int v = -1;; ++v) {
-                    if (!finishing && copier) {
+                    drain_vm_ops = 0;
+                    if (!finishing) {
                         if (N_has && giN == NST) {
                             itemN += (int)gridDim.x;
                             if (itemN < nitems) {
@@ -1529,22 +1637,24 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                         }
                         if (N_has) {
                             X6C_T0();
-                            const int bs = v >= 0 ? (bsel ^ 1) : bsel;
-                            direct_stage(giN, bs, 0);
-                            direct_stage(giN, bs, 1);
+                            direct_stage(giN, v >= 0 ? (bsel ^ 1) : bsel, fkL);
                             ++giN;
                             if (wave == 4) X6C_TACC(13);
                         }
+                        if (v >= 0 && giC == NST - 1) stage_aux(itemC);
                     }
-                    if (tile_item >= 0 && (finishing || v >= 0)) {
+#ifndef PASE_HIPEMU
+                    asm volatile("" ::: "memory");      // the stores below stay behind the DMA above (the wait counts on it)
+#endif
+                    if (tile_item >= 0 && (finishing || (v >= 0 && giC >= 1))) {
                         X6C_T0();
                         if (drain_step(tile_item, giC, finishing)) tile_item = -1;
-                        if (dwi == 0) X6C_TACC(8);
+                        if (wave == 4) X6C_TACC(8);
                     }
                     if (finishing) break;
-                    if (copier) {
+                    {
                         X6C_T0();
-                        x6c_vm_drain();
+                        x6c_vmwait_le(drain_vm_ops);
                         if (wave == 4) X6C_TACC(10);
                     }
                     {
@@ -2891,6 +3001,12 @@ bool pase_x6c_plan(const PaseConvGemm& p, PaseX6cPlan& pl) {
         // fires); it is compiled with -DPASE_X6C_STREAM_REG for A/B runs.
         if (!(xp_want && p.xp6 != nullptr)) ok = false;
 #endif
+        // pre-split streamed form: three stages per item (drain window + the tick that copies the next drain's bias / labels),
+        // and the label slab of a 128-row tile must fit its LDS region (20 label channels, 128 + r - 1 <= 136 columns)
+        if (xp_want && p.xp6 != nullptr) {
+            if (GS < 3) ok = false;
+            if (p.epilogue == PASE_EPI_MSE_CTX && (p.r_ctx < 7 || p.r_ctx > 9)) ok = false;
+        }
 #if defined(PASE_X6C_NODL) || defined(PASE_X6C_OLDLOOP) || defined(PASE_X6C_EARLYPRO)
         ok = false;      // A/B builds of the unstreamed loop's variants
 #endif

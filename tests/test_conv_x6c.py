@@ -432,10 +432,10 @@ def test_zero_padded_data_gradient_with_interior_and_edge_lanes(dev, S, Cin, Cou
 def _stream_case(dev, case):
     """(reference fp64 output, callable that launches and returns (y, stat or None, extra))"""
     torch.manual_seed(31)
-    if case in ("two-stages", "stride2", "one-by-one-ragged-cols", "slice-of-wider-output"):
-        Cin, Cout, k, stride, T, S = {"two-stages": (32, 130, 11, 1, 250, 3), "stride2": (24, 200, 11, 2, 420, 3),
-                                      "one-by-one-ragged-cols": (96, 200, 1, 1, 90, 5),
-                                      "slice-of-wider-output": (48, 70, 3, 1, 131, 4)}[case]
+    if case in ("three-stages", "stride2", "one-by-one-ragged-cols", "slice-of-wider-output"):
+        Cin, Cout, k, stride, T, S = {"three-stages": (48, 130, 11, 1, 250, 3), "stride2": (24, 200, 11, 2, 420, 3),
+                                      "one-by-one-ragged-cols": (144, 200, 1, 1, 90, 5),
+                                      "slice-of-wider-output": (80, 70, 3, 1, 131, 4)}[case]
         x = torch.randn(S, Cin, T)
         w = torch.randn(Cout, Cin, k) * 0.2
         b = torch.randn(Cout)
@@ -480,7 +480,7 @@ def _stream_case(dev, case):
 
 
 @pytest.mark.parametrize("maxwg", [1, 2, 3, 0])
-@pytest.mark.parametrize("case", ["two-stages", "stride2", "one-by-one-ragged-cols", "slice-of-wider-output", "mse-ragged"])
+@pytest.mark.parametrize("case", ["three-stages", "stride2", "one-by-one-ragged-cols", "slice-of-wider-output", "mse-ragged"])
 def test_streamed_form_matches_fp64_and_the_unstreamed_form(dev, monkeypatch, case, maxwg):
     """Every eligible launch runs the streamed form by default; here with 1, 2, 3 workgroups (every workgroup walks several
     items: the load / store / compute cursors cross item boundaries, the tile is drained one stage later, uneven item
