@@ -247,6 +247,39 @@ __device__ __forceinline__ void x6c_load_lds4(const void* src, float* lds_wave_b
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
 #endif
+// The same two copies HIDDEN from the compiler (STREAM on pre-split operands).  The compiler tracks pending LDS DMA and puts
+// s_waitcnt vmcnt(0) in front of every later LDS read it cannot prove disjoint from the DMA's destination -- here: in front of
+// the drain's reads of the accumulator tile, i.e. the wave that had just issued a stage's DMA waited for it (and, the counter
+// being in order, for all its earlier stores) before it drained a single row.  Issued as inline asm the copy is invisible; the
+// wave waits for it by hand (x6c_vmwait_le) in front of the barrier that publishes the stage.  M0 (the LDS base of the copy) is
+// saved and restored around the instruction: it is a reserved register the compiler may hold a value in.
+#ifdef PASE_HIPEMU
+__device__ __forceinline__ void x6c_dma16_hidden(const void* src, u32x4* lds_wave_base, int lane) {
+    __builtin_memcpy(&lds_wave_base[lane], src, 16);
+}
+__device__ __forceinline__ void x6c_dma4_hidden(const void* src, float* lds_wave_base, int lane) {
+    __builtin_memcpy(&lds_wave_base[lane], src, 4);
+}
+#else
+__device__ __forceinline__ void x6c_dma16_hidden(const void* src, u32x4* lds_wave_base, int) {
+    const unsigned lds = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)(unsigned)(size_t)(__attribute__((address_space(3))) u32x4*)lds_wave_base);
+    unsigned m0_saved;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved)
+                 : "v"(src), "s"(lds)
+                 : "memory");
+}
+__device__ __forceinline__ void x6c_dma4_hidden(const void* src, float* lds_wave_base, int) {
+    const unsigned lds = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)(unsigned)(size_t)(__attribute__((address_space(3))) float*)lds_wave_base);
+    unsigned m0_saved;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved)
+                 : "v"(src), "s"(lds)
+                 : "memory");
+}
+#endif
 struct alignas(16) X6cF4 { float x, y, z, w; };
 // Staging registers: eight fp32 values per slot as two 4-vectors (the row-coalesced weight-gradient path fills them with two
 // global_load_dwordx4, every other path with eight global_load_dword).
@@ -438,10 +471,15 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     // nor the compiler ever wait on the vector memory counter except for the operand DMA itself (see the tick below).
     constexpr int SLAB_ROWS = 20, SLAB_P = 136;
     constexpr int AUX_CHUNKS = (STREAM && ZP) ? (SLAB_ROWS * SLAB_P * 4 + BM * 4) / 16 : 0;
-    __shared__ __attribute__((aligned(16))) u32x4 Xs[2 * BUF + RED_CHUNKS + TR_CHUNKS + TILE_CHUNKS + AUX_CHUNKS];
+    __shared__ __attribute__((aligned(16))) u32x4 Xs[2 * BUF + RED_CHUNKS + TR_CHUNKS];
+    // (an LDS object of its own: the compiler inserts s_waitcnt vmcnt(0) in front of every LDS read that MAY alias the
+    //  destination of a pending LDS DMA -- with the tile inside Xs every read of the drain waited for the operand DMA of the same
+    //  tick and, the counter being in order, for every store issued before it)
+    __shared__ __attribute__((aligned(16))) u32x4 Ys[TILE_CHUNKS + 1];
+    __shared__ __attribute__((aligned(16))) u32x4 Zs[AUX_CHUNKS + 1];      // (bias / label slab: a DMA destination itself)
     float (*red)[BM][2] = reinterpret_cast<float (*)[BM][2]>(&Xs[2 * BUF]);
-    float* const acc_tile = reinterpret_cast<float*>(&Xs[2 * BUF + RED_CHUNKS + TR_CHUNKS]);
-    float* const aux_slab = reinterpret_cast<float*>(&Xs[2 * BUF + RED_CHUNKS + TR_CHUNKS + TILE_CHUNKS]);
+    float* const acc_tile = reinterpret_cast<float*>(&Ys[0]);
+    float* const aux_slab = reinterpret_cast<float*>(&Zs[0]);
     float* const aux_bias = aux_slab + SLAB_ROWS * SLAB_P;
 
     const int tid = threadIdx.x;
@@ -1186,6 +1224,12 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                         }
                     }
                 }
+#if !defined(PASE_HIPEMU)
+                // (close the compiler's books on this branch's ordinary loads: left pending at the join with the lean branch they
+                //  made it guard "their" registers with s_waitcnt vmcnt(0) all over the lean code -- each one a wait for the
+                //  hidden DMA and every store in flight)
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
                 }
                 if (last && p.stat_part != nullptr) {      // uniform
                     // BatchNorm partial sums of the tile (sum, sum of squares of y = tile + bias over the row's valid output
@@ -1370,6 +1414,9 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                         }
                     }
                 }
+#if !defined(PASE_HIPEMU)
+                __builtin_amdgcn_s_waitcnt(0x0F70);      // (see the store branch)
+#endif
                 }
                 if (last) {
                     const float ls = pase_wave_sum64(drain_lsum);
@@ -1392,13 +1439,13 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             const int target = fin ? NGRP : min(NGRP, gi_c * drain_gpt);                      // gi_c == 0: nothing yet
             for (int cc = drain_pos; cc < target; cc += MAXG)
                 drain_tile(item, cc, min(cc + MAXG, target), min(cc + MAXG, target) == NGRP);
-            drain_pos = target;
-            if (target < NGRP) {
-                drain_prefetch(item, target, min(target + 2, min(NGRP, (gi_c + 1) * drain_gpt)));
-                return false;
+            const bool tile_done = target >= NGRP;
+            drain_pos = tile_done ? 0 : target;          // (ONE assignment: two stores behind a branch became a store through a
+                                                         //  selected address, and the counter lived in scratch memory)
+            if constexpr (PFG > 0) {
+                if (!tile_done) drain_prefetch(item, target, min(target + 2, min(NGRP, (gi_c + 1) * drain_gpt)));
             }
-            drain_pos = 0;
-            return true;
+            return tile_done;
         };
 
         if constexpr (STREAM && !ZP) {
@@ -1549,6 +1596,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             // allocated on top of the load destinations -- the staging waves ran one memory latency per slot, 90 % busy, and
             // the weight gradients at 1290 clocks per step against 790 of MFMA work.)
             auto direct_stage = [&](int g, int bs, int fk) __attribute__((always_inline)) {      // fk: octet of the k-groups (0 / 1)
+                // (STREAM: the copies are hidden from the compiler, see x6c_dma16_hidden)
                 pase_static_for<NSLOT>([&](auto sl_tag) __attribute__((always_inline)) {
                     constexpr int sl = decltype(sl_tag)::value;
                     constexpr int kg = sl / NPS, ps = sl % NPS, par = kg & (NPAR - 1);
@@ -1567,8 +1615,10 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                             const int gidx = min(g * KGS + kg, pl.G - 1);
                             const unsigned off = (unsigned)((gidx * 2 + fk) * p.S) * (unsigned)pl.xp_tpad + pos_xoff[par][ps];
 #pragma unroll
-                            for (int pz = 0; pz < 3; ++pz)
-                                x6c_load_lds16(xpc + (size_t)pz * (size_t)pl.xp_plane + off, dst + pz * PLANE, lane);
+                            for (int pz = 0; pz < 3; ++pz) {
+                                if constexpr (STREAM) x6c_dma16_hidden(xpc + (size_t)pz * (size_t)pl.xp_plane + off, dst + pz * PLANE, lane);
+                                else x6c_load_lds16(xpc + (size_t)pz * (size_t)pl.xp_plane + off, dst + pz * PLANE, lane);
+                            }
                         }
                     }
                 });
@@ -1593,29 +1643,24 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                     if (p.bias != nullptr && wave == 4) {
 #pragma unroll
                         for (int h = 0; h < 2; ++h)
-                            if (m0 + 64 * h + lane < p.M) x6c_load_lds4(p.bias + m0 + 64 * h + lane, aux_bias + 64 * h, lane);
+                            if (m0 + 64 * h + lane < p.M) x6c_dma4_hidden(p.bias + m0 + 64 * h + lane, aux_bias + 64 * h, lane);
                     }
                     if (p.epilogue == PASE_EPI_MSE_CTX) {      // uniform
                         const int half = p.r_ctx / 2;
                         const int d_first = (int)div_magic((unsigned)m0, pl.rctx_magic);
                         const int d_last = (int)div_magic((unsigned)min(m0 + BM - 1, p.M - 1), pl.rctx_magic);
-                        unsigned csrc[3];
-                        bool cval[3];
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) {
+                        const int nrows = min(d_last - d_first + 1, SLAB_ROWS);
+                        pase_static_for<3>([&](auto k_tag) __attribute__((always_inline)) {
+                            constexpr int k = decltype(k_tag)::value;
                             const int cc = 64 * k + lane;
                             const int nn = n0 + cc - half;
-                            cval[k] = cc < SLAB_P && nn >= 0 && nn < ntot;
-                            const unsigned nu = (unsigned)(cval[k] ? nn : 0);
+                            const bool cval = cc < SLAB_P && nn >= 0 && nn < ntot;
+                            const unsigned nu = (unsigned)(cval ? nn : 0);
                             const int s_ = (int)div_magic(nu, pl.ncols_magic);
-                            csrc[k] = (unsigned)(s_ * p.label_D * p.Ncols + ((int)nu - s_ * p.Ncols));
-                        }
-                        for (int dl = wave - 4; dl <= d_last - d_first && dl < SLAB_ROWS; dl += 4) {
-                            const float* lrow = p.label + (size_t)(d_first + dl) * (size_t)p.Ncols;
-#pragma unroll
-                            for (int k = 0; k < 3; ++k)
-                                if (cval[k]) x6c_load_lds4(lrow + csrc[k], aux_slab + dl * SLAB_P + 64 * k, lane);
-                        }
+                            const float* src = p.label + ((size_t)s_ * p.label_D + d_first) * (size_t)p.Ncols + ((int)nu - s_ * p.Ncols);
+                            for (int dl = wave - 4; dl < nrows; dl += 4)
+                                if (cval) x6c_dma4_hidden(src + (size_t)dl * (size_t)p.Ncols, aux_slab + dl * SLAB_P + 64 * k, lane);
+                        });
                     }
                 };
                 // One tick of a staging wave: (1) operand DMA of the stage this tick's barrier publishes; at the item's last
