@@ -482,7 +482,8 @@ def _stream_case(dev, case):
 @pytest.mark.parametrize("maxwg", [1, 2, 3, 0])
 @pytest.mark.parametrize("case", ["three-stages", "stride2", "one-by-one-ragged-cols", "slice-of-wider-output", "mse-ragged"])
 def test_streamed_form_matches_fp64_and_the_unstreamed_form(dev, monkeypatch, case, maxwg):
-    """Every eligible launch runs the streamed form by default; here with 1, 2, 3 workgroups (every workgroup walks several
+    """The streamed form of the kernel (conv_x6c_kernel<..., STREAM>; built, correct, and measured SLOWER than the unstreamed
+    form on the PASE+ step -- DESIGN.md section 3.0f -- hence only on request: PaseConvGemm::x6_ctl bit 16); here with 1, 2, 3 workgroups (every workgroup walks several
     items: the load / store / compute cursors cross item boundaries, the tile is drained one stage later, uneven item
     counts) and uncapped (one item per workgroup: first item = last item).  Shapes: exactly two stages per item (the
     minimum), a strided layer, a 1x1 layer whose column quads straddle sequences (90 columns per sequence), a channel slice
@@ -494,7 +495,7 @@ def test_streamed_form_matches_fp64_and_the_unstreamed_form(dev, monkeypatch, ca
     ref, run = _stream_case(dev, case)
     got = {}
     for streamed in (True, False):
-        monkeypatch.setenv("PASE_X6C_STREAM", "1" if streamed else "0")
+        monkeypatch.setenv("PASE_X6C_STREAM", "2" if streamed else "0")      # (2: on request -- the shipped routing does not stream)
         y, stat, extra = run()
         # (the shipped library streams launches whose activation is pre-split -- the `presplit` pass of this file, stride-1
         #  shapes only; the other pass checks that everything else is routed to the unstreamed form)

@@ -128,7 +128,7 @@ def main():
     dev = torch.device("cuda:0")
     NI = 64
     buf = (C.c_ulonglong * (2 * NI * 20))()
-    for name, mode in [(n_, m_) for n_ in shapes for m_ in ("1", "0")]:
+    for name, mode in [(n_, m_) for n_ in shapes for m_ in ("2", "0")]:
         os.environ["PASE_X6C_STREAM"] = mode
         fn = run_shape(name, dev)
         fn()
