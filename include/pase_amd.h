@@ -99,8 +99,7 @@ typedef struct PaseConvGemm {
                               most 64 rows; bit 5: the general epilogue on every tile (no lean store / MSE path); bit 6: the bias
                               added in the epilogue instead of being the accumulators' initial value; bit 7: never the
                               streamed form (per-item prologue and epilogue on the multiplying waves, as until round 4), bit 16: the
-                              streamed form on every launch it can run (not only where it measured faster); bit 17: no
-                              transposed epilogue (accumulator tile through LDS: 16-byte stores, row-per-lane sums); bits 8-15: start
+                              streamed form on every launch it can run (not only where it measured faster); bits 8-15: start
                               the persistent workgroups n x 512 clocks out of phase (A/B runs and tests; the library
                               itself reads NO environment variables)                                             */
     int max_wg;            /* cap on the persistent grid of the split-bf16 kernel (0 = one workgroup per CU, 256):

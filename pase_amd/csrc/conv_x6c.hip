@@ -464,8 +464,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     // STREAM: the accumulator tile, [row][column] fp32 with a pitch of 136 floats (the two 32-lane halves of a compute wave
     // write rows 4 apart: 4 * 136 floats = 32 banks apart; a drain lane reads 16 contiguous bytes of a row)
     constexpr int TILE_P = 136;
-    // (also the unstreamed 128 x 128 convolution instantiations: their epilogue turns the tile through LDS, see `ple.te`)
-    constexpr int TILE_CHUNKS = (STREAM || (!TM && !NARROW)) ? BM * TILE_P * 4 / 16 : 0;
+    constexpr int TILE_CHUNKS = STREAM ? BM * TILE_P * 4 / 16 : 0;
     // STREAM on pre-split operands: what the drain reads besides the tile -- the bias of the tile's rows and, for the fused MSE,
     // the slab of labels the tile's rows and columns touch ([label channel][column + context halo], SLAB_ROWS x SLAB_P floats)
     // -- is copied into LDS by DMA a tick ahead: the draining waves then issue NO load from global memory, so neither they
@@ -2405,58 +2404,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         };
         const bool fast = rows_full && pe.post_op == PASE_POST_NONE && pase_wave_all(interior) != 0;
         if (wave == 0) X6C_FSTAMP(17);
-        bool te_done = false;
-        if constexpr (!NARROW && !STREAM) {
-        if (ple.te && fast && !pshuf && ple.splitk == 1 && ple.epi32 && (pe.Ncols & 3) == 0 && (p.bias == nullptr || bias_init)) {
-            // TRANSPOSED EPILOGUE (round 5).  In the accumulator layout a lane holds ONE column of 16 rows: 64 dword stores
-            // per lane, 32 lanes x 4 bytes per row and instruction.  Turned through LDS -- each wave dumps its own 32 rows (64
-            // ds_write_b32, wave-private: no barrier) and reads them back by rows -- a lane holds four consecutive columns:
-            // 16 stores of 16 bytes, 512 contiguous bytes per row, and the BatchNorm partial sums become a row-per-lane pass
-            // over LDS without a cross-lane reduction per row.  (The streamed form's drain, run by the waves whose matrix pipe
-            // is idle anyway: the part of that experiment that pays.)
-            float* const td = acc_tile + (wm * 32 + 4 * fk) * TILE_P + fr;
-#pragma unroll
-            for (int j = 0; j < NBT; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) td[((r & 3) + 8 * (r >> 2)) * TILE_P + 32 * j] = acc[j][r];
-            pase_wave_sync();
-            const int cl = 4 * (lane & 31);
-            const unsigned nq = (unsigned)(n0 + cl);
-            const int sq_ = (int)div_magic(nq, ple.ncols_magic);
-            const int qq_ = (int)nq - sq_ * pe.Ncols;
-            const unsigned cb4 = (unsigned)((sq_ * pe.y_ctot + pe.y_coff) * pe.Tout + qq_ + pe.poff + (lane >> 5) * pe.Tout) * 4u;
-            const unsigned to8 = (unsigned)pe.Tout * 8u;
-            char* yrow = reinterpret_cast<char*>(p.y) + (size_t)(m0 + wm * 32) * (size_t)pe.Tout * 4u;
-            const float* tr = acc_tile + (wm * 32 + (lane >> 5)) * TILE_P + cl;
-#pragma unroll 8
-            for (int it = 0; it < 16; ++it) {
-                const X6cF4 t = *reinterpret_cast<const X6cF4*>(tr + 2 * it * TILE_P);
-                const float v[4] = {t.x, t.y, t.z, t.w};
-                pase_store_run4(reinterpret_cast<float*>(yrow + cb4), v);
-                yrow += to8;
-            }
-            if (p.stat_part) {      // uniform: row rl of this wave, columns [64 part, 64 part + 64)
-                const int rl = lane & 31, part = lane >> 5;
-                const float* trow = acc_tile + (wm * 32 + rl) * TILE_P + 64 * part;
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll 8
-                for (int k = 0; k < 16; ++k) {
-                    const X6cF4 t = *reinterpret_cast<const X6cF4*>(trow + 4 * k);
-                    s1 += (t.x + t.y) + (t.z + t.w);
-                    s2 = fmaf(t.x, t.x, fmaf(t.y, t.y, fmaf(t.z, t.z, fmaf(t.w, t.w, s2))));
-                }
-                s1 += __shfl_xor(s1, 32);
-                s2 += __shfl_xor(s2, 32);
-                if (part == 0) {
-                    red[0][wm * 32 + rl][0] = s1;
-                    red[0][wm * 32 + rl][1] = s2;
-                }
-            }
-            te_done = true;
-        }
-        }
-        if (te_done) {
-        } else if (fast && !pshuf && ple.splitk == 1 && ple.epi32) {
+        if (fast && !pshuf && ple.splitk == 1 && ple.epi32) {
             // The common tile (whole rows, interior columns, plain store): the address arithmetic is the epilogue's cost --
             // one compute wave per SIMD, so every VALU instruction here is an idle matrix core.  Row pointers are wave-uniform
             // (scalar unit), the lane's part of the address is one 32-bit byte offset per column block (computed once): a
@@ -2661,79 +2609,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         bool allc = true;
 #pragma unroll
         for (int j = 0; j < NBT; ++j) allc = allc && cok[j];
-        bool te_done = false;
-        if constexpr (!NARROW && !STREAM) {
-        if (ple.te && rows_full && pase_wave_all(allc) != 0 && ple.epi32 && (pe.Ncols & 3) == 0 && (p.bias == nullptr || bias_init)) {
-            // transposed epilogue (see the store branch): the four targets of a lane's column quad are four consecutive label
-            // samples -- one 16-byte load where the context window stays inside the sequence -- and ALL sixteen passes' targets are
-            // requested before the first is used (the accumulators are in LDS by then: their registers are free)
-            float* const td = acc_tile + (wm * 32 + 4 * fk) * TILE_P + fr;
-#pragma unroll
-            for (int j = 0; j < NBT; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) td[((r & 3) + 8 * (r >> 2)) * TILE_P + 32 * j] = acc[j][r];
-            pase_wave_sync();
-            const int cl = 4 * (lane & 31);
-            const unsigned nq = (unsigned)(n0 + cl);
-            const int sq_ = (int)div_magic(nq, ple.ncols_magic);
-            const int qq_ = (int)nq - sq_ * pe.Ncols;
-            const unsigned nc4 = (unsigned)pe.Ncols * 4u;
-            const unsigned ooff = (unsigned)((sq_ * pe.M + (lane >> 5)) * pe.Ncols + qq_) * 4u;
-            const unsigned loff = (unsigned)(sq_ * pe.label_D * pe.Ncols + qq_ - half) * 4u;
-            const int tb0 = qq_ - half;
-            const int mrow0 = m0 + wm * 32 + (lane >> 5);
-            const char* lab = reinterpret_cast<const char*>(p.label);
-            float tg[16][4];
-#pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int m = mrow0 + 2 * it;
-                const int d = (int)div_magic((unsigned)m, ple.rctx_magic);
-                const int jj = m - d * pe.r_ctx;
-                const unsigned la = loff + (unsigned)(d * pe.Ncols + jj) * 4u;
-                const int tb = tb0 + jj;
-                if (tb >= 0 && tb + 3 < pe.Ncols) {
-                    const pase_f4u t = *reinterpret_cast<const pase_f4u*>(lab + la);
-                    tg[it][0] = t.x;
-                    tg[it][1] = t.y;
-                    tg[it][2] = t.z;
-                    tg[it][3] = t.w;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        tg[it][e] = 0.f;
-                        if ((unsigned)(tb + e) < (unsigned)pe.Ncols) tg[it][e] = *reinterpret_cast<const float*>(lab + (la + 4u * e));
-                    }
-                }
-            }
-            const size_t rowb0 = (size_t)(m0 + wm * 32) * (size_t)nc4;
-            char* yrow = p.y ? reinterpret_cast<char*>(p.y) + rowb0 : nullptr;
-            char* grow = p.grad_out ? reinterpret_cast<char*>(p.grad_out) + rowb0 : nullptr;
-            const float* tr = acc_tile + (wm * 32 + (lane >> 5)) * TILE_P + cl;
-#pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const X6cF4 t = *reinterpret_cast<const X6cF4*>(tr + 2 * it * TILE_P);
-                const float pr[4] = {t.x, t.y, t.z, t.w};          // (bias included: bias_init)
-                float df[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    df[e] = pr[e] - tg[it][e];
-                    lsum = fmaf(df[e], df[e], lsum);
-                    df[e] *= pe.grad_scale;
-                }
-                if (yrow) {
-                    pase_store_run4(reinterpret_cast<float*>(yrow + ooff), pr);
-                    yrow += 2 * nc4;
-                }
-                if (grow) {
-                    pase_store_run4(reinterpret_cast<float*>(grow + ooff), df);
-                    grow += 2 * nc4;
-                }
-            }
-            te_done = true;
-        }
-        }
-        if (te_done) {
-        } else if (rows_full && pase_wave_all(allc) != 0) {
+        if (rows_full && pase_wave_all(allc) != 0) {
             if (!ple.epi32) mse_rows(std::true_type{});
             else if (p.y && p.grad_out) mse_lean(std::true_type{}, std::true_type{});
             else if (p.grad_out) mse_lean(std::false_type{}, std::true_type{});
@@ -3148,7 +3024,6 @@ bool pase_x6c_plan(const PaseConvGemm& p, PaseX6cPlan& pl) {
         splitk = (GS + g_per - 1) / g_per;
     }
     pl.splitk = splitk;
-    pl.te = (!narrow && !(p.x6_ctl & 0x20000)) ? 1 : 0;
     // The streamed form (conv_x6c_kernel<..., STREAM>): 128 x 128 tiles, one split, at least two stages per item (the
     // staging waves' load and store cursors then never span more than two items), and an epilogue the drain implements --
     // plain stores (+ BatchNorm partial sums) without pixel shuffle or post-op, or the r-context MSE.  x6_ctl bit 7 forbids

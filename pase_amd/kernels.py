@@ -136,7 +136,6 @@ def _conv_desc(x, w, y, *, S, Cin, Tin, M, K, taps, Ncols, Tout, ldw=None, bias=
                 | (64 if os.environ.get("PASE_X6C_BIASINIT", "1") == "0" else 0)
                 | (128 if os.environ.get("PASE_X6C_STREAM", "1") == "0" else 0)
                 | (0x10000 if os.environ.get("PASE_X6C_STREAM", "1") == "2" else 0)
-                | (0x20000 if os.environ.get("PASE_X6C_TE", "1") == "0" else 0)
                 | ((int(os.environ.get("PASE_X6C_STAGGER", "0")) & 255) << 8))
     d.max_wg = _max_wg(max_wg)
     return d
