@@ -132,11 +132,6 @@ long pase_conv_gemm_x6_bytes(const PaseConvGemm* desc);
  * fragment order of the launch desc describes (tile, stage and tap padding are functions of the descriptor: pack and
  * launch must see the same one).  Like pase_pack_wt it runs once per weight use. */
 int pase_pack_x6(const PaseConvGemm* desc, void* stream);
-/* Only the per-channel on-load parameters (in_scale / in_shift / in_alpha, expanded behind the weight planes of desc->wx6).  A weight
- * changes once per optimizer step, so its planes can be packed ahead of time (pase_pack_x6 with in_scale = NULL, e.g. right after
- * the optimizer, off the step's critical path); the BatchNorm scale / shift of the launch's input exist only a moment before the
- * launch and are added with this call.  (reference: weights change in worker_scheduler.py:43-75 `step()`, once per iteration) */
-int pase_pack_x6_prm(const PaseConvGemm* desc, void* stream);
 /* bytes of PaseConvGemm::xp6 the launch described by desc (xp6 ignored) wants; 0 = the launch splits while staging */
 long pase_conv_gemm_xp_bytes(const PaseConvGemm* desc);
 /* desc->xp6 (pase_conv_gemm_xp_bytes(desc) bytes, 16-B aligned, caller-owned scratch, read by that one launch) <-

@@ -1192,18 +1192,6 @@ extern "C" long pase_conv_gemm_x6_bytes(const PaseConvGemm* d) {
     return h.pl.CB >= 1 ? h.x6_chunks * 16 : 0;
 }
 
-// only the on-load parameters behind an existing split-bf16 weight pack (wx6): for packs made ahead of time (a weight changes
-// once per optimizer step, the BatchNorm scale / shift of its input once per forward)
-extern "C" int pase_pack_x6_prm(const PaseConvGemm* d, void* stream) {
-    const PaseConvGemm p = *d;
-    if (!p.wx6 || (((unsigned long long)(size_t)p.wx6) % 16) != 0) return -10;
-    if (p.K != p.Cin * p.taps) return -4;
-    const HostPlan h = make_plan(p, true);
-    if (h.sinc) return 0;                  // (the one-channel layer has no on-load transform in its pack)
-    if (!h.x6c) return -11;
-    return pase_x6c_pack_prm(p, h.c, (hipStream_t)stream);
-}
-
 extern "C" long pase_conv_gemm_xp_bytes(const PaseConvGemm* d) {
     if (d->M <= 0 || d->K <= 0 || d->S <= 0 || d->Ncols <= 0 || d->K != d->Cin * d->taps) return 0;
     if (d->tapstep != 1 && d->tapstep != -1) return 0;

@@ -48,7 +48,6 @@ struct PaseX6cPlan {
 // false: the launch has no x6c plan (the caller falls back to the span-major split-bf16 / fp32 kernels)
 bool pase_x6c_plan(const PaseConvGemm& p, PaseX6cPlan& pl);
 int pase_x6c_pack(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st);
-int pase_x6c_pack_prm(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st);
 int pase_x6c_launch(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st);
 int pase_x6c_pack_xp(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st);
 

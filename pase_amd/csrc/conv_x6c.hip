@@ -2707,19 +2707,7 @@ __global__ void pack_x6c_kernel(const float* __restrict__ wt, u32x4* __restrict_
 }
 
 // on-load parameters per channel' behind the weight chunks: [scale | shift | alpha], prm_n floats each (identity where
-// the descriptor has none, and for the zero channels' that pad the last stage).  On their own (pase_pack_x6_prm): a weight pack
-// that was made ahead of time -- once per optimizer step, off the step's critical path -- takes the BatchNorm scale / shift of
-// the CURRENT step this way (they are produced a moment before the launch; the weights and the PReLU slopes are not).
-__global__ void pack_prm_x6c_kernel(int Cin, int P, int CinP, const float* in_scale, const float* in_shift, const float* in_alpha,
-                                    float* prm, int prm_n) {
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < prm_n; c += gridDim.x * blockDim.x) {
-        const int ci = min(c / P, Cin - 1);
-        const bool ok = c < CinP;
-        prm[c] = (ok && in_scale) ? in_scale[ci] : 1.f;
-        prm[prm_n + c] = (ok && in_scale) ? in_shift[ci] : 0.f;
-        prm[2 * prm_n + c] = (ok && in_alpha) ? in_alpha[ci] : 1.f;
-    }
-}
+// the descriptor has none, and for the zero channels' that pad the last stage)
 // rows of an activation tensor -> fragment-ordered bf16 planes with the contraction over POSITIONS (weight gradients):
 // out[((rt32 * steps + st) * 3 + plane) * 64 + lane], step st = k-group (sequence s = st / QP16, positions 16 (st % QP16) ..),
 // lane = (fk, row): element e = position 16 (st % QP16) + 8 fk + e of row 32 rt32 + row, after its on-load transform
@@ -3087,14 +3075,6 @@ int pase_x6c_pack(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st) 
                 pl.steps_total, total, pl.xPerm ? p.ps : 1, p.Cout_store, p.in_scale, p.in_shift, p.in_alpha,
                 reinterpret_cast<float*>(reinterpret_cast<u32x4*>(const_cast<void*>(p.wx6)) + pl.pack_chunks), pl.prm_n,
                 p.w, p.ldw, p.tap_major);
-    PASE_CHECK_LAUNCH();
-    return 0;
-}
-
-int pase_x6c_pack_prm(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st) {
-    const int nb = (pl.prm_n + 255) / 256;
-    PASE_LAUNCH(pack_prm_x6c_kernel, dim3((unsigned)(nb < 1 ? 1 : nb)), dim3(256), st, p.Cin, pl.P, pl.CinP, p.in_scale, p.in_shift,
-                p.in_alpha, reinterpret_cast<float*>(reinterpret_cast<u32x4*>(const_cast<void*>(p.wx6)) + pl.pack_chunks), pl.prm_n);
     PASE_CHECK_LAUNCH();
     return 0;
 }

@@ -533,7 +533,7 @@ def _encoder_forward(fe, x, training, S, max_wg=0):
             torch.cuda.current_stream().wait_stream(pool_stream)
         else:
             pool_skips()
-        wcat = K.cached_cat([fe.W.weight.view(emb, -1)] + [p.weight.view(emb, -1) for p in fe.denseskips], 1)
+        wcat = torch.cat([fe.W.weight.view(emb, -1)] + [p.weight.view(emb, -1) for p in fe.denseskips], dim=1)
         ain = Act(acat, C=ccat)
     else:
         wcat = fe.W.weight.view(emb, -1)
@@ -896,8 +896,8 @@ def mlp_group_step(workers, a: Act, targets, sink, accs=None, max_wg=0):
     hs = [w.blocks[0].fmaps for w in workers]
     offs = [sum(hs[:i]) for i in range(len(hs))]
     htot = sum(hs)
-    w1cat = K.cached_cat([w.blocks[0].W.weight.view(h, -1) for w, h in zip(workers, hs)], 0)
-    b1cat = K.cached_cat([w.blocks[0].W.bias for w in workers], 0)
+    w1cat = torch.cat([w.blocks[0].W.weight.view(h, -1) for w, h in zip(workers, hs)], dim=0)
+    b1cat = torch.cat([w.blocks[0].W.bias for w in workers], dim=0)
     z_all, _ = conv_fwd(a, w1cat, b1cat, Cout=htot, taps=1, Tout=F_, max_wg=max_wg)
     dz_all = _new((B, htot, F_), x)
     out = {}

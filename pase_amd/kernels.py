@@ -53,8 +53,6 @@ def declare(l):
     l.pase_conv_gemm_streamed.restype = C.c_int
     l.pase_pack_x6.argtypes = [C.POINTER(PaseConvGemm), C.c_void_p]
     l.pase_pack_x6.restype = C.c_int
-    l.pase_pack_x6_prm.argtypes = [C.POINTER(PaseConvGemm), C.c_void_p]
-    l.pase_pack_x6_prm.restype = C.c_int
     l.pase_conv_gemm_xp_bytes.argtypes = [C.POINTER(PaseConvGemm)]
     l.pase_conv_gemm_xp_bytes.restype = C.c_long
     l.pase_pack_xp.argtypes = [C.POINTER(PaseConvGemm), C.c_void_p]
@@ -201,75 +199,6 @@ class GemmTimer(object):
 
 
 GEMM_TIMER = None
-
-
-class PackCache(object):
-    """Operand formats DERIVED FROM WEIGHTS -- split-bf16 fragment packs (pase_pack_x6), K-major packs (pase_pack_wt,
-    pase_pack_dgrad_t), concatenations of parameter views -- made once per weight VERSION instead of once per use.
-
-    A weight changes once per training step, in the optimizer (worker_scheduler.py:43-75 `step()`); until round 5 every launch
-    re-packed its weight in front of itself: 41 + 11 + 5 small launches and 13 concatenations per bs32 step, each on the
-    critical path of the GEMM behind it and -- in the overlapped step -- each waiting for a CU behind the other stream's
-    persistent grids (27 us apiece in profiles/bench_r04_kernel_stats.csv against 5 us alone).  Now an entry remembers how it
-    was built; the trainer calls refresh() right after the Adam kernels, where nothing competes for the chip, and the next
-    step's launches find their operands ready.  Inference gets the same for free (weights never change: packed once).
-
-    Validity is checked at every use: an entry is valid while the tensors it was derived from still have the same storage and
-    the same version -- torch's per-storage version counter catches every in-place change made through torch (load_state_dict,
-    copy_, broadcast, ...), `bump()` (FusedAdam.step) announces the changes the Adam kernel makes behind torch's back.  What
-    NEITHER sees is a write through `param.data` (it has a version counter of its own): therefore the cache is trusted only
-    inside the fused trainer's step (`active`, set by trainer._eager_step) -- the owner of the update path; every other entry
-    point (the drop-in forward / autograd bridge, evaluation) packs per use as before.  A caller that edits `param.data`
-    between two train steps calls PACKS.bump()."""
-
-    def __init__(self):
-        self.entries = {}
-        self.gen = 0
-        self.active = False
-        self.enabled = os.environ.get("PASE_PACK_CACHE", "1") != "0"
-
-    def _stamp(self, deps):
-        return (self.gen, tuple((t.data_ptr(), t._version) for t in deps))
-
-    def get(self, key, deps, build):
-        """build(prev_value_or_None) -> value (a tensor or tuple of tensors, reusing prev's storage when it can)"""
-        if not (self.enabled and self.active):
-            return build(None)
-        if len(self.entries) > 1024:          # (models come and go in one process: tests, sweeps)
-            self.entries.clear()
-        ent = self.entries.get(key)
-        stamp = self._stamp(deps)
-        if ent is not None and ent[0] == stamp:
-            ent[4] = 0
-            return ent[1]
-        val = build(ent[1] if ent is not None else None)
-        self.entries[key] = [stamp, val, tuple(deps), build, 0]
-        return val
-
-    def bump(self):
-        self.gen += 1
-
-    def refresh(self):
-        """rebuild (in creation order: a K-major pack before the fragment pack made from it) every entry used since the last
-        refresh; entries idle for several refreshes are dropped (their weights are gone or unused)"""
-        if not self.enabled:
-            return
-        for key in list(self.entries.keys()):
-            ent = self.entries[key]
-            if ent[4] >= 3:
-                del self.entries[key]
-                continue
-            ent[4] += 1
-            stamp = self._stamp(ent[2])
-            if ent[0] != stamp:
-                ent[1] = ent[3](ent[1])
-                ent[0] = self._stamp(ent[2])
-
-    def clear(self):
-        self.entries.clear()
-
-
-PACKS = PackCache()
 LAST_WGRAD_X6 = None       # did the most recent wgrad_gemm launch run on the split-bf16 kernel
 LAST_WGRAD_KIND = None     # ... and in which orientation (pase_wgrad_plan_kind: 0 fp32 pipe, 1 / 2 / 3)
 LAST_XP = None             # did the most recent conv_gemm launch stage a pre-split activation (pase_pack_xp)
@@ -277,61 +206,10 @@ LAST_PLAN_KIND = None      # plan kind of the most recent conv_gemm launch (0 fp
 LAST_STREAMED = None       # ... and whether it ran the streamed form of that kernel (pase_conv_gemm_streamed)
 
 
-def weight_deps(t):
-    """the tensors a derived operand format must be re-made for when THEY change: the tensor itself, or what a cached derived
-    tensor (a K-major pack, a concatenation) was made from"""
-    return getattr(t, "_pase_deps", None) or (t,)
-
-
-def cacheable(t):
-    """is `t` (derived from) a parameter -- something that changes only when an optimizer or a checkpoint load changes it?  The
-    SincNet filters, test operands and other per-call tensors are packed per use as before."""
-    if getattr(t, "_pase_deps", None):
-        return True
-    b = t._base if t._base is not None else t
-    return isinstance(b, torch.nn.Parameter) or bool(b.requires_grad)
-
-
-def _desc_key(d):
-    """every integer field of the descriptor (the pack's layout is a function of the plan, the plan of the descriptor)"""
-    return tuple(getattr(d, n) for n, t in PaseConvGemm._fields_ if t is C.c_int)
-
-
-def _cached_x6_pack(d, nbytes, x, w, kw):
-    """the split-bf16 pack of the launch's weight, from the cache (packed ahead by PackCache.refresh) or made now; the
-    BatchNorm scale / shift of the launch's input -- new tensors every step -- are added per launch (pase_pack_x6_prm)"""
-    src = kw.get("wt") if kw.get("wt") is not None else w
-    alpha = kw.get("in_alpha")
-    deps = tuple(weight_deps(src)) + ((alpha,) if alpha is not None else ())
-    has_aff = kw.get("in_scale") is not None
-    key = ("x6", src.data_ptr(), 0 if alpha is None else alpha.data_ptr(), has_aff, nbytes, _desc_key(d))
-    # the descriptor as the pack sees it: no pointer that does not outlive the step (activations, outputs, statistics)
-    tmpl = PaseConvGemm()
-    C.memmove(C.byref(tmpl), C.byref(d), C.sizeof(PaseConvGemm))
-    tmpl.x = tmpl.y = tmpl.label = tmpl.grad_out = tmpl.loss_acc = tmpl.xp6 = None
-    tmpl.in_scale = tmpl.in_shift = None
-    tmpl.bias = None
-    if d.stat_part:
-        tmpl.stat_part = 1          # (non-NULL marker: the plan depends on whether statistics are written)
-
-    def build(prev):
-        buf = prev if (prev is not None and prev.numel() == nbytes) else torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        tmpl.wx6 = buf.data_ptr()
-        _check(_lib.lib().pase_pack_x6(C.byref(tmpl), _stream()), "pase_pack_x6")
-        return buf
-    # (the closure keeps src / alpha alive: the template holds their raw pointers)
-    build._keep = (src, alpha, w)
-    wx6 = PACKS.get(key, deps, build) if cacheable(src) else build(None)
-    if has_aff:
-        d.wx6 = wx6.data_ptr()
-        _check(_lib.lib().pase_pack_x6_prm(C.byref(d), _stream()), "pase_pack_x6_prm")
-    return wx6
-
-
-def pack_wt(w, *, M, K, Cin, taps, ldw=None, tap_major=0, out=None):
+def pack_wt(w, *, M, K, Cin, taps, ldw=None, tap_major=0):
     """K-major pack (K, ldwt) of the logical A operand (M, K) held row-major in `w` (pase_pack_wt)."""
     ldwt = (M + 3) // 4 * 4
-    wt = out if (out is not None and tuple(out.shape) == (K, ldwt)) else torch.empty(K, ldwt, device=w.device, dtype=torch.float32)
+    wt = torch.empty(K, ldwt, device=w.device, dtype=torch.float32)
     _check(_lib.lib().pase_pack_wt(_ptr(w), _ptr(wt), M, K, Cin, taps, K if ldw is None else ldw, tap_major, ldwt,
                                    _stream()), "pase_pack_wt")
     return wt
@@ -398,8 +276,9 @@ def conv_gemm(x, w, y, want_stats=False, y_zeroed=False, **kw):
         # see PaseConvGemm::wx6) for the launch shapes the library has a split-bf16 plan for
         nbytes = _lib.lib().pase_conv_gemm_x6_bytes(C.byref(d))
         if nbytes > 0:
-            wx6 = _cached_x6_pack(d, nbytes, x, w, kw)
+            wx6 = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
             d.wx6 = wx6.data_ptr()
+            _check(_lib.lib().pase_pack_x6(C.byref(d), _stream()), "pase_pack_x6")
             # ... and, where the library asks for it, the activation pre-split once for this launch (staging = copy)
             xbytes = _lib.lib().pase_conv_gemm_xp_bytes(C.byref(d))
             if xbytes > 0:
@@ -409,12 +288,7 @@ def conv_gemm(x, w, y, want_stats=False, y_zeroed=False, **kw):
                 LAST_XP = True
     if not d.wx6 and not d.wt:
         # the fp32-pipe kernels read the K-major pack of the weight (a split-bf16 launch packs straight from `w`)
-        pk = dict(M=kw["M"], K=kw["K"], Cin=kw["Cin"], taps=kw["taps"], ldw=kw.get("ldw"), tap_major=kw.get("tap_major", 0))
-        if cacheable(w):
-            wt = PACKS.get(("wt", w.data_ptr(), tuple(sorted(pk.items(), key=lambda it: (it[0], str(it[1]))))), weight_deps(w),
-                           lambda prev: pack_wt(w, out=prev, **pk))
-        else:
-            wt = pack_wt(w, **pk)
+        wt = pack_wt(w, M=kw["M"], K=kw["K"], Cin=kw["Cin"], taps=kw["taps"], ldw=kw.get("ldw"), tap_major=kw.get("tap_major", 0))
         d.wt, d.ldwt = wt.data_ptr(), wt.shape[1]
     stat = None
     if want_stats:
@@ -680,40 +554,17 @@ def pack_dgrad(src, dst, *, R, O, k, st, s_red, s_out, s_k):
 
 
 def pack_dgrad_t(src, *, R, O, k, st, s_red, s_out, s_k):
-    """K-major data-gradient / transposed-conv weight pack, ready to be conv_gemm's wt= operand (cached per weight version:
-    PackCache).  A 1x1 weight stored (R, O) row-major already IS that pack: it is returned as is when aligned."""
+    """K-major data-gradient / transposed-conv weight pack, ready to be conv_gemm's wt= operand.
+    A 1x1 weight stored (R, O) row-major already IS that pack: it is returned as is when aligned."""
     taps_p = -(-k // st)
     if (k == 1 and st == 1 and s_red == O and s_out == 1 and O % 4 == 0 and src.data_ptr() % 16 == 0
             and src.is_contiguous()):
-        v = src.view(R, O)
-        v._pase_deps = tuple(weight_deps(src))
-        return v
+        return src.view(R, O)
     ldt = (st * O + 3) // 4 * 4
-    deps = tuple(weight_deps(src))
-
-    def build(prev):
-        dst = prev if (prev is not None and tuple(prev.shape) == (R * taps_p, ldt)) else \
-            torch.empty(R * taps_p, ldt, device=src.device, dtype=torch.float32)
-        _check(_lib.lib().pase_pack_dgrad_t(_ptr(src), _ptr(dst), R, O, k, st, s_red, s_out, s_k, ldt, _stream()),
-               "pase_pack_dgrad_t")
-        dst._pase_deps = deps
-        return dst
-    if not cacheable(src):
-        return build(None)
-    return PACKS.get(("dgrad_t", src.data_ptr(), R, O, k, st, s_red, s_out, s_k), deps, build)
-
-
-def cached_cat(tensors, dim):
-    """torch.cat of parameter views, re-made only when one of them changes (PackCache)"""
-    deps = tuple(t for ts in tensors for t in weight_deps(ts))
-
-    def build(prev):
-        with torch.no_grad():
-            srcs = [t.detach() for t in tensors]
-            out = torch.cat(srcs, dim=dim, out=prev) if prev is not None else torch.cat(srcs, dim=dim)
-        out._pase_deps = deps
-        return out
-    return PACKS.get(("cat", dim, tuple(t.data_ptr() for t in tensors), tuple(tuple(t.shape) for t in tensors)), deps, build)
+    dst = torch.empty(R * taps_p, ldt, device=src.device, dtype=torch.float32)
+    _check(_lib.lib().pase_pack_dgrad_t(_ptr(src), _ptr(dst), R, O, k, st, s_red, s_out, s_k, ldt, _stream()),
+           "pase_pack_dgrad_t")
+    return dst
 
 
 def adam_step(p, g, m, v, lr, step, *, beta1=0.9, beta2=0.999, eps=1e-8, grad_mul=1.0):

@@ -109,7 +109,6 @@ class FusedAdam(object):
             K.step_tick(self.step_t)
         K.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.lr_t, self.step_t,
                     beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, grad_mul=grad_mul)
-        K.PACKS.bump()          # (the kernel writes the parameters behind torch's version counters)
 
     def state_dict(self):
         step = int(self.step_t.item())
@@ -350,8 +349,6 @@ class trainer(object):
                 self._zero_arena = engine.ZeroArena()
             self._zero_arena.begin_step(dev)
             engine._ARENA = self._zero_arena
-        cache_was = K.PACKS.active
-        K.PACKS.active = True          # weight-derived operand formats are made once per weight version (kernels.PackCache)
         try:
             if self.world > 1 and not local_only:
                 losses = self._step_ddp(batch, sink, device)
@@ -364,7 +361,6 @@ class trainer(object):
                 self._step_all(1.0)
         finally:
             engine._ARENA = None
-            K.PACKS.active = cache_was
         return losses
 
     def _frontend_buckets(self):
@@ -487,9 +483,6 @@ class trainer(object):
         torch._foreach_add_([o.step_t for o in opts], 1)
         for opt in opts:
             opt.step(grad_mul=grad_mul, tick=False)
-        # every weight has just changed: re-make the operand formats derived from them NOW, at the step's tail where nothing
-        # competes for the chip, instead of in front of each GEMM of the next step (kernels.PackCache)
-        K.PACKS.refresh()
 
     def adjust_lr(self, bidx, epoch, losses=None):
         """trainer.py:245-254 (called every log_freq iterations in the reference)."""

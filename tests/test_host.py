@@ -143,39 +143,3 @@ def test_ddp_frontend_buckets_partition_the_gradient_buffer():
         assert head_elems == want
     finally:
         _lib.use_library(None, "cuda")
-
-
-def test_pack_cache_validity_rules():
-    """kernels.PackCache: an operand format derived from weights is re-made exactly when one of its sources changes -- through
-    torch (version counter), through the Adam kernel (bump), never for tensors that are not parameters, and never outside the
-    fused trainer step (`active`)."""
-    import torch.nn as nn
-    from pase_amd import kernels as K
-    pc = K.PackCache()
-    w = nn.Parameter(torch.randn(4, 3))
-    builds = []
-
-    def build(prev):
-        builds.append(prev is not None)
-        return (w.detach() * 2).clone()
-    assert not pc.active
-    pc.get("k", (w,), build)
-    pc.get("k", (w,), build)
-    assert len(builds) == 2                      # outside the trainer's step: per use, as before
-    pc.active = True
-    a = pc.get("k", (w,), build)
-    b = pc.get("k", (w,), build)
-    assert len(builds) == 3 and a is b           # made once
-    with torch.no_grad():
-        w.mul_(0.5)                               # torch sees it
-    c = pc.get("k", (w,), build)
-    assert len(builds) == 4 and builds[-1] and torch.equal(c, w.detach() * 2)
-    pc.bump()                                     # the Adam kernel wrote the weights
-    pc.refresh()                                  # ... and the trainer re-makes the formats at the step's tail
-    assert len(builds) == 5
-    pc.get("k", (w,), build)
-    assert len(builds) == 5                      # ready when the next step asks
-    for _ in range(4):
-        pc.refresh()                              # idle entries age out
-    assert "k" not in pc.entries
-    assert not K.cacheable(torch.randn(3)) and K.cacheable(w) and K.cacheable(w.view(-1))
