@@ -50,7 +50,7 @@ def synthetic_batch(seed, B, T, raw, device):
     return batch
 
 
-def cpu_baseline(raw, fe_cfg, seconds_budget=25.0):
+def cpu_baseline(raw, fe_cfg, seconds_budget=25.0, B=2, max_steps=20):
     """The CPU oracle (port of the reference step: oracle/pase_oracle.py) timed on the host cores on a
     bounded sample: full-width PASE+ / workers+ model, B=2 utterances x 32 000 samples, fwd + losses
     + backward + Adam, as many steps as fit the budget (>= 1 after one warm-up)."""
@@ -75,7 +75,7 @@ def cpu_baseline(raw, fe_cfg, seconds_budget=25.0):
     for n in names:
         P[n].requires_grad_(True)
     opt = torch.optim.Adam([P[n] for n in names], lr=5e-4)
-    B, T = 2, 32000
+    T = 32000
     batch = synthetic_batch(99, B, T, raw, torch.device("cpu"))
 
     def step():
@@ -96,7 +96,7 @@ def cpu_baseline(raw, fe_cfg, seconds_budget=25.0):
         while True:
             step()
             n += 1
-            if time.time() - t0 > seconds_budget or n >= 20:
+            if time.time() - t0 > seconds_budget or n >= max_steps:
                 break
     dt = (time.time() - t0) / n
     return {"value": round(B / dt, 4), "unit": "utterances/s", "cores": cores, "kind": "port",
@@ -224,6 +224,9 @@ def main():
     ap.add_argument("--reserve-cus", type=int, default=-1,
                     help="N > 1: CUs the persistent split-bf16 GEMM grids leave free for RCCL's channel kernels (grid cap = "
                          "CUs of the device - this); -1 = 32 for N > 1 (one CU per shader engine: DESIGN.md section 6), 0 for N = 1")
+    ap.add_argument("--cpu-baseline-bs32", action="store_true",
+                    help="time the CPU baseline at the benchmark's own batch size (32 utterances, 3 steps after one warm-up: "
+                         "minutes of host time) instead of the bounded B = 2 sample of the default run")
     ap.add_argument("--no-capped-leg", action="store_true",
                     help="N = 1: skip the extra K steps that price the data-parallel CU reservation (n_gt1_cap_cost)")
     ap.add_argument("--producer", action="store_true",
@@ -528,7 +531,8 @@ def main():
                                                 % (world, ndev))
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(raw, fe_cfg)
+                out["cpu_baseline"] = (cpu_baseline(raw, fe_cfg, seconds_budget=600.0, B=32, max_steps=3)
+                                       if args.cpu_baseline_bs32 else cpu_baseline(raw, fe_cfg))
             except Exception as e:  # the baseline leg must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "utterances/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}

@@ -489,6 +489,8 @@ def test_streamed_form_matches_fp64_and_the_unstreamed_form(dev, monkeypatch, ca
     minimum), a strided layer, a 1x1 layer whose column quads straddle sequences (90 columns per sequence), a channel slice
     of a wider output, and the fused MSE epilogue with a ragged row tile.  Checked against fp64 AND against the unstreamed
     form (PaseConvGemm::x6_ctl bit 7) of the same library."""
+    if dev.type == "cpu" and maxwg in (1, 3):
+        pytest.skip("emulator: two of the four workgroup counts (the CPU suite's time budget); all four run on the GPU")
     if maxwg:
         monkeypatch.setenv("PASE_X6C_MAXWG", str(maxwg))
     monkeypatch.setenv("PASE_X6C_FORCE", "1")       # (the 96-channel 1x1 case is routed to the fp32 pipe otherwise)
