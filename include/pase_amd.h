@@ -231,6 +231,15 @@ typedef struct PaseActBwd {
 } PaseActBwd;
 int pase_act_bwd_reduce(const PaseActBwd* desc, void* stream);
 int pase_act_bwd_apply(const PaseActBwd* desc, void* stream);
+/* pase_wgrad_gemm whose gradient operand is not read from desc->g (ignored, may be NULL) but evaluated while it is staged as
+ * the APPLY pass of g_bwd: same arithmetic as pase_act_bwd_apply, dy never written (g_bwd->dy ignored).  g_bwd->sums must be
+ * complete (pase_act_bwd_reduce enqueued earlier on the same stream); g_bwd->S / C / T = desc->S / M / Ncols; has_bn 0..2.
+ * For the layer whose dy has no other consumer: the SincNet layer's 786 MB dy at bs32 -- the first layer needs no data
+ * gradient (autograd of F.conv1d w.r.t. the filters only, pase/models/modules.py:932) -- so its apply pass (read y, read dA,
+ * write dy) and the weight gradient's read of dy become one read of y and dA.  Only the one-input-channel plan
+ * (pase_wgrad_plan_kind 5) has this form: -11 when desc would run on another kernel (x6 bit 0 and gx6 are required),
+ * -13 when g_bwd does not describe desc's gradient operand (shape mismatch, g_alpha / dbias set, norms 3 / 4). */
+int pase_wgrad_gemm_act_bwd(const PaseWgrad* desc, const PaseActBwd* g_bwd, void* stream);
 
 /* Per-sample normalisations of the other norm_type values (pase/models/modules.py:77-109): nn.InstanceNorm1d
  * ('inorm', 'affinorm', and WaveFe.norm_out when norm_type != 'bnorm', frontend.py:206-210; mode 0: statistics per

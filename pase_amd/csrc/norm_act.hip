@@ -10,6 +10,7 @@
 //
 // Roofline: every kernel here streams each tensor once with consecutive lanes on consecutive
 // addresses; they are priced against HBM bandwidth (bytes = 4 * elements touched).
+#include "act_bwd.h"
 #include "hip_compat.h"
 #include "pase_amd.h"
 
@@ -112,40 +113,6 @@ __global__ void __launch_bounds__(NT) bn_act_apply_kernel(const float* y, float*
     }
 }
 
-// ---- gradient w.r.t. the post-activation tensor, assembled from its producers -------------------
-//   * dsrc: data-gradient written by conv_gemm in *padded* coordinates (length Tp, left pad padL);
-//           reflect padding folds the mirrored edges back (autograd of F.pad(mode='reflect')),
-//   * dpool: gradient of the mean-pooled dense-skip branch, broadcast back over its d inputs.
-// pool_magic: ceil(2^32 / pool_d) (0: divide) -- t / pool_d as one v_mul_hi_u32 instead of a ~20-instruction integer
-// division per element (fewer instructions; measured no change in the passes' duration: they are memory-bound)
-__device__ __forceinline__ unsigned act_pool_magic(const PaseActBwd& p) {
-    if (!p.dpool || p.pool_d <= 1) return 0u;
-    if ((unsigned long long)p.T * (unsigned)p.pool_d >= 0x100000000ULL) return 0u;       // exactness domain of the multiply
-    return (unsigned)((0x100000000ULL + (unsigned)p.pool_d - 1u) / (unsigned)p.pool_d);
-}
-
-__device__ __forceinline__ float grad_post_act(const PaseActBwd& p, int s, int c, int t, unsigned pool_magic) {
-    float v = 0.f;
-    if (p.dsrc) {
-        const float* row = p.dsrc + ((size_t)s * p.dsrc_ctot + p.dsrc_coff + c) * (size_t)p.Tp;
-        const int i = t + p.padL;
-        if (i < p.Tp) v = row[i];
-        if (p.pad_mode == PASE_PAD_REFLECT) {
-            const int padR = p.Tp - p.T - p.padL;
-            // (only the first padL + 1 and the last padR + 1 steps receive a mirrored contribution)
-            if (t <= p.padL || t >= p.T - 1 - padR) {
-                if (t >= 1 && t <= p.padL) v += row[p.padL - t];
-                if (t >= p.T - 1 - padR && t <= p.T - 2) v += row[p.padL + 2 * (p.T - 1) - t];
-            }
-        }
-    }
-    if (p.dpool) {
-        const int f = pool_magic ? (int)(((unsigned long long)(unsigned)t * pool_magic) >> 32) : (p.pool_d > 1 ? t / p.pool_d : t);
-        if (f < p.pool_F) v += p.dpool[((size_t)s * p.dpool_ctot + p.dpool_coff + c) * (size_t)p.pool_F + f] * p.pool_inv;
-    }
-    return v;
-}
-
 // ---- E4 / E5 work decomposition -------------------------------------------------------------------
 // A unit of work is a SEGMENT: `seg_len` consecutive time steps of one (sequence, channel) row.  Long rows
 // (T >= 2048) are cut into segments of <= 8192 elements handled by a whole 256-thread block; short rows (the
@@ -246,15 +213,7 @@ __global__ void __launch_bounds__(NT) act_bwd_apply_kernel(PaseActBwd p, ActBwdG
     act_bwd_locate(p, g, row, t0, t1, lid, nl);
     if (row < 0) return;
     const int s = row / p.C, c = row % p.C;
-    const float a = p.scale ? p.scale[c] : 1.f, b = p.shift ? p.shift[c] : 0.f;
-    const float al = p.alpha ? p.alpha[c] : 1.f;
-    const float mean = p.mean ? p.mean[c] : 0.f, rstd = p.rstd ? p.rstd[c] : 1.f;
-    float m1 = 0.f, m2 = 0.f;
-    if (p.has_bn == 1) {
-        const double n = (double)p.S * (double)p.T;
-        m1 = (float)(p.sums[(size_t)c * 3 + 0] / n);
-        m2 = (float)(p.sums[(size_t)c * 3 + 1] / n);
-    }
+    const ActBwdRow rc = act_bwd_row(p, c);
     const float* yrow = p.y + ((size_t)s * p.y_ctot + p.y_coff + c) * (size_t)p.T;
     float* drow = p.dy + ((size_t)s * p.y_ctot + p.y_coff + c) * (size_t)p.T;
     for (int tb = t0 + lid; tb < t1; tb += 4 * nl) {
@@ -268,16 +227,7 @@ __global__ void __launch_bounds__(NT) act_bwd_apply_kernel(PaseActBwd p, ActBwdG
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int t = tb + u * nl;
-            const float z = yv[u] * a + b;
-            const float dz = z > 0.f ? dA[u] : dA[u] * al;
-            float out = dz;
-            if (p.has_bn == 1) {
-                const float xhat = (yv[u] - mean) * rstd;
-                out = a * (dz - m1 - xhat * m2);
-            } else if (p.has_bn == 2) {
-                out = a * dz;
-            }
-            if (t < t1) drow[t] = out;
+            if (t < t1) drow[t] = act_bwd_dy(rc, p.has_bn, yv[u], dA[u]);
         }
     }
 }

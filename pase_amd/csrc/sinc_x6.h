@@ -15,4 +15,6 @@ bool pase_sinc_x6_plan(const PaseConvGemm& p, PaseSincPlan& pl);
 int pase_sinc_x6_pack(const PaseConvGemm& p, const PaseSincPlan& pl, hipStream_t st);
 int pase_sinc_x6_launch(const PaseConvGemm& p, const PaseSincPlan& pl, hipStream_t st);
 bool pase_sinc_x6_wgrad_plan(const PaseWgrad& w, PaseSincPlan& pl);
-int pase_sinc_x6_wgrad_launch(const PaseWgrad& w, const PaseSincPlan& pl, hipStream_t st);
+// ab != nullptr: the gradient operand is the apply pass of *ab evaluated on load (w.g is not read)
+bool pase_sinc_x6_wgrad_act_bwd_ok(const PaseWgrad& w, const PaseActBwd& ab);
+int pase_sinc_x6_wgrad_launch(const PaseWgrad& w, const PaseSincPlan& pl, hipStream_t st, const PaseActBwd* ab = nullptr);

@@ -19,6 +19,7 @@
 //   Weight gradient: BOTH operands are staged (g is converted on the fly: each element exactly once, the 64 x 256 tile is the
 //   whole problem), contraction over positions in stages of 64, split over the grid, fp32 atomics into dfilt.
 #include "sinc_x6.h"
+#include "act_bwd.h"
 
 namespace {
 
@@ -29,6 +30,27 @@ constexpr int SX_NW = SX_BN + 16 * SX_KGMAX - 8;      // 504 windows of a forwar
 constexpr int SW_POS = 64;                    // weight gradient: positions per stage (4 k-groups)
 constexpr int SW_NW = SX_BN + SW_POS;         // 320 windows of a weight-gradient stage
 constexpr int SW_ACH = (SW_POS / 8) * 64;     // chunks per plane of the g image: [8 position octets][64 rows]
+constexpr int SW_RP = SW_POS + 4;             // on-load form: floats per row of the raw y / dA tiles (16-byte aligned rows, a
+                                              // bank shift of four per row for the 16-byte reads of 16 rows x 4 parts)
+
+// one dword per lane straight from global memory into LDS (global_load_lds_dword: destination = wave-uniform LDS address +
+// 4 * lane for the active lanes; no VGPR holds the data while it is in flight)
+#ifdef PASE_HIPEMU
+__device__ __forceinline__ void sx_load_lds4(const float* src, float* lds_wave_base, int lane) { lds_wave_base[lane] = *src; }
+#else
+__device__ __forceinline__ void sx_load_lds4(const float* src, float* lds_wave_base, int) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+#endif
+// the wave's own LDS DMA has landed (each wave converts exactly the rows it copied: no barrier).  The compiler's own
+// bookkeeping would put this wait in front of the first read of the raw tiles as well; it is spelled out because the CPU
+// emulator's lanes are fibers that only meet at wave-level exchanges: there it is the point where they do.
+#ifdef PASE_HIPEMU
+__device__ __forceinline__ void sx_dma_wait() { hipemu::sync_wave(); }
+#else
+__device__ __forceinline__ void sx_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
 
 __device__ __forceinline__ int sx_reflect(int u, int T) {
     u = max(u, -u);
@@ -193,9 +215,27 @@ __global__ void sinc_x6_pack_kernel(const float* __restrict__ wt, u32x4* __restr
 // ================================================================================================================
 // weight gradient
 // ================================================================================================================
-__global__ void __launch_bounds__(SX_NT, 2) sinc_x6_wgrad_kernel(PaseWgrad p, PaseSincPlan pl) {
+// AB: the gradient operand is not read from p.g but evaluated while it is staged as the APPLY pass of the BatchNorm + PReLU
+// backward `ab` (act_bwd.h: the same element functions as norm_act.hip's act_bwd_apply_kernel; ab.sums complete, i.e. the
+// reduce pass enqueued earlier on this stream).  The SincNet layer's dy (786 MB at bs32) has no other consumer -- the first
+// layer needs no data gradient -- so the apply pass over it (read y, read dA, write dy) and this kernel's read of dy become
+// one read of y and dA.
+//   The plain form keeps the next stage's 16 gradient values per thread in registers under this stage's MFMAs (the kernel
+//   sits at its 256-register budget: two workgroups per CU).  Twice that (y and dA) does not fit -- a register build of this
+//   form spilled 80 VGPRs and ran 2.8 ms against 1.2 ms for apply pass + plain launch -- so the raw 64 x 64 tiles of y and of
+//   the padded data gradient travel by LDS DMA (one 256-byte row per instruction, each wave the 16 rows it converts itself:
+//   no barrier between the copy and its use, only the wave's own vmcnt) and are turned into dy, split and written to the
+//   g image at the top of the next stage.  The pooled dense-skip gradient (one or two frames per run of 16 positions) is
+//   prefetched into two registers; the reflect-padding fold touches the first and last stage of a sequence only and is
+//   read there directly.
+template <bool AB>
+__global__ void __launch_bounds__(SX_NT, 2) sinc_x6_wgrad_kernel(PaseWgrad p, PaseSincPlan pl, PaseActBwd ab) {
     // one LDS image per stage: g [plane][position octet c (8)][row (64)] and the window image of x [plane][320]
     __shared__ __attribute__((aligned(16))) u32x4 Ws[3 * SW_ACH + 3 * SW_NW];
+    // (objects of their own: the compiler tracks pending LDS DMA and would wait for it in front of every read of Ws otherwise)
+    __shared__ __attribute__((aligned(16))) float Yr[AB ? 64 * SW_RP : 4];
+    __shared__ __attribute__((aligned(16))) float Dr[AB ? 64 * SW_RP : 4];
+    __shared__ __attribute__((aligned(16))) float Xr[AB ? SW_NW + 8 + 56 : 4];      // raw samples of the window image (328, in 64s)
     u32x4* As = Ws;
     u32x4* Bs = Ws + 3 * SW_ACH;
 
@@ -212,36 +252,121 @@ __global__ void __launch_bounds__(SX_NT, 2) sinc_x6_wgrad_kernel(PaseWgrad p, Pa
     // staging roles: g -- thread -> (row = tid >> 2, 16 positions 16 (tid & 3) ..);  x -- thread -> windows 2 tid, 2 tid + 1
     const int grow = tid >> 2, gpart = tid & 3;
     const bool grow_ok = grow < p.M;
-    const float g_al = (p.g_alpha && grow_ok) ? p.g_alpha[grow] : 1.f;
-    float gv[16], xv[9];
+    const float g_al = (!AB && p.g_alpha && grow_ok) ? p.g_alpha[grow] : 1.f;
+    ActBwdRow rc = {};
+    unsigned pmagic = 0u;
+    if (AB) {
+        rc = act_bwd_row(ab, grow_ok ? grow : 0);
+        pmagic = act_pool_magic(ab);
+    }
+    auto frame_of = [&](int t) __attribute__((always_inline)) {
+        return pmagic ? (int)(((unsigned long long)(unsigned)t * pmagic) >> 32) : (ab.pool_d > 1 ? t / ab.pool_d : t);
+    };
+    float gv[AB ? 1 : 16], xv[AB ? 1 : 9];
+    float dp0 = 0.f, dp1 = 0.f;       // AB: pooled-branch gradient of the first / last frame of the staged run
+    int f_first = 0;
+    int s_ld = 0, q0_ld = 0;          // AB: (sequence, first position) of the stage whose raw tiles are in flight / in LDS
     auto load_stage = [&](long st) __attribute__((always_inline)) {
         const int s = (int)(st / pl.tiles_per_seq);
         const int q0 = (int)(st - (long)s * pl.tiles_per_seq) * SW_POS;
-        const float* grw = p.g + ((size_t)s * p.g_ctot + p.g_coff + (grow_ok ? grow : 0)) * (size_t)p.Tg;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int q = q0 + 16 * gpart + e;
-            gv[e] = (grow_ok && q < p.Ncols) ? grw[q] : 0.f;
-        }
-        if (2 * tid < SW_NW) {
+        if constexpr (AB) {
+            s_ld = s;
+            q0_ld = q0;
+            const int nq = p.Ncols - q0;                                   // live positions of the stage (>= 1)
+#pragma unroll 4
+            for (int rr = 0; rr < 16; ++rr) {
+                const int row = wave * 16 + rr;                            // (wave-uniform)
+                if (row >= p.M) break;
+                const float* yrw = ab.y + ((size_t)s * ab.y_ctot + ab.y_coff + row) * (size_t)ab.T + q0;
+                if (lane < nq) sx_load_lds4(yrw + lane, &Yr[row * SW_RP], lane);
+                if (ab.dsrc) {
+                    const float* drw = ab.dsrc + ((size_t)s * ab.dsrc_ctot + ab.dsrc_coff + row) * (size_t)ab.Tp + ab.padL + q0;
+                    if (lane < nq) sx_load_lds4(drw + lane, &Dr[row * SW_RP], lane);
+                }
+            }
+            if (ab.dpool && grow_ok) {
+                const int qa = q0 + 16 * gpart;
+                const float* prow = ab.dpool + ((size_t)s * ab.dpool_ctot + ab.dpool_coff + grow) * (size_t)ab.pool_F;
+                f_first = frame_of(qa);
+                const int f_last = frame_of(min(qa + 15, ab.T - 1));
+                dp0 = f_first < ab.pool_F ? prow[f_first] : 0.f;          // (times 1 / d where it is used: no wait here)
+                dp1 = f_last < ab.pool_F ? prow[f_last] : 0.f;
+            }
+            // raw samples x[q0 - padL + i], i < 328 (windows 0 .. 319 need eight more), chunks of 64 shared out over the waves
             const float* xrow = p.z + ((size_t)s * p.z_ctot + p.z_coff) * (size_t)p.Tz;
-            const int u0 = q0 - p.padL + 2 * tid;
 #pragma unroll
-            for (int e = 0; e < 9; ++e) {
-                int u = u0 + e;
+            for (int c = 0; c < 2; ++c) {
+                const int ch = wave + 4 * c;                                // (wave-uniform)
+                if (64 * ch >= SW_NW + 8) break;
+                int u = q0 - p.padL + 64 * ch + lane;
                 if (p.pad_mode == PASE_PAD_REFLECT) u = sx_reflect(u, p.Tz);
-                xv[e] = (u >= 0 && u < p.Tz) ? xrow[u] : 0.f;
+                if (64 * ch + lane < SW_NW + 8 && u >= 0 && u < p.Tz) sx_load_lds4(xrow + u, &Xr[64 * ch], lane);
+            }
+        } else {
+            const float* grw = p.g + ((size_t)s * p.g_ctot + p.g_coff + (grow_ok ? grow : 0)) * (size_t)p.Tg;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int q = q0 + 16 * gpart + e;
+                gv[e] = (grow_ok && q < p.Ncols) ? grw[q] : 0.f;
+            }
+            if (2 * tid < SW_NW) {
+                const float* xrow = p.z + ((size_t)s * p.z_ctot + p.z_coff) * (size_t)p.Tz;
+                const int u0 = q0 - p.padL + 2 * tid;
+#pragma unroll
+                for (int e = 0; e < 9; ++e) {
+                    int u = u0 + e;
+                    if (p.pad_mode == PASE_PAD_REFLECT) u = sx_reflect(u, p.Tz);
+                    xv[e] = (u >= 0 && u < p.Tz) ? xrow[u] : 0.f;
+                }
             }
         }
     };
     auto store_stage = [&]() __attribute__((always_inline)) {
+        const int padR = ab.Tp - ab.T - ab.padL;
+        // does this stage touch the steps that receive a mirrored contribution of the reflect padding?
+        const bool fold = AB && ab.dsrc && ab.pad_mode == PASE_PAD_REFLECT &&
+                          (q0_ld <= ab.padL || q0_ld + SW_POS - 1 >= ab.T - 1 - padR);
+        if constexpr (AB) {
+            if (fold && grow_ok) {
+                // the mirrored edge gradients, added into the raw tile in place (each thread patches the 16 values it reads
+                // itself; two stages per sequence, a rolled loop: nothing of it is in the other stages' code path)
+                const float* row = ab.dsrc + ((size_t)s_ld * ab.dsrc_ctot + ab.dsrc_coff + grow) * (size_t)ab.Tp;
+                float* dl = &Dr[grow * SW_RP + 16 * gpart];
+#pragma unroll 1
+                for (int e = 0; e < 16; ++e) {
+                    const int q = q0_ld + 16 * gpart + e;
+                    if (q >= p.Ncols) break;
+                    float a = dl[e];
+                    if (q >= 1 && q <= ab.padL) a += row[ab.padL - q];
+                    if (q >= ab.T - 1 - padR && q <= ab.T - 2) a += row[ab.padL + 2 * (ab.T - 1) - q];
+                    dl[e] = a;
+                }
+            }
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             float v[8];
+            if constexpr (AB) {
+                const f32x4* yl = reinterpret_cast<const f32x4*>(&Yr[grow * SW_RP + 16 * gpart + 8 * h]);
+                const f32x4* dl = reinterpret_cast<const f32x4*>(&Dr[grow * SW_RP + 16 * gpart + 8 * h]);
+                const f32x4 y0 = yl[0], y1 = yl[1], d0 = dl[0], d1 = dl[1];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float t = gv[8 * h + e];
-                v[e] = (p.g_alpha && t < 0.f) ? t * g_al : t;
+                for (int e = 0; e < 8; ++e) {
+                    const int q = q0_ld + 16 * gpart + 8 * h + e;
+                    const bool ok = grow_ok && q < p.Ncols;
+                    const float yv = e < 4 ? y0[e & 3] : y1[e & 3];
+                    // dA in grad_post_act's order: padded data gradient (+ mirrored edges, patched in above), pooled branch
+                    float dA = ab.dsrc ? (e < 4 ? d0[e & 3] : d1[e & 3]) : 0.f;
+                    if (ab.dpool) dA += (frame_of(q) == f_first ? dp0 : dp1) * ab.pool_inv;
+                    // (positions past Ncols / rows past M must come out as zeros, not as -scale * (m1 + xhat m2))
+                    v[e] = ok ? act_bwd_dy(rc, ab.has_bn, yv, dA) : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float t = gv[8 * h + e];
+                    v[e] = (p.g_alpha && t < 0.f) ? t * g_al : t;
+                }
             }
             u32x4 o[3];
             pase_split_bf16x3_rne(v, o);
@@ -250,7 +375,19 @@ __global__ void __launch_bounds__(SX_NT, 2) sinc_x6_wgrad_kernel(PaseWgrad p, Pa
         }
         if (2 * tid < SW_NW) {
             u32x4 w0[3], w1[3];
-            pase_split_two_windows(xv, w0, w1);
+            if constexpr (AB) {
+                float xw[9];
+                const int u0 = q0_ld - p.padL + 2 * tid;
+#pragma unroll
+                for (int e = 0; e < 9; ++e) {
+                    const int u = u0 + e;
+                    // (zero padding: samples outside the sequence were not copied; reflect padding has none outside)
+                    xw[e] = (p.pad_mode == PASE_PAD_REFLECT || (u >= 0 && u < p.Tz)) ? Xr[2 * tid + e] : 0.f;
+                }
+                pase_split_two_windows(xw, w0, w1);
+            } else {
+                pase_split_two_windows(xv, w0, w1);
+            }
 #pragma unroll
             for (int pz = 0; pz < 3; ++pz) {
                 Bs[pz * SW_NW + 2 * tid] = w0[pz];
@@ -268,6 +405,10 @@ __global__ void __launch_bounds__(SX_NT, 2) sinc_x6_wgrad_kernel(PaseWgrad p, Pa
             accS[j][r] = 0.f;
         }
     load_stage(st_begin);
+    if (AB) {                 // (the plain form's first loads are waited for by their first use)
+        sx_dma_wait();
+        __syncthreads();
+    }
     for (long st = st_begin; st < st_end; ++st) {
         store_stage();
         __syncthreads();
@@ -296,6 +437,7 @@ __global__ void __launch_bounds__(SX_NT, 2) sinc_x6_wgrad_kernel(PaseWgrad p, Pa
                 accH[jp + 1] = pase_mfma_bf16_32x32x16(a[0], b1[0], accH[jp + 1]);
             }
         }
+        if (AB) sx_dma_wait();                              // this wave's copies of the next stage's raw tiles have landed ...
         __syncthreads();                                    // every wave has read the image: the next stage may overwrite it
     }
 
@@ -355,14 +497,29 @@ bool pase_sinc_x6_wgrad_plan(const PaseWgrad& w, PaseSincPlan& pl) {
     return true;
 }
 
-int pase_sinc_x6_wgrad_launch(const PaseWgrad& w, const PaseSincPlan& pl, hipStream_t st) {
+// the one-channel plan with its gradient operand evaluated on load (sinc_x6_wgrad_kernel<true>): ab describes the same
+// (S, M, Ncols) tensor the plain launch would read from w.g
+bool pase_sinc_x6_wgrad_act_bwd_ok(const PaseWgrad& w, const PaseActBwd& ab) {
+    if (ab.S != w.S || ab.C != w.M || ab.T != w.Ncols || !ab.y) return false;
+    if (ab.has_bn < 0 || ab.has_bn > 2 || (ab.has_bn == 1 && !ab.sums)) return false;
+    if (w.g_alpha || w.dbias) return false;
+    if (ab.dpool && ab.pool_d < 16) return false;        // a staged run of 16 positions must touch at most two pooled frames
+    if (ab.dsrc && (ab.padL < 0 || ab.Tp < ab.T + ab.padL)) return false;      // every step has its own column in the padded gradient
+    return true;
+}
+
+int pase_sinc_x6_wgrad_launch(const PaseWgrad& w, const PaseSincPlan& pl, hipStream_t st, const PaseActBwd* ab) {
     const long total = (long)w.S * pl.tiles_per_seq;
     // two workgroups per CU; at least 8 stages per workgroup (the atomic flush of a 64 x 256 tile costs about two stages)
     long nwg = w.max_wg > 0 ? 2L * w.max_wg : 512;
     if (w.splitk > 0) nwg = w.splitk;
     if (nwg > (total + 7) / 8) nwg = (total + 7) / 8;
     if (nwg < 1) nwg = 1;
-    PASE_LAUNCH(sinc_x6_wgrad_kernel, dim3((unsigned)nwg), dim3(SX_NT), st, w, pl);
+    if (ab) {
+        PASE_LAUNCH(sinc_x6_wgrad_kernel<true>, dim3((unsigned)nwg), dim3(SX_NT), st, w, pl, *ab);
+    } else {
+        PASE_LAUNCH(sinc_x6_wgrad_kernel<false>, dim3((unsigned)nwg), dim3(SX_NT), st, w, pl, PaseActBwd{});
+    }
     PASE_CHECK_LAUNCH();
     return 0;
 }

@@ -154,14 +154,17 @@ def conv_dgrad(dy, w_nat, *, R, O, k, stride, Tin, padL, padR, s_red, s_out, s_k
 
 
 def conv_wgrad(dy, a: Act, dw2d, dbias, *, taps, stride=1, padL=0, pad_mode=K.PAD_ZERO, tap_major=0, tapstep=1,
-               g_ctot=None, g_coff=0, M=None, Ncols=None, g_alpha=None, dw_col_off=0, max_wg=0):
+               g_ctot=None, g_coff=0, M=None, Ncols=None, g_alpha=None, dw_col_off=0, max_wg=0, g_bwd=None, g_shape=None):
+    """g_bwd (with g_shape = (S, M, T) of the gradient it stands for, dy = None): see kernels.wgrad_gemm; returns False
+    when that launch has no on-load form."""
     S = a.S
-    M = dy.shape[1] if M is None else M
-    K.wgrad_gemm(dy, a.t, dw2d, S=S, M=M, Tg=dy.shape[2], Ncols=dy.shape[2] if Ncols is None else Ncols, Cin=a.C,
-                 Tz=a.T, taps=taps, ldw=dw2d.shape[1], dbias=dbias, g_ctot=dy.shape[1] if g_ctot is None else g_ctot,
-                 g_coff=g_coff, z_ctot=a.ctot, z_coff=a.coff, in_scale=a.scale, in_shift=a.shift, in_alpha=a.alpha,
-                 tap_major=tap_major, stride=stride, tapstep=tapstep, padL=padL, pad_mode=pad_mode,
-                 g_alpha=g_alpha, dw_col_off=dw_col_off, max_wg=max_wg)
+    gs = tuple(dy.shape) if dy is not None else tuple(g_shape)
+    M = gs[1] if M is None else M
+    return K.wgrad_gemm(dy, a.t, dw2d, S=S, M=M, Tg=gs[2], Ncols=gs[2] if Ncols is None else Ncols, Cin=a.C,
+                        Tz=a.T, taps=taps, ldw=dw2d.shape[1], dbias=dbias, g_ctot=gs[1] if g_ctot is None else g_ctot,
+                        g_coff=g_coff, z_ctot=a.ctot, z_coff=a.coff, in_scale=a.scale, in_shift=a.shift, in_alpha=a.alpha,
+                        tap_major=tap_major, stride=stride, tapstep=tapstep, padL=padL, pad_mode=pad_mode,
+                        g_alpha=g_alpha, dw_col_off=dw_col_off, max_wg=max_wg, g_bwd=g_bwd)
 
 
 def deconv_fwd(a: Act, w_nat, bias, *, Cout, k, stride, max_wg=0):
@@ -255,20 +258,34 @@ def rownorm_backward(y, norm, kind, alpha, mean, rstd, *, dsrc=None, dsrc_ctot=N
 
 def act_backward(y, *, C, T, S, has_bn, scale=None, shift=None, alpha=None, mean=None, rstd=None, dsrc=None,
                  dsrc_ctot=None, dsrc_coff=0, Tp=None, padL=0, pad_mode=K.PAD_ZERO, dpool=None, dpool_ctot=0,
-                 dpool_coff=0, pool_F=0, pool_d=1, y_ctot=None, y_coff=0, dy_out=None):
+                 dpool_coff=0, pool_F=0, pool_d=1, y_ctot=None, y_coff=0, dy_out=None, defer_apply=False):
     """Backward of a = PReLU(BN(y)): returns (dy, sums) with sums (C,3) double =
     {dbeta | sum dz, dgamma, dalpha}.  has_bn: False/0 none, True/1 batch statistics, 2 frozen (eval-mode)
-    statistics, whose backward is dy = scale*dz (torch's batch_norm backward with training=False)."""
+    statistics, whose backward is dy = scale*dz (torch's batch_norm backward with training=False).
+    defer_apply: only the reduce pass runs and dy is not written; returns (apply, sums) where `apply` holds the apply pass's
+    arguments for the consumer that evaluates it on load (kernels.wgrad_gemm(g_bwd=apply)) -- or for act_backward_apply()."""
     sums = _zeros((C, 3), y, torch.float64)
-    dy = dy_out if dy_out is not None else _new(tuple(y.shape), y)
     kw = dict(S=S, C_=C, T=T, y_ctot=y_ctot, y_coff=y_coff, dsrc=dsrc, dsrc_ctot=dsrc_ctot, dsrc_coff=dsrc_coff, Tp=Tp, padL=padL,
               pad_mode=pad_mode, dpool=dpool, dpool_ctot=dpool_ctot, dpool_coff=dpool_coff, pool_F=pool_F,
-              pool_d=pool_d, scale=scale, shift=shift, alpha=alpha, mean=mean, rstd=rstd, sums=sums, dy=dy,
+              pool_d=pool_d, scale=scale, shift=shift, alpha=alpha, mean=mean, rstd=rstd, sums=sums, dy=None,
               has_bn=int(has_bn))
+    if defer_apply:
+        K.act_bwd_reduce(y, **kw)        # (dy NULL: sums only, whatever has_bn is)
+        return dict(kw, y=y), sums
+    kw["dy"] = dy = dy_out if dy_out is not None else _new(tuple(y.shape), y)
     K.act_bwd_reduce(y, **kw)
     if int(has_bn) == 1:             # without a BatchNorm / behind a frozen one the reduce pass has already written dy
         K.act_bwd_apply(y, **kw)
     return dy, sums
+
+
+def act_backward_apply(apply):
+    """materialise the dy of a deferred act_backward (its consumer had no on-load form)"""
+    kw = dict(apply)
+    y = kw.pop("y")
+    kw["dy"] = dy = _new(tuple(y.shape), y)
+    K.act_bwd_apply(y, **kw)
+    return dy
 
 
 _WIDE_HEAD_ELEMS = 16 * 1024 * 1024     # prediction elements above which a head fills the chip by itself
@@ -658,10 +675,13 @@ def encoder_backward(fe, ctx, demb, sink, want_dx=False, on_ready=None, max_wg=0
             sink.add_cols(sums, 3, C, [(blk.norm.bias if aff else None, 0), (blk.norm.weight if aff else None, 1),
                                        (blk.act.weight, 2)])
         else:
+            # the SincNet layer's dy feeds its weight gradient and nothing else (no data gradient below the first layer):
+            # only the reduce pass runs here and the weight-gradient launch evaluates the apply pass on load
+            defer = bool(blk.sincnet and n == 0 and not want_dx and y.shape[1] == C)
             dy, sums = act_backward(y, C=C, T=Tn, S=S, has_bn=bn_mode if rec["has_bn"] else 0, scale=rec["scale"],
                                     shift=rec["shift"], alpha=blk.act.weight, mean=rec["mean"], rstd=rec["rstd"],
                                     dsrc=dsrc, dsrc_ctot=dsrc_ctot, dsrc_coff=dsrc_coff, Tp=dsrc_Tp, padL=dsrc_padL,
-                                    pad_mode=dsrc_mode, **kw)
+                                    pad_mode=dsrc_mode, defer_apply=defer, **kw)
             bn_aff = rec["has_bn"] and blk.norm.affine
             no_bn_bias = (not rec["has_bn"]) and not blk.sincnet      # bias gradient = sum dz when no norm follows
             sink.add_cols(sums, 3, C, [(blk.norm.bias if bn_aff else (blk.conv.bias if no_bn_bias else None), 0),
@@ -671,7 +691,13 @@ def encoder_backward(fe, ctx, demb, sink, want_dx=False, on_ready=None, max_wg=0
         if blk.sincnet:
             conv = blk.conv
             dfilt = _zeros((C, taps), x)
-            conv_wgrad(dy, inp, dfilt, None, taps=taps, stride=blk.stride, padL=rec["padL"], pad_mode=K.PAD_REFLECT, max_wg=max_wg)
+            if isinstance(dy, dict):
+                if not conv_wgrad(None, inp, dfilt, None, taps=taps, stride=blk.stride, padL=rec["padL"],
+                                  pad_mode=K.PAD_REFLECT, max_wg=max_wg, g_bwd=dy, g_shape=(S, C, Tn)):
+                    dy = act_backward_apply(dy)
+            if not isinstance(dy, dict):
+                conv_wgrad(dy, inp, dfilt, None, taps=taps, stride=blk.stride, padL=rec["padL"], pad_mode=K.PAD_REFLECT,
+                           max_wg=max_wg)
             dlow, dband = _new((C,), x), _new((C,), x)
             K.sinc_filters_bwd(conv.low_hz_, conv.band_hz_, conv.n_, conv.window_, dfilt, dlow, dband, C_=C, Kw=taps,
                                min_low=float(conv.min_low_hz), min_band=float(conv.min_band_hz),

@@ -353,6 +353,7 @@ class PaseAddBlocks(C.Structure):
 _i, _f, _d, _l = C.c_int, C.c_float, C.c_double, C.c_long
 _SIMPLE.update({
     "pase_wgrad_gemm": [C.POINTER(PaseWgrad), _fp],
+    "pase_wgrad_gemm_act_bwd": [C.POINTER(PaseWgrad), C.POINTER(PaseActBwd), _fp],
     "pase_bn_finalize": [_fp, _i, _i, _d, _fp, _fp, _f, _f, _fp, _fp, _fp, _fp, _fp, _fp, _fp],
     "pase_bn_act_pool": [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp],
     "pase_bn_act_apply": [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp],
@@ -407,7 +408,10 @@ def abi_check(l):
 
 def wgrad_gemm(g, z, dw, *, S, M, Tg, Ncols, Cin, Tz, taps, ldw=None, dbias=None, g_ctot=None, g_coff=0,
                z_ctot=None, z_coff=0, in_scale=None, in_shift=None, in_alpha=None, tap_major=0, stride=1,
-               tapstep=1, padL=0, pad_mode=PAD_ZERO, splitk=0, g_alpha=None, dw_col_off=0, max_wg=0):
+               tapstep=1, padL=0, pad_mode=PAD_ZERO, splitk=0, g_alpha=None, dw_col_off=0, max_wg=0, g_bwd=None):
+    """g_bwd: a dict of act_bwd_apply's keyword arguments (its `y` included) -- the gradient operand is then that apply pass
+    evaluated on load (pase_wgrad_gemm_act_bwd; g is not read and may be None).  Only the one-channel SincNet plan has it:
+    returns False, with nothing enqueued, when the launch would run on another kernel (the caller then materialises dy)."""
     d = PaseWgrad()
     d.g_alpha = _ptr(g_alpha)
     d.g, d.z, d.dw, d.dbias = _ptr(g), _ptr(z), _ptr(dw) + 4 * dw_col_off, _ptr(dbias)
@@ -436,16 +440,24 @@ def wgrad_gemm(g, z, dw, *, S, M, Tg, Ncols, Cin, Tz, taps, ldw=None, dbias=None
         # split-bf16 contraction (conv_x6c.hip, T-mode): one operand is packed into this scratch by the launch itself
         nbytes = _lib.lib().pase_wgrad_x6_bytes(C.byref(d))
         if nbytes > 0:
-            gx6 = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
+            gx6 = torch.empty(nbytes, dtype=torch.uint8, device=z.device)
             d.gx6 = gx6.data_ptr()
             LAST_WGRAD_X6 = True
             LAST_WGRAD_KIND = _lib.lib().pase_wgrad_plan_kind(C.byref(d))
+    if g_bwd is not None and LAST_WGRAD_KIND != 5:
+        return False
     ev0 = GEMM_TIMER.start() if GEMM_TIMER is not None else None
-    _check(_lib.lib().pase_wgrad_gemm(C.byref(d), _stream()), "pase_wgrad_gemm")
+    if g_bwd is not None:
+        kw = dict(g_bwd)
+        ab = _act_bwd_desc(kw.pop("y"), **kw)
+        _check(_lib.lib().pase_wgrad_gemm_act_bwd(C.byref(d), C.byref(ab), _stream()), "pase_wgrad_gemm_act_bwd")
+    else:
+        _check(_lib.lib().pase_wgrad_gemm(C.byref(d), _stream()), "pase_wgrad_gemm")
     if ev0 is not None:
         GEMM_TIMER.stop("wgrad_gemm", 2.0 * S * Ncols * M * (Cin * taps + (1 if dbias is not None else 0)), ev0,
                         "M%d Kw%d(Cin%d x %d) N%dx%d s%d" % (M, Cin * taps, Cin, taps, S, Ncols, d.stride),
                         pipe="x6" if LAST_WGRAD_X6 else "f32")
+    return True
 
 
 def bn_finalize(stat_part, C_, count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift,

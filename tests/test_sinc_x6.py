@@ -95,3 +95,77 @@ def test_the_fp32_pipe_is_still_selectable(dev, monkeypatch):
                 pad_mode=K.PAD_REFLECT)
     assert K.LAST_PLAN_KIND == 0
     assert _rel(y, ref) < 2e-6
+
+
+@pytest.mark.parametrize("M,taps,T,S,has_bn,pool_d,splitk", [
+    (64, 251, 640, 2, 1, 160, 0),      # the PASE+ layer: batch statistics, reflect-folded data gradient, pooled dense-skip gradient
+    (64, 251, 700, 2, 1, 0, 3),        # ragged last stage, no pooled branch, stages of two sequences in one workgroup
+    (30, 101, 300, 2, 2, 0, 1),        # frozen statistics (dy = scale * dz), fewer filters than the row tile
+    (48, 65, 200, 1, 0, 50, 0),        # no norm (dy = dz)
+])
+def test_sinc_weight_gradient_with_the_norm_backward_on_load(dev, M, taps, T, S, has_bn, pool_d, splitk):
+    """pase_wgrad_gemm_act_bwd: the gradient operand is the apply pass of the BatchNorm + PReLU backward evaluated while it is
+    staged (dy never written).  Judged against an fp64 autograd evaluation of the same chain
+    (F.pad(reflect) / view(..).mean(3) / batch_norm / prelu, pase/models/modules.py:1061-1077, frontend.py:213-232), and
+    against the two-launch form (apply pass, then the plain weight gradient) on the same device."""
+    torch.manual_seed(5)
+    x = torch.randn(S, 1, T) * 0.3
+    y = torch.randn(S, M, T) * 1.5 + 0.2
+    gamma, beta, alpha = torch.rand(M) + 0.5, torch.randn(M) * 0.2, torch.rand(M) * 0.5
+    pL, pR = 9, 10
+    dsrc = torch.randn(S, M + 3, T + pL + pR) * 0.1                  # a channel slice of a wider padded data gradient
+    F_ = T // pool_d if pool_d else 0
+    dpool = torch.randn(S, M + 2, F_) * 0.1 if pool_d else None
+    # ---- fp64 reference ---------------------------------------------------------------------------------------------------
+    yd = y.double().requires_grad_(True)
+    mean, var = yd.detach().mean((0, 2)), yd.detach().var((0, 2), unbiased=False)
+    if has_bn == 1:
+        z = F.batch_norm(yd, None, None, gamma.double(), beta.double(), True, 0.0, 1e-5)
+    elif has_bn == 2:
+        z = F.batch_norm(yd, mean.clone(), var.clone(), gamma.double(), beta.double(), False, 0.0, 1e-5)
+    else:
+        z = yd
+    a = F.prelu(z, alpha.double())
+    loss = (F.pad(a, (pL, pR), mode="reflect") * dsrc[:, 1:1 + M].double()).sum()
+    if pool_d:
+        loss = loss + (a[:, :, :F_ * pool_d].reshape(S, M, F_, pool_d).mean(3) * dpool[:, 2:2 + M].double()).sum()
+    dy_ref, = torch.autograd.grad(loss, yd)
+    P = (taps // 2, taps // 2)
+    filt = torch.zeros(M, taps, dtype=torch.float64, requires_grad=True)
+    (F.conv1d(F.pad(x.double(), P, mode="reflect"), filt[:, None, :]) * dy_ref).sum().backward()
+    # ---- device -----------------------------------------------------------------------------------------------------------
+    rstd = (var + 1e-5).rsqrt()
+    scale = (gamma.double() * rstd).float() if has_bn else None
+    shift = (beta.double() - mean * gamma.double() * rstd).float() if has_bn else None
+    t = lambda v: None if v is None else v.to(dev)
+    sums = torch.zeros(M, 3, dtype=torch.float64, device=dev)
+    kw = dict(S=S, C_=M, T=T, dsrc=t(dsrc), dsrc_ctot=M + 3, dsrc_coff=1, Tp=T + pL + pR, padL=pL, pad_mode=K.PAD_REFLECT,
+              dpool=t(dpool), dpool_ctot=M + 2 if pool_d else 0, dpool_coff=2 if pool_d else 0, pool_F=F_, pool_d=max(1, pool_d),
+              scale=t(scale), shift=t(shift), alpha=t(alpha), mean=t(mean.float()) if has_bn else None,
+              rstd=t(rstd.float()) if has_bn else None, sums=sums, dy=None, has_bn=has_bn)
+    yv = y.to(dev)
+    K.act_bwd_reduce(yv, **kw)
+    dw = torch.full((M, taps), 0.5, device=dev)
+    assert K.wgrad_gemm(None, x.to(dev), dw, S=S, M=M, Tg=T, Ncols=T, Cin=1, Tz=T, taps=taps, padL=P[0], pad_mode=K.PAD_REFLECT,
+                        splitk=splitk, g_bwd=dict(kw, y=yv))
+    assert K.LAST_WGRAD_X6 and K.LAST_WGRAD_KIND == 5
+    assert _rel(dw - 0.5, filt.grad) < 1e-6
+    # the two-launch form
+    dy = torch.empty(S, M, T, device=dev)
+    if has_bn == 1:
+        K.act_bwd_apply(yv, **dict(kw, dy=dy))
+    else:
+        K.act_bwd_reduce(yv, **dict(kw, dy=dy, sums=torch.zeros_like(sums)))
+    assert _rel(dy, dy_ref) < 1e-6
+    dw2 = torch.zeros(M, taps, device=dev)
+    K.wgrad_gemm(dy, x.to(dev), dw2, S=S, M=M, Tg=T, Ncols=T, Cin=1, Tz=T, taps=taps, padL=P[0], pad_mode=K.PAD_REFLECT,
+                 splitk=splitk)
+    assert _rel(dw - 0.5, dw2.cpu().double()) < 1e-6
+
+
+def test_the_on_load_form_exists_only_on_the_one_channel_plan(dev):
+    S, M, Cin, T = 1, 64, 8, 128
+    g_bwd = dict(y=torch.zeros(S, M, T, device=dev), S=S, C_=M, T=T, has_bn=0)
+    dw = torch.zeros(M, Cin * 3, device=dev)
+    assert K.wgrad_gemm(None, torch.zeros(S, Cin, T, device=dev), dw, S=S, M=M, Tg=T, Ncols=T, Cin=Cin, Tz=T, taps=3, padL=1,
+                        g_bwd=g_bwd) is False
