@@ -282,6 +282,43 @@ int pase_head1_bwd(const float* z, const float* in_alpha, const float* w, const 
 int pase_ctx_loss(const float* pred, const float* label, float* dpred, double* loss_acc, int B, int M, int F,
                   int r_ctx, int label_D, int loss_type, float grad_scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The pointwise tail of a decoder worker, forward, loss and backward in ONE pass over its input:
+ *   a0 = PReLU(y, alpha0);  y1 = W1 a0 + b1  (MLPBlock, context 1, pase/models/modules.py:527-556);  a1 = PReLU(y1, alpha1);
+ *   pred = w2 . a1 + b2  (DecoderMinion.W = Conv1d(hidden, 1, 1), Minions/minions.py:416-417,446);  loss(pred, target)
+ *   (pase/losses.py:33-37, r = None)  and the autograd of all of it down to dy = d(loss * grad_scale') / dy.
+ * y is the raw output of the layer below (a GDeconv1DBlock with norm_type None, modules.py:558-589: nothing but its PReLU
+ * stands between the layers).  Replaces, for that tail, pase_conv_gemm (64-row 1x1) + pase_head1_fwd + pase_head1_bwd +
+ * pase_wgrad_gemm (1x1) + pase_conv_gemm (1x1 data gradient) + pase_act_bwd_reduce over y: y1, dy1 and the gradient of
+ * a0 are never written.  Exact-fp32 matrix pipe (the arithmetic of the launches it replaces).
+ *   Outputs: dy (S, C, T);  pred (S, T) or NULL;  loss_acc += sum of per-element losses;  dw1 (H, C) += ;
+ *   sums0 (C, 3) doubles += {sum dy (the bias gradient of the layer below), -, dalpha0}   (PaseActBwd::sums layout);
+ *   sums1 (H, 3) + 1 doubles += {dw2, dalpha1, sum dy1 (= db1)} then db2 at [3 H]        (pase_head1_bwd layout).
+ * Specialised for C = 128, H = 64 (cfg/workers/workers+.cfg "cchunk"): pase_mlp_head1_supported says whether a shape has the
+ * form; pase_mlp_head1_step returns -11 otherwise and the caller runs the six launches.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct PaseMlpHead1 {
+    const float* y;        /* (S, C, T)                                                           */
+    const float* alpha0;   /* (C) PReLU slopes of the layer below, NULL = identity                */
+    const float* w1;       /* (H, C) row-major                                                    */
+    const float* b1;       /* (H) or NULL                                                         */
+    const float* alpha1;   /* (H) or NULL                                                         */
+    const float* w2;       /* (H)                                                                 */
+    const float* b2;       /* (1) or NULL                                                         */
+    const float* target;   /* (S, T); NULL with PASE_LOSS_NONE                                    */
+    float* pred;           /* (S, T) or NULL                                                      */
+    float* dy;             /* (S, C, T)                                                           */
+    double* loss_acc;      /* (1)                                                                 */
+    double* sums0;         /* (C, 3)                                                              */
+    double* sums1;         /* (3 H + 1)                                                           */
+    float* dw1;            /* (H, C)                                                              */
+    int S, C, T, H, loss_type;
+    float grad_scale;      /* dpred = dloss/dpred * grad_scale (loss weight / number of elements) */
+    int max_wg;            /* cap on the persistent grid (0 = 256), see PaseConvGemm::max_wg      */
+} PaseMlpHead1;
+int pase_mlp_head1_supported(const PaseMlpHead1* desc);
+int pase_mlp_head1_step(const PaseMlpHead1* desc, void* stream);
+
 /* Sinc band-pass bank: SincConv_fast.forward filter synthesis (pase/models/modules.py:881-915) and
  * its gradient w.r.t. low_hz_ / band_hz_.  n_ and window_ are the module's constant buffers. */
 int pase_sinc_filters(const float* low_hz_, const float* band_hz_, const float* n_, const float* window_,

@@ -8,6 +8,7 @@ extern "C" int pase_abi_sizeof(int which) {
         case 1: return (int)sizeof(PaseWgrad);
         case 2: return (int)sizeof(PaseActBwd);
         case 3: return (int)sizeof(PaseAddBlocks);
+        case 4: return (int)sizeof(PaseMlpHead1);
         default: return -1;
     }
 }

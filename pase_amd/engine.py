@@ -767,7 +767,21 @@ class WorkerCtx:
     pass
 
 
-def worker_forward(layers, out_conv, a: Act, *, loss=None, want_pred=True, max_wg=0):
+def _fused_tail_ok(layers, out_conv, loss):
+    """The decoder worker's pointwise tail -- [.., GDeconv1DBlock (no norm), MLPBlock(context 1)] -> Conv1d(hidden, 1, 1) with
+    a plain (r = None) loss -- has a one-pass forward + backward (kernels.mlp_head1_step) when the library has the shape."""
+    if loss is None or len(layers) < 2 or out_conv.out_channels != 1 or out_conv.kernel_size[0] != 1:
+        return False
+    if loss.get("r") not in (None, 1) or loss["name"] not in LOSS_TYPES:
+        return False
+    mlp, prev = layers[-1], layers[-2]
+    if hasattr(mlp, "deconv") or not hasattr(prev, "deconv") or getattr(mlp, "context", 0) != 1:
+        return False
+    import os
+    return os.environ.get("PASE_MLP_HEAD1", "1") != "0"
+
+
+def worker_forward(layers, out_conv, a: Act, *, loss=None, want_pred=True, max_wg=0, sink=None):
     """Forward of a Minion.  layers: list of GDeconv1DBlock / MLPBlock containers; out_conv: the final
     nn.Conv1d(hidden, num_outputs*r, 1).  loss: None or dict(name=<nn loss name>, r=<int|None>,
     target=<tensor>, weight=<float>) -> fused loss + d(loss*weight)/d(pred).
@@ -775,8 +789,10 @@ def worker_forward(layers, out_conv, a: Act, *, loss=None, want_pred=True, max_w
     .numel, .dpred."""
     ctx = WorkerCtx()
     ctx.recs = []
+    ctx.fused_tail = None
     cur = a
-    for blk in layers:
+    fuse = sink is not None and _fused_tail_ok(layers, out_conv, loss)
+    for blk in (layers[:-1] if fuse else layers):
         if hasattr(blk, "deconv"):
             dc = blk.deconv
             z = deconv_fwd(cur, dc.weight, dc.bias, Cout=dc.out_channels, k=blk.kwidth, stride=blk.stride, max_wg=max_wg)
@@ -788,6 +804,37 @@ def worker_forward(layers, out_conv, a: Act, *, loss=None, want_pred=True, max_w
                             padR=k // 2, pad_mode=K.PAD_ZERO, max_wg=max_wg)
             ctx.recs.append(("conv", blk, cur, z))
             cur = Act(z, C=blk.fmaps, alpha=blk.act.weight)
+    if fuse:
+        mlp = layers[-1]
+        H = mlp.fmaps
+        if (cur.scale is None and cur.coff == 0 and cur.ctot == cur.C and cur.t.is_contiguous()
+                and K.mlp_head1_supported(S=cur.S, C_=cur.C, T=cur.T, H=H)):
+            # forward, loss and backward of the tail in one pass over the deconvolution's output: its data gradient (dz of
+            # the last GDeconv1DBlock), the tail's parameter gradients straight into the sink's buffers
+            B, T, C = cur.S, cur.T, cur.C
+            ctx.last = cur
+            ctx.head1 = False
+            ctx.numel = B * T
+            ctx.dpred = None
+            ctx.loss_acc = loss["acc"] if loss.get("acc") is not None else _zeros((1,), cur.t, torch.float64)
+            ctx.pred = _new((B, 1, T), cur.t) if want_pred else None
+            dz = _new((B, C, T), cur.t)
+            sums0 = _zeros((C, 3), cur.t, torch.float64)
+            sums1 = _zeros((3 * H + 1,), cur.t, torch.float64)
+            K.mlp_head1_step(cur.t, cur.alpha, mlp.W.weight.view(H, C), mlp.W.bias, mlp.act.weight,
+                             out_conv.weight.view(-1), out_conv.bias, loss["target"].contiguous(), ctx.pred, dz,
+                             ctx.loss_acc, sums0, sums1, sink.buf(mlp.W.weight).view(H, C), S=B, C_=C, T=T, H=H,
+                             loss_type=LOSS_TYPES[loss["name"]], grad_scale=float(loss.get("weight", 1.0)) / ctx.numel,
+                             max_wg=max_wg)
+            ctx.fused_tail = (mlp, dz, sums0, sums1)
+            return ctx
+        # (no one-pass form for this shape: the tail's layers one by one)
+        blk = layers[-1]
+        k = blk.context
+        z, _ = conv_fwd(cur, blk.W.weight.view(blk.fmaps, -1), blk.W.bias, Cout=blk.fmaps, taps=k, padL=k // 2,
+                        padR=k // 2, pad_mode=K.PAD_ZERO, max_wg=max_wg)
+        ctx.recs.append(("conv", blk, cur, z))
+        cur = Act(z, C=blk.fmaps, alpha=blk.act.weight)
     ctx.last = cur
     nout = out_conv.out_channels
     B, T = cur.S, cur.T
@@ -846,7 +893,14 @@ def worker_backward(layers, out_conv, ctx, dpred, sink, need_dinput=True, max_wg
     B, T = cur.S, cur.T
     nout = out_conv.out_channels
     x = cur.t
-    if ctx.head1:
+    if getattr(ctx, "fused_tail", None) is not None:
+        mlp, dz, sums0, sums1 = ctx.fused_tail
+        H = mlp.fmaps
+        sink.add_cols(sums1, 3, H, [(out_conv.weight, 0), (mlp.act.weight, 1), (mlp.W.bias, 2)])
+        sink.add_cols(sums1[H * 3:], 1, 1, [(out_conv.bias, 0)])
+        psums, pcols = sums0, (2, 0)            # (dalpha, sum dz) columns for the deconvolution below
+        have_dz = True
+    elif ctx.head1:
         C = cur.C
         sums = _zeros((C * 3 + 1,), x, torch.float64)
         dz = _new((B, C, T), x)

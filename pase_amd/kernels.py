@@ -350,8 +350,16 @@ class PaseAddBlocks(C.Structure):
     _fields_ = [("n", C.c_int), ("seg", PaseAddBlock * 16)]
 
 
+class PaseMlpHead1(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("y", "alpha0", "w1", "b1", "alpha1", "w2", "b2", "target", "pred", "dy", "loss_acc",
+                                          "sums0", "sums1", "dw1")] + \
+               [(n, C.c_int) for n in ("S", "C", "T", "H", "loss_type")] + [("grad_scale", C.c_float), ("max_wg", C.c_int)]
+
+
 _i, _f, _d, _l = C.c_int, C.c_float, C.c_double, C.c_long
 _SIMPLE.update({
+    "pase_mlp_head1_supported": [C.POINTER(PaseMlpHead1)],
+    "pase_mlp_head1_step": [C.POINTER(PaseMlpHead1), _fp],
     "pase_wgrad_gemm": [C.POINTER(PaseWgrad), _fp],
     "pase_wgrad_gemm_act_bwd": [C.POINTER(PaseWgrad), C.POINTER(PaseActBwd), _fp],
     "pase_bn_finalize": [_fp, _i, _i, _d, _fp, _fp, _f, _f, _fp, _fp, _fp, _fp, _fp, _fp, _fp],
@@ -404,6 +412,8 @@ def abi_check(l):
         raise _lib.PaseLibraryError("ABI mismatch: PaseActBwd")
     if l.pase_abi_sizeof(3) != C.sizeof(PaseAddBlocks):
         raise _lib.PaseLibraryError("ABI mismatch: PaseAddBlocks")
+    if l.pase_abi_sizeof(4) != C.sizeof(PaseMlpHead1):
+        raise _lib.PaseLibraryError("ABI mismatch: PaseMlpHead1")
 
 
 def wgrad_gemm(g, z, dw, *, S, M, Tg, Ncols, Cin, Tz, taps, ldw=None, dbias=None, g_ctot=None, g_coff=0,
@@ -542,6 +552,37 @@ def head1_fwd(z, w, bias, *, S, C_, T, in_scale=None, in_shift=None, in_alpha=No
 def head1_bwd(z, in_alpha, w, dy, dz, sums, *, S, C_, T):
     _check(_lib.lib().pase_head1_bwd(_ptr(z), _ptr(in_alpha), _ptr(w), _ptr(dy), _ptr(dz),
                                      _ptr(sums, torch.float64), S, C_, T, _stream()), "pase_head1_bwd")
+
+
+def _mlp_head1_desc(y, alpha0, w1, b1, alpha1, w2, b2, target, pred, dy, loss_acc, sums0, sums1, dw1, *, S, C_, T, H,
+                    loss_type, grad_scale, max_wg=0):
+    d = PaseMlpHead1()
+    d.y, d.alpha0, d.w1, d.b1, d.alpha1, d.w2, d.b2 = (_ptr(v) for v in (y, alpha0, w1, b1, alpha1, w2, b2))
+    d.target, d.pred, d.dy, d.dw1 = _ptr(target), _ptr(pred), _ptr(dy), _ptr(dw1)
+    d.loss_acc, d.sums0, d.sums1 = (_ptr(v, torch.float64) for v in (loss_acc, sums0, sums1))
+    d.S, d.C, d.T, d.H, d.loss_type, d.grad_scale = S, C_, T, H, loss_type, grad_scale
+    d.max_wg = _max_wg(max_wg)
+    return d
+
+
+def mlp_head1_supported(*, S, C_, T, H):
+    d = PaseMlpHead1()
+    d.S, d.C, d.T, d.H = S, C_, T, H
+    return bool(_lib.lib().pase_mlp_head1_supported(C.byref(d)))
+
+
+MLP_HEAD1_CALLS = 0        # launches of the one-pass decoder tail so far (tests assert the path they mean to exercise ran)
+
+
+def mlp_head1_step(y, alpha0, w1, b1, alpha1, w2, b2, target, pred, dy, loss_acc, sums0, sums1, dw1, **kw):
+    global MLP_HEAD1_CALLS
+    MLP_HEAD1_CALLS += 1
+    d = _mlp_head1_desc(y, alpha0, w1, b1, alpha1, w2, b2, target, pred, dy, loss_acc, sums0, sums1, dw1, **kw)
+    ev0 = GEMM_TIMER.start() if GEMM_TIMER is not None else None
+    _check(_lib.lib().pase_mlp_head1_step(C.byref(d), _stream()), "pase_mlp_head1_step")
+    if ev0 is not None:
+        GEMM_TIMER.stop("mlp_head1", 2.0 * d.S * d.T * (3 * d.C * d.H + 2 * d.H), ev0,
+                        "C%d H%d N%dx%d fwd + bwd" % (d.C, d.H, d.S, d.T), pipe="f32")
 
 
 def ctx_loss(pred, label, dpred, loss_acc, *, B, M, F, r_ctx, label_D, loss_type, grad_scale):

@@ -251,7 +251,7 @@ class pase(Model):
             wctx = engine.worker_forward(list(worker.blocks), worker.W, Act(chunk, C=E),
                                          loss=dict(name=loss.loss_name, r=loss.r, target=tgt,
                                                    weight=worker.loss_weight, acc=book.slot(worker.name)),
-                                         want_pred=False, max_wg=max_wg)
+                                         want_pred=False, max_wg=max_wg, sink=sink)
             dsrc = engine.worker_backward(list(worker.blocks), worker.W, wctx, wctx.dpred, sink, max_wg=max_wg)
             demb[:B] += dsrc.dense(E, F_)
             book.scale(worker.name, worker.loss_weight / wctx.numel)

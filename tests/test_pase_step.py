@@ -51,6 +51,36 @@ def test_fused_step_losses_and_grads(dev):
     _check_grads(m, P)
 
 
+@pytest.mark.parametrize("one_pass", [True, False], ids=["one-pass-tail", "six-launches"])
+def test_fused_step_with_the_decoder_tail_at_its_real_width(dev, monkeypatch, one_pass):
+    """cchunk's last deconvolution 128 channels wide and its MLPBlock 64: the shape whose pointwise tail has the one-pass
+    forward + backward (pase_mlp_head1_step); same oracle comparison with the tail run layer by layer (PASE_MLP_HEAD1=0)."""
+    from pase_amd import kernels as K
+    from pase_amd.pase import pase
+    monkeypatch.setenv("PASE_MLP_HEAD1", "1" if one_pass else "0")
+    raw = mini_workers()
+    raw["regr"][0].update(fmaps=[10, 8, 128], hidden_size=64)
+    seed_all(11)
+    wk = mini_workers()
+    wk["regr"][0].update(fmaps=[10, 8, 128], hidden_size=64)
+    m = quiet(pase, frontend_cfg=dict(MINI_FE), minions_cfg=with_losses(wk), cls_lst=["mi", "cmi"],
+              regr_lst=["cchunk", "lps", "prosody"])
+    randomize_affine(m)
+    m = m.to(dev)
+    P = oracle_params(m)
+    batch = _mini_batch(seed=12, T=1600)
+    h, chunk, preds, labels = O.pase_forward(P, MINI_FE, raw, batch, True)
+    lo = O.pase_losses(raw, preds, labels)
+    lo["total"].backward()
+    m.train()
+    n0 = K.MLP_HEAD1_CALLS
+    lf = m.loss_and_grads({k: v.to(dev) for k, v in batch.items()})
+    assert K.MLP_HEAD1_CALLS == n0 + (1 if one_pass else 0)
+    for k, v in lo.items():
+        assert abs(float(lf[k]) - float(v)) <= 1e-4 * max(1.0, abs(float(v))), (k, float(lf[k]), float(v))
+    _check_grads(m, P)
+
+
 def test_api_compat_forward_and_autograd(dev):
     """pase.forward(batch) -> (h, chunk, preds, labels) + worker.loss(...) + .backward(): the
     reference's own calling convention (trainer.py:229, worker_scheduler.py:43-75)."""
