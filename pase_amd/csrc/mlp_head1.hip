@@ -35,6 +35,49 @@ constexpr int MH_PW = MH_C + 1;       // floats per hidden row of W1
 constexpr int MH_PD = MH_H + 1;       // floats per time step of the transposed dy1 tile
 constexpr int MH_UB = 4;              // MFMA steps whose fragments are read ahead together
 
+// (tools/mlp_head1_ablate.sh: timing builds that leave one phase out -- never defined in the product build)
+#ifdef MH_ABL_NO1
+#define MH_MFMA1(a, b, c) mh_fake(a, b, c)
+#else
+#define MH_MFMA1(a, b, c) pase_mfma_32x32x2(a, b, c)
+#endif
+#ifdef MH_ABL_NO2
+#define MH_MFMA2(a, b, c) mh_fake(a, b, c)
+#else
+#define MH_MFMA2(a, b, c) pase_mfma_32x32x2(a, b, c)
+#endif
+#ifdef MH_ABL_NO3
+#define MH_MFMA3(a, b, c) mh_fake(a, b, c)
+#else
+#define MH_MFMA3(a, b, c) pase_mfma_32x32x2(a, b, c)
+#endif
+__device__ __forceinline__ f32x16 mh_fake(float a, float b, f32x16 c) {      // keeps the operand reads alive, one VALU instead of an MFMA
+    c[0] = fmaf(a, b, c[0]);
+    return c;
+}
+
+// -DMH_TRACE (tools/mlp_head1_ablate.sh trace): shader-clock stamps at the phase boundaries of wave 0 of workgroups 0 and 131,
+// summed over the workgroup's tiles: slot i = clocks from stamp i's predecessor to stamp i
+#ifdef MH_TRACE
+__device__ unsigned long long g_mh_trace[2 * 16];
+#define MH_TRACE_BEGIN() unsigned long long mh_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, mh_last = clock64()
+#define MH_STAMP(i)                                   \
+    do {                                              \
+        const unsigned long long mh_now = clock64();  \
+        mh_t[i] += mh_now - mh_last;                  \
+        mh_last = mh_now;                             \
+    } while (0)
+#define MH_TRACE_END()                                                                            \
+    do {                                                                                          \
+        if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 131))                           \
+            for (int i = 0; i < 10; ++i) g_mh_trace[(blockIdx.x ? 16 : 0) + i] = mh_t[i];         \
+    } while (0)
+#else
+#define MH_TRACE_BEGIN() ((void)0)
+#define MH_STAMP(i) ((void)0)
+#define MH_TRACE_END() ((void)0)
+#endif
+
 __device__ __forceinline__ int mh_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
 // one dword per lane straight from global memory into LDS (global_load_lds_dword: destination = wave-uniform LDS address +
@@ -50,6 +93,9 @@ __device__ __forceinline__ void mh_load_lds4(const float* src, float* lds_wave_b
 __device__ __forceinline__ void mh_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #endif
 
+// LOSS: the loss of the head, a compile-time constant -- as a run-time switch inside the unrolled head the compiler laid all
+// three losses (the BCE's exp / log1p expansions included) out sixteen times: 4 600 instructions, 10 k clocks per tile
+template <int LOSS>
 __global__ void __launch_bounds__(MH_NT) mlp_head1_kernel(PaseMlpHead1 p, int tiles_per_seq, long ntiles) {
     __shared__ float Ys[MH_C * MH_PY];
     __shared__ float W1s[MH_H * MH_PW];
@@ -87,7 +133,9 @@ __global__ void __launch_bounds__(MH_NT) mlp_head1_kernel(PaseMlpHead1 p, int ti
     float st_dy0[4] = {0.f, 0.f, 0.f, 0.f}, st_da0[4] = {0.f, 0.f, 0.f, 0.f};           // channel 32 c + l31
     double lsum = 0.0, s_db2 = 0.0;
 
+    MH_TRACE_BEGIN();
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        MH_STAMP(8);
         const int s = (int)(tile / tiles_per_seq);
         const int t0 = (int)(tile - (long)s * tiles_per_seq) * MH_P;
         const int nv = min(MH_P, p.T - t0);                                   // live time steps of the tile
@@ -116,7 +164,7 @@ __global__ void __launch_bounds__(MH_NT) mlp_head1_kernel(PaseMlpHead1 p, int ti
         float tgv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) tgv[r] = 0.f;
-        if (p.loss_type != PASE_LOSS_NONE) {
+        if (LOSS != PASE_LOSS_NONE) {
             const float* tgb = p.target + ob;
             if (nv == MH_P) {
 #pragma unroll
@@ -131,6 +179,10 @@ __global__ void __launch_bounds__(MH_NT) mlp_head1_kernel(PaseMlpHead1 p, int ti
         //      32 w ..), time steps past the end of a ragged tile are zeros ------------------------------------------------
         {
             const float* yb = p.y + ((size_t)s * MH_C + 32 * wave) * (size_t)p.T + t0;      // (uniform)
+#ifdef MH_ABL_NOCOPY
+            if (tile != (long)blockIdx.x) {
+            } else
+#endif
             if (nv == MH_P) {       // uniform
 #pragma unroll 8
                 for (int rr = 0; rr < 32; ++rr) {
@@ -144,6 +196,7 @@ __global__ void __launch_bounds__(MH_NT) mlp_head1_kernel(PaseMlpHead1 p, int ti
             }
         }
         __syncthreads();
+        MH_STAMP(0);
 
         // ---- 1. Y1^T = A0^T W1^T for this wave's 32 time steps: rows = steps, columns = hidden 32 t + l31 ---------------
         f32x16 acc1[2];
@@ -175,7 +228,7 @@ __global__ void __launch_bounds__(MH_NT) mlp_head1_kernel(PaseMlpHead1 p, int ti
                     const float neg = yc[u] * lc[u];
                     const float a = yc[u] > 0.f ? yc[u] : neg;
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) acc1[t] = pase_mfma_32x32x2(a, bc[u][t], acc1[t]);
+                    for (int t = 0; t < 2; ++t) acc1[t] = MH_MFMA1(a, bc[u][t], acc1[t]);
                 }
                 if (blk + 1 < MH_C / 2 / MH_UB) {
 #pragma unroll
@@ -188,6 +241,7 @@ __global__ void __launch_bounds__(MH_NT) mlp_head1_kernel(PaseMlpHead1 p, int ti
                 }
             }
         }
+        MH_STAMP(1);
         // ---- head: register r = time step p0w + mh_row(r, half); the 64 hidden values of a step sit in the 32 lanes of
         //      this half (two row tiles): pred = xor-shuffle sum ------------------------------------------------------------
         float dpred[16];
@@ -204,6 +258,7 @@ __global__ void __launch_bounds__(MH_NT) mlp_head1_kernel(PaseMlpHead1 p, int ti
                 }
             }
             // the five exchange rounds over all 16 values at once (16 independent exchanges in flight per round)
+#ifndef MH_ABL_NOHEAD
 #pragma unroll
             for (int m = 1; m < 32; m <<= 1) {
                 float o[16];
@@ -212,6 +267,7 @@ __global__ void __launch_bounds__(MH_NT) mlp_head1_kernel(PaseMlpHead1 p, int ti
 #pragma unroll
                 for (int r = 0; r < 16; ++r) part[r] += o[r];
             }
+#endif
             float lt = 0.f, dt = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -219,15 +275,15 @@ __global__ void __launch_bounds__(MH_NT) mlp_head1_kernel(PaseMlpHead1 p, int ti
                 const bool ok = p0w + mh_row(r, half) < nv;
                 const float tg = tgv[r];
                 float l = 0.f, g = 0.f;
-                if (p.loss_type == PASE_LOSS_L1) {           // (uniform)
+                if constexpr (LOSS == PASE_LOSS_L1) {
                     const float d = pred - tg;
                     l = fabsf(d);
                     g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-                } else if (p.loss_type == PASE_LOSS_MSE) {
+                } else if constexpr (LOSS == PASE_LOSS_MSE) {
                     const float d = pred - tg;
                     l = d * d;
                     g = 2.f * d;
-                } else if (p.loss_type == PASE_LOSS_BCE_LOGITS) {
+                } else if constexpr (LOSS == PASE_LOSS_BCE_LOGITS) {
                     l = fmaxf(pred, 0.f) - pred * tg + log1pf(expf(-fabsf(pred)));
                     g = 1.f / (1.f + expf(-pred)) - tg;
                 }
@@ -235,7 +291,12 @@ __global__ void __launch_bounds__(MH_NT) mlp_head1_kernel(PaseMlpHead1 p, int ti
                 dpred[r] = dp;
                 lt += ok ? l : 0.f;
                 dt += dp;
-                if (p.pred && ok && l31 == 0) (p.pred + ob)[hq + (unsigned)mh_row(r, 0)] = pred;
+                part[r] = pred;
+            }
+            if (p.pred && l31 == 0) {       // (inference-style callers only: the training step does not ask for it)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (p0w + mh_row(r, half) < nv) (p.pred + ob)[hq + (unsigned)mh_row(r, 0)] = part[r];
             }
             if (l31 == 0) {
                 lsum += (double)lt;
@@ -252,11 +313,12 @@ __global__ void __launch_bounds__(MH_NT) mlp_head1_kernel(PaseMlpHead1 p, int ti
                 const float da1 = w2v[t] * dpred[r];
                 const float dy1 = y1 > 0.f ? da1 : da1 * a1v[t];
                 st_dw2[t] = fmaf(dpred[r], a1, st_dw2[t]);
-                st_da1[t] += y1 > 0.f ? 0.f : da1 * y1;
+                st_da1[t] = fmaf(da1, fminf(y1, 0.f), st_da1[t]);
                 st_db1[t] += dy1;
                 Ds[ds_st + mh_row(r, 0) * MH_PD + 32 * t] = dy1;
             }
         pase_wave_sync();                 // (the rows this wave reads next are the rows it has just written)
+        MH_STAMP(2);
 
         // ---- 2. dA0^T = dY1^T W1 for the same 32 time steps: rows = steps, columns = channels 32 c + l31 -----------------
         f32x16 acc2[4];
@@ -283,7 +345,7 @@ __global__ void __launch_bounds__(MH_NT) mlp_head1_kernel(PaseMlpHead1 p, int ti
 #pragma unroll
                 for (int u = 0; u < MH_UB; ++u)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) acc2[c] = pase_mfma_32x32x2(ac[u], bc[u][c], acc2[c]);
+                    for (int c = 0; c < 4; ++c) acc2[c] = MH_MFMA2(ac[u], bc[u][c], acc2[c]);
                 if (blk + 1 < MH_H / 2 / MH_UB) {
 #pragma unroll
                     for (int u = 0; u < MH_UB; ++u) {
@@ -294,6 +356,8 @@ __global__ void __launch_bounds__(MH_NT) mlp_head1_kernel(PaseMlpHead1 p, int ti
                 }
             }
         }
+        MH_STAMP(3);
+        const bool fast_store = vec4 && nv == MH_P;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int ch = 32 * c + l31;
@@ -310,10 +374,13 @@ __global__ void __launch_bounds__(MH_NT) mlp_head1_kernel(PaseMlpHead1 p, int ti
                     const float dA = acc2[c][4 * g + e];                      // (steps past the end: dpred = 0 -> dA = 0)
                     o[e] = yv > 0.f ? dA : dA * a0v[c];
                     st_dy0[c] += o[e];
-                    st_da0[c] += yv > 0.f ? 0.f : dA * yv;
+                    st_da0[c] = fmaf(dA, fminf(yv, 0.f), st_da0[c]);     // dA * y where y <= 0 (one use of the comparison: no mask to keep)
                 }
                 float* dst = dyb + (lo + 8u * (unsigned)g);
-                if (vec4 && p0w + q + 3 < nv) {
+#ifdef MH_ABL_NOSTORE
+                if (o[0] == 12345.678f)
+#endif
+                if (fast_store) {       // (uniform: whole tile, aligned rows -- no per-store range test, no scalar twin of the store)
                     f32x4 v4;
                     v4[0] = o[0]; v4[1] = o[1]; v4[2] = o[2]; v4[3] = o[3];
                     *reinterpret_cast<f32x4*>(dst) = v4;
@@ -323,8 +390,12 @@ __global__ void __launch_bounds__(MH_NT) mlp_head1_kernel(PaseMlpHead1 p, int ti
                         if (p0w + q + e < nv) dst[e] = o[e];
                 }
             }
+            PASE_SCHED_BARRIER();       // (one channel block at a time: hoisted together, the 64 comparisons' lane masks were
+                                        //  parked in spilled SGPRs -- 380 v_writelane / v_readlane with their hazard nops)
         }
+        MH_STAMP(4);
         __syncthreads();                                               // every wave's dy1 is in Ds
+        MH_STAMP(5);
 
         // ---- 3. dW1^T += A0 dY1^T over the tile's 128 time steps; this wave's 32 channels ----------------------------
         {
@@ -348,7 +419,7 @@ __global__ void __launch_bounds__(MH_NT) mlp_head1_kernel(PaseMlpHead1 p, int ti
                     const float neg = yc[u] * a0_mine;
                     const float a = yc[u] > 0.f ? yc[u] : neg;
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) acc3[t] = pase_mfma_32x32x2(a, bc[u][t], acc3[t]);
+                    for (int t = 0; t < 2; ++t) acc3[t] = MH_MFMA3(a, bc[u][t], acc3[t]);
                 }
                 if (blk + 1 < MH_P / 2 / MH_UB) {
 #pragma unroll
@@ -360,9 +431,12 @@ __global__ void __launch_bounds__(MH_NT) mlp_head1_kernel(PaseMlpHead1 p, int ti
                 }
             }
         }
+        MH_STAMP(6);
         __syncthreads();                                               // the next tile overwrites Ys / Ds
+        MH_STAMP(7);
     }
 
+    MH_TRACE_END();
     const int l31 = l31_k, half = half_k;
     // ---- flush: dW1 (+=), the per-row sums (doubles, += : PaseActBwd::sums / pase_head1_bwd layouts), loss --------------
 #pragma unroll
@@ -402,6 +476,13 @@ __global__ void __launch_bounds__(MH_NT) mlp_head1_kernel(PaseMlpHead1 p, int ti
 
 }  // namespace
 
+#ifdef MH_TRACE
+extern "C" int pase_mlp_head1_trace_read(unsigned long long* host) {
+    hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_mh_trace), sizeof(unsigned long long) * 32);
+}
+#endif
+
 extern "C" int pase_mlp_head1_supported(const PaseMlpHead1* d) {
     return (d->C == MH_C && d->H == MH_H && d->S > 0 && d->T > 0) ? 1 : 0;
 }
@@ -417,7 +498,13 @@ extern "C" int pase_mlp_head1_step(const PaseMlpHead1* d, void* stream) {
     const long ntiles = (long)p.S * tps;
     long nwg = p.max_wg > 0 ? p.max_wg : 256;
     if (nwg > ntiles) nwg = ntiles;
-    PASE_LAUNCH(mlp_head1_kernel, dim3((unsigned)nwg), dim3(MH_NT), (hipStream_t)stream, p, tps, ntiles);
+    switch (p.loss_type) {
+        case PASE_LOSS_NONE: PASE_LAUNCH(mlp_head1_kernel<PASE_LOSS_NONE>, dim3((unsigned)nwg), dim3(MH_NT), (hipStream_t)stream, p, tps, ntiles); break;
+        case PASE_LOSS_L1: PASE_LAUNCH(mlp_head1_kernel<PASE_LOSS_L1>, dim3((unsigned)nwg), dim3(MH_NT), (hipStream_t)stream, p, tps, ntiles); break;
+        case PASE_LOSS_MSE: PASE_LAUNCH(mlp_head1_kernel<PASE_LOSS_MSE>, dim3((unsigned)nwg), dim3(MH_NT), (hipStream_t)stream, p, tps, ntiles); break;
+        case PASE_LOSS_BCE_LOGITS: PASE_LAUNCH(mlp_head1_kernel<PASE_LOSS_BCE_LOGITS>, dim3((unsigned)nwg), dim3(MH_NT), (hipStream_t)stream, p, tps, ntiles); break;
+        default: return -2;
+    }
     PASE_CHECK_LAUNCH();
     return 0;
 }

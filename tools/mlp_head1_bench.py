@@ -61,6 +61,21 @@ def six():
     E.act_backward(y, C=C, T=T, S=S, has_bn=False, alpha=a0, dsrc=din, dsrc_ctot=C, Tp=T)
 
 
+if len(sys.argv) > 1 and sys.argv[1] == "trace":        # -DMH_TRACE build (tools/mlp_head1_ablate.sh): phase clocks of one launch
+    import ctypes
+    from pase_amd import _lib
+    fused()
+    buf = (ctypes.c_ulonglong * 32)()
+    _lib.lib().pase_mlp_head1_trace_read(buf)
+    names = ["copy+wait+barrier", "stage 1", "head", "stage 2 mfma", "epilogue 2", "barrier 2", "stage 3", "end barrier", "tile setup, targets"]
+    order = [8, 0, 1, 2, 3, 4, 5, 6, 7]
+    for wg, off in ((0, 0), (131, 16)):
+        tot = sum(buf[off + i] for i in range(9))
+        print("workgroup %3d: %d clocks over its tiles | " % (wg, tot) + "  ".join("%s %.1f%%" % (names[i], 100.0 * buf[off + i] / max(1, tot)) for i in order))
+    sys.exit(0)
 t_f = timed(fused)
+if len(sys.argv) > 1 and sys.argv[1] == "fused":        # tools/mlp_head1_ablate.sh
+    print("fused %.3f ms" % t_f)
+    sys.exit(0)
 t_6 = timed(six)
 print("fused %.3f ms | six launches %.3f ms" % (t_f, t_6))
