@@ -23,6 +23,8 @@
 //   3. dW1^T (128 x 64) += A0 (128 x P) dY1^T (P x 64)  contraction over the tile's 128 time steps behind one barrier, wave w
 //      owning channels 32 w .. 32 w + 31; accumulated across the workgroup's tiles, one atomic flush.
 // 384 MFMAs per wave and tile; HBM traffic = one read of y, one write of dy.
+#include <type_traits>
+
 #include "hip_compat.h"
 #include "pase_amd.h"
 
@@ -132,12 +134,13 @@ __global__ void __launch_bounds__(MH_NT) mlp_head1_kernel(PaseMlpHead1 p, int ti
     float st_dw2[2] = {0.f, 0.f}, st_da1[2] = {0.f, 0.f}, st_db1[2] = {0.f, 0.f};      // hidden row 32 t + l31, this half's steps
     float st_dy0[4] = {0.f, 0.f, 0.f, 0.f}, st_da0[4] = {0.f, 0.f, 0.f, 0.f};           // channel 32 c + l31
     double lsum = 0.0, s_db2 = 0.0;
+    float pf0 = 0.f, pf1 = 0.f;       // L2 prefetch of the next tile (stage 3)
 
     MH_TRACE_BEGIN();
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         MH_STAMP(8);
-        const int s = (int)(tile / tiles_per_seq);
-        const int t0 = (int)(tile - (long)s * tiles_per_seq) * MH_P;
+        const int s = (int)((unsigned)tile / (unsigned)tiles_per_seq);        // (32-bit: the 64-bit scalar division is a ~130-
+        const int t0 = ((int)tile - s * tiles_per_seq) * MH_P;                //  instruction routine, once more for the prefetch)
         const int nv = min(MH_P, p.T - t0);                                   // live time steps of the tile
         // LDS indices = a per-lane base + a compile-time constant (the pitches are odd: left to the compiler, "(row) * 129 +
         // col" with the row depending on the half or the wave became ~40 hoisted address registers, most of them spilled).
@@ -190,6 +193,9 @@ __global__ void __launch_bounds__(MH_NT) mlp_head1_kernel(PaseMlpHead1 p, int ti
                     mh_load_lds4(yb + (size_t)rr * p.T + 64 + lane, &Ys[(32 * wave + rr) * MH_PY + 64], lane);
                 }
                 mh_dma_wait();
+#ifndef PASE_HIPEMU
+                asm volatile("" ::"v"(pf0), "v"(pf1));      // (the prefetch loads' destination registers stay theirs until here)
+#endif
             } else {
                 for (int rr = 0; rr < 32; ++rr)
                     for (int q = lane; q < MH_P; q += 64) Ys[(32 * wave + rr) * MH_PY + q] = q < nv ? yb[(size_t)rr * p.T + q] : 0.f;
@@ -357,47 +363,73 @@ __global__ void __launch_bounds__(MH_NT) mlp_head1_kernel(PaseMlpHead1 p, int ti
             }
         }
         MH_STAMP(3);
-        const bool fast_store = vec4 && nv == MH_P;
+        // whole-tile form (uniform: every step live, rows 16-byte aligned) without range tests or a scalar twin of the store; a
+        // channel block's 16 y values are read together in front of its arithmetic (read per register quad they were one LDS
+        // latency per quad: the stamps had this epilogue at 13 % of a tile)
+        auto epilogue2 = [&](auto fast_tag) __attribute__((always_inline)) {
+            constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int ch = 32 * c + l31;
-            float* dyb = p.dy + ((size_t)s * MH_C + 32 * c) * (size_t)p.T + t0 + p0w;      // (uniform)
-            const unsigned lo = (unsigned)l31 * (unsigned)p.T + hq;                     // this lane's row, this half's steps
-            const float* yrow = &Ys[ys_ch + 32 * c * MH_PY];
+            for (int c = 0; c < 4; ++c) {
+                float* dyb = p.dy + ((size_t)s * MH_C + 32 * c) * (size_t)p.T + t0 + p0w;      // (uniform)
+                const unsigned lo = (unsigned)l31 * (unsigned)p.T + hq;                     // this lane's row, this half's steps
+                const float* yrow = &Ys[ys_ch + 32 * c * MH_PY];
+                float yq[16];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int q = 8 * g + 4 * half;                               // registers 4 g .. 4 g + 3 = steps q .. q + 3
-                float o[4];
+                for (int r = 0; r < 16; ++r) yq[r] = yrow[8 * (r >> 2) + (r & 3)];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float yv = yrow[8 * g + e];
-                    const float dA = acc2[c][4 * g + e];                      // (steps past the end: dpred = 0 -> dA = 0)
-                    o[e] = yv > 0.f ? dA : dA * a0v[c];
-                    st_dy0[c] += o[e];
-                    st_da0[c] = fmaf(dA, fminf(yv, 0.f), st_da0[c]);     // dA * y where y <= 0 (one use of the comparison: no mask to keep)
-                }
-                float* dst = dyb + (lo + 8u * (unsigned)g);
+                for (int g = 0; g < 4; ++g) {
+                    const int q = 8 * g + 4 * half;                           // registers 4 g .. 4 g + 3 = steps q .. q + 3
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float yv = yq[4 * g + e];
+                        const float dA = acc2[c][4 * g + e];                  // (steps past the end: dpred = 0 -> dA = 0)
+                        o[e] = yv > 0.f ? dA : dA * a0v[c];
+                        st_dy0[c] += o[e];
+                        st_da0[c] = fmaf(dA, fminf(yv, 0.f), st_da0[c]);      // dA * y where y <= 0 (one use of the comparison)
+                    }
+                    float* dst = dyb + (lo + 8u * (unsigned)g);
 #ifdef MH_ABL_NOSTORE
-                if (o[0] == 12345.678f)
+                    if (o[0] == 12345.678f)
 #endif
-                if (fast_store) {       // (uniform: whole tile, aligned rows -- no per-store range test, no scalar twin of the store)
-                    f32x4 v4;
-                    v4[0] = o[0]; v4[1] = o[1]; v4[2] = o[2]; v4[3] = o[3];
-                    *reinterpret_cast<f32x4*>(dst) = v4;
-                } else {
+                    if constexpr (FAST) {
+                        f32x4 v4;
+                        v4[0] = o[0]; v4[1] = o[1]; v4[2] = o[2]; v4[3] = o[3];
+                        *reinterpret_cast<f32x4*>(dst) = v4;
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (p0w + q + e < nv) dst[e] = o[e];
+                        for (int e = 0; e < 4; ++e)
+                            if (p0w + q + e < nv) dst[e] = o[e];
+                    }
                 }
-            }
-            PASE_SCHED_BARRIER();       // (one channel block at a time: hoisted together, the 64 comparisons' lane masks were
+                PASE_SCHED_BARRIER();   // (one channel block at a time: hoisted together, the 64 comparisons' lane masks were
                                         //  parked in spilled SGPRs -- 380 v_writelane / v_readlane with their hazard nops)
-        }
+            }
+        };
+        if (vec4 && nv == MH_P) epilogue2(std::true_type{});
+        else epilogue2(std::false_type{});
         MH_STAMP(4);
         __syncthreads();                                               // every wave's dy1 is in Ds
         MH_STAMP(5);
 
         // ---- 3. dW1^T += A0 dY1^T over the tile's 128 time steps; this wave's 32 channels ----------------------------
+        // The next tile's copy cannot start before this stage has read Ys (single-buffered) and was 13-16 % of a tile, exposed:
+        // one dword of every 128-byte line of this wave's rows of the NEXT tile is requested here, so that the copy at the top
+        // of the next tile finds its lines in L2.  (Plain loads the compiler can see; their values are only "used" by the empty
+        // asm behind the next tile's wait.)
+#ifndef MH_ABL_NOPF
+        if (tile + gridDim.x < ntiles) {
+            const long nt = tile + gridDim.x;
+            const int s2 = (int)((unsigned)nt / (unsigned)tiles_per_seq);
+            const int t2 = ((int)nt - s2 * tiles_per_seq) * MH_P;
+            const float* yb2 = p.y + ((size_t)s2 * MH_C + 32 * wave) * (size_t)p.T + t2;      // (uniform)
+            const unsigned col = 32u * ((unsigned)lane & 3u);
+            if ((int)col < p.T - t2) {
+                pf0 = yb2[((unsigned)lane >> 2) * (unsigned)p.T + col];
+                pf1 = yb2[(16u + ((unsigned)lane >> 2)) * (unsigned)p.T + col];
+            }
+        }
+#endif
         {
             float yc[MH_UB], bc[MH_UB][2];
             auto ld = [&](int blk, float (&yy)[MH_UB], float (&bb)[MH_UB][2]) __attribute__((always_inline)) {
@@ -492,6 +524,7 @@ extern "C" int pase_mlp_head1_step(const PaseMlpHead1* d, void* stream) {
     if (p.S <= 0 || p.T <= 0) return 0;
     if (!pase_mlp_head1_supported(d)) return -11;
     if ((long)p.C * p.T >= (1L << 29)) return -8;            // 32-bit byte offsets inside one sequence
+    if ((long)p.S * ((p.T + MH_P - 1) / MH_P) >= 0x7fffffffL) return -8;      // 32-bit tile index
     if (!p.y || !p.w1 || !p.w2 || !p.dy || !p.dw1 || !p.sums0 || !p.sums1) return -2;
     if (p.loss_type != PASE_LOSS_NONE && (!p.target || !p.loss_acc)) return -2;
     const int tps = (p.T + MH_P - 1) / MH_P;

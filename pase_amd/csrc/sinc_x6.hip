@@ -18,6 +18,8 @@
 //   tile (128 VGPRs); two workgroups per CU so that one's staging / epilogue runs under the other's MFMAs.
 //   Weight gradient: BOTH operands are staged (g is converted on the fly: each element exactly once, the 64 x 256 tile is the
 //   whole problem), contraction over positions in stages of 64, split over the grid, fp32 atomics into dfilt.
+#include <type_traits>
+
 #include "sinc_x6.h"
 #include "act_bwd.h"
 
@@ -228,7 +230,10 @@ __global__ void sinc_x6_pack_kernel(const float* __restrict__ wt, u32x4* __restr
 //   g image at the top of the next stage.  The pooled dense-skip gradient (one or two frames per run of 16 positions) is
 //   prefetched into two registers; the reflect-padding fold touches the first and last stage of a sequence only and is
 //   read there directly.
-template <bool AB>
+//   HB: ab.has_bn as a compile-time constant (the element function's norm switch sat inside the unrolled conversion: with the
+//   per-element range tests, 127 exec-mask regions per stage); whole stages (64 live rows, 64 live positions) take a path
+//   without range tests.
+template <bool AB, int HB>
 __global__ void __launch_bounds__(SX_NT, 2) sinc_x6_wgrad_kernel(PaseWgrad p, PaseSincPlan pl, PaseActBwd ab) {
     // one LDS image per stage: g [plane][position octet c (8)][row (64)] and the window image of x [plane][320]
     __shared__ __attribute__((aligned(16))) u32x4 Ws[3 * SW_ACH + 3 * SW_NW];
@@ -343,6 +348,9 @@ __global__ void __launch_bounds__(SX_NT, 2) sinc_x6_wgrad_kernel(PaseWgrad p, Pa
                 }
             }
         }
+        const bool whole = AB && p.M == 64 && q0_ld + SW_POS <= p.Ncols;       // (uniform)
+        auto convert_g = [&](auto whole_tag) __attribute__((always_inline)) {
+        constexpr bool WHOLE = decltype(whole_tag)::value;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             float v[8];
@@ -353,13 +361,13 @@ __global__ void __launch_bounds__(SX_NT, 2) sinc_x6_wgrad_kernel(PaseWgrad p, Pa
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int q = q0_ld + 16 * gpart + 8 * h + e;
-                    const bool ok = grow_ok && q < p.Ncols;
+                    const bool ok = WHOLE || (grow_ok && q < p.Ncols);
                     const float yv = e < 4 ? y0[e & 3] : y1[e & 3];
                     // dA in grad_post_act's order: padded data gradient (+ mirrored edges, patched in above), pooled branch
                     float dA = ab.dsrc ? (e < 4 ? d0[e & 3] : d1[e & 3]) : 0.f;
                     if (ab.dpool) dA += (frame_of(q) == f_first ? dp0 : dp1) * ab.pool_inv;
                     // (positions past Ncols / rows past M must come out as zeros, not as -scale * (m1 + xhat m2))
-                    v[e] = ok ? act_bwd_dy(rc, ab.has_bn, yv, dA) : 0.f;
+                    v[e] = ok ? act_bwd_dy(rc, HB, yv, dA) : 0.f;
                 }
             } else {
 #pragma unroll
@@ -373,6 +381,9 @@ __global__ void __launch_bounds__(SX_NT, 2) sinc_x6_wgrad_kernel(PaseWgrad p, Pa
 #pragma unroll
             for (int pz = 0; pz < 3; ++pz) As[pz * SW_ACH + (2 * gpart + h) * 64 + grow] = o[pz];
         }
+        };
+        if (whole) convert_g(std::true_type{});
+        else convert_g(std::false_type{});
         if (2 * tid < SW_NW) {
             u32x4 w0[3], w1[3];
             if constexpr (AB) {
@@ -515,10 +526,14 @@ int pase_sinc_x6_wgrad_launch(const PaseWgrad& w, const PaseSincPlan& pl, hipStr
     if (w.splitk > 0) nwg = w.splitk;
     if (nwg > (total + 7) / 8) nwg = (total + 7) / 8;
     if (nwg < 1) nwg = 1;
-    if (ab) {
-        PASE_LAUNCH(sinc_x6_wgrad_kernel<true>, dim3((unsigned)nwg), dim3(SX_NT), st, w, pl, *ab);
+    if (ab && ab->has_bn == 1) {
+        PASE_LAUNCH((sinc_x6_wgrad_kernel<true, 1>), dim3((unsigned)nwg), dim3(SX_NT), st, w, pl, *ab);
+    } else if (ab && ab->has_bn == 2) {
+        PASE_LAUNCH((sinc_x6_wgrad_kernel<true, 2>), dim3((unsigned)nwg), dim3(SX_NT), st, w, pl, *ab);
+    } else if (ab) {
+        PASE_LAUNCH((sinc_x6_wgrad_kernel<true, 0>), dim3((unsigned)nwg), dim3(SX_NT), st, w, pl, *ab);
     } else {
-        PASE_LAUNCH(sinc_x6_wgrad_kernel<false>, dim3((unsigned)nwg), dim3(SX_NT), st, w, pl, PaseActBwd{});
+        PASE_LAUNCH((sinc_x6_wgrad_kernel<false, 0>), dim3((unsigned)nwg), dim3(SX_NT), st, w, pl, PaseActBwd{});
     }
     PASE_CHECK_LAUNCH();
     return 0;

@@ -3,7 +3,7 @@
 #   bash tools/mlp_head1_ablate.sh build        (CPU container: hipcc cross-compiles)
 #   bash tools/mlp_head1_ablate.sh run          (GPU box)
 cd "$(dirname "$0")/.." || exit 1
-VARS="base: no1:-DMH_ABL_NO1 no2:-DMH_ABL_NO2 no3:-DMH_ABL_NO3 nocopy:-DMH_ABL_NOCOPY nohead:-DMH_ABL_NOHEAD nostore:-DMH_ABL_NOSTORE nomfma:-DMH_ABL_NO1,-DMH_ABL_NO2,-DMH_ABL_NO3 trace:-DMH_TRACE"
+VARS="base: no1:-DMH_ABL_NO1 no2:-DMH_ABL_NO2 no3:-DMH_ABL_NO3 nocopy:-DMH_ABL_NOCOPY nohead:-DMH_ABL_NOHEAD nostore:-DMH_ABL_NOSTORE nopf:-DMH_ABL_NOPF nomfma:-DMH_ABL_NO1,-DMH_ABL_NO2,-DMH_ABL_NO3 trace:-DMH_TRACE"
 if [ "$1" = build ]; then
   mkdir -p tools/_ab/obj_mh
   for f in pase_amd/csrc/*.hip; do
