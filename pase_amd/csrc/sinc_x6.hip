@@ -70,7 +70,10 @@ __global__ void __launch_bounds__(SX_NT, 2) sinc_x6_fwd_kernel(PaseConvGemm p, P
     const int tid = threadIdx.x, lane = tid & 63, wave = pase_uniform(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;
     const int fr = lane & 31, fk = lane >> 5;
-    const int tile = blockIdx.x;
+    // persistent: a workgroup walks tiles blockIdx.x, + gridDim.x, ... (two workgroups per CU; launched one tile per workgroup,
+    // 12 000 workgroups of ~18 us, a third of the kernel's time was between workgroups -- in-kernel stamps against its duration)
+    const int ntiles = p.S * pl.tiles_per_seq;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int s = tile / pl.tiles_per_seq;
     const int q0 = (tile - s * pl.tiles_per_seq) * SX_BN;
     const float* xrow = p.x + ((size_t)s * p.x_ctot + p.x_coff) * (size_t)p.Tin;
@@ -150,39 +153,52 @@ __global__ void __launch_bounds__(SX_NT, 2) sinc_x6_fwd_kernel(PaseConvGemm p, P
 
     // ---- epilogue: store, BatchNorm partial sums per (tile, row) ------------------------------------------------------
     // D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    // Round 5 (in-kernel stamps: this epilogue was 58 % of a workgroup's time, 27-31 k clocks against 16-21 k for the 384-MFMA
+    // loop): the bias load sat inside the row loop behind a branch, so every use of its register -- one per store, each in a
+    // block of its own behind the range tests -- carried s_waitcnt vmcnt(0), which, the counter being in order, also waited for
+    // the previous STORE: 64 stores, one completion latency each (whether or not the layer has a bias).  Now the 16 bias
+    // values are loaded in front of the first store, whole tiles take a path without range tests (one basic block), and an
+    // address is a wave-uniform base plus one 32-bit lane offset.
     const int rbase = wm * 32 + 4 * fk;
-    int qcol[4];
-    bool cok[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        qcol[j] = q0 + wn * 128 + j * 32 + fr;
-        cok[j] = qcol[j] < p.Ncols;
-    }
+    float bvs[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = rbase + (r & 3) + 8 * (r >> 2);
-        const bool mok = m < p.M;
-        const float bv = (p.bias && mok) ? p.bias[m] : 0.f;
-        float* yrow = p.y + ((size_t)s * p.y_ctot + p.y_coff + (mok ? m : 0)) * (size_t)p.Tout;
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float v = accH[j][r] + accS[j][r] + bv;
-            if (mok && cok[j]) {
-                yrow[qcol[j]] = v;
-                s1 += v;
-                s2 += v * v;
-            }
-        }
-        if (p.stat_part) {      // uniform
-            s1 = pase_half_sum_lane31(s1);
-            s2 = pase_half_sum_lane31(s2);
-            if (fr == 31) {
-                red[wn][m][0] = s1;
-                red[wn][m][1] = s2;
-            }
-        }
+        bvs[r] = (p.bias && m < p.M) ? p.bias[m] : 0.f;
     }
+    float* ybase = p.y + ((size_t)s * p.y_ctot + p.y_coff + wm * 32) * (size_t)p.Tout + q0 + wn * 128;      // (uniform)
+    const unsigned lane_off = (unsigned)(4 * fk) * (unsigned)p.Tout + (unsigned)fr;
+    const bool whole = p.M == 64 && q0 + SX_BN <= p.Ncols;                                                  // (uniform)
+    auto store_rows = [&](auto whole_tag) __attribute__((always_inline)) {
+        constexpr bool WHOLE = decltype(whole_tag)::value;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mr = (r & 3) + 8 * (r >> 2);                           // row inside the wave's 32 (plus 4 fk: lane_off)
+            const int m = rbase + mr;
+            const bool mok = WHOLE || m < p.M;
+            float* yrow = ybase + (size_t)mr * p.Tout;                       // (uniform)
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = accH[j][r] + accS[j][r] + bvs[r];
+                if (WHOLE || (mok && q0 + wn * 128 + j * 32 + fr < p.Ncols)) {
+                    yrow[lane_off + 32u * (unsigned)j] = v;
+                    s1 += v;
+                    s2 += v * v;
+                }
+            }
+            if (p.stat_part) {      // uniform
+                s1 = pase_half_sum_lane31(s1);
+                s2 = pase_half_sum_lane31(s2);
+                if (fr == 31) {
+                    red[wn][m][0] = s1;
+                    red[wn][m][1] = s2;
+                }
+            }
+        }
+    };
+    if (whole) store_rows(std::true_type{});
+    else store_rows(std::false_type{});
     if (p.stat_part) {
         __syncthreads();
         if (tid < 64 && tid < p.M) {
@@ -191,6 +207,8 @@ __global__ void __launch_bounds__(SX_NT, 2) sinc_x6_fwd_kernel(PaseConvGemm p, P
             dst[1] = red[0][tid][1] + red[1][tid][1];
         }
     }
+    __syncthreads();      // the next tile's window image / partial sums overwrite this one's
+  }
 }
 
 // filt (K-major fp32 pack wt[kk * ldwt + m]) -> fragment-ordered bf16 planes [32-row tile (2)][k-group][plane][lane]:
@@ -474,6 +492,7 @@ bool pase_sinc_x6_plan(const PaseConvGemm& p, PaseSincPlan& pl) {
     if (p.in_scale || p.in_alpha) return false;
     if (p.pad_mode == PASE_PAD_REFLECT && p.padL >= p.Tin) return false;
     if (p.Cout_store != p.M) return false;
+    if (p.Tout >= (1 << 28)) return false;                  // the epilogue's 32-bit lane offsets (4 rows of the output)
     pl.n_kg = (p.taps + 15) / 16;
     pl.nwin = SX_BN + 16 * pl.n_kg - 8;
     pl.tiles_per_seq = (p.Ncols + SX_BN - 1) / SX_BN;
@@ -491,7 +510,10 @@ int pase_sinc_x6_pack(const PaseConvGemm& p, const PaseSincPlan& pl, hipStream_t
 }
 
 int pase_sinc_x6_launch(const PaseConvGemm& p, const PaseSincPlan& pl, hipStream_t st) {
-    PASE_LAUNCH(sinc_x6_fwd_kernel, dim3((unsigned)(p.S * pl.tiles_per_seq)), dim3(SX_NT), st, p, pl);
+    const long ntiles = (long)p.S * pl.tiles_per_seq;
+    long nwg = p.max_wg > 0 ? 2L * p.max_wg : 512;          // two workgroups per CU
+    if (nwg > ntiles) nwg = ntiles;
+    PASE_LAUNCH(sinc_x6_fwd_kernel, dim3((unsigned)nwg), dim3(SX_NT), st, p, pl);
     PASE_CHECK_LAUNCH();
     return 0;
 }
