@@ -238,8 +238,13 @@ int pase_act_bwd_apply(const PaseActBwd* desc, void* stream);
  * gradient (autograd of F.conv1d w.r.t. the filters only, pase/models/modules.py:932) -- so its apply pass (read y, read dA,
  * write dy) and the weight gradient's read of dy become one read of y and dA.  Only the one-input-channel plan
  * (pase_wgrad_plan_kind 5) has this form: -11 when desc would run on another kernel (x6 bit 0 and gx6 are required),
- * -13 when g_bwd does not describe desc's gradient operand (shape mismatch, g_alpha / dbias set, norms 3 / 4). */
+ * -13 when g_bwd does not describe desc's gradient operand or the kernel cannot evaluate it while staging: shape mismatch,
+ * y NULL, g_alpha / dbias set, norms 3 / 4 (has_bn outside 0..2), has_bn 1 without sums, a pooled branch with pool_d < 16
+ * (a staged run of 16 positions may touch at most two pooled frames), a padded data gradient with Tp < T + padL.
+ * pase_wgrad_gemm_act_bwd_ok answers the same question without enqueueing anything (1 = the launch would be accepted,
+ * 0 = -11 / -13): callers test it and otherwise materialise dy with pase_act_bwd_apply and run the plain pase_wgrad_gemm. */
 int pase_wgrad_gemm_act_bwd(const PaseWgrad* desc, const PaseActBwd* g_bwd, void* stream);
+int pase_wgrad_gemm_act_bwd_ok(const PaseWgrad* desc, const PaseActBwd* g_bwd);
 
 /* Per-sample normalisations of the other norm_type values (pase/models/modules.py:77-109): nn.InstanceNorm1d
  * ('inorm', 'affinorm', and WaveFe.norm_out when norm_type != 'bnorm', frontend.py:206-210; mode 0: statistics per

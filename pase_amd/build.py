@@ -212,7 +212,12 @@ def check_x6c_staging_isa(asm_text):
 
 
 def build_hip(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).
+
+    Order matters: the shipped library is linked and stamped only AFTER the resource check and the staging-load ISA lint of
+    conv_x6c.hip have passed -- a build that fails either leaves no stamped .so behind for _lib._check_fresh() to accept.  The
+    lint runs on EVERY build (PASE_BUILD_NO_AUTOWAIT=1 only skips the second, compiler-waited compile that the bit-for-bit
+    GPU test needs)."""
     import json
     srcs = _sources()
     flags = _hip_flags()
@@ -223,56 +228,80 @@ def build_hip(force=False, verbose=False):
     if not force and _up_to_date(HIP_SO, digest) and (not want_aw or _up_to_date(AUTOWAIT_SO, digest)):
         return HIP_SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
-    procs = []
+    need_main = force or not _up_to_date(HIP_SO, digest)
+    objs = [s[:-4] + ".o" for s in srcs]
     cflags = [f for f in flags if f != "-shared"]
-    for s in srcs:
-        o = s[:-4] + ".o"
-        objs.append(o)
-        extra = ["-Rpass-analysis=kernel-resource-usage"] if s.endswith("conv_x6c.hip") else []
-        procs.append(subprocess.Popen([hipcc, "-c", s, "-o", o] + cflags + extra,
-                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    # (in parallel: conv_x6c.hip once more with the compiler's own waits, for the bit-for-bit GPU test)
     x6c = os.path.join(CSRC, "conv_x6c.hip")
     aw_obj = os.path.join(CSRC, "conv_x6c.autowait.o")
-    aw = subprocess.Popen([hipcc, "-c", x6c, "-o", aw_obj, "-DPASE_X6C_AUTOWAIT"] + cflags,
-                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) if want_aw else None
-    # (in parallel as well: the device assembly of conv_x6c.hip for the staging-load lint; skipped with the autowait build)
     lint_s = os.path.join(CSRC, "conv_x6c.lint.s")
-    lint = subprocess.Popen([hipcc, "-S", "--cuda-device-only", x6c, "-o", lint_s] + [f for f in cflags if f != "-fPIC"],
-                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) if want_aw else None
-    for pr, s in zip(procs, srcs):
+    running = []
+
+    def spawn(cmd):
+        pr = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        running.append(pr)
+        return pr
+
+    def reap(pr, what):
         out, _ = pr.communicate()
+        running.remove(pr)
         if pr.returncode != 0:
             sys.stderr.write(out)
-            raise RuntimeError("hipcc failed on " + s)
-        if s.endswith("conv_x6c.hip"):
-            res = _kernel_resources(out)
-            check_x6c_resources(res)
-            with open(RESOURCES, "w") as f:
-                json.dump({k: v for k, v in sorted(res.items()) if "conv_x6c_kernel" in k}, f, indent=1)
-        elif verbose and out:
-            print(out)
-    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_SO] + objs)
-    with open(HIP_SO + ".sha256", "w") as f:
-        f.write(digest)
-    if aw is None:
-        return HIP_SO
-    out, _ = lint.communicate()
-    if lint.returncode != 0:
-        sys.stderr.write(out)
-        raise RuntimeError("hipcc -S failed on conv_x6c.hip")
-    with open(lint_s) as f:
-        check_x6c_staging_isa(f.read())
-    os.remove(lint_s)
-    out, _ = aw.communicate()
-    if aw.returncode != 0:
-        sys.stderr.write(out)
-        raise RuntimeError("hipcc failed on conv_x6c.hip (-DPASE_X6C_AUTOWAIT)")
-    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", AUTOWAIT_SO] +
-         [aw_obj if o.endswith("conv_x6c.o") else o for o in objs])
-    with open(AUTOWAIT_SO + ".sha256", "w") as f:
-        f.write(digest)
+            raise RuntimeError("hipcc failed on " + what)
+        return out
+
+    def invalidate(so):
+        for f in (so, so + ".sha256"):
+            if os.path.exists(f):
+                os.remove(f)
+
+    try:
+        procs = []
+        if need_main:
+            invalidate(HIP_SO)            # nothing stale may survive a failed build
+            for s, o in zip(srcs, objs):
+                extra = ["-Rpass-analysis=kernel-resource-usage"] if s == x6c else []
+                procs.append(spawn([hipcc, "-c", s, "-o", o] + cflags + extra))
+        # (in parallel: the device assembly of conv_x6c.hip for the staging-load lint -- every build -- and conv_x6c.hip once
+        #  more with the compiler's own waits, for the bit-for-bit GPU test)
+        lint = spawn([hipcc, "-S", "--cuda-device-only", x6c, "-o", lint_s] + [f for f in cflags if f != "-fPIC"]) \
+            if need_main else None
+        aw = None
+        if want_aw:
+            invalidate(AUTOWAIT_SO)
+            aw = spawn([hipcc, "-c", x6c, "-o", aw_obj, "-DPASE_X6C_AUTOWAIT"] + cflags)
+        for pr, s in zip(procs, srcs):
+            out = reap(pr, s)
+            if s == x6c:
+                res = _kernel_resources(out)
+                check_x6c_resources(res)
+                with open(RESOURCES, "w") as f:
+                    json.dump({k: v for k, v in sorted(res.items()) if "conv_x6c_kernel" in k}, f, indent=1)
+            elif verbose and out:
+                print(out)
+        if lint is not None:
+            reap(lint, "conv_x6c.hip (-S, staging-load lint)")
+            with open(lint_s) as f:
+                check_x6c_staging_isa(f.read())
+            os.remove(lint_s)
+        if need_main:
+            _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_SO] + objs)
+            with open(HIP_SO + ".sha256", "w") as f:
+                f.write(digest)
+        if aw is not None:
+            reap(aw, "conv_x6c.hip (-DPASE_X6C_AUTOWAIT)")
+            missing = [o for o in objs if not os.path.exists(o)]
+            if missing:
+                raise RuntimeError("build: object files of the shipped library are missing (%r); rebuild with --force" % missing[:3])
+            _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", AUTOWAIT_SO] +
+                 [aw_obj if o.endswith("conv_x6c.o") else o for o in objs])
+            with open(AUTOWAIT_SO + ".sha256", "w") as f:
+                f.write(digest)
+    except BaseException:
+        # a failed check must not leave compilers running behind the raised error (nor a half-written library)
+        for pr in list(running):
+            pr.kill()
+            pr.communicate()
+        raise
     return HIP_SO
 
 

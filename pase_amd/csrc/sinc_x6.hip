@@ -409,9 +409,13 @@ __global__ void __launch_bounds__(SX_NT, 2) sinc_x6_wgrad_kernel(PaseWgrad p, Pa
                 const int u0 = q0_ld - p.padL + 2 * tid;
 #pragma unroll
                 for (int e = 0; e < 9; ++e) {
-                    const int u = u0 + e;
-                    // (zero padding: samples outside the sequence were not copied; reflect padding has none outside)
-                    xw[e] = (p.pad_mode == PASE_PAD_REFLECT || (u >= 0 && u < p.Tz)) ? Xr[2 * tid + e] : 0.f;
+                    int u = u0 + e;
+                    // samples outside the sequence were not copied (zero padding; with reflect padding the ones a single
+                    // reflection does not bring back inside: sequences shorter than the window image).  Their LDS words are
+                    // whatever the previous stage left -- possibly NaN / Inf patterns -- and 0 * NaN would reach dfilt through
+                    // dead positions: select 0 exactly as the plain path does
+                    if (p.pad_mode == PASE_PAD_REFLECT) u = sx_reflect(u, p.Tz);
+                    xw[e] = (u >= 0 && u < p.Tz) ? Xr[2 * tid + e] : 0.f;
                 }
                 pase_split_two_windows(xw, w0, w1);
             } else {

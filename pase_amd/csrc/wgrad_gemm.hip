@@ -667,13 +667,26 @@ extern "C" int pase_wgrad_plan_kind(const PaseWgrad* d) {
     return pase_x6c_wgrad_plan(*d, o) ? (o.pl.zp ? 4 : o.pl.tmode) : 0;
 }
 
+// 0 = accepted; the refusal code otherwise (shared by the launch and the query so that the two cannot disagree)
+static int wgrad_act_bwd_refusal(const PaseWgrad& p, const PaseActBwd* g_bwd, PaseSincPlan& sp) {
+    if (p.pad_mode == PASE_PAD_REFLECT && p.padL >= p.Tz) return -3;
+    if (!(p.x6 & 1) || !p.gx6 || (p.x6 & 1024) || !pase_sinc_x6_wgrad_plan(p, sp)) return -11;      // only the one-channel plan
+    if (!g_bwd || !pase_sinc_x6_wgrad_act_bwd_ok(p, *g_bwd)) return -13;
+    return 0;
+}
+
+extern "C" int pase_wgrad_gemm_act_bwd_ok(const PaseWgrad* d, const PaseActBwd* g_bwd) {
+    if (!d || d->M <= 0 || d->Cin <= 0 || d->S <= 0 || d->Ncols <= 0) return 0;
+    PaseSincPlan sp;
+    return wgrad_act_bwd_refusal(*d, g_bwd, sp) == 0 ? 1 : 0;
+}
+
 extern "C" int pase_wgrad_gemm_act_bwd(const PaseWgrad* d, const PaseActBwd* g_bwd, void* stream) {
     PaseWgrad p = *d;
     if (p.M <= 0 || p.Cin <= 0 || p.S <= 0 || p.Ncols <= 0) return 0;
-    if (p.pad_mode == PASE_PAD_REFLECT && p.padL >= p.Tz) return -3;
     PaseSincPlan sp;
-    if (!(p.x6 & 1) || !p.gx6 || (p.x6 & 1024) || !pase_sinc_x6_wgrad_plan(p, sp)) return -11;      // only the one-channel plan
-    if (!g_bwd || !pase_sinc_x6_wgrad_act_bwd_ok(p, *g_bwd)) return -13;
+    const int rc = wgrad_act_bwd_refusal(p, g_bwd, sp);
+    if (rc) return rc;
     return pase_sinc_x6_wgrad_launch(p, sp, (hipStream_t)stream, g_bwd);
 }
 

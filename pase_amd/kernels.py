@@ -362,6 +362,7 @@ _SIMPLE.update({
     "pase_mlp_head1_step": [C.POINTER(PaseMlpHead1), _fp],
     "pase_wgrad_gemm": [C.POINTER(PaseWgrad), _fp],
     "pase_wgrad_gemm_act_bwd": [C.POINTER(PaseWgrad), C.POINTER(PaseActBwd), _fp],
+    "pase_wgrad_gemm_act_bwd_ok": [C.POINTER(PaseWgrad), C.POINTER(PaseActBwd)],
     "pase_bn_finalize": [_fp, _i, _i, _d, _fp, _fp, _f, _f, _fp, _fp, _fp, _fp, _fp, _fp, _fp],
     "pase_bn_act_pool": [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _fp],
     "pase_bn_act_apply": [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _fp],
@@ -454,12 +455,16 @@ def wgrad_gemm(g, z, dw, *, S, M, Tg, Ncols, Cin, Tz, taps, ldw=None, dbias=None
             d.gx6 = gx6.data_ptr()
             LAST_WGRAD_X6 = True
             LAST_WGRAD_KIND = _lib.lib().pase_wgrad_plan_kind(C.byref(d))
-    if g_bwd is not None and LAST_WGRAD_KIND != 5:
-        return False
-    ev0 = GEMM_TIMER.start() if GEMM_TIMER is not None else None
+    ab = None
     if g_bwd is not None:
+        # the library's own answer (plan kind AND what the on-load kernel can evaluate while staging, e.g. a dense-skip pooled
+        # branch needs pool_d >= 16): anything it would refuse is the caller's to materialise -- nothing is enqueued
         kw = dict(g_bwd)
         ab = _act_bwd_desc(kw.pop("y"), **kw)
+        if LAST_WGRAD_KIND != 5 or not _lib.lib().pase_wgrad_gemm_act_bwd_ok(C.byref(d), C.byref(ab)):
+            return False
+    ev0 = GEMM_TIMER.start() if GEMM_TIMER is not None else None
+    if g_bwd is not None:
         _check(_lib.lib().pase_wgrad_gemm_act_bwd(C.byref(d), C.byref(ab), _stream()), "pase_wgrad_gemm_act_bwd")
     else:
         _check(_lib.lib().pase_wgrad_gemm(C.byref(d), _stream()), "pase_wgrad_gemm")

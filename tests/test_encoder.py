@@ -46,6 +46,45 @@ def test_mini_train_forward_backward(dev, cfg):
     assert int(sd["blocks.1.norm.num_batches_tracked"]) == 1
 
 
+def test_dense_skips_with_a_small_downstream_stride_product(dev):
+    """the SincNet layer's deferred dy (weight gradient evaluating the BatchNorm + PReLU backward on load) exists
+    only for pooled dense-skip branches with pool_d >= 16.  A frontend whose downstream stride product is below 16 -- here
+    strides [1, 2, 2, 2]: block 0 pools by 8 -- on the one-channel split-bf16 plan (>= 32 taps) must fall back to the
+    materialised dy instead of failing with -13, and still match the oracle."""
+    from pase_amd import kernels as K
+    cfg = dict(kwidths=[33, 11, 11, 11], strides=[1, 2, 2, 2], fmaps=[4, 4, 6, 6], emb_dim=12, rnn_dim=10, denseskips=True,
+               norm_out=True, rnn_pool=True, rnn_layers=1)
+    fe = _build(cfg, dev)
+    P = oracle_params(fe)
+    x = torch.randn(3, 1, 320) * 0.3
+    fe.train()
+    seen = []
+    real = K.wgrad_gemm
+
+    def spy(*a, **kw):
+        r = real(*a, **kw)
+        if kw.get("g_bwd") is not None:
+            seen.append((r, K.LAST_WGRAD_KIND, kw["g_bwd"].get("pool_d")))
+        return r
+    K.wgrad_gemm = spy
+    try:
+        y = fe(x.to(dev))
+        yo = O.encoder_forward(P, cfg, x, True, {})
+        assert_close(y, yo, rtol=1e-4, atol=1e-4, what="forward")
+        g = torch.randn_like(yo)
+        (yo * g).sum().backward()
+        (y * g.to(dev)).sum().backward()
+    finally:
+        K.wgrad_gemm = real
+    # the on-load form was asked for on the one-channel plan and refused (pool_d 8), nothing was enqueued by that call
+    assert seen == [(False, 5, 8)], seen
+    for n, p in fe.named_parameters():
+        if is_noise_grad(n):
+            continue
+        ref = P[n].grad
+        assert_close(p.grad, ref, rtol=1e-3, atol=1e-4 * max(1.0, float(ref.abs().max())), what=n)
+
+
 def test_mini_eval_modes_and_dict_input(dev):
     cfg = MINI_FE
     fe = _build(cfg, dev, seed=3)

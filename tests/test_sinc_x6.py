@@ -163,6 +163,69 @@ def test_sinc_weight_gradient_with_the_norm_backward_on_load(dev, M, taps, T, S,
     assert _rel(dw - 0.5, dw2.cpu().double()) < 1e-6
 
 
+def test_on_load_form_on_sequences_shorter_than_the_window_image(dev):
+    """with reflect padding and a sequence shorter than the staged window image (Tz below ~330) some window samples
+    stay outside [0, Tz) after ONE reflection; the on-load form never copies them into its raw-sample LDS buffer and must
+    select 0 there (as the plain form does) instead of reading what the previous stage / launch left behind: those windows
+    only meet dead positions (g = 0), but 0 * NaN is NaN.  A first launch whose samples are all NaN leaves NaN patterns in
+    that buffer (the emulator's LDS persists per worker thread; on the GPU LDS contents are simply undefined), the second,
+    short launch must come out finite and equal to fp64."""
+    M, taps, S = 48, 65, 3
+    P = (taps // 2, taps // 2)
+
+    def run(x, y, T):
+        sums = torch.zeros(M, 3, dtype=torch.float64, device=dev)
+        kw = dict(S=S, C_=M, T=T, alpha=(torch.rand(M) * 0.5 + 0.75).to(dev), sums=sums, dy=None, has_bn=0)
+        yv = y.to(dev)
+        K.act_bwd_reduce(yv, **kw)
+        dw = torch.zeros(M, taps, device=dev)
+        assert K.wgrad_gemm(None, x.to(dev), dw, S=S, M=M, Tg=T, Ncols=T, Cin=1, Tz=T, taps=taps, padL=P[0],
+                            pad_mode=K.PAD_REFLECT, g_bwd=dict(kw, y=yv))
+        assert K.LAST_WGRAD_KIND == 5
+        return dw, kw["alpha"]
+    torch.manual_seed(11)
+    for _ in range(3):            # poison every worker's buffer
+        run(torch.full((S, 1, 640), float("nan")), torch.randn(S, M, 640), 640)
+    T = 40
+    x, y = torch.randn(S, 1, T) * 0.3, torch.randn(S, M, T)
+    dw, alpha = run(x, y, T)
+    assert bool(torch.isfinite(dw).all())
+    # without a norm and without a data gradient / pooled branch dA = 0: dy = 0, so dfilt must be exactly zero ...
+    assert float(dw.abs().max()) == 0.0
+    # ... and with a data gradient: against fp64 autograd
+    dsrc = torch.randn(S, M, T) * 0.1
+    sums = torch.zeros(M, 3, dtype=torch.float64, device=dev)
+    kw = dict(S=S, C_=M, T=T, alpha=alpha, dsrc=dsrc.to(dev), dsrc_ctot=M, Tp=T, padL=0, pad_mode=K.PAD_ZERO, sums=sums, dy=None,
+              has_bn=0)
+    yv = y.to(dev)
+    K.act_bwd_reduce(yv, **kw)
+    dw = torch.zeros(M, taps, device=dev)
+    assert K.wgrad_gemm(None, x.to(dev), dw, S=S, M=M, Tg=T, Ncols=T, Cin=1, Tz=T, taps=taps, padL=P[0], pad_mode=K.PAD_REFLECT,
+                        g_bwd=dict(kw, y=yv))
+    yd = y.double().requires_grad_(True)
+    dy_ref, = torch.autograd.grad((F.prelu(yd, alpha.cpu().double()) * dsrc.double()).sum(), yd)
+    filt = torch.zeros(M, taps, dtype=torch.float64, requires_grad=True)
+    (F.conv1d(F.pad(x.double(), P, mode="reflect"), filt[:, None, :]) * dy_ref).sum().backward()
+    assert bool(torch.isfinite(dw).all())
+    assert _rel(dw, filt.grad) < 1e-6
+
+
+def test_the_on_load_form_refuses_what_it_cannot_stage_and_enqueues_nothing(dev):
+    """pase_wgrad_gemm_act_bwd_ok: a pooled dense-skip branch with pool_d < 16 (a staged run of 16 positions would touch more
+    than two pooled frames) has no on-load form; wgrad_gemm(g_bwd=...) returns False and leaves dw untouched."""
+    S, M, T, taps = 2, 16, 128, 65
+    y = torch.randn(S, M, T, device=dev)
+    dpool = torch.randn(S, M, T // 8, device=dev)
+    dw = torch.full((M, taps), 0.25, device=dev)
+    g_bwd = dict(y=y, S=S, C_=M, T=T, has_bn=0, dpool=dpool, dpool_ctot=M, pool_F=T // 8, pool_d=8)
+    args = dict(S=S, M=M, Tg=T, Ncols=T, Cin=1, Tz=T, taps=taps, padL=32, pad_mode=K.PAD_REFLECT)
+    assert K.wgrad_gemm(None, torch.randn(S, 1, T, device=dev), dw, g_bwd=g_bwd, **args) is False
+    assert K.LAST_WGRAD_KIND == 5                      # the plan was right, the operand description was not
+    assert float((dw - 0.25).abs().max()) == 0.0
+    assert K.wgrad_gemm(None, torch.randn(S, 1, T, device=dev), dw, g_bwd=dict(g_bwd, pool_d=16, pool_F=T // 16,
+                        dpool=dpool[:, :, :T // 16].contiguous()), **args) is True
+
+
 def test_the_on_load_form_exists_only_on_the_one_channel_plan(dev):
     S, M, Cin, T = 1, 64, 8, 128
     g_bwd = dict(y=torch.zeros(S, M, T, device=dev), S=S, C_=M, T=T, has_bn=0)
