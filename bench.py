@@ -24,15 +24,27 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-GFLOP_PER_UTT_TRAIN = 122.0      # SURVEY.md 8(d) / BASELINE.md section 3: canonical algorithmic FLOPs
+GFLOP_PER_UTT_TRAIN = 122.0      # SURVEY.md 8(d) / BASELINE.md section 3: canonical algorithmic FLOPs (PASE+ / workers+)
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
 X6_MFMA_PER_PRODUCT = 6          # split-bf16 contraction: hh + hm + mh + hl + lh + mm per fp32 product
 
 
-def load_cfgs():
+# BASELINE.json configs[4]: the dense PASE+ encoder with two QRNN layers and norm_type 'lnorm', emb_dim 256, 64 utterances per
+# GPU (/root/reference/template_scripts/run_pase_train_50h_2xQRNN_addrev_lnorm_EMB256.sh:6 names a cfg file the reference does
+# not ship: built from PASE+.cfg through WaveFe's own keyword arguments, as tests/test_bench_config.py's `emb256` gate does)
+VARIANTS = {"pase+": dict(fe_over={}, batch=32, gflop_per_utt=GFLOP_PER_UTT_TRAIN,
+                          workload="PASE+.cfg + workers+.cfg self-supervised train step (BASELINE.json configs[2])"),
+            "emb256": dict(fe_over=dict(rnn_layers=2, norm_type="lnorm"), batch=64,
+                           # one more QRNN layer: + 30.20 GMAC forward per 32-utterance step, x 3 x 2
+                           gflop_per_utt=GFLOP_PER_UTT_TRAIN + 6.0 * 30.20 / 32.0,
+                           workload="PASE+ EMB256 variant: PASE+.cfg with rnn_layers=2, norm_type='lnorm' (LayerNorm blocks, "
+                                    "InstanceNorm norm_out) + workers+.cfg, 64 utterances per GPU (BASELINE.json configs[4], one GPU)")}
+
+
+def load_cfgs(variant="pase+"):
     with open(os.path.join(ROOT, "cfg", "frontend", "PASE+.cfg")) as f:
-        fe = json.load(f)
+        fe = dict(json.load(f), **VARIANTS[variant]["fe_over"])
     from pase_amd.utils import strip_transforms, worker_parser
     wk = strip_transforms(worker_parser(os.path.join(ROOT, "cfg", "workers", "workers+.cfg")))
     with open(os.path.join(ROOT, "cfg", "workers", "workers+.cfg")) as f:
@@ -50,10 +62,11 @@ def synthetic_batch(seed, B, T, raw, device):
     return batch
 
 
-def cpu_baseline(raw, fe_cfg, seconds_budget=25.0, B=2, max_steps=20):
+def cpu_baseline(raw, fe_cfg, seconds_budget=45.0, B=32, max_steps=2):
     """The CPU oracle (port of the reference step: oracle/pase_oracle.py) timed on the host cores on a
-    bounded sample: full-width PASE+ / workers+ model, B=2 utterances x 32 000 samples, fwd + losses
-    + backward + Adam, as many steps as fit the budget (>= 1 after one warm-up)."""
+    bounded sample of the benchmark's own workload: full-width model, B utterances x 32 000 samples (default: the
+    benchmark's batch size, SURVEY 8d "same synthetic batch, same step definition"), fwd + losses + backward + Adam,
+    as many steps as fit the budget (>= 1 after one warm-up; about 20 s per step at B = 32 on 32 threads)."""
     from oracle import pase_oracle as O
     from pase_amd.pase import pase
     from pase_amd.utils import strip_transforms, worker_parser
@@ -209,24 +222,33 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=0, help="utterances per GPU (default: 32; 64 for --variant emb256)")
     ap.add_argument("--chunk", type=int, default=32000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the second timed leg (batch handed over as host buffers)")
     ap.add_argument("--graph", action="store_true",
                     help="capture the step in a hipGraph (trainer.capture_step) and time the replays (N=1 only)")
     ap.add_argument("--torch-gpu-baseline", action="store_true",
-                    help="also time the torch-op restatement of the reference step on this GPU (stock PyTorch-ROCm "
-                         "kernels) and report it as `torch_rocm_baseline`")
+                    help="(default since round 6; kept for old command lines) time the torch-op restatement of the reference "
+                         "step on this GPU (stock PyTorch-ROCm kernels) and report it as `torch_rocm_baseline`")
     ap.add_argument("--rccl-max-nchannels", type=int, default=0,
                     help="N > 1: NCCL_MAX_NCHANNELS for RCCL (each channel occupies a CU that the backward's kernels then do "
                          "not get); 0 = leave RCCL's default")
     ap.add_argument("--reserve-cus", type=int, default=-1,
                     help="N > 1: CUs the persistent split-bf16 GEMM grids leave free for RCCL's channel kernels (grid cap = "
                          "CUs of the device - this); -1 = 32 for N > 1 (one CU per shader engine: DESIGN.md section 6), 0 for N = 1")
+    ap.add_argument("--cpu-baseline-b2", action="store_true",
+                    help="time the CPU baseline on a B = 2 sample (about 25 s) instead of the benchmark's own batch size "
+                         "(default: B = --batch, 1 warm-up + up to 2 timed steps, about a minute of host time)")
     ap.add_argument("--cpu-baseline-bs32", action="store_true",
-                    help="time the CPU baseline at the benchmark's own batch size (32 utterances, 3 steps after one warm-up: "
-                         "minutes of host time) instead of the bounded B = 2 sample of the default run")
+                    help="the CPU baseline with 3 timed steps at the benchmark's batch size (SURVEY 8d's '>= 3 steps after 1 "
+                         "warm-up': about 80 s of host time)")
+    ap.add_argument("--variant", choices=sorted(VARIANTS), default="pase+",
+                    help="pase+ = BASELINE.json configs[2] (the headline workload); emb256 = configs[4]'s model on one GPU "
+                         "(2 x QRNN, lnorm, 64 utterances per GPU unless --batch is given)")
+    ap.add_argument("--no-torch-gpu-baseline", action="store_true",
+                    help="skip the stock-PyTorch-ROCm comparator (SURVEY 8d: the reference step's module code on torch ops, "
+                         "same GPU, same batch size, 3 timed steps)")
     ap.add_argument("--no-capped-leg", action="store_true",
                     help="N = 1: skip the extra K steps that price the data-parallel CU reservation (n_gt1_cap_cost)")
     ap.add_argument("--producer", action="store_true",
@@ -267,7 +289,9 @@ def main():
     _lib.lib()   # fail loudly if the HIP library is missing
     from pase_amd.trainer import trainer
 
-    fe_cfg, wk_cfg, raw = load_cfgs()
+    fe_cfg, wk_cfg, raw = load_cfgs(args.variant)
+    if args.batch <= 0:
+        args.batch = VARIANTS[args.variant]["batch"]
     torch.manual_seed(2)             # train.py:376 default seed
     with contextlib.redirect_stdout(io.StringIO()):
         tr = trainer(frontend_cfg=dict(fe_cfg), minions_cfg=wk_cfg,
@@ -416,15 +440,16 @@ def main():
         tr._eager_step(batch)          # (eager even when the timed steps were graph replays: per-launch events)
     fams = K.GEMM_TIMER.summary()
     fams_pipe = K.GEMM_TIMER.summary(by_pipe=True)
+    fams_kern = K.GEMM_TIMER.summary(by_kernel=True)
     K.GEMM_TIMER = None
     traffic = None
     traffic_src = None
+    prof = None
     try:
         # HBM traffic cannot be counted from inside the run (PMC passes need rocprofv3): it comes from this round's
         # profile summary, and ONLY if that profile was taken of the very library that is loaded now (source digest)
         from pase_amd import build as _B
-        prof = None
-        for tag in ("r05", "r04"):          # the newest profile summary taken of the very library loaded now
+        for tag in ("r06", "r05", "r04"):   # the newest profile summary taken of the very library loaded now
             fn = os.path.join(ROOT, "profiles", "summary_%s.json" % tag)
             if os.path.exists(fn):
                 with open(fn) as f:
@@ -437,7 +462,7 @@ def main():
         # PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs) summed over every conv_gemm
         # instantiation, GB per launch; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B
         # requests as 64 B)
-        conv_k = ("conv_gemm_kernel<", "conv_x6c_kernel<192", "conv_x6c_kernel<128, 3", "sinc_x6_fwd_kernel")   # every pase_conv_gemm kernel
+        conv_k = ("conv_gemm_kernel<", "conv_x6c_kernel<192", "conv_x6c_kernel<128, 3, false", "conv_x6c_kernel<320", "sinc_x6_fwd_kernel")   # every pase_conv_gemm kernel
         mb = sum(row["fetch_MB_x2"] + row["write_MB"] for row in prof.get("hbm_traffic_per_step", [])
                  if row["kernel"].startswith(conv_k))
         calls = sum(k["calls"] for k in prof["step_kernel_time"]["families"] if k["kernel"].startswith(conv_k))
@@ -446,8 +471,42 @@ def main():
     except Exception:
         traffic = None
 
+    # ---- the dominant kernel INSTANTIATION (most HIP-event time over the launches that ran it), so that a reader can recompute
+    # its roofline fraction in one comparison: live numbers from the events above, PMC numbers from the digest-matched profile
+    dominant = None
+    try:
+        named = {k: v for k, v in fams_kern.items() if k}
+        kname = max(named, key=lambda k: named[k]["ms"])
+        v = named[kname]
+        x6k = kname.startswith(("conv_x6c_kernel", "sinc_x6"))
+        kpeak = PEAK_BF16_MFMA_TFLOPS / X6_MFMA_PER_PRODUCT if x6k else PEAK_F32_MFMA_TFLOPS
+        dominant = {"kernel": kname, "launches_per_step": v["launches"] // extra, "ms_per_step": round(v["ms"] / extra, 3),
+                    "algorithmic_gflop": round(v["flops"] / extra / 1e9, 1),
+                    "achieved": round(v["flops"] / v["ms"] / 1e9, 2), "peak": round(kpeak, 1), "unit": "TFLOP/s",
+                    "frac": round(v["flops"] / v["ms"] / 1e9 / kpeak, 4),
+                    "how": "sum over the launches that ran this instantiation of 2*S*Ncols*M*K (the descriptors' contraction "
+                           "sizes) / sum of their HIP-event durations on the launch stream (each launch's own operand packs "
+                           "included), streams serialised; mfma_util / traffic_GB / profile_ms_per_step: rocprofv3 passes of "
+                           "exactly this build (null otherwise)",
+                    "mfma_util": None, "traffic_GB": None, "profile_ms_per_step": None, "profile_source": None}
+        if prof is not None:
+            for row in prof.get("sq_counters_per_step", []):
+                if row["kernel"].startswith(kname):
+                    dominant["mfma_util"] = row.get("mfma_util")
+            for row in prof.get("hbm_traffic_per_step", []):
+                if row["kernel"].startswith(kname):
+                    dominant["traffic_GB"] = round((row["fetch_MB_x2"] + row["write_MB"]) / 1e3, 3)
+            for row in prof["step_kernel_time"]["families"]:
+                if row["kernel"].startswith(kname):
+                    dominant["profile_ms_per_step"] = round(row["total_us"] / 1e3, 3)
+                    dominant["profile_launches_per_step"] = row["calls"]
+            dominant["profile_source"] = traffic_src
+    except Exception as e:
+        dominant = {"kernel": None, "error": repr(e)}
+
     if rank == 0:
-        achieved = GFLOP_PER_UTT_TRAIN * utt_s / world / 1e3     # TFLOP/s per GPU (algorithmic)
+        gflop_utt = VARIANTS[args.variant]["gflop_per_utt"]
+        achieved = gflop_utt * utt_s / world / 1e3     # TFLOP/s per GPU (algorithmic)
         cg = fams.get("conv_gemm", dict(launches=1, flops=0.0, ms=1.0))
         wg = fams.get("wgrad_gemm", dict(launches=1, flops=0.0, ms=1.0))
         cg_tf = cg["flops"] / cg["ms"] / 1e9
@@ -472,8 +531,7 @@ def main():
             "config": {"workload": ("PASE+.cfg + workers+.cfg train step with the batch produced on device each step: crops "
                                     "of a resident pool, Reverb(24000-tap synthetic IRs, p=0.5) + additive noise (p=0.5), "
                                     "LPS/FBANK/gammatone/MFCC targets from the clean chunk (BASELINE.json configs[3] shape)")
-                       if args.producer else
-                       "PASE+.cfg + workers+.cfg self-supervised train step (BASELINE.json configs[2])",
+                       if args.producer else VARIANTS[args.variant]["workload"],
                        "batch_per_gpu": B, "global_batch": B * world, "chunk_samples": T,
                        "targets": ("lps/lps_long/fbank/fbank_long/gtn/gtn_long/mfcc/mfcc_long/prosody all computed on device from the clean chunk"
                                    if args.producer else "given (N(0,1) tensors resident in HBM)"), "parallelism": "dp%d" % world,
@@ -488,6 +546,7 @@ def main():
                          "peak_note": peak_note, "traffic": traffic,
                          "traffic_unit": "GB per launch (PMC FETCH_SIZE x2 + WRITE_SIZE); null when no PMC profile of "
                                          "exactly this build exists", "traffic_source": traffic_src,
+                         "dominant": dominant,
                          "launches_per_step": cg["launches"] // extra,
                          "avg_launch_ms": round(cg["ms"] / cg["launches"], 4),
                          "algorithmic_gflop_per_launch": round(cg["flops"] / cg["launches"] / 1e9, 2),
@@ -510,8 +569,8 @@ def main():
             "roofline_step": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
                               "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                               "frac_of_fp32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                              "note": "canonical algorithmic FLOPs (122.0 GFLOP per utterance, SURVEY 8d: minimal "
-                                      "algorithm, dense skips pooled first) x utterances/s per GPU"},
+                              "note": "canonical algorithmic FLOPs (%.1f GFLOP per utterance, SURVEY 8d: minimal "
+                                      "algorithm, dense skips pooled first) x utterances/s per GPU" % gflop_utt},
         }
         if h2d is not None:
             out["h2d"] = h2d
@@ -531,8 +590,12 @@ def main():
                                                 % (world, ndev))
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = (cpu_baseline(raw, fe_cfg, seconds_budget=600.0, B=32, max_steps=3)
-                                       if args.cpu_baseline_bs32 else cpu_baseline(raw, fe_cfg))
+                if args.cpu_baseline_b2:
+                    out["cpu_baseline"] = cpu_baseline(raw, fe_cfg, seconds_budget=25.0, B=2, max_steps=20)
+                elif args.cpu_baseline_bs32:
+                    out["cpu_baseline"] = cpu_baseline(raw, fe_cfg, seconds_budget=600.0, B=B, max_steps=3)
+                else:
+                    out["cpu_baseline"] = cpu_baseline(raw, fe_cfg, B=B)
             except Exception as e:  # the baseline leg must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "utterances/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
@@ -541,7 +604,7 @@ def main():
                 out["cpu_targets_baseline"] = cpu_targets_baseline(raw, T)
             except Exception as e:
                 out["cpu_targets_baseline"] = {"value": None, "sample": "failed: %r" % (e,)}
-        if world == 1 and args.torch_gpu_baseline:
+        if world == 1 and not args.producer and not args.no_torch_gpu_baseline:
             try:
                 del tr, batch
                 torch.cuda.empty_cache()

@@ -247,10 +247,72 @@ def gen_perturbed(only=None):
                             perturb=mode)
 
 
+def comb_index(numel, n):
+    """n evenly strided flat positions (odd stride) of a tensor with numel elements -- the embedding / prediction samples of
+    the benchmark-size golden (the tensors themselves are 6 ... 550 MB)."""
+    if numel <= n:
+        return np.arange(numel)
+    st = numel // n
+    st += (st % 2 == 0)
+    return (np.arange(n) * st) % numel
+
+
+def gen_bs32(mode="smooth", seed=2, B=32, T=32000, stem=None, only=None):
+    """ONE live-reference step at the BENCHMARK's own size (BASELINE.json configs[2]: PASE+.cfg + workers+.cfg, 32 utterances x
+    32 000 samples), fp32 and fp64 -- round-5 review: the bs32 gates compared the HIP path with the oracle port only; this is
+    the reference-generated anchor at that size.  Stored compactly (a few MB): parameter checksums, the 13 losses, per-tensor
+    checksums + a 65 536-sample comb of the embedding, combs of four prediction tensors, gradient / post-Adam norms and the
+    2 048-sample gradient combs of every parameter in fp32 and fp64 (same files / same keys as the B = 2 goldens, so
+    tests/test_pase_step.py judges them with the same code).  About 17 GB (fp32) / 35 GB (fp64) of host memory and ~20 min
+    on 8 cores: run in the build container, `python oracle/make_golden.py bs32 [smooth|perturbed] [f32|f64]`."""
+    stem = stem or ("pase_plus_step_bs32_%s" % mode)
+    perturb = "smooth" if mode == "smooth" else True
+    if only in (None, "f32"):
+        model, (names, sums, sq), losses, chunk, preds = _ref_step(seed, B, T, "PASE+.cfg", "workers+.cfg", perturb=perturb)
+        gnames = [n for n, p in model.named_parameters()]
+        gsq = np.array([float((p.grad.double() ** 2).sum()) for n, p in model.named_parameters()])
+        gsum = np.array([float(p.grad.double().sum()) for n, p in model.named_parameters()])
+        post_sq = np.array([float((p.detach().double() ** 2).sum()) for n, p in model.named_parameters()])
+        post_sum = np.array([float(p.detach().double().sum()) for n, p in model.named_parameters()])
+        combs = {}
+        for key, t in (("chunk_emb", chunk), ("pred_mi", preds["mi"]), ("pred_cmi", preds["cmi"]), ("pred_mfcc", preds["mfcc"]),
+                       ("pred_cchunk", preds["cchunk"]), ("pred_lps", preds["lps"])):
+            flat = t.detach().reshape(-1)
+            idx = comb_index(flat.numel(), 65536 if key == "chunk_emb" else 16384)
+            combs[key + "_comb"] = flat[torch.as_tensor(idx)].numpy()
+            combs[key + "_sum"] = float(flat.double().sum())
+            combs[key + "_sq"] = float((flat.double() ** 2).sum())
+            combs[key + "_numel"] = flat.numel()
+        np.savez(os.path.join(GOLD, stem + ".npz"), seed=seed, B=B, T=T, compact=1, param_names=np.array(names), param_sum=sums,
+                 param_sq=sq, loss_names=np.array(list(losses.keys())), loss_values=np.array([float(v) for v in losses.values()]),
+                 grad_names=np.array(gnames), grad_sq=gsq, grad_sum=gsum, post_sq=post_sq, post_sum=post_sum, **combs)
+        _save_grad_comb(model, losses, os.path.join(GOLD, stem + "_grads.npz"), seed, B, T, False)
+        del model, chunk, preds, losses
+    if only in (None, "f64"):
+        model, _cs, losses, chunk, preds = _ref_step(seed, B, T, "PASE+.cfg", "workers+.cfg", double=True, perturb=perturb)
+        _save_grad_comb(model, losses, os.path.join(GOLD, stem + "_grads_f64.npz"), seed, B, T, True)
+
+
+def _save_grad_comb(model, losses, path, seed, B, T, double):
+    gnames, vals, offs, gmax = [], [], [0], []
+    for n, p in model.named_parameters():
+        g = p.grad.detach().reshape(-1).numpy()
+        idx = grad_sample_index(g.size)
+        gnames.append(n)
+        vals.append(g[idx].astype(np.float64 if double else np.float32))
+        offs.append(offs[-1] + idx.size)
+        gmax.append(float(np.abs(g).max()))
+    np.savez(path, seed=seed, B=B, T=T, grad_names=np.array(gnames), grad_values=np.concatenate(vals),
+             grad_offsets=np.array(offs), grad_absmax=np.array(gmax), n_samples=GRAD_SAMPLES, loss_total=float(losses["total"]))
+
+
 if __name__ == "__main__":
     ref_shim.install()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
+    if sys.argv[1:2] == ["bs32"]:          # the benchmark-size golden (minutes, tens of GB): bs32 [smooth|perturbed] [f32|f64]
+        gen_bs32(sys.argv[2] if len(sys.argv) > 2 else "smooth", only=sys.argv[3] if len(sys.argv) > 3 else None)
+        sys.exit(0)
     if sys.argv[1:2] == ["perturbed"]:     # only the perturbed-slope steps (optionally: only files whose stem contains argv[2])
         gen_perturbed(sys.argv[2] if len(sys.argv) > 2 else None)
         sys.exit(0)

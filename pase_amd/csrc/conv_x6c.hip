@@ -50,7 +50,14 @@ namespace {
 
 constexpr int NT = 512;        // 4 compute waves (one per SIMD) + 4 staging waves
 constexpr int HALO_MAX = 64;      // extra positions a stage holds beyond its BN columns (halo of every sequence touched)
-constexpr int TMZ_KGS = 5;        // k-groups per stage buffer of the weight-gradient kernel on pre-split planes (<128, TMZ_KGS, true, true>)
+#ifdef PASE_X6C_NOAL              // A/B builds (tools/ab_build.sh): the packed operand of the pre-split weight gradients as buffer loads of
+constexpr bool X6C_AL = false;    // the compute waves, five k-groups per stage (the form until round 5)
+constexpr int TMZ_KGS = 5;
+#else
+constexpr bool X6C_AL = true;
+constexpr int TMZ_KGS = 3;        // k-groups per stage buffer of the weight-gradient kernel on pre-split planes (<128, TMZ_KGS, true, true>):
+                                  // 2 x 3 x (12 KB staged columns + 12 KB packed rows) = 144 KB of LDS
+#endif
 
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
     const int q = nwg / 8, r = nwg % 8;
@@ -81,11 +88,6 @@ __device__ __forceinline__ int zp_tap_of(int r, const PaseX6cPlan& pl) {
     return pl.zp_rem + q + pl.t_stride * (r2 - q * pl.zp_n);
 }
 
-#ifdef PASE_X6C_EARLYPRO    // A/B builds (tools/ab_build.sh): the next item's prologue BEFORE the last stage's barrier (see the staging loop)
-#define X6C_EARLY_PRO 1
-#else
-#define X6C_EARLY_PRO 0
-#endif
 #ifdef PASE_X6C_TRACE   // tools/trace_x6c.py only: per-item phase timestamps (shader clock) of workgroups 0 and 131
 #define X6C_TRACE_ITEMS 64
 __device__ unsigned long long g_x6c_trace[2 * X6C_TRACE_ITEMS * 20];
@@ -247,39 +249,6 @@ __device__ __forceinline__ void x6c_load_lds4(const void* src, float* lds_wave_b
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
 #endif
-// The same two copies HIDDEN from the compiler (STREAM on pre-split operands).  The compiler tracks pending LDS DMA and puts
-// s_waitcnt vmcnt(0) in front of every later LDS read it cannot prove disjoint from the DMA's destination -- here: in front of
-// the drain's reads of the accumulator tile, i.e. the wave that had just issued a stage's DMA waited for it (and, the counter
-// being in order, for all its earlier stores) before it drained a single row.  Issued as inline asm the copy is invisible; the
-// wave waits for it by hand (x6c_vmwait_le) in front of the barrier that publishes the stage.  M0 (the LDS base of the copy) is
-// saved and restored around the instruction: it is a reserved register the compiler may hold a value in.
-#ifdef PASE_HIPEMU
-__device__ __forceinline__ void x6c_dma16_hidden(const void* src, u32x4* lds_wave_base, int lane) {
-    __builtin_memcpy(&lds_wave_base[lane], src, 16);
-}
-__device__ __forceinline__ void x6c_dma4_hidden(const void* src, float* lds_wave_base, int lane) {
-    __builtin_memcpy(&lds_wave_base[lane], src, 4);
-}
-#else
-__device__ __forceinline__ void x6c_dma16_hidden(const void* src, u32x4* lds_wave_base, int) {
-    const unsigned lds = (unsigned)__builtin_amdgcn_readfirstlane(
-        (int)(unsigned)(size_t)(__attribute__((address_space(3))) u32x4*)lds_wave_base);
-    unsigned m0_saved;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(m0_saved)
-                 : "v"(src), "s"(lds)
-                 : "memory");
-}
-__device__ __forceinline__ void x6c_dma4_hidden(const void* src, float* lds_wave_base, int) {
-    const unsigned lds = (unsigned)__builtin_amdgcn_readfirstlane(
-        (int)(unsigned)(size_t)(__attribute__((address_space(3))) float*)lds_wave_base);
-    unsigned m0_saved;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(m0_saved)
-                 : "v"(src), "s"(lds)
-                 : "memory");
-}
-#endif
 struct alignas(16) X6cF4 { float x, y, z, w; };
 // Staging registers: eight fp32 values per slot as two 4-vectors (the row-coalesced weight-gradient path fills them with two
 // global_load_dwordx4, every other path with eight global_load_dword).
@@ -301,16 +270,10 @@ __device__ __forceinline__ void x6c_gload_x8(x6c_f4 (&q)[2], const float* base, 
     q[0] = x6c_f4{lo.x, lo.y, lo.z, lo.w};
     q[1] = x6c_f4{hi.x, hi.y, hi.z, hi.w};
 }
-template <int E, int RS>
-__device__ __forceinline__ void x6c_gload(float (&q)[8], const float* base, unsigned voff_bytes) {
-    q[E] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + voff_bytes);
-}
 template <int N>
 __device__ __forceinline__ void x6c_vmwait() {}
 template <int RS>
 __device__ __forceinline__ void x6c_claim(x6c_f4 (&)[2]) {}
-template <int RS>
-__device__ __forceinline__ void x6c_claim(float (&)[8]) {}
 #else
 // The staging waves' loads are HIDDEN from the compiler (cdna_hip_programming.md 5.7 form (ii)): issued as inline asm two
 // stages before their conversion, waited for with hand-counted s_waitcnt vmcnt(N) (every live slot issues the same number
@@ -319,26 +282,14 @@ __device__ __forceinline__ void x6c_claim(float (&)[8]) {}
 // address temporaries allocated on top of the load destinations made it wait vmcnt(0) in front of every load group and
 // every conversion -- the compute waves of the 1x1 / stride-2 / swapped launches spent 11 ... 60 % of their loop in the stage
 // barrier (tools/trace_x6c.py: LPS data gradient 60 %, LPS weight gradient 47 %, blocks 6 / 7 11 %).
-// RS = the register set the load belongs to, spelled into the asm text.  The STREAM form selects the set at run time
-// (`if (set == 0) load_stage<0> else if (set == 1) ...`): with IDENTICAL asm statements in the three branches the optimiser
-// merged them into one load whose result was then copied into the chosen set -- a copy of a register whose load had not
-// landed (seen in the ISA: destinations v32 ... v43 reused as scratch two instructions later; non-finite outputs on the GPU,
-// while the emulator passed).  Distinct asm strings cannot be merged: every load writes its home register.
+// RS = the register set the load belongs to, spelled into the asm text: IDENTICAL asm statements in sibling branches are
+// merged by the optimiser into one load whose result is then copied -- a copy of a register whose load has not landed
+// (round 5, seen in the ISA of a loop that chose the set at run time).  Distinct asm strings cannot be merged: every load
+// writes its home register, and pase_amd/build.py's ISA lint checks set membership.
 template <int E, int RS>
 __device__ __forceinline__ void x6c_gload(x6c_f4 (&q)[2], const float* base, unsigned voff_bytes) {
     asm volatile("global_load_dword %0, %1, %2 ; staging set %3"
                  : "=v"(q[E >> 2][E & 3])
-                 : "v"(voff_bytes), "s"(base), "n"(RS)
-                 : "memory");
-}
-// STREAM: eight SCALAR destinations per slot.  An element of a 4-vector as asm output makes the compiler assemble the vector
-// (REG_SEQUENCE) when it is claimed -- in the streamed loop it placed the four loads of a vector in non-consecutive registers
-// and copied them together at the claim, i.e. while the loads were in flight (ISA: set 1 loaded into v32-35 / v40-43 / ...,
-// claimed as v[32:39]).  A scalar needs no assembling: it stays where its load put it.
-template <int E, int RS>
-__device__ __forceinline__ void x6c_gload(float (&q)[8], const float* base, unsigned voff_bytes) {
-    asm volatile("global_load_dword %0, %1, %2 ; staging set %3"
-                 : "=v"(q[E])
                  : "v"(voff_bytes), "s"(base), "n"(RS)
                  : "memory");
 }
@@ -359,12 +310,6 @@ __device__ __forceinline__ void x6c_claim(x6c_f4 (&q)[2]) {
     //  conversion are the very registers the set's loads were issued into -- a value that was copied while in flight is stale)
     asm volatile("; claim staging set %2 regs %0 %1" : "+v"(q[0]), "+v"(q[1]) : "n"(RS));
 }
-template <int RS>
-__device__ __forceinline__ void x6c_claim(float (&q)[8]) {
-    asm volatile("; claim staging set %8 regs %0 %1 %2 %3 %4 %5 %6 %7"
-                 : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7])
-                 : "n"(RS));
-}
 #endif
 // wait until at most `per_slot` * nslots of this wave's loads are outstanding (nslots: uniform, 0 .. 5; per_slot 8, or 2 on the
 // row-coalesced weight-gradient path)
@@ -383,30 +328,6 @@ __device__ __forceinline__ void x6c_vmwait_slots(int nslots, bool two_per_slot) 
         default: x6c_vmwait<40>(); break;
     }
 }
-
-// at most n (rounded DOWN to a multiple of four, at most 32) of this wave's vector memory operations outstanding (real in every
-// hardware build, like x6c_vm_drain: it guards LDS DMA)
-#ifdef PASE_HIPEMU
-__device__ __forceinline__ void x6c_vmwait_le(int) {}
-#else
-template <int N>
-__device__ __forceinline__ void x6c_vm_wait_imm() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-__device__ __forceinline__ void x6c_vmwait_le(int n) {
-    switch (n < 0 ? 0 : (n > 32 ? 8 : n >> 2)) {
-        case 0: x6c_vm_wait_imm<0>(); break;
-        case 1: x6c_vm_wait_imm<4>(); break;
-        case 2: x6c_vm_wait_imm<8>(); break;
-        case 3: x6c_vm_wait_imm<12>(); break;
-        case 4: x6c_vm_wait_imm<16>(); break;
-        case 5: x6c_vm_wait_imm<20>(); break;
-        case 6: x6c_vm_wait_imm<24>(); break;
-        case 7: x6c_vm_wait_imm<28>(); break;
-        default: x6c_vm_wait_imm<32>(); break;
-    }
-}
-#endif
 
 // NPOS: positions (16-byte chunks) per (plane, fk) row of a k-group; KGS_T: k-groups a stage buffer holds.
 //   <192, 2>: convolutions (128 columns + up to 64 halo positions)      <128, 3>: 1x1 layers (no halo)
@@ -432,21 +353,9 @@ __device__ __forceinline__ void x6c_vmwait_le(int n) {
 // NARROW (convolutions of at most 64 rows: block 1 of the encoder): workgroup tile 64 x 256, compute waves 2 (rows) x 2 (column
 // halves) -- the 128-row tile would spend half of every MFMA on zero rows.  Same wave tile (32 x 128), same loop; the stage
 // holds 256 + 64 positions (<320, 2>).
-// STREAM (round 5; convolutions with a plain-store / BatchNorm-statistics or fused-MSE epilogue, no split-K, no pixel shuffle,
-// at least two stages per item): the two gaps of the persistent loop are closed.  (1) The staging waves run ONE continuous
-// stage stream across the items of the workgroup -- the next item's first stages are loaded / converted while the current item's
-// last stages are multiplied (geometry of the item being loaded and of the item being stored are separate state), so no item
-// starts with a prologue of 7 ... 16 k clocks during which the matrix core idles.  (2) The compute waves end an item by adding
-// their two accumulator sets and DUMPING the 128 x 128 fp32 tile into LDS (64 ds_write_b32 per lane) and go straight on to the
-// next item; the staging waves drain the tile to HBM one stage later -- bias, BatchNorm partial sums or the r-context MSE and
-// its gradient included -- beside the next item's MFMAs.  No barrier is added: the dump is published by the barrier that ends
-// the next item's first stage, the drain runs in that item's second stage, and the tile is free again before the item's last
-// barrier.  (tools/trace_x6c.py, round 4: the compute waves spent 8 ... 19 k clocks per item between the last MFMA of one tile
-// and the first of the next -- 13.6 k of a 38 k-clock item on the LPS heads.)
-template <int NPOS, int KGS_T, bool TM = false, bool ZP = false, bool NARROW = false, bool STREAM = false>
+template <int NPOS, int KGS_T, bool TM = false, bool ZP = false, bool NARROW = false>
 __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6cPlan pl) {
     static_assert(!(NARROW && TM), "the 64 x 256 tile is a convolution tile");
-    static_assert(!(STREAM && (TM || NARROW)), "the streamed form is a 128 x 128 convolution tile");
     constexpr int WM = NARROW ? 2 : 4, WN = NARROW ? 2 : 1, NBT = 4;
     constexpr int BM = 32 * WM, BN = 32 * NBT * WN;
     constexpr int NPS = (NPOS + 127) / 128;        // position slots per thread and k-group
@@ -458,29 +367,22 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     constexpr int RED_CHUNKS = (int)(sizeof(float) * WN * BM * 2 / 16);
     // TM, transposed accumulation (modes 2 / 3): each compute wave turns 64 columns x 32 rows of its tile through a private
     // [64][33]-float LDS block so that the atomics run along the rows of dw
+    // (pre-split weight gradients are tmode 1: row-contiguous atomics, no transposed flush)
     constexpr int TR_FLOATS = 64 * 33;
-    constexpr int TR_CHUNKS = TM ? (4 * TR_FLOATS * 4 + 15) / 16 : 0;
+    constexpr int TR_CHUNKS = (TM && !ZP) ? (4 * TR_FLOATS * 4 + 15) / 16 : 0;
+    // AL (weight gradients on pre-split planes): the PACKED operand (rows of g, fragment order) travels through LDS as well --
+    // per k-group 4 row tiles x 3 planes x 64 lanes 16-byte chunks = 12 KB beside the 12 KB of staged columns, copied by the
+    // staging waves' LDS DMA one stage ahead.  The pack has no reuse inside a workgroup and is far larger than the L2: as
+    // buffer loads of the compute waves (two steps = ~2 k clocks ahead) every miss stalled the matrix pipe -- an ablation
+    // without those loads ran 17 % faster (round 4) -- whereas a DMA issued a whole stage ahead has landed when the stage
+    // barrier publishes it, and the compute waves issue no vector-memory instruction inside the loop at all.
+    constexpr bool AL = TM && ZP && X6C_AL;
+    constexpr int AKG = 4 * 192;                   // chunks of the packed operand per k-group
+    constexpr int ABUF = AL ? KGS_T * AKG : 0;
     // two stage buffers + the epilogue scratch (its own region: the next item's first stage is staged during the epilogue)
-    // STREAM: the accumulator tile, [row][column] fp32 with a pitch of 136 floats (the two 32-lane halves of a compute wave
-    // write rows 4 apart: 4 * 136 floats = 32 banks apart; a drain lane reads 16 contiguous bytes of a row)
-    constexpr int TILE_P = 136;
-    constexpr int TILE_CHUNKS = STREAM ? BM * TILE_P * 4 / 16 : 0;
-    // STREAM on pre-split operands: what the drain reads besides the tile -- the bias of the tile's rows and, for the fused MSE,
-    // the slab of labels the tile's rows and columns touch ([label channel][column + context halo], SLAB_ROWS x SLAB_P floats)
-    // -- is copied into LDS by DMA a tick ahead: the draining waves then issue NO load from global memory, so neither they
-    // nor the compiler ever wait on the vector memory counter except for the operand DMA itself (see the tick below).
-    constexpr int SLAB_ROWS = 20, SLAB_P = 136;
-    constexpr int AUX_CHUNKS = (STREAM && ZP) ? (SLAB_ROWS * SLAB_P * 4 + BM * 4) / 16 : 0;
-    __shared__ __attribute__((aligned(16))) u32x4 Xs[2 * BUF + RED_CHUNKS + TR_CHUNKS];
-    // (an LDS object of its own: the compiler inserts s_waitcnt vmcnt(0) in front of every LDS read that MAY alias the
-    //  destination of a pending LDS DMA -- with the tile inside Xs every read of the drain waited for the operand DMA of the same
-    //  tick and, the counter being in order, for every store issued before it)
-    __shared__ __attribute__((aligned(16))) u32x4 Ys[TILE_CHUNKS + 1];
-    __shared__ __attribute__((aligned(16))) u32x4 Zs[AUX_CHUNKS + 1];      // (bias / label slab: a DMA destination itself)
+    __shared__ __attribute__((aligned(16))) u32x4 Xs[2 * BUF + RED_CHUNKS + TR_CHUNKS + 2 * ABUF];
+    u32x4* const As = &Xs[2 * BUF + RED_CHUNKS + TR_CHUNKS];      // AL: [buffer][k-group][row tile][plane][lane]
     float (*red)[BM][2] = reinterpret_cast<float (*)[BM][2]>(&Xs[2 * BUF]);
-    float* const acc_tile = reinterpret_cast<float*>(&Ys[0]);
-    float* const aux_slab = reinterpret_cast<float*>(&Zs[0]);
-    float* const aux_bias = aux_slab + SLAB_ROWS * SLAB_P;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -550,9 +452,6 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     unsigned pos_valid = 0u, pos_inter = 0u;       // bit par * NPS + ps
     unsigned live = 0u, full = 0u;
     unsigned inter_slots = 0u;     // slots whose 64 positions (of this wave) are all in-range samples: no padding arithmetic
-    // STREAM: the loads run two stages ahead of the conversion ACROSS item boundaries -- the three wave-uniform masks above
-    // describe the item whose stages are being LOADED; these are the ones of the item whose stages are being CONVERTED
-    unsigned liveS = 0u, fullS = 0u, interS = 0u;
     // TM: per column (lane): channel row offset + tap offset (relative to the smallest tap offset), the tap offset itself,
     // on-load parameters, "all-ones column" flag (bias gradient); running column sums of the staged values (tmode 2)
     int t_koff[NPAR][NPS];
@@ -727,12 +626,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     const bool has_aff = p.in_scale != nullptr, has_alpha = p.in_alpha != nullptr;       // uniform
     const float* xbase = p.x + (size_t)p.x_coff * p.Tin;
 
-    x6c_f4 xreg[XR][(ZP || STREAM) ? 1 : NSLOT][2];
-    float xsc[XR][(STREAM && !ZP) ? NSLOT : 1][8];      // STREAM: the same staging registers as scalars (see x6c_gload)
-    auto xr_of = [&](auto rs_tag, auto sl_tag) -> decltype(auto) {
-        if constexpr (STREAM && !ZP) return (xsc[decltype(rs_tag)::value][decltype(sl_tag)::value]);
-        else return (xreg[decltype(rs_tag)::value][decltype(sl_tag)::value]);
-    };
+    x6c_f4 xreg[XR][ZP ? 1 : NSLOT][2];
     unsigned xmask[XR][ZP ? 1 : NSLOT];         // bit e: element e of the slot is a real sample (else: zero AFTER the transform)
     u32x4 xpl[XR][ZP ? NSLOT : 1][3];           // ZP: the slot's three plane chunks as loaded
     const unsigned short* zpb = reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(p.wx6) + pl.zp_off);
@@ -748,9 +642,6 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     };
     auto slot_live = [&](int kg, int ps) __attribute__((always_inline)) {
         return kg < KGS && ((live >> ((kg & (NPAR - 1)) * NPS + ps)) & 1u) != 0;
-    };
-    auto slot_live_s = [&](int kg, int ps) __attribute__((always_inline)) {      // ... of the item being converted
-        return kg < KGS && (((STREAM ? liveS : live) >> ((kg & (NPAR - 1)) * NPS + ps)) & 1u) != 0;
     };
     // TM: k-group (g, kg) -> sequence s, first position of this wave's octet; is every sample of the octet, for every tap,
     // an in-range sample of a real sequence (uniform)
@@ -836,7 +727,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             const float* bp = xbase + (size_t)c0l * p.Tin;
             pase_static_for<8>([&](auto et) __attribute__((always_inline)) {
                 constexpr int e = decltype(et)::value;
-                x6c_gload<e, rs>(xr_of(r_tag, sl_tag), bp, pos_voff[par][ps] * 4u);
+                x6c_gload<e, rs>(xreg[rs][sl], bp, pos_voff[par][ps] * 4u);
                 bp += p.Tin;
             });
             xmask[rs][sl] = (0u - vbit) & 0xffu;
@@ -850,7 +741,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             const int to_next = p.Tin - (pl.P - 1);
             pase_static_for<8>([&](auto et) __attribute__((always_inline)) {
                 constexpr int e = decltype(et)::value;
-                x6c_gload<e, rs>(xr_of(r_tag, sl_tag), bp, pos_voff[par][ps] * 4u);
+                x6c_gload<e, rs>(xreg[rs][sl], bp, pos_voff[par][ps] * 4u);
                 const bool wrap = ++bph == pl.P;                                  // uniform
                 bp += wrap ? to_next : 1;
                 bph = wrap ? 0 : bph;
@@ -864,7 +755,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 int ci, b;
                 bool chok;
                 chan_of(g, kg, e, ci, b, chok);
-                x6c_gload<e, rs>(xr_of(r_tag, sl_tag), xbase + (size_t)ci * p.Tin + b, pos_voff[par][ps] * 4u);
+                x6c_gload<e, rs>(xreg[rs][sl], xbase + (size_t)ci * p.Tin + b, pos_voff[par][ps] * 4u);
             });
             xmask[rs][sl] = (0u - vbit) & 0xffu;
         } else {
@@ -879,7 +770,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 int u = pos_u0[par][ps] + b;
                 if (p.pad_mode == PASE_PAD_REFLECT) u = x6c_reflect(u, p.Tin);
                 const unsigned okb = vbit & x6c_in_range(u, p.Tin);
-                x6c_gload<e, rs>(xr_of(r_tag, sl_tag), xbase + (size_t)ci * p.Tin, ((pos_sbase[par][ps] + (unsigned)u) & (0u - okb)) * 4u);
+                x6c_gload<e, rs>(xreg[rs][sl], xbase + (size_t)ci * p.Tin, ((pos_sbase[par][ps] + (unsigned)u) & (0u - okb)) * 4u);
                 mask |= okb << e;
             });
             xmask[rs][sl] = mask;
@@ -899,15 +790,10 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             }
             return;
         } else {
-        x6c_claim<rs>(xr_of(r_tag, sl_tag));
+        x6c_claim<rs>(xreg[rs][sl]);
         float v[8];
-        if constexpr (STREAM && !ZP) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = xsc[rs][sl][e];
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = xreg[rs][sl][e >> 2][e & 3];
-        }
+        for (int e = 0; e < 8; ++e) v[e] = xreg[rs][sl][e >> 2][e & 3];
         if constexpr (TM) {
             if (pl.t_vec) {
                 constexpr int h = (sl >> 1) & 1;
@@ -979,8 +865,8 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * al[e];
         }
         // zero padding applies AFTER the transform (skipped when every lane of the wave holds real samples)
-        const bool all_inter = (((STREAM ? interS : inter_slots) >> (par * NPS + ps)) & 1u) != 0;     // uniform (as in load_slot)
-        const bool pos_full = (((STREAM ? fullS : full) >> (par * NPS + ps)) & 1u) != 0;              // uniform
+        const bool all_inter = ((inter_slots >> (par * NPS + ps)) & 1u) != 0;     // uniform (as in load_slot)
+        const bool pos_full = ((full >> (par * NPS + ps)) & 1u) != 0;              // uniform
         if (!(all_inter && pos_full && chan_full)) {
             const int nch = pl.CinP - c0;                                                 // uniform
             const unsigned m = xmask[rs][sl] & (nch >= 8 ? 0xffu : nch > 0 ? (1u << nch) - 1u : 0u);
@@ -1009,7 +895,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         };
         auto store_stage = [&](auto r_tag, int g, int bs) __attribute__((always_inline)) {
             pase_static_for<NSLOT>([&](auto sl) __attribute__((always_inline)) {
-                if (slot_live_s(decltype(sl)::value / NPS, decltype(sl)::value % NPS)) store_slot(r_tag, sl, g, bs);
+                if (slot_live(decltype(sl)::value / NPS, decltype(sl)::value % NPS)) store_slot(r_tag, sl, g, bs);
             });
         };
         int nlive = 0;                 // live slots of this wave for the current item: 8 * nlive loads per stage
@@ -1042,552 +928,8 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             return item;
         };
 
-        // ---- STREAM: the accumulator tile of a finished item, LDS -> HBM with the epilogue arithmetic, by the staging waves.
-        // Wave w (0 .. 3) takes tile rows 32 w .. 32 w + 31, two rows per pass: lanes 0-31 / 32-63 read 16 bytes each of one
-        // row (columns 4 (lane & 31) ..) -- a 512-byte contiguous run per row in LDS and, for interior tiles, in HBM.
-        //   PASE_EPI_STORE:   y = tile + bias, BatchNorm partial sums (sum, sum of squares over the valid columns of the
-        //                     row) straight into stat_part[column tile][row] -- a row lives in ONE half wave: no LDS, no barrier
-        //   PASE_EPI_MSE_CTX: rows m = d * r + j, target = label[b, d, t + j - r / 2] (zero outside the sequence), loss
-        //                     partial per wave -> one fp64 atomic, prediction and / or gradient stored
-        // (reference ops: nn.BatchNorm1d statistics of FeBlock modules.py:1073-1075; ContextualizedLoss losses.py:6-37)
-        float drain_lsum = 0.f;          // MSE: this lane's loss partial of the tile being drained (summed over its row chunks)
-        int drain_vm_ops = 0;            // vector memory operations the drain issued this tick -- a LOWER bound (lean tiles count
-                                         // their stores exactly; anything else sets it negative = unknown)
-        // Who drains.  Operands split while staged (registers): all four staging waves, 32 tile rows each.  Pre-split operands
-        // (LDS DMA): waves 6 / 7 drain, 64 rows each, and waves 4 / 5 issue ALL the DMA -- a wave that waits for its DMA with
-        // vmcnt(0) in front of every barrier would wait for the drain's label loads and store acknowledgements as well (one
-        // counter per wave, in order): with the roles apart the drain never sits on the stage's critical path.
-        constexpr int DW = 4;                           // draining waves (all four staging waves, 32 tile rows each)
-        constexpr int RPW = BM / DW;                    // tile rows per draining wave
-        constexpr int NGRP = RPW / 8;                   // groups of eight rows (four passes of two rows) per draining wave
-        const int dwi = wave - 4;                       // index among the draining waves
-        // Labels and bias of the NEXT chunk (at most two groups) are loaded one tick ahead: a draining wave is alone with its
-        // memory latencies -- loads issued and consumed inside one chunk cost a round trip per group (measured: the LPS heads
-        // 0.59 -> 0.91 ms with the drain latency-bound on two waves) -- whereas a tick later they have simply arrived.
-        // (pre-split operands only -- there the draining waves hold nothing else; the waves that convert operands keep three
-        //  register sets of staged activations and have no room for 40 more registers: the build's spill guard fired)
-        constexpr int PFG = 0;                          // groups a prefetch holds (0: prefetch off -- superseded for the pre-split form by
-                                                        // the LDS copies of bias and labels, see AUX_CHUNKS; kept for A/B builds)
-        constexpr int MAXG = ZP ? 2 : 1;                // groups one drain_tile call takes (register budget of the converting waves)
-        float pf_tg[PFG ? PFG : 1][4][4], pf_bv[PFG ? PFG : 1][4];
-        int pf_c0 = -1, pf_n = 0;                       // groups [pf_c0, pf_c0 + pf_n) of the tile are prefetched (lean tiles only)
-        auto drain_prefetch = [&](int item, int c0, int c1) __attribute__((always_inline)) {
-            if constexpr (STREAM) {
-            pf_c0 = -1;
-            pf_n = 0;
-            if constexpr (PFG == 0) return;
-            if (dwi < 0 || c1 - c0 > 2 || c1 <= c0) return;          // uniform
-            const int tl = xcd_swizzle(item, ntiles);
-            const int nt_ = tl / pl.n_row_tiles, mt_ = tl - nt_ * pl.n_row_tiles;
-            const int m0 = mt_ * BM, n0 = nt_ * BN;
-            const int n = n0 + 4 * (lane & 31);
-            const bool ok3 = n + 3 < ntot;
-            const unsigned n0u = (unsigned)(n < ntot ? n : 0), n3u = (unsigned)(ok3 ? n + 3 : 0);
-            const int s0_ = (int)div_magic(n0u, pl.ncols_magic), s3_ = (int)div_magic(n3u, pl.ncols_magic);
-            const int q0_ = (int)n0u - s0_ * p.Ncols;
-            const bool run = ok3 && s3_ == s0_;
-            const int rw0 = RPW * dwi;
-            const int mrow0 = m0 + rw0 + (lane >> 5);
-            const bool rows_full = m0 + rw0 + RPW <= p.M;
-            bool lean = pl.epi32 && rows_full;
-            if (p.epilogue == PASE_EPI_STORE) {
-                const int pos0 = q0_ + p.poff;
-                lean = lean && pase_wave_all(run && pos0 >= 0 && pos0 + 3 < p.Tout) != 0;
-            } else {
-                lean = lean && pase_wave_all(run) != 0;
-            }
-            if (!lean) return;                                        // uniform
-            const int half = p.r_ctx / 2;
-            const unsigned loff = (unsigned)(s0_ * p.label_D * p.Ncols + q0_ - half) * 4u;
-            const int tb0 = q0_ - half;
-            const char* lab = reinterpret_cast<const char*>(p.label);
-            pase_static_for<2>([&](auto g_tag) __attribute__((always_inline)) {
-                constexpr int g = decltype(g_tag)::value;
-                if (c0 + g < c1) {                                    // uniform
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int m = mrow0 + 2 * (4 * (c0 + g) + i);
-                        pf_bv[g < PFG ? g : 0][i] = p.bias != nullptr ? p.bias[m] : 0.f;
-                        if (p.epilogue != PASE_EPI_STORE) {          // uniform
-                            const int d = (int)div_magic((unsigned)m, pl.rctx_magic);
-                            const int jj = m - d * p.r_ctx;
-                            const unsigned la = loff + (unsigned)(d * p.Ncols + jj) * 4u;
-                            const int tb = tb0 + jj;
-                            if (tb >= 0 && tb + 3 < p.Ncols) {
-                                const pase_f4u t = *reinterpret_cast<const pase_f4u*>(lab + la);
-                                pf_tg[g < PFG ? g : 0][i][0] = t.x;
-                                pf_tg[g < PFG ? g : 0][i][1] = t.y;
-                                pf_tg[g < PFG ? g : 0][i][2] = t.z;
-                                pf_tg[g < PFG ? g : 0][i][3] = t.w;
-                            } else {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    pf_tg[g < PFG ? g : 0][i][e] = 0.f;
-                                    if ((unsigned)(tb + e) < (unsigned)p.Ncols) pf_tg[g < PFG ? g : 0][i][e] = *reinterpret_cast<const float*>(lab + (la + 4u * e));
-                                }
-                            }
-                        }
-                    }
-                }
-            });
-            pf_c0 = c0;
-            pf_n = c1 - c0;
-            }
-        };
-        // groups [c0, c1), c1 - c0 <= MAXG, of each draining wave's NGRP: the drain of a tile is spread over several ticks; `last`:
-        // the tile's final chunk (BatchNorm partial sums of the whole tile / loss partial -> atomic)
-        auto drain_tile = [&](int item, int c0, int c1, bool last) __attribute__((always_inline)) {
-            if constexpr (STREAM) {
-            if (dwi < 0) return;                          // uniform
-            const int tl = xcd_swizzle(item, ntiles);
-            const int nt_ = tl / pl.n_row_tiles, mt_ = tl - nt_ * pl.n_row_tiles;
-            const int m0 = mt_ * BM, n0 = nt_ * BN;
-            const int cl = 4 * (lane & 31);
-            const int n = n0 + cl;                                    // first of this lane's four columns
-            // (sequence, position) of the four columns; `run`: all four are real columns of ONE sequence
-            int sq[4], qq[4];
-            bool okc[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                okc[e] = n + e < ntot;
-                const unsigned ne = (unsigned)(okc[e] ? n + e : 0);
-                sq[e] = (int)div_magic(ne, pl.ncols_magic);
-                qq[e] = (int)ne - sq[e] * p.Ncols;
-            }
-            const bool run = okc[3] && sq[3] == sq[0];
-            const int rw0 = RPW * dwi;                                 // this wave's first tile row
-            const float* tl_rows = acc_tile + (rw0 + (lane >> 5)) * TILE_P + cl;
-            const int mrow0 = m0 + rw0 + (lane >> 5);
-            const bool rows_full = m0 + rw0 + RPW <= p.M;             // uniform
-            if (p.epilogue == PASE_EPI_STORE) {      // uniform
-                // output element offsets of the four columns (ps == 1): (s * y_ctot + y_coff) * Tout + q + poff, + m * Tout per row
-                size_t ob[4];
-                bool oko[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int pos = qq[e] + p.poff;
-                    oko[e] = okc[e] && pos >= 0 && pos < p.Tout;
-                    ob[e] = ((size_t)sq[e] * p.y_ctot + p.y_coff) * (size_t)p.Tout + (size_t)(oko[e] ? pos : 0);
-                }
-                const bool run_o = run && oko[0] && oko[3];
-                const bool lean = pl.epi32 && rows_full && pase_wave_all(run_o) != 0;      // uniform
-                if (lean) {
-                    // The common tile (whole rows, every column quad one contiguous run): every vector-ALU instruction of a
-                    // staging wave issues between the compute wave's MFMAs at ~10 cycles apiece, so the pass is pared down to
-                    // LDS read, bias add, one 16-byte store -- row pointer wave-uniform (scalar unit), the lane's part of the
-                    // address one 32-bit byte offset -- and the BatchNorm sums are taken in a pass of their own below.
-                    const unsigned cb4 = (unsigned)(ob[0] + (size_t)(lane >> 5) * (size_t)p.Tout) * 4u;
-                    const unsigned to8 = (unsigned)p.Tout * 8u;
-                    char* yrow = reinterpret_cast<char*>(p.y) + (size_t)(m0 + rw0 + 8 * c0) * (size_t)p.Tout * 4u;
-                    const bool use_pf = pf_c0 == c0 && pf_n >= c1 - c0;          // uniform
-                    pase_static_for<MAXG>([&](auto g_tag) __attribute__((always_inline)) {
-                        constexpr int g = decltype(g_tag)::value;
-                        const int c = c0 + g;
-                        if (c < c1) {                                            // uniform
-                            float bv[4];
-                            X6cF4 t4[4];
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                if (PFG > 0 && use_pf) bv[i] = pf_bv[g < PFG ? g : 0][i];
-                                else if (ZP) bv[i] = p.bias != nullptr ? aux_bias[rw0 + (lane >> 5) + 2 * (4 * c + i)] : 0.f;
-                                else bv[i] = p.bias != nullptr ? p.bias[mrow0 + 2 * (4 * c + i)] : 0.f;
-                                t4[i] = *reinterpret_cast<const X6cF4*>(tl_rows + 2 * (4 * c + i) * TILE_P);
-                            }
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const float v[4] = {t4[i].x + bv[i], t4[i].y + bv[i], t4[i].z + bv[i], t4[i].w + bv[i]};
-                                pase_store_run4(reinterpret_cast<float*>(yrow + cb4), v);
-                                yrow += to8;
-                            }
-                            drain_vm_ops += 4;
-                        }
-                    });
-                } else {
-                drain_vm_ops = -1000;
-                // edge tiles (ragged rows / columns, a quad across two sequences): one pass of two rows at a time, plainly --
-                // rare, and the converting waves have no registers to spare for a wider form
-#pragma unroll 1
-                for (int it = 4 * c0; it < 4 * c1; ++it) {
-                    const int m = mrow0 + 2 * it;
-                    const bool mok = m < p.M;
-                    const float bvv = (p.bias != nullptr && mok) ? p.bias[m] : 0.f;
-                    const X6cF4 t4 = *reinterpret_cast<const X6cF4*>(tl_rows + 2 * it * TILE_P);
-                    float v[4] = {t4.x + bvv, t4.y + bvv, t4.z + bvv, t4.w + bvv};
-                    float* yr = p.y + (size_t)(mok ? m : 0) * (size_t)p.Tout;
-                    if (mok) {
-                        if (run_o) {
-                            pase_store_run4(yr + ob[0], v);
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (oko[e]) yr[ob[e]] = v[e];
-                        }
-                    }
-                }
-#if !defined(PASE_HIPEMU)
-                // (close the compiler's books on this branch's ordinary loads: left pending at the join with the lean branch they
-                //  made it guard "their" registers with s_waitcnt vmcnt(0) all over the lean code -- each one a wait for the
-                //  hidden DMA and every store in flight)
-                __builtin_amdgcn_s_waitcnt(0x0F70);
-#endif
-                }
-                if (last && p.stat_part != nullptr) {      // uniform
-                    // BatchNorm partial sums of the tile (sum, sum of squares of y = tile + bias over the row's valid output
-                    // columns): a lane owns one row (and, with four draining waves, one half of its columns), reads it from
-                    // the LDS tile 16 bytes at a time and accumulates in registers -- no cross-lane reduction per pass.
-                    constexpr int NPART = 64 / RPW;                    // lanes per row: 2 (32 rows per wave) or 1 (64)
-                    constexpr int NQ = BN / 4 / NPART;                 // column quads per lane
-                    const int rl = lane & (RPW - 1), part = lane / RPW;
-                    const int m = m0 + rw0 + rl;
-                    const float b = p.bias == nullptr ? 0.f : (ZP ? aux_bias[rw0 + rl] : (m < p.M ? p.bias[m] : 0.f));
-                    const float* trow = acc_tile + (rw0 + rl) * TILE_P + part * (BN / NPART);
-                    float s1 = 0.f, s2 = 0.f;
-                    const int ncol_t = min(BN, ntot - n0);            // real columns of the tile (uniform)
-                    const bool cols_plain = ncol_t == BN && p.poff == 0 && p.Tout >= p.Ncols;      // uniform: every column is stored
-#pragma unroll 4
-                    for (int k = 0; k < NQ; ++k) {
-                        const X6cF4 t = *reinterpret_cast<const X6cF4*>(trow + 4 * k);
-                        const float v[4] = {t.x + b, t.y + b, t.z + b, t.w + b};
-                        if (cols_plain) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                s1 += v[e];
-                                s2 = fmaf(v[e], v[e], s2);
-                            }
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const int ce = part * (BN / NPART) + 4 * k + e;
-                                bool ok = ce < ncol_t;
-                                if (ok) {
-                                    const unsigned ne = (unsigned)(n0 + ce);
-                                    const int se = (int)div_magic(ne, pl.ncols_magic);
-                                    const int pos = (int)ne - se * p.Ncols + p.poff;
-                                    ok = pos >= 0 && pos < p.Tout;
-                                }
-                                if (ok) {
-                                    s1 += v[e];
-                                    s2 = fmaf(v[e], v[e], s2);
-                                }
-                            }
-                        }
-                    }
-                    if constexpr (NPART == 2) {
-                        s1 += __shfl_xor(s1, 32);
-                        s2 += __shfl_xor(s2, 32);
-                    }
-                    if (part == 0 && m < p.M) {
-                        float* dst = p.stat_part + ((size_t)nt_ * p.M + m) * 2;
-                        dst[0] = s1;
-                        dst[1] = s2;
-                    }
-                }
-            } else {      // PASE_EPI_MSE_CTX
-                const int half = p.r_ctx / 2;
-                const bool lean = pl.epi32 && rows_full && pase_wave_all(run) != 0;          // uniform
-                if (lean) {
-                    // lean form (see the store branch): 32-bit byte offsets off wave-uniform row pointers; the four targets of a
-                    // column quad are four consecutive label samples -- one unaligned 16-byte load where the context window
-                    // stays inside the sequence, four predicated loads at its edges
-                    const unsigned nc4 = (unsigned)p.Ncols * 4u;
-                    const unsigned ooff = (unsigned)(((size_t)sq[0] * p.M + (size_t)(lane >> 5)) * (size_t)p.Ncols + (size_t)qq[0]) * 4u;
-                    const unsigned loff = (unsigned)(sq[0] * p.label_D * p.Ncols + qq[0] - half) * 4u;
-                    const int tb0 = qq[0] - half;
-                    const int d_first = (int)div_magic((unsigned)m0, pl.rctx_magic);
-                    const size_t rowb0 = (size_t)(m0 + rw0 + 8 * c0) * (size_t)nc4;
-                    char* yrow = p.y ? reinterpret_cast<char*>(p.y) + rowb0 : nullptr;
-                    char* grow = p.grad_out ? reinterpret_cast<char*>(p.grad_out) + rowb0 : nullptr;
-                    const char* lab = reinterpret_cast<const char*>(p.label);
-                    const bool use_pf = pf_c0 == c0 && pf_n >= c1 - c0;          // uniform
-                    pase_static_for<MAXG>([&](auto g_tag) __attribute__((always_inline)) {
-                        constexpr int g = decltype(g_tag)::value;
-                        const int c = c0 + g;
-                        if (c < c1) {                                            // uniform
-                            float bv[4], tg[4][4];
-                            X6cF4 t4[4];
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const int m = mrow0 + 2 * (4 * c + i);
-                                t4[i] = *reinterpret_cast<const X6cF4*>(tl_rows + 2 * (4 * c + i) * TILE_P);
-                                if (PFG > 0 && use_pf) {
-                                    bv[i] = pf_bv[g < PFG ? g : 0][i];
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) tg[i][e] = pf_tg[g < PFG ? g : 0][i][e];
-                                } else if (ZP) {
-                                    // bias and labels out of LDS (copied there a tick ago: stage_aux): slab row = label channel
-                                    // d - d_first, slab column = tile column + context index
-                                    bv[i] = p.bias != nullptr ? aux_bias[rw0 + (lane >> 5) + 2 * (4 * c + i)] : 0.f;
-                                    const int d = (int)div_magic((unsigned)m, pl.rctx_magic);
-                                    const int jj = m - d * p.r_ctx;
-                                    const float* sl = aux_slab + (d - d_first) * SLAB_P + cl + jj;
-                                    const int tb = tb0 + jj;
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) {
-                                        const float t = sl[e];
-                                        tg[i][e] = (unsigned)(tb + e) < (unsigned)p.Ncols ? t : 0.f;
-                                    }
-                                } else {
-                                    bv[i] = p.bias != nullptr ? p.bias[m] : 0.f;
-                                    const int d = (int)div_magic((unsigned)m, pl.rctx_magic);
-                                    const int jj = m - d * p.r_ctx;
-                                    const unsigned la = loff + (unsigned)(d * p.Ncols + jj) * 4u;
-                                    const int tb = tb0 + jj;
-                                    if (tb >= 0 && tb + 3 < p.Ncols) {
-                                        const pase_f4u t = *reinterpret_cast<const pase_f4u*>(lab + la);
-                                        tg[i][0] = t.x;
-                                        tg[i][1] = t.y;
-                                        tg[i][2] = t.z;
-                                        tg[i][3] = t.w;
-                                    } else {
-#pragma unroll
-                                        for (int e = 0; e < 4; ++e) {
-                                            tg[i][e] = 0.f;
-                                            if ((unsigned)(tb + e) < (unsigned)p.Ncols) tg[i][e] = *reinterpret_cast<const float*>(lab + (la + 4u * e));
-                                        }
-                                    }
-                                }
-                            }
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const float tv[4] = {t4[i].x, t4[i].y, t4[i].z, t4[i].w};
-                                float pr[4], df[4];
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    pr[e] = tv[e] + bv[i];
-                                    df[e] = pr[e] - tg[i][e];
-                                    drain_lsum = fmaf(df[e], df[e], drain_lsum);
-                                    df[e] *= p.grad_scale;
-                                }
-                                if (yrow) {
-                                    pase_store_run4(reinterpret_cast<float*>(yrow + ooff), pr);
-                                    yrow += 2 * nc4;
-                                }
-                                if (grow) {
-                                    pase_store_run4(reinterpret_cast<float*>(grow + ooff), df);
-                                    grow += 2 * nc4;
-                                }
-                            }
-                            drain_vm_ops += 4 * ((yrow ? 1 : 0) + (grow ? 1 : 0));
-                        }
-                    });
-                } else {
-                drain_vm_ops = -1000;
-                size_t ob[4], lb[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    ob[e] = (size_t)sq[e] * p.M * (size_t)p.Ncols + (size_t)qq[e];
-                    lb[e] = (size_t)sq[e] * p.label_D * (size_t)p.Ncols;
-                }
-#pragma unroll 1
-                for (int it = 4 * c0; it < 4 * c1; ++it) {
-                    const int m = mrow0 + 2 * it;
-                    const bool mok = m < p.M;
-                    const int mm = mok ? m : 0;
-                    const float bvv = (p.bias != nullptr && mok) ? p.bias[mm] : 0.f;
-                    const X6cF4 t4 = *reinterpret_cast<const X6cF4*>(tl_rows + 2 * it * TILE_P);
-                    const int d = (int)div_magic((unsigned)mm, pl.rctx_magic);
-                    const int jj = mm - d * p.r_ctx;
-                    const float tv[4] = {t4.x, t4.y, t4.z, t4.w};
-                    float pr[4], df[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int tb = qq[e] - half + jj;
-                        float tg = 0.f;
-                        if (mok && okc[e] && (unsigned)tb < (unsigned)p.Ncols) tg = p.label[lb[e] + (size_t)d * p.Ncols + tb];
-                        pr[e] = tv[e] + bvv;
-                        df[e] = pr[e] - tg;
-                        if (mok && okc[e]) drain_lsum += df[e] * df[e];
-                        df[e] *= p.grad_scale;
-                    }
-                    const size_t ro = (size_t)mm * (size_t)p.Ncols;
-                    if (mok) {
-                        if (run) {
-                            if (p.y) pase_store_run4(p.y + ro + ob[0], pr);
-                            if (p.grad_out) pase_store_run4(p.grad_out + ro + ob[0], df);
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (okc[e]) {
-                                    if (p.y) p.y[ro + ob[e]] = pr[e];
-                                    if (p.grad_out) p.grad_out[ro + ob[e]] = df[e];
-                                }
-                        }
-                    }
-                }
-#if !defined(PASE_HIPEMU)
-                __builtin_amdgcn_s_waitcnt(0x0F70);      // (see the store branch)
-#endif
-                }
-                if (last) {
-                    const float ls = pase_wave_sum64(drain_lsum);
-                    drain_lsum = 0.f;
-                    if (lane == 0) atomicAdd(p.loss_acc, (double)ls);
-                }
-            }
-            }
-        };
-        // A tile is drained during the ticks 1 .. stages - 1 of the item that follows it, `drain_gpt` groups per tick (the tile is
-        // free again before the barrier that ends that item's last stage); tick 0 prefetches the first chunk.  drain_tile takes
-        // at most two groups per call.
-        // (pre-split form: the item's LAST tick copies the tile's bias / labels into LDS -- stage_aux -- so the drain of the
-        //  previous tile must be over one tick earlier)
-        const int drain_ticks = ZP ? GS - 2 : GS - 1;
-        const int drain_gpt = (NGRP + drain_ticks - 1) / drain_ticks;
-        int drain_pos = 0;                            // groups of the pending tile already drained
-        auto drain_step = [&](int item, int gi_c, bool fin) __attribute__((always_inline)) {      // -> true: the tile is done
-            // (ONE call site of drain_tile and one of drain_prefetch: every inlined copy costs the converting waves registers)
-            const int target = fin ? NGRP : min(NGRP, gi_c * drain_gpt);                      // gi_c == 0: nothing yet
-            for (int cc = drain_pos; cc < target; cc += MAXG)
-                drain_tile(item, cc, min(cc + MAXG, target), min(cc + MAXG, target) == NGRP);
-            const bool tile_done = target >= NGRP;
-            drain_pos = tile_done ? 0 : target;          // (ONE assignment: two stores behind a branch became a store through a
-                                                         //  selected address, and the counter lived in scratch memory)
-            if constexpr (PFG > 0) {
-                if (!tile_done) drain_prefetch(item, target, min(target + 2, min(NGRP, (gi_c + 1) * drain_gpt)));
-            }
-            return tile_done;
-        };
-
-        if constexpr (STREAM && !ZP) {
-            // ---- STREAM, operands split while they are staged (registers).  One stage per tick, three cursors along the
-            // workgroup's stage stream (items blockIdx.x, + gridDim.x, ...; every item has GS >= 2 stages, no split-K):
-            //   C  the stage the compute waves multiply during this tick (LDS buffer bsel),
-            //   S  = C + 1: waited for, converted and written to the other LDS buffer (register set (stream stage) mod 3),
-            //   L  = C + 3: its loads are issued into the register set C's stage left free one tick ago.
-            // Ticks -3 .. -1 fill the pipeline (the barrier that ends tick -1 is the compute waves' first barrier); an item
-            // boundary is nothing special for S and L except that each takes the next item's geometry when it crosses one --
-            // L by setup_item (live / full / inter_slots and the per-lane position arrays), S by copying the three uniform
-            // masks L holds at that moment (L entered the item two ticks earlier and, with >= 2 stages per item, has not left it).
-            const int NST = GS;
-            int itemL = (int)blockIdx.x - (int)gridDim.x, itemG = -1, giL = NST, nliveL = 0;
-            bool L_has = true;
-            int itemS = -1, giS = NST;
-            bool S_has = true;
-            int itemC = (int)blockIdx.x, giC = 0;
-            int c_last = 0, tile_item = -1;
-            bool finishing = false;
-            // (the tick is unrolled three times with STATIC register sets, as in the unstreamed loop: a set chosen at run time makes
-            //  the staging registers loop-carried values that cross if-chains, and the compiler then moves them between
-            //  registers while their loads are in flight -- pase_amd/build.py's ISA lint rejects such a build)
-            int v = -3;
-            bool done = false;
-            auto tick = [&](auto r_tag) __attribute__((always_inline)) {
-                constexpr int r = decltype(r_tag)::value;           // register set of stream stage v + 3 (and of stage v)
-                constexpr int rn = (r + 1) % XR;                     // ... of stream stage v + 1
-                if (!finishing) {
-                    // ---- S: stream stage v + 1
-                    if (v >= -1 && S_has) {
-                        if (giS == NST) {
-                            if (itemG != itemS) {
-                                itemS = itemG;
-                                giS = 0;
-                                liveS = live;
-                                fullS = full;
-                                interS = inter_slots;
-                            } else {
-                                S_has = false;
-                            }
-                        }
-                        if (S_has) {
-                            X6C_T0();
-                            {
-                                X6C_T0();
-                                x6c_vmwait_slots(c_last, false);   // everything but the loads of stream stage v + 2 has landed
-                                if (wave == 4) X6C_TACC(10);
-                            }
-                            const int bs = v >= 0 ? (bsel ^ 1) : bsel;
-                            store_stage(std::integral_constant<int, rn>{}, giS, bs);
-                            ++giS;
-                            if (wave == 4) X6C_TACC(11);
-                        }
-                    }
-                }
-                // ---- position arithmetic of the next item / the drain of the previous item's tile: big straight-line code with
-                // many live values.  NOTHING hidden may be in flight across it: the compiler believes the staging registers
-                // defined when their asm load was ISSUED, and where register pressure is high it splits live ranges with
-                // copies -- a copy of a register whose load has not landed keeps the old content (seen on the GPU in the first
-                // form of this loop: non-finite outputs at item boundaries while the emulator passed).  So: wait for
-                // everything (the loads of stream stage v + 2 were issued a whole tick ago), THEN run that code, and issue
-                // this tick's loads last.
-                const bool crossing = !finishing && L_has && giL == NST;
-                const bool drain_now = tile_item >= 0 && (finishing || v >= 0);
-                if (crossing || drain_now) {
-                    X6C_T0();
-                    x6c_vmwait<0>();
-                    if (wave == 4) X6C_TACC(15);
-                }
-                if (crossing) {
-                    X6C_T0();
-                    itemL += (int)gridDim.x;
-                    if (itemL < nitems) {
-                        setup_item(itemL);
-                        itemG = itemL;
-                        giL = 0;
-                        nliveL = 0;
-                        pase_static_for<NSLOT>([&](auto sl) __attribute__((always_inline)) {
-                            if (slot_live(decltype(sl)::value / NPS, decltype(sl)::value % NPS)) ++nliveL;
-                        });
-                    } else {
-                        L_has = false;
-                    }
-                    if (wave == 4) X6C_TACC(12);
-                }
-                // ---- the previous item's accumulator tile: published by the barrier that ended this item's first stage
-                if (drain_now) {
-                    X6C_T0();
-                    if (drain_step(tile_item, giC, finishing)) tile_item = -1;
-                    if (wave == 4) X6C_TACC(8);
-                }
-                // ---- L: stream stage v + 3
-                if (!finishing) {
-                    if (L_has) {
-                        X6C_T0();
-                        load_stage(r_tag, giL);
-                        ++giL;
-                        c_last = nliveL;
-                        if (wave == 4) X6C_TACC(13);
-                    } else {
-                        c_last = 0;
-                    }
-                }
-                if (finishing) {
-                    done = true;
-                    return;
-                }
-                if (v >= -1) {
-                    X6C_T0();
-                    __syncthreads();
-                    if (wave == 4) X6C_TACC(14);
-                }
-                if (v >= 0) {
-                    bsel ^= 1;
-                    if (++giC == NST) {
-                        if (wave == 4) X6C_STAMP(6);
-                        X6C_TRACE_NEXT();
-                        tile_item = itemC;
-                        itemC += (int)gridDim.x;
-                        giC = 0;
-                        if (itemC >= nitems) {
-                            finishing = true;
-                            __syncthreads();       // the compute waves have dumped the last item's accumulators
-                        }
-                    }
-                }
-                ++v;
-            };
-            while (true) {
-                tick(std::integral_constant<int, 0>{});
-                if (done) break;
-                tick(std::integral_constant<int, 1>{});
-                if (done) break;
-                tick(std::integral_constant<int, 2>{});
-                if (done) break;
-            }
-            return;
-        }
         const bool spectrum = p.post_op == PASE_POST_POW || p.post_op == PASE_POST_LOGPOW || p.post_op == PASE_POST_MAG;
         const bool epi_barrier = TM ? false : (p.epilogue == PASE_EPI_STORE ? (!spectrum && p.stat_part != nullptr) : true);
-#ifndef PASE_X6C_NODL     // (A/B builds, tools/ab_build.sh: the pre-split operands through registers as until round 4)
         if constexpr (ZP) {
             // Pre-split operands (weight gradients on phase planes, convolutions on channel-minor planes): a stage is a COPY,
             // and the stage buffers' chunk order is lane-linear -- global_load_lds_dwordx4 does it without registers, vector
@@ -1596,7 +938,6 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             // allocated on top of the load destinations -- the staging waves ran one memory latency per slot, 90 % busy, and
             // the weight gradients at 1290 clocks per step against 790 of MFMA work.)
             auto direct_stage = [&](int g, int bs, int fk) __attribute__((always_inline)) {      // fk: octet of the k-groups (0 / 1)
-                // (STREAM: the copies are hidden from the compiler, see x6c_dma16_hidden)
                 pase_static_for<NSLOT>([&](auto sl_tag) __attribute__((always_inline)) {
                     constexpr int sl = decltype(sl_tag)::value;
                     constexpr int kg = sl / NPS, ps = sl % NPS, par = kg & (NPAR - 1);
@@ -1615,115 +956,27 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                             const int gidx = min(g * KGS + kg, pl.G - 1);
                             const unsigned off = (unsigned)((gidx * 2 + fk) * p.S) * (unsigned)pl.xp_tpad + pos_xoff[par][ps];
 #pragma unroll
-                            for (int pz = 0; pz < 3; ++pz) {
-                                if constexpr (STREAM) x6c_dma16_hidden(xpc + (size_t)pz * (size_t)pl.xp_plane + off, dst + pz * PLANE, lane);
-                                else x6c_load_lds16(xpc + (size_t)pz * (size_t)pl.xp_plane + off, dst + pz * PLANE, lane);
-                            }
+                            for (int pz = 0; pz < 3; ++pz)
+                                x6c_load_lds16(xpc + (size_t)pz * (size_t)pl.xp_plane + off, dst + pz * PLANE, lane);
                         }
                     }
                 });
+                if constexpr (AL) {
+                    // the packed operand: this wave copies row tile (wave - 4) of every k-group of the stage -- three 1 KB
+                    // plane blocks in fragment order = lane-linear (k-groups past the last real one are zeros in the pack)
+                    const char* arow = reinterpret_cast<const char*>(p.wx6) +
+                                       ((size_t)(t_mt * 4 + (wave - 4)) * (size_t)pl.steps_total + (size_t)g * KGS) * 3072u + 16u * lane;
+                    pase_static_for<KGS_T>([&](auto kg_tag) __attribute__((always_inline)) {
+                        constexpr int kg = decltype(kg_tag)::value;
+                        if (kg < KGS) {                                           // uniform
+#pragma unroll
+                            for (int pz = 0; pz < 3; ++pz)
+                                x6c_load_lds16(arow + kg * 3072 + pz * 1024, &As[bs * ABUF + kg * AKG + (wave - 4) * 192 + pz * 64], lane);
+                        }
+                    });
+                }
             };
 
-            if constexpr (STREAM) {
-                // ---- STREAM, pre-split activation copied by LDS DMA: one cursor N = C + 1 (the stage published by this tick's
-                // barrier), same tick / drain structure as the register form above
-                const int NST = GS;
-                int itemN = (int)blockIdx.x - (int)gridDim.x, giN = NST;
-                bool N_has = true;
-                int itemC = (int)blockIdx.x, giC = 0, tile_item = -1;
-                bool finishing = false;
-                // bias and label slab of a tile -> LDS, by DMA, shared out over the four staging waves (wave w: slab rows w - 4,
-                // w, ... ; wave 4 also the bias).  Slab row dl = label channel d_first + dl, slab column cc = tile column + context
-                // index, i.e. flattened output column n0 + cc - r / 2 (columns outside the data are not copied: the drain's
-                // range check zeroes what it reads there).
-                auto stage_aux = [&](int item) __attribute__((always_inline)) {
-                    const int tl = xcd_swizzle(item, ntiles);
-                    const int nt_ = tl / pl.n_row_tiles, mt_ = tl - nt_ * pl.n_row_tiles;
-                    const int m0 = mt_ * BM, n0 = nt_ * BN;
-                    if (p.bias != nullptr && wave == 4) {
-#pragma unroll
-                        for (int h = 0; h < 2; ++h)
-                            if (m0 + 64 * h + lane < p.M) x6c_dma4_hidden(p.bias + m0 + 64 * h + lane, aux_bias + 64 * h, lane);
-                    }
-                    if (p.epilogue == PASE_EPI_MSE_CTX) {      // uniform
-                        const int half = p.r_ctx / 2;
-                        const int d_first = (int)div_magic((unsigned)m0, pl.rctx_magic);
-                        const int d_last = (int)div_magic((unsigned)min(m0 + BM - 1, p.M - 1), pl.rctx_magic);
-                        const int nrows = min(d_last - d_first + 1, SLAB_ROWS);
-                        pase_static_for<3>([&](auto k_tag) __attribute__((always_inline)) {
-                            constexpr int k = decltype(k_tag)::value;
-                            const int cc = 64 * k + lane;
-                            const int nn = n0 + cc - half;
-                            const bool cval = cc < SLAB_P && nn >= 0 && nn < ntot;
-                            const unsigned nu = (unsigned)(cval ? nn : 0);
-                            const int s_ = (int)div_magic(nu, pl.ncols_magic);
-                            const float* src = p.label + ((size_t)s_ * p.label_D + d_first) * (size_t)p.Ncols + ((int)nu - s_ * p.Ncols);
-                            for (int dl = wave - 4; dl < nrows; dl += 4)
-                                if (cval) x6c_dma4_hidden(src + (size_t)dl * (size_t)p.Ncols, aux_slab + dl * SLAB_P + 64 * k, lane);
-                        });
-                    }
-                };
-                // One tick of a staging wave: (1) operand DMA of the stage this tick's barrier publishes; at the item's last
-                // tick also the tile's bias / labels (the drain that needs them starts a tick later, or behind the final
-                // barrier); (2) its share of the previous tile's drain: LDS reads and global STORES only; (3) wait until at
-                // most (number of those stores) vector memory operations are outstanding -- the counter retires in order, so
-                // that is exactly "the DMA has landed", and nobody waits for a store acknowledgement -- then the barrier.
-                for (int v = -1;; ++v) {
-                    drain_vm_ops = 0;
-                    if (!finishing) {
-                        if (N_has && giN == NST) {
-                            itemN += (int)gridDim.x;
-                            if (itemN < nitems) {
-                                setup_item(itemN);
-                                giN = 0;
-                            } else {
-                                N_has = false;
-                            }
-                        }
-                        if (N_has) {
-                            X6C_T0();
-                            direct_stage(giN, v >= 0 ? (bsel ^ 1) : bsel, fkL);
-                            ++giN;
-                            if (wave == 4) X6C_TACC(13);
-                        }
-                        if (v >= 0 && giC == NST - 1) stage_aux(itemC);
-                    }
-#ifndef PASE_HIPEMU
-                    asm volatile("" ::: "memory");      // the stores below stay behind the DMA above (the wait counts on it)
-#endif
-                    if (tile_item >= 0 && (finishing || (v >= 0 && giC >= 1))) {
-                        X6C_T0();
-                        if (drain_step(tile_item, giC, finishing)) tile_item = -1;
-                        if (wave == 4) X6C_TACC(8);
-                    }
-                    if (finishing) break;
-                    {
-                        X6C_T0();
-                        x6c_vmwait_le(drain_vm_ops);
-                        if (wave == 4) X6C_TACC(10);
-                    }
-                    {
-                        X6C_T0();
-                        __syncthreads();
-                        if (wave == 4) X6C_TACC(14);
-                    }
-                    if (v >= 0) {
-                        bsel ^= 1;
-                        if (++giC == NST) {
-                            if (wave == 4) X6C_STAMP(6);
-                            X6C_TRACE_NEXT();
-                            tile_item = itemC;
-                            itemC += (int)gridDim.x;
-                            giC = 0;
-                            if (itemC >= nitems) {
-                                finishing = true;
-                                __syncthreads();
-                            }
-                        }
-                    }
-                }
-                return;
-            }
             auto prologue_dl = [&](int item) __attribute__((always_inline)) {
                 if (wave == 4) X6C_STAMP(4);
                 setup_item(item);
@@ -1757,7 +1010,6 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             }
             return;
         }
-#endif
         int item = next_item((int)blockIdx.x - (int)gridDim.x);
         if (item < nitems) prologue(item);
         while (item < nitems) {
@@ -1766,7 +1018,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 pase_static_for<XR>([&](auto r) __attribute__((always_inline)) {
                     constexpr int rn = (decltype(r)::value + 1) % XR;          // register set of stage gi + 1
                     const int gi = gb + decltype(r)::value;                     // stage (relative) being multiplied
-                    if (gi < nst - X6C_EARLY_PRO) {
+                    if (gi < nst) {
                         X6C_T0();
 #ifdef PASE_X6C_TRACE
                         if (!(pl.prio & 128))      // ablation: the staging waves only keep the barriers (results are garbage)
@@ -1815,44 +1067,14 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 }
             }
             item = next_item(item);
-#if X6C_EARLY_PRO
-            // Measured variant (round 4, NOT the default): the compute waves are multiplying the item's LAST stage and nothing
-            // is left to stage for it, so the next item's prologue (position arithmetic, first loads, first stage into the
-            // other buffer -- free since the barrier that ended the stage before) could run under that stage instead of
-            // beside the compute waves' epilogue.  It is slower (PASE+ bs32 step 29.9 -> 30.8 ms, same box): the prologue
-            // (7 ... 16 k clocks) is longer than the last stage of most launches, so the compute waves now wait for it at the
-            // stage's barrier and only then start an epilogue that is no faster alone than beside the prologue.
-            if (item < nitems) {
-                bsel ^= 1;
-                prologue(item);
-                bsel ^= 1;
-            }
-            __syncthreads();               // end of the last stage
-            bsel ^= 1;
-#else
             if (item < nitems) prologue(item);
-#endif
             // the barrier of the compute waves' epilogue (partial BatchNorm sums / loss partials go through LDS)
             if (epi_barrier) __syncthreads();
         }
         return;
     }
 
-  // (accumulators live across the item loop: STREAM dumps an item's sums at the START of the next item's turn, behind that
-  //  item's first two weight-fragment loads, so that those have landed when its first MFMA step wants them)
   f32x16 accH[4], accS[4];
-  bool have_prev = false;
-  auto dump_tile = [&]() __attribute__((always_inline)) {
-      // STREAM: hh + (the five small terms) -> the LDS tile (D layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4
-      // (lane >> 5)); the staging waves drain it during the next item's second stage (drain_tile).  The tile is free: its
-      // previous content was drained before the barrier that ended the dumped item's last stage.
-      float* const td = acc_tile + (wm * 32 + 4 * fk) * TILE_P + fr;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-              td[((r & 3) + 8 * (r >> 2)) * TILE_P + 32 * j] = accH[j][r] + accS[j][r];
-  };
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     // ---- tile decode -----------------------------------------------------------------------
     const int split = item / ntiles;
@@ -1890,11 +1112,11 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     // 2.9 k clocks per tile -- a load there waits behind whatever the memory pipeline holds at that point, and the compute
     // wave is alone on its SIMD: nothing hides it (tools/trace_x6c.py, `qrnn` against `qrnn_nb`).
     static_assert(NBT == 4, "accumulators are declared for four B tiles");
-    if constexpr (!STREAM) {
+    {
         float binit[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) binit[r] = 0.f;
-        if (!TM && !STREAM && bias_init && split == 0) {      // uniform (STREAM: the drain adds the bias)
+        if (!TM && bias_init && split == 0) {      // uniform
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 32 + 4 * fk + (r & 3) + 8 * (r >> 2);
@@ -1980,37 +1202,6 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             for (int pz = 0; pz < 3; ++pz) ab[pz] += adv;
         }
     };
-#ifdef PASE_X6C_OLDLOOP      // A/B builds only (tools/ab_build.sh): round 3's step, fragments read right in front of their use
-    // (Three hand-pinned schedules were measured against leaving the 12 ds_read_b128 + 24 MFMAs of a step to the compiler:
-    //  (1) prefetching the next pair of B tiles before each block of 12 MFMAs, two tiles alternating: 4 ... 14 % SLOWER on
-    //  every convolution of the PASE+ step;  (2) units of (planes m, l) / (plane h) with all four tiles rotating and the next
-    //  unit's fragments in flight: +-0 (29.5 vs 29.4 ms of GEMM time) at 256 VGPRs;  (3) the same units as single asm blocks
-    //  of 12 back-to-back MFMAs, same-accumulator products adjacent, one s_waitcnt in front: +-0 (30.3 ms on a box that gives
-    //  29.9 ... 30.7).  An 11-tap layer runs a step in ~1050-1100 s_memtime ticks against 768 MFMA-pipe cycles with 1 % of
-    //  the loop in barriers, the staging waves 47 % busy, LDS bank conflicts 0.3 % and no change when every A fragment load
-    //  hits L1 (tools/trace_x6c.py ablations) -- what holds the pipe at ~70 % inside the loop is not identified.)
-    auto mfma_step = [&](const u32x4 (&a)[3], const u32x4* xb) __attribute__((always_inline)) {
-        // plane pairs of the five small terms, smallest first: mm, hl, lh, hm, mh -> accS; hh -> accH
-        constexpr int PZA[5] = {1, 0, 2, 0, 1}, PZB[5] = {1, 2, 0, 1, 0};
-#pragma unroll
-        for (int jp = 0; jp < NBT; jp += 2) {
-            u32x4 b0[3], b1[3];
-#pragma unroll
-            for (int pz = 0; pz < 3; ++pz) {
-                b0[pz] = xb[pz * PLANE + bbase[jp]];
-                b1[pz] = xb[pz * PLANE + bbase[jp + 1]];
-            }
-#pragma unroll
-            for (int pi = 0; pi < 5; ++pi) {
-                accS[jp] = pase_mfma_bf16_32x32x16(a[PZA[pi]], b0[PZB[pi]], accS[jp]);
-                accS[jp + 1] = pase_mfma_bf16_32x32x16(a[PZA[pi]], b1[PZB[pi]], accS[jp + 1]);
-            }
-            accH[jp] = pase_mfma_bf16_32x32x16(a[0], b0[0], accH[jp]);
-            accH[jp + 1] = pase_mfma_bf16_32x32x16(a[0], b1[0], accH[jp + 1]);
-        }
-    };
-
-#else
     // The step's 12 B fragments are SOFTWARE-PIPELINED over its two halves (tiles {0, 1} and {2, 3}): the six ds_read_b128 of
     // the next half -- the second half of this step, then the first half of the next step of the stage -- are issued one per
     // two MFMAs of the current half, so a fragment has ~10 MFMAs (320+ cycles) to arrive.  Round 3 read a half's six fragments
@@ -2058,7 +1249,6 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         }
     };
 
-#endif
     // ---- main loop: stage = KGS k-groups x A taps; step st = kg * A + t -------------------------------------
     u32x4 a0[3], a1[3], a2[3];
 #ifdef PASE_ABL_NOA
@@ -2068,60 +1258,11 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         asm volatile("" : "+v"(a0[pz]), "+v"(a1[pz]), "+v"(a2[pz]));
     }
 #endif
-    load_a(a0);
-    load_a(a1);
-    if constexpr (STREAM) {
-        // the previous item's accumulators -> LDS tile, then zero (the drain adds the bias)
-        if (have_prev) {
-            dump_tile();
-            if (wave == 0) X6C_STAMP(3);
-        }
-#pragma unroll
-        for (int j = 0; j < NBT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                accH[j][r] = 0.f;
-                accS[j][r] = 0.f;
-            }
+    if constexpr (!AL) {
+        load_a(a0);
+        load_a(a1);
     }
-#ifdef PASE_X6C_A3        // A/B builds: weight-gradient fragments THREE steps ahead (four register sets)
-    constexpr bool A3 = TM;
-#else
-    constexpr bool A3 = false;
-#endif
-    u32x4 a3[3];
-    if constexpr (A3) load_a(a2);
-#ifdef PASE_X6C_OLDLOOP
     __syncthreads();
-    if (wave == 0) X6C_STAMP(1);
-    int gi = 0, st = 0, kg = 0, t = 0;
-    bool done = false;
-    auto step = [&](const u32x4 (&acur)[3], u32x4 (&anxt)[3]) __attribute__((always_inline)) {
-        const bool last = (gi == nst - 1) && (st == nsteps - 1);            // uniform
-        load_a(anxt);
-        mfma_step(acur, &Xs[bsel * BUF + kg * KGC + t]);
-        ++st;
-        if (++t == pl.A) {
-            t = 0;
-            ++kg;
-        }
-        if (st == nsteps) {
-            st = 0;
-            kg = 0;
-            ++gi;
-            {
-                X6C_T0();
-                __syncthreads();
-                if (wave == 0) X6C_TACC(9);
-            }
-            bsel ^= 1;
-        }
-        done = last;
-    };
-#else
-    // (STREAM: only the workgroup's first item starts behind a barrier -- every later item's first stage was published by the
-    //  barrier that ended the previous item's last stage)
-    if (!STREAM || item == (int)blockIdx.x) __syncthreads();
     if (wave == 0) X6C_STAMP(1);
     // step bookkeeping in increments (no multiplies, four scalar counters): chunk offset of the step's fragments inside Xs,
     // taps left in the k-group, steps left in the stage, stages left in the item
@@ -2151,16 +1292,53 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         }
         done = stages_left == 0;
     };
+    if constexpr (AL) {
+        // packed operand out of LDS, ONE step ahead (the next k-group of the stage; behind a stage barrier the first k-group
+        // of the new stage, together with load_first's fragments): two register sets
+        // (the stage / k-group part of the address stays on the scalar unit -- a chunk offset that advances per step, like the
+        //  staged operand's xoff -- and the lane's part is one loop-invariant VGPR: with both in ONE per-lane integer the
+        //  compiler moved the whole step bookkeeping, bsel and xoff included, to the vector ALU and spilled 238 registers)
+        int axoff = bsel * ABUF;
+        const int alane = wm * 192 + lane;
+        auto read_a = [&](u32x4 (&a)[3], const u32x4* src) __attribute__((always_inline)) {
+#ifndef PASE_ABL_NOA
+#pragma unroll
+            for (int pz = 0; pz < 3; ++pz) a[pz] = src[alane + 64 * pz];
 #endif
-    if constexpr (A3) {
+        };
+        read_a(a0, &As[axoff]);
+        auto step_al = [&](const u32x4 (&acur)[3], u32x4 (&anxt)[3]) __attribute__((always_inline)) {
+            const u32x4* xb = &Xs[xoff];
+            xoff += KGC;                                                          // (weight gradients: one "tap" per k-group)
+            const bool stage_end = --steps_left == 0;                             // uniform
+            // (unconditional: at the stage's last step a harmless re-read of the current fragments -- a read behind a branch
+            //  would sit in a block of its own, outside the step's pinned schedule)
+            axoff += stage_end ? 0 : AKG;
+            read_a(anxt, &As[axoff]);
+            PASE_SGB(0x100, 3);
+            mfma_step(acur, xb, stage_end ? xb : &Xs[xoff]);
+            if (stage_end) {
+                {
+                    X6C_T0();
+                    __syncthreads();
+                    if (wave == 0) X6C_TACC(9);
+                }
+                bsel ^= 1;
+                xoff = bsel * BUF;
+                axoff = bsel * ABUF;
+                steps_left = nsteps;
+                --stages_left;
+                load_first(&Xs[xoff]);                // (past the last stage: a harmless read of the other buffer)
+                read_a(anxt, &As[axoff]);
+            }
+            done = stages_left == 0;
+        };
         while (true) {
-            step(a0, a3);
+            step_al(a0, a1);
             if (done) break;
-            step(a1, a0);
+            step_al(a1, a2);
             if (done) break;
-            step(a2, a1);
-            if (done) break;
-            step(a3, a2);
+            step_al(a2, a0);
             if (done) break;
         }
     } else {
@@ -2175,11 +1353,6 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     }
 
     if (wave == 0) X6C_STAMP(2);
-    if constexpr (STREAM) {
-        have_prev = true;        // dumped at the start of the next item's turn, or behind the loop
-        X6C_TRACE_NEXT();
-        continue;
-    }
     // ---- accumulators: hh + (the five small terms) -------------------------------------------------------
     // From here on the descriptor is read through the kernel-argument segment again (`p` is the first argument): the two
     // dozen fields only the epilogue needs then do not occupy scalar registers during the main loop (the compiler loads
@@ -2416,12 +1589,6 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             for (int j = 0; j < NBT; ++j) cb4[j] = (unsigned)(cbase[j] + 4 * fk * pe.Tout) * 4u;
             char* ybase = reinterpret_cast<char*>(p.y);
             if (wave == 0) X6C_FSTAMP(18);
-#ifdef PASE_ABL_EPI2      // trace ablation: the row pass twice (slot 13 = end of the first, cold, pass; slot 14 = end of the second)
-#pragma unroll 1
-            for (int rep = 0; rep < 2; ++rep) {
-            asm volatile("" : "+v"(cb4[0]));
-            if (rep == 1 && wave == 0) X6C_FSTAMP(14);
-#endif
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int mu = mu0 + (r & 3) + 8 * (r >> 2);                    // uniform; this lane's row = mu + 4 * fk
@@ -2430,18 +1597,12 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
 #pragma unroll
                 for (int j = 0; j < NBT; ++j) {
                     const float v = acc[j][r];               // (bias included: !pshuf, see bias_init)
-#ifdef PASE_ABL_NOSTORE      // trace ablation: everything but the store instructions
-                    asm volatile("" ::"v"(v), "v"(cb4[j]), "s"(yrow));
-#else
                     *reinterpret_cast<float*>(yrow + cb4[j]) = v;
-#endif
                     s1 += v;
                     s2 += v * v;
                 }
-#ifndef PASE_ABL_EPI2
                 if (r == 0 && wave == 0) X6C_FSTAMP(14);
                 if (r == 7 && wave == 0) X6C_FSTAMP(15);
-#endif
                 if (p.stat_part) {   // uniform branch
                     s1 = pase_half_sum_lane31(s1);
                     s2 = pase_half_sum_lane31(s2);
@@ -2452,9 +1613,6 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                     }
                 }
             }
-#ifdef PASE_ABL_EPI2
-            }
-#endif
         } else {
         load_bias();
         if (ple.splitk > 1) {
@@ -2630,24 +1788,13 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     X6C_TRACE_NEXT();
   }   // items
 #if !defined(PASE_HIPEMU)
-  if constexpr (!STREAM) {
-      // (every instantiation: see the STREAM branch below -- the unstreamed 1x1 and weight-gradient kernels carried the same
-      //  compiler-inserted waits inside their hidden load sequences)
-      __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
-  }
+  // Close the compiler's vector-memory books before this path joins the staging waves' code in the control-flow graph (the
+  // compiler lays the role branch and this exit through one block): the weight-fragment prefetches past the last step are
+  // never consumed, hence never waited for, and -- reaching the staging loop as "pending loads" -- they made the compiler put
+  // s_waitcnt vmcnt(1 .. 2) into the hidden load sequences of the staging waves (round 5, seen in the ISA of the 1x1 and
+  // weight-gradient instantiations; pase_amd/build.py lints for it)
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
 #endif
-  if constexpr (STREAM) {
-      if (have_prev) dump_tile();
-#if !defined(PASE_HIPEMU)
-      // Close the compiler's vector-memory books before this path joins the staging waves' code in the control-flow graph (the
-      // compiler lays the role branch and this exit through one block): the weight-fragment prefetches past the last step are
-      // never consumed, hence never waited for, and -- reaching the staging loop as "pending loads" of v[130:137] -- they made
-      // the compiler put s_waitcnt vmcnt(1 .. 2) into every hidden load sequence of the staging waves: a synchronous pipeline
-      // (seen in the ISA; the strided and 1x1 launches ran 14 ... 80 % slower than unstreamed).
-      __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
-#endif
-      __syncthreads();      // the staging waves drain the last item's tile behind this barrier
-  }
 }
 
 #ifdef PASE_X6C_TRACE
@@ -3024,46 +2171,6 @@ bool pase_x6c_plan(const PaseConvGemm& p, PaseX6cPlan& pl) {
         splitk = (GS + g_per - 1) / g_per;
     }
     pl.splitk = splitk;
-    // The streamed form (conv_x6c_kernel<..., STREAM>): 128 x 128 tiles, one split, at least two stages per item (the
-    // staging waves' load and store cursors then never span more than two items), and an epilogue the drain implements --
-    // plain stores (+ BatchNorm partial sums) without pixel shuffle or post-op, or the r-context MSE.  x6_ctl bit 7 forbids
-    // it (A/B measurements, tests of the unstreamed form).
-    {
-        const bool epi_ok = p.epilogue == PASE_EPI_MSE_CTX ||
-                            (p.epilogue == PASE_EPI_STORE && p.ps == 1 && p.post_op == PASE_POST_NONE);
-        bool ok = !narrow && epi_ok && splitk == 1 && GS >= 2 && !(p.x6_ctl & 128);
-        // Measured on the PASE+ bs32 step (same-box A/B, round 5): the streamed form wins where the staging waves have slack --
-        // pre-split operands (LDS DMA: they are idle) and stride-1 layers with >= 8 taps (a converted element feeds >= 32 MFMAs)
-        // -- and loses 8 ... 25 % where they are the bottleneck already (strided layers: 6 taps' per conversion; 1x1 and
-        // stride-10 layers split while staged), because the drain and the next item's position arithmetic land on them.
-        // x6_ctl bit 0 (tests, A/B runs) skips this rule like the other routing rules.
-#ifdef PASE_X6C_STREAM_REG
-        if (!force && !(p.x6_ctl & 0x10000) && !(xp_want && p.xp6 != nullptr) && !(pl.P == 1 && pl.A >= 8)) ok = false;      // (bit 16: A/B runs stream every eligible launch)
-#else
-        // The shipped library streams the pre-split launches only.  The form that converts while it stages is correct (GPU:
-        // bit-identical to the compiler-waited build) but buys 0 ... 3 % on the stride-1 11-tap layers, loses everywhere else,
-        // and its converting waves sit at the register limit (the lean drain + prefetch made them spill: the build's guard
-        // fires); it is compiled with -DPASE_X6C_STREAM_REG for A/B runs.
-        if (!(xp_want && p.xp6 != nullptr)) ok = false;
-        // ... and only on request (x6_ctl bit 16: tests, A/B runs, tools/trace_x6c.py).  Measured on the PASE+ bs32 step (same-box
-        // A/B, round 5): even with every wait the staging waves did not need removed (hidden DMA, bias / labels out of LDS, the
-        // operand DMA waited for by counting stores) a staging wave drains 32 tile rows in ~17 k clocks beside a compute wave that
-        // never leaves the matrix pipe -- the four compute waves do the same epilogue in 9 ... 13 k with the pipe idle.  LPS heads
-        // 0.59 -> 0.73 ms, QRNN projection 0.34 -> 0.36, 840-row heads + 18 %: the epilogue's instructions issue several times
-        // slower on the staging waves than the 8 ... 12 cycles per instruction their conversion work had suggested.
-        if (!(p.x6_ctl & 0x10000)) ok = false;
-#endif
-        // pre-split streamed form: three stages per item (drain window + the tick that copies the next drain's bias / labels),
-        // and the label slab of a 128-row tile must fit its LDS region (20 label channels, 128 + r - 1 <= 136 columns)
-        if (xp_want && p.xp6 != nullptr) {
-            if (GS < 3) ok = false;
-            if (p.epilogue == PASE_EPI_MSE_CTX && (p.r_ctx < 7 || p.r_ctx > 9)) ok = false;
-        }
-#if defined(PASE_X6C_NODL) || defined(PASE_X6C_OLDLOOP) || defined(PASE_X6C_EARLYPRO)
-        ok = false;      // A/B builds of the unstreamed loop's variants
-#endif
-        pl.stream = ok ? 1 : 0;
-    }
     return true;
 }
 
@@ -3087,17 +2194,6 @@ int pase_x6c_launch(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st
     const dim3 grid((unsigned)nwg), block(NT);
     if (pl.WM == 2) {
         PASE_LAUNCH((conv_x6c_kernel<320, 2, false, false, true>), grid, block, st, p, pl);
-    } else if (pl.stream) {
-        if (pl.xp) {
-            if (pl.A == 1) PASE_LAUNCH((conv_x6c_kernel<128, 3, false, true, false, true>), grid, block, st, p, pl);
-            else PASE_LAUNCH((conv_x6c_kernel<192, 2, false, true, false, true>), grid, block, st, p, pl);
-        }
-#ifdef PASE_X6C_STREAM_REG
-        else if (pl.A == 1) PASE_LAUNCH((conv_x6c_kernel<128, 3, false, false, false, true>), grid, block, st, p, pl);
-        else PASE_LAUNCH((conv_x6c_kernel<192, 2, false, false, false, true>), grid, block, st, p, pl);
-#else
-        else return -12;
-#endif
     } else if (pl.xp) {
         if (pl.A == 1) PASE_LAUNCH((conv_x6c_kernel<128, 3, false, true>), grid, block, st, p, pl);
         else PASE_LAUNCH((conv_x6c_kernel<192, 2, false, true>), grid, block, st, p, pl);
@@ -3225,8 +2321,10 @@ bool pase_x6c_wgrad_plan(const PaseWgrad& w, PaseX6cWgrad& o) {
     if (Gk * 16 >= LIM) return false;
     pl.P = QP16; pl.A = 1; pl.G = (int)Gk; pl.CinP = 0x7fffffff;
     // k-groups (16 positions) per stage.  A stage ends in a barrier and the first fragment reads of the next one, ~1.4 k clocks
-    // against 0.8 k per step: the pre-split planes' kernel holds TMZ_KGS of them (LDS: 2 x 12 KB per k-group)
-    const int kgs_cap = pl.zp ? ((w.x6 >> 12) & 7 ? (int)((w.x6 >> 12) & 7) : TMZ_KGS) : 4;
+    // against 0.8 k per step: the pre-split planes' kernel holds TMZ_KGS of them (LDS: 2 x (12 + 12) KB per k-group -- the packed
+    // operand is staged too; round 4 measured 3, 4 and 5 k-groups per stage at the same time per launch)
+    const int kgs_req = (int)((w.x6 >> 12) & 7);           // (A/B runs: fewer k-groups per stage than the buffers hold)
+    const int kgs_cap = pl.zp ? (kgs_req && kgs_req < TMZ_KGS ? kgs_req : TMZ_KGS) : 4;
     pl.KGS = Gk >= kgs_cap ? kgs_cap : (int)Gk;
     const int GS = (pl.G + pl.KGS - 1) / pl.KGS;
     pl.steps_total = GS * pl.KGS;

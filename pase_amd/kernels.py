@@ -49,8 +49,8 @@ def declare(l):
     l.pase_conv_gemm_x6_bytes.restype = C.c_long
     l.pase_conv_gemm_plan_kind.argtypes = [C.POINTER(PaseConvGemm)]
     l.pase_conv_gemm_plan_kind.restype = C.c_int
-    l.pase_conv_gemm_streamed.argtypes = [C.POINTER(PaseConvGemm)]
-    l.pase_conv_gemm_streamed.restype = C.c_int
+    l.pase_conv_gemm_kernel_id.argtypes = [C.POINTER(PaseConvGemm)]
+    l.pase_conv_gemm_kernel_id.restype = C.c_int
     l.pase_pack_x6.argtypes = [C.POINTER(PaseConvGemm), C.c_void_p]
     l.pase_pack_x6.restype = C.c_int
     l.pase_conv_gemm_xp_bytes.argtypes = [C.POINTER(PaseConvGemm)]
@@ -134,8 +134,6 @@ def _conv_desc(x, w, y, *, S, Cin, Tin, M, K, taps, Ncols, Tout, ldw=None, bias=
                 | (16 if os.environ.get("PASE_X6C_NARROW", "1") == "0" else 0)
                 | (32 if os.environ.get("PASE_X6C_LEANEPI", "1") == "0" else 0)
                 | (64 if os.environ.get("PASE_X6C_BIASINIT", "1") == "0" else 0)
-                | (128 if os.environ.get("PASE_X6C_STREAM", "1") == "0" else 0)
-                | (0x10000 if os.environ.get("PASE_X6C_STREAM", "1") == "2" else 0)
                 | ((int(os.environ.get("PASE_X6C_STAGGER", "0")) & 255) << 8))
     d.max_wg = _max_wg(max_wg)
     return d
@@ -168,42 +166,58 @@ class GemmTimer(object):
         self.records = []
         self.tags = []
         self.pipes = []          # per launch: "x6" (split-bf16 kernel) or "f32" (exact-fp32 MFMA kernels)
+        self.kernels = []        # per launch: the kernel instantiation as rocprofv3 names it (prefix)
 
     def start(self):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream())
         return ev
 
-    def stop(self, family, flops, ev0, tag=None, pipe="f32"):
+    def stop(self, family, flops, ev0, tag=None, pipe="f32", kernel=None):
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record(torch.cuda.current_stream())
         self.records.append((family, flops, ev0, ev1))
         self.tags.append(tag)
         self.pipes.append(pipe)
+        self.kernels.append(kernel)
 
     def per_launch(self):
         """[(family, tag, flops, ms)] in launch order (tools/step_breakdown.py)."""
         torch.cuda.synchronize()
         return [(f, t, fl, e0.elapsed_time(e1)) for (f, fl, e0, e1), t in zip(self.records, self.tags)]
 
-    def summary(self, by_pipe=False):
-        """{family: launches / flops / ms}; by_pipe: {(family, pipe): ...}"""
+    def summary(self, by_pipe=False, by_kernel=False):
+        """{family: launches / flops / ms}; by_pipe: {(family, pipe): ...}; by_kernel: {kernel instantiation: ...}"""
         torch.cuda.synchronize()
         fam = {}
-        for (family, flops, e0, e1), pipe in zip(self.records, self.pipes):
-            f = fam.setdefault((family, pipe) if by_pipe else family, dict(launches=0, flops=0.0, ms=0.0))
+        for (family, flops, e0, e1), pipe, kern in zip(self.records, self.pipes, self.kernels):
+            f = fam.setdefault(kern if by_kernel else ((family, pipe) if by_pipe else family), dict(launches=0, flops=0.0, ms=0.0))
             f["launches"] += 1
             f["flops"] += flops
             f["ms"] += e0.elapsed_time(e1)
         return fam
 
 
+def conv_kernel_name(kid):
+    """pase_conv_gemm_kernel_id -> the prefix rocprofv3 shows for that instantiation"""
+    if kid == 0:
+        return "conv_gemm_kernel<"
+    if kid == 1:
+        return "sinc_x6_fwd_kernel"
+    b = lambda v: "true" if v else "false"
+    return "conv_x6c_kernel<%d, %d, false, %s, %s>" % (kid // 100, (kid // 10) % 10, b((kid % 10) & 2), b((kid % 10) & 1))
+
+
+WGRAD_KERNEL_NAMES = {0: "wgrad_", 1: "conv_x6c_kernel<128, 4, true, false, false>", 2: "conv_x6c_kernel<128, 4, true, false, false>",
+                      3: "conv_x6c_kernel<128, 4, true, false, false>", 4: "conv_x6c_kernel<128, 3, true, true, false>",
+                      5: "sinc_x6_wgrad_kernel<"}
+
 GEMM_TIMER = None
 LAST_WGRAD_X6 = None       # did the most recent wgrad_gemm launch run on the split-bf16 kernel
 LAST_WGRAD_KIND = None     # ... and in which orientation (pase_wgrad_plan_kind: 0 fp32 pipe, 1 / 2 / 3)
 LAST_XP = None             # did the most recent conv_gemm launch stage a pre-split activation (pase_pack_xp)
 LAST_PLAN_KIND = None      # plan kind of the most recent conv_gemm launch (0 fp32 pipe, 2 split-bf16 x6c): tests / reports
-LAST_STREAMED = None       # ... and whether it ran the streamed form of that kernel (pase_conv_gemm_streamed)
+LAST_KERNEL = None         # ... and the kernel instantiation it ran, as rocprofv3 names it (conv_kernel_name)
 
 
 def pack_wt(w, *, M, K, Cin, taps, ldw=None, tap_major=0):
@@ -302,14 +316,15 @@ def conv_gemm(x, w, y, want_stats=False, y_zeroed=False, **kw):
     if d.splitk != 1 and not y_zeroed:
         if _lib.lib().pase_conv_gemm_splitk(C.byref(d)) > 1:
             y.zero_()
-    global LAST_PLAN_KIND, LAST_STREAMED
+    global LAST_PLAN_KIND, LAST_KERNEL
     LAST_PLAN_KIND = _lib.lib().pase_conv_gemm_plan_kind(C.byref(d))
-    LAST_STREAMED = bool(_lib.lib().pase_conv_gemm_streamed(C.byref(d)))
+    LAST_KERNEL = conv_kernel_name(_lib.lib().pase_conv_gemm_kernel_id(C.byref(d)))
     _check(_lib.lib().pase_conv_gemm(C.byref(d), _stream()), "pase_conv_gemm")
     if ev0 is not None:
         GEMM_TIMER.stop("conv_gemm", 2.0 * d.S * d.Ncols * d.M * d.K, ev0,
                         "M%d K%d(Cin%d x %d) N%dx%d s%d ps%d epi%d" % (d.M, d.K, d.Cin, d.taps, d.S, d.Ncols, d.stride,
-                                                                    d.ps, d.epilogue), pipe="x6" if LAST_PLAN_KIND else "f32")
+                                                                    d.ps, d.epilogue), pipe="x6" if LAST_PLAN_KIND else "f32",
+                        kernel=LAST_KERNEL)
     return stat
 
 
@@ -471,7 +486,7 @@ def wgrad_gemm(g, z, dw, *, S, M, Tg, Ncols, Cin, Tz, taps, ldw=None, dbias=None
     if ev0 is not None:
         GEMM_TIMER.stop("wgrad_gemm", 2.0 * S * Ncols * M * (Cin * taps + (1 if dbias is not None else 0)), ev0,
                         "M%d Kw%d(Cin%d x %d) N%dx%d s%d" % (M, Cin * taps, Cin, taps, S, Ncols, d.stride),
-                        pipe="x6" if LAST_WGRAD_X6 else "f32")
+                        pipe="x6" if LAST_WGRAD_X6 else "f32", kernel=WGRAD_KERNEL_NAMES.get(LAST_WGRAD_KIND))
     return True
 
 
@@ -587,7 +602,7 @@ def mlp_head1_step(y, alpha0, w1, b1, alpha1, w2, b2, target, pred, dy, loss_acc
     _check(_lib.lib().pase_mlp_head1_step(C.byref(d), _stream()), "pase_mlp_head1_step")
     if ev0 is not None:
         GEMM_TIMER.stop("mlp_head1", 2.0 * d.S * d.T * (3 * d.C * d.H + 2 * d.H), ev0,
-                        "C%d H%d N%dx%d fwd + bwd" % (d.C, d.H, d.S, d.T), pipe="f32")
+                        "C%d H%d N%dx%d fwd + bwd" % (d.C, d.H, d.S, d.T), pipe="f32", kernel="mlp_head1_kernel<")
 
 
 def ctx_loss(pred, label, dpred, loss_acc, *, B, M, F, r_ctx, label_D, loss_type, grad_scale):

@@ -270,7 +270,8 @@ def test_bs32_ten_adam_steps_track(setup):
     # statistic / LayerNorm + twice the sequences) measured 3.1e-3 at step 5: two fp32 evaluations whose round-off Adam
     # turns into +-lr steps drift apart that fast; the first step, before any update, agrees to 1e-5 everywhere
     assert rel[0] <= 1e-5, rel
-    assert max(rel) <= (2e-3 if variant == "pase+" else 5e-3), rel
+    # (round 6: gates at what was measured + a margin -- 1.4e-3 -> 2e-3, 3.1e-3 -> 4e-3)
+    assert max(rel) <= (2e-3 if variant == "pase+" else 4e-3), rel
     assert ours[-1] < ours[0]              # and it trains
     # parameters after 10 Adam steps: Adam normalises every gradient to a +-lr step, so an element whose gradient is
     # round-off-sized (dense-skip and decoder weights early in training) moves by lr per step in a direction both

@@ -123,3 +123,12 @@ def grad_sample_index(numel, n=2048):
     st = numel // n
     st += (st % 2 == 0)
     return (np.arange(n) * st) % numel
+
+
+def comb_index(numel, n):
+    """same comb as oracle/make_golden.py:comb_index (benchmark-size golden: samples of the large tensors)"""
+    if numel <= n:
+        return np.arange(numel)
+    st = numel // n
+    st += (st % 2 == 0)
+    return (np.arange(n) * st) % numel

@@ -3,7 +3,7 @@
 #   1. kernel trace + stats of the bench command (per-kernel time),
 #   2. PMC passes in their OWN runs (--kernel-trace only beside --pmc): FETCH_SIZE, WRITE_SIZE, SQ counters,
 #   3. tools/summarize_profiles.py -> profiles/summary_<tag>.json (carries the kernel-source digest).
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 mkdir -p gpurun_out

@@ -28,17 +28,19 @@ NREP = 3
 for _ in range(NREP):
     tr.train_step(batch)
 rows = K.GEMM_TIMER.per_launch()
+kernels = list(K.GEMM_TIMER.kernels)
 K.GEMM_TIMER = None
 n = len(rows) // NREP
 agg = []
 for i in range(n):
     ms = sorted(rows[i + r * n][3] for r in range(NREP))[NREP // 2]
     f, tag, fl, _ = rows[i]
-    agg.append(dict(i=i, family=f, shape=tag, gflop=round(fl / 1e9, 2), ms=round(ms, 4), tflops=round(fl / ms / 1e9, 1)))
+    agg.append(dict(i=i, family=f, shape=tag, gflop=round(fl / 1e9, 2), ms=round(ms, 4), tflops=round(fl / ms / 1e9, 1),
+                    kernel=kernels[i]))
 tot = sum(a["ms"] for a in agg)
 print("launch  family       ms      TF/s   GFLOP  shape")
 for a in sorted(agg, key=lambda a: -a["ms"]):
-    print("%3d  %-11s %7.3f  %6.1f  %7.1f  %s" % (a["i"], a["family"], a["ms"], a["tflops"], a["gflop"], a["shape"]))
+    print("%3d  %-11s %7.3f  %6.1f  %7.1f  %-52s %s" % (a["i"], a["family"], a["ms"], a["tflops"], a["gflop"], a["shape"], a["kernel"]))
 print("total MFMA-kernel ms/step: %.2f over %d launches" % (tot, n))
 if len(sys.argv) > 1:
     json.dump(agg, open(sys.argv[1], "w"), indent=0)

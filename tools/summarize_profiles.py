@@ -54,9 +54,11 @@ def union_us(iv):
     return tot / 1e3
 
 
-FAMILY = (("split-bf16 convolutions / data gradients", ("conv_x6c_kernel<192", "conv_x6c_kernel<128, 3", "conv_x6c_kernel<320",
+# (template arguments <NPOS, KGS, TM, ZP, NARROW>: TM = true marks a weight gradient; first match wins)
+FAMILY = (("split-bf16 weight gradients", ("conv_x6c_kernel<128, 3, true", "conv_x6c_kernel<128, 4, true", "conv_x6c_kernel<128, 5, true",
+                                           "sinc_x6_wgrad")),
+          ("split-bf16 convolutions / data gradients", ("conv_x6c_kernel<192", "conv_x6c_kernel<128, 3, false", "conv_x6c_kernel<320",
                                                          "sinc_x6_fwd")),
-          ("split-bf16 weight gradients", ("conv_x6c_kernel<128, 4", "conv_x6c_kernel<128, 5", "sinc_x6_wgrad")),
           ("exact-fp32 GEMMs", ("conv_gemm_kernel", "wgrad_gemm_kernel", "wgrad_flat_kernel")),
           ("operand packs", ("pack_",)),
           ("elementwise / normalisation / scan / heads", ("act_bwd", "bn_", "qrnn_", "head1_", "adam", "commit_cols", "rownorm",

@@ -22,7 +22,7 @@ from pase_amd.engine import Act  # noqa: E402
 
 def build_trace_lib():
     # built in the CPU container (hipcc cross-compiles) so that no GPU minutes go into compiling: `python tools/trace_x6c.py build`
-    # PASE_TRACE_FLAGS: extra -D flags of an A/B variant (e.g. -DPASE_X6C_OLDLOOP), PASE_TRACE_TAG: its file name suffix
+    # PASE_TRACE_FLAGS: extra -D flags of an A/B variant (e.g. -DPASE_ABL_NOA), PASE_TRACE_TAG: its file name suffix
     extra = os.environ.get("PASE_TRACE_FLAGS", "").split()
     out = os.path.join(ROOT, "tools", "_trace", "libpase_trace%s.so" % os.environ.get("PASE_TRACE_TAG", ""))
     stamp = out + ".digest"
@@ -128,8 +128,7 @@ def main():
     dev = torch.device("cuda:0")
     NI = 64
     buf = (C.c_ulonglong * (2 * NI * 20))()
-    for name, mode in [(n_, m_) for n_ in shapes for m_ in ("2", "0")]:
-        os.environ["PASE_X6C_STREAM"] = mode
+    for name in shapes:
         fn = run_shape(name, dev)
         fn()
         fn()
@@ -142,31 +141,18 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)
         assert lib.pase_x6c_trace_read(buf) == 0
-        print("== %s [stream=%s]: %.3f ms per call (pack launches included), plan kind %s streamed %s" % (name, mode, ms, K.LAST_PLAN_KIND, K.LAST_STREAMED))
+        print("== %s: %.3f ms per call (pack launches included), plan kind %s, %s" % (name, ms, K.LAST_PLAN_KIND, K.LAST_KERNEL))
         for wg in (0, 1):
             rows = []
             for i in range(NI):
                 t = [buf[(wg * NI + i) * 20 + s] for s in range(20)]
-                if (t[2] if K.LAST_STREAMED else t[3]) == 0 or (not K.LAST_STREAMED and t[3] < t[0]):
+                if t[3] == 0 or t[3] < t[0]:
                     break
                 rows.append(t)
             if len(rows) < 1:
                 print("   workgroup %s: no items traced" % ("0" if wg == 0 else "131"))
                 continue
             mid = rows[1:-1] if len(rows) >= 3 else rows
-            if K.LAST_STREAMED:
-                def avg(f):
-                    v = [f(r) for r in mid]
-                    return sum(v) / len(v)
-                print("   workgroup %-3s items %2d STREAMED | compute: turn-over (decode, A loads, dump) %6.0f  mfma %7.0f (in barriers %7.0f)  "
-                      "item-to-item %7.0f | staging per item: S wait %6.0f  S wait+convert %7.0f  L issue %6.0f  setup %6.0f  "
-                      "pre-drain wait %6.0f  drain %6.0f  in barriers %7.0f" % (
-                          "0" if wg == 0 else "131", len(rows), avg(lambda r: r[1] - r[0]), avg(lambda r: r[2] - r[1]),
-                          avg(lambda r: r[9]), (rows[-1][0] - rows[0][0]) / max(1, len(rows) - 1), avg(lambda r: r[10]),
-                          avg(lambda r: r[11]), avg(lambda r: r[13]), avg(lambda r: r[12]), avg(lambda r: r[15]), avg(lambda r: r[8]),
-                          avg(lambda r: r[14])))
-                continue
-
             def avg(f):
                 v = [f(r) for r in mid]
                 return sum(v) / len(v)
@@ -178,9 +164,7 @@ def main():
                       avg(lambda r: r[3] - r[13]), (rows[-1][0] - rows[0][0]) / max(1, len(rows) - 1),
                       avg(lambda r: r[5] - r[4]), avg(lambda r: r[6] - r[5]), avg(lambda r: r[8]), avg(lambda r: r[10]),
                       avg(lambda r: r[11])))
-            if mid[0][14] and not mid[0][15]:     # -DPASE_ABL_EPI2: the row pass of the lean store epilogue ran twice
-                print("        rows: first pass %6.0f, second pass %6.0f" % (avg(lambda r: r[14] - r[12]), avg(lambda r: r[13] - r[14])))
-            elif mid[0][14]:                      # lean store epilogue: bias wait + first row / rows 1-7 / rows 8-15
+            if mid[0][14]:                      # lean store epilogue: bias wait + first row / rows 1-7 / rows 8-15
                 print("        rows: first %6.0f, next seven %6.0f, last eight %6.0f" % (
                     avg(lambda r: r[14] - r[12]), avg(lambda r: r[15] - r[14]), avg(lambda r: r[13] - r[15])))
                 if mid[0][18]:
