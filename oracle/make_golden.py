@@ -257,7 +257,7 @@ def comb_index(numel, n):
     return (np.arange(n) * st) % numel
 
 
-def gen_bs32(mode="smooth", seed=2, B=32, T=32000, stem=None, only=None):
+def gen_bs32(mode="smooth", seed=2, B=32, T=32000, stem=None, only=None, fe_name="PASE+.cfg", wk_name="workers+.cfg"):
     """ONE live-reference step at the BENCHMARK's own size (BASELINE.json configs[2]: PASE+.cfg + workers+.cfg, 32 utterances x
     32 000 samples), fp32 and fp64 -- round-5 review: the bs32 gates compared the HIP path with the oracle port only; this is
     the reference-generated anchor at that size.  Stored compactly (a few MB): parameter checksums, the 13 losses, per-tensor
@@ -268,15 +268,15 @@ def gen_bs32(mode="smooth", seed=2, B=32, T=32000, stem=None, only=None):
     stem = stem or ("pase_plus_step_bs32_%s" % mode)
     perturb = "smooth" if mode == "smooth" else True
     if only in (None, "f32"):
-        model, (names, sums, sq), losses, chunk, preds = _ref_step(seed, B, T, "PASE+.cfg", "workers+.cfg", perturb=perturb)
+        model, (names, sums, sq), losses, chunk, preds = _ref_step(seed, B, T, fe_name, wk_name, perturb=perturb)
         gnames = [n for n, p in model.named_parameters()]
         gsq = np.array([float((p.grad.double() ** 2).sum()) for n, p in model.named_parameters()])
         gsum = np.array([float(p.grad.double().sum()) for n, p in model.named_parameters()])
         post_sq = np.array([float((p.detach().double() ** 2).sum()) for n, p in model.named_parameters()])
         post_sum = np.array([float(p.detach().double().sum()) for n, p in model.named_parameters()])
         combs = {}
-        for key, t in (("chunk_emb", chunk), ("pred_mi", preds["mi"]), ("pred_cmi", preds["cmi"]), ("pred_mfcc", preds["mfcc"]),
-                       ("pred_cchunk", preds["cchunk"]), ("pred_lps", preds["lps"])):
+        for key, t in [("chunk_emb", chunk)] + [("pred_" + k_, preds[k_]) for k_ in ("mi", "cmi", "mfcc", "cchunk", "lps", "spc")
+                                                if k_ in preds]:
             flat = t.detach().reshape(-1)
             idx = comb_index(flat.numel(), 65536 if key == "chunk_emb" else 16384)
             combs[key + "_comb"] = flat[torch.as_tensor(idx)].numpy()
@@ -289,7 +289,7 @@ def gen_bs32(mode="smooth", seed=2, B=32, T=32000, stem=None, only=None):
         _save_grad_comb(model, losses, os.path.join(GOLD, stem + "_grads.npz"), seed, B, T, False)
         del model, chunk, preds, losses
     if only in (None, "f64"):
-        model, _cs, losses, chunk, preds = _ref_step(seed, B, T, "PASE+.cfg", "workers+.cfg", double=True, perturb=perturb)
+        model, _cs, losses, chunk, preds = _ref_step(seed, B, T, fe_name, wk_name, double=True, perturb=perturb)
         _save_grad_comb(model, losses, os.path.join(GOLD, stem + "_grads_f64.npz"), seed, B, T, True)
 
 
@@ -312,6 +312,11 @@ if __name__ == "__main__":
     torch.set_num_threads(os.cpu_count())
     if sys.argv[1:2] == ["bs32"]:          # the benchmark-size golden (minutes, tens of GB): bs32 [smooth|perturbed] [f32|f64]
         gen_bs32(sys.argv[2] if len(sys.argv) > 2 else "smooth", only=sys.argv[3] if len(sys.argv) > 3 else None)
+        sys.exit(0)
+    if sys.argv[1:2] == ["cfg2bs32"]:      # BASELINE.json configs[1] at its full size: PASE.cfg + workers.cfg, 32 x 16 000
+        gen_bs32(sys.argv[2] if len(sys.argv) > 2 else "smooth", seed=4, B=32, T=16000, fe_name="PASE.cfg", wk_name="workers.cfg",
+                 stem="pase_step_cfg2_bs32_%s" % (sys.argv[2] if len(sys.argv) > 2 else "smooth"),
+                 only=sys.argv[3] if len(sys.argv) > 3 else None)
         sys.exit(0)
     if sys.argv[1:2] == ["perturbed"]:     # only the perturbed-slope steps (optionally: only files whose stem contains argv[2])
         gen_perturbed(sys.argv[2] if len(sys.argv) > 2 else None)

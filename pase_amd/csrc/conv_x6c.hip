@@ -50,14 +50,7 @@ namespace {
 
 constexpr int NT = 512;        // 4 compute waves (one per SIMD) + 4 staging waves
 constexpr int HALO_MAX = 64;      // extra positions a stage holds beyond its BN columns (halo of every sequence touched)
-#ifdef PASE_X6C_NOAL              // A/B builds (tools/ab_build.sh): the packed operand of the pre-split weight gradients as buffer loads of
-constexpr bool X6C_AL = false;    // the compute waves, five k-groups per stage (the form until round 5)
-constexpr int TMZ_KGS = 5;
-#else
-constexpr bool X6C_AL = true;
-constexpr int TMZ_KGS = 3;        // k-groups per stage buffer of the weight-gradient kernel on pre-split planes (<128, TMZ_KGS, true, true>):
-                                  // 2 x 3 x (12 KB staged columns + 12 KB packed rows) = 144 KB of LDS
-#endif
+constexpr int TMZ_KGS = 5;        // k-groups per stage buffer of the weight-gradient kernel on pre-split planes (<128, TMZ_KGS, true, true>)
 
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
     const int q = nwg / 8, r = nwg % 8;
@@ -370,18 +363,12 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     // (pre-split weight gradients are tmode 1: row-contiguous atomics, no transposed flush)
     constexpr int TR_FLOATS = 64 * 33;
     constexpr int TR_CHUNKS = (TM && !ZP) ? (4 * TR_FLOATS * 4 + 15) / 16 : 0;
-    // AL (weight gradients on pre-split planes): the PACKED operand (rows of g, fragment order) travels through LDS as well --
-    // per k-group 4 row tiles x 3 planes x 64 lanes 16-byte chunks = 12 KB beside the 12 KB of staged columns, copied by the
-    // staging waves' LDS DMA one stage ahead.  The pack has no reuse inside a workgroup and is far larger than the L2: as
-    // buffer loads of the compute waves (two steps = ~2 k clocks ahead) every miss stalled the matrix pipe -- an ablation
-    // without those loads ran 17 % faster (round 4) -- whereas a DMA issued a whole stage ahead has landed when the stage
-    // barrier publishes it, and the compute waves issue no vector-memory instruction inside the loop at all.
-    constexpr bool AL = TM && ZP && X6C_AL;
-    constexpr int AKG = 4 * 192;                   // chunks of the packed operand per k-group
-    constexpr int ABUF = AL ? KGS_T * AKG : 0;
+    // (Round 6 measured the PACKED operand through LDS as well -- 12 KB per k-group copied by the staging waves' DMA one stage
+    //  ahead, no vector-memory instruction left in the compute waves' loop, three k-groups per stage to fit 2 x 24 KB per
+    //  k-group: 4 ... 9 % SLOWER on all eight pre-split weight gradients of the PASE+ step, same box.  An LDS-DMA instruction
+    //  costs the issuing wave 100+ cycles beside busy LDS / MFMA pipes; six per step and staging wave is the step's length.)
     // two stage buffers + the epilogue scratch (its own region: the next item's first stage is staged during the epilogue)
-    __shared__ __attribute__((aligned(16))) u32x4 Xs[2 * BUF + RED_CHUNKS + TR_CHUNKS + 2 * ABUF];
-    u32x4* const As = &Xs[2 * BUF + RED_CHUNKS + TR_CHUNKS];      // AL: [buffer][k-group][row tile][plane][lane]
+    __shared__ __attribute__((aligned(16))) u32x4 Xs[2 * BUF + RED_CHUNKS + TR_CHUNKS];
     float (*red)[BM][2] = reinterpret_cast<float (*)[BM][2]>(&Xs[2 * BUF]);
 
     const int tid = threadIdx.x;
@@ -525,6 +512,8 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                     //  element earlier, so every chunk address is a multiple of 4 bytes -- tools/experiments/window_load_probe:
                     //  a wave's 16-byte loads at 2-byte-aligned addresses take 256 ticks each, at 4-byte-aligned ones 64;
                     //  in the kernel: 14 % fewer cycles per item)
+                    // (round 6, with the planes staged by LDS DMA: odd shifts read from the FIRST copy at 2-byte-aligned addresses are
+                    //  correct and cost 5 ... 8 % per launch, +0.3 ms per step -- what writing the second copy costs: kept)
                     const int odd = sh & 1;
                     zp_col[par] = (unsigned)odd * (unsigned)(pl.t_plane / 2) + (unsigned)(row * p.S) * (unsigned)pl.t_lseg +
                                   (unsigned)(sh - odd + fkL * 8);
@@ -961,20 +950,6 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                         }
                     }
                 });
-                if constexpr (AL) {
-                    // the packed operand: this wave copies row tile (wave - 4) of every k-group of the stage -- three 1 KB
-                    // plane blocks in fragment order = lane-linear (k-groups past the last real one are zeros in the pack)
-                    const char* arow = reinterpret_cast<const char*>(p.wx6) +
-                                       ((size_t)(t_mt * 4 + (wave - 4)) * (size_t)pl.steps_total + (size_t)g * KGS) * 3072u + 16u * lane;
-                    pase_static_for<KGS_T>([&](auto kg_tag) __attribute__((always_inline)) {
-                        constexpr int kg = decltype(kg_tag)::value;
-                        if (kg < KGS) {                                           // uniform
-#pragma unroll
-                            for (int pz = 0; pz < 3; ++pz)
-                                x6c_load_lds16(arow + kg * 3072 + pz * 1024, &As[bs * ABUF + kg * AKG + (wave - 4) * 192 + pz * 64], lane);
-                        }
-                    });
-                }
             };
 
             auto prologue_dl = [&](int item) __attribute__((always_inline)) {
@@ -1258,10 +1233,8 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         asm volatile("" : "+v"(a0[pz]), "+v"(a1[pz]), "+v"(a2[pz]));
     }
 #endif
-    if constexpr (!AL) {
-        load_a(a0);
-        load_a(a1);
-    }
+    load_a(a0);
+    load_a(a1);
     __syncthreads();
     if (wave == 0) X6C_STAMP(1);
     // step bookkeeping in increments (no multiplies, four scalar counters): chunk offset of the step's fragments inside Xs,
@@ -1292,56 +1265,6 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         }
         done = stages_left == 0;
     };
-    if constexpr (AL) {
-        // packed operand out of LDS, ONE step ahead (the next k-group of the stage; behind a stage barrier the first k-group
-        // of the new stage, together with load_first's fragments): two register sets
-        // (the stage / k-group part of the address stays on the scalar unit -- a chunk offset that advances per step, like the
-        //  staged operand's xoff -- and the lane's part is one loop-invariant VGPR: with both in ONE per-lane integer the
-        //  compiler moved the whole step bookkeeping, bsel and xoff included, to the vector ALU and spilled 238 registers)
-        int axoff = bsel * ABUF;
-        const int alane = wm * 192 + lane;
-        auto read_a = [&](u32x4 (&a)[3], const u32x4* src) __attribute__((always_inline)) {
-#ifndef PASE_ABL_NOA
-#pragma unroll
-            for (int pz = 0; pz < 3; ++pz) a[pz] = src[alane + 64 * pz];
-#endif
-        };
-        read_a(a0, &As[axoff]);
-        auto step_al = [&](const u32x4 (&acur)[3], u32x4 (&anxt)[3]) __attribute__((always_inline)) {
-            const u32x4* xb = &Xs[xoff];
-            xoff += KGC;                                                          // (weight gradients: one "tap" per k-group)
-            const bool stage_end = --steps_left == 0;                             // uniform
-            // (unconditional: at the stage's last step a harmless re-read of the current fragments -- a read behind a branch
-            //  would sit in a block of its own, outside the step's pinned schedule)
-            axoff += stage_end ? 0 : AKG;
-            read_a(anxt, &As[axoff]);
-            PASE_SGB(0x100, 3);
-            mfma_step(acur, xb, stage_end ? xb : &Xs[xoff]);
-            if (stage_end) {
-                {
-                    X6C_T0();
-                    __syncthreads();
-                    if (wave == 0) X6C_TACC(9);
-                }
-                bsel ^= 1;
-                xoff = bsel * BUF;
-                axoff = bsel * ABUF;
-                steps_left = nsteps;
-                --stages_left;
-                load_first(&Xs[xoff]);                // (past the last stage: a harmless read of the other buffer)
-                read_a(anxt, &As[axoff]);
-            }
-            done = stages_left == 0;
-        };
-        while (true) {
-            step_al(a0, a1);
-            if (done) break;
-            step_al(a1, a2);
-            if (done) break;
-            step_al(a2, a0);
-            if (done) break;
-        }
-    } else {
     while (true) {
         step(a0, a2);
         if (done) break;
@@ -1349,7 +1272,6 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         if (done) break;
         step(a2, a1);
         if (done) break;
-    }
     }
 
     if (wave == 0) X6C_STAMP(2);
@@ -2321,8 +2243,7 @@ bool pase_x6c_wgrad_plan(const PaseWgrad& w, PaseX6cWgrad& o) {
     if (Gk * 16 >= LIM) return false;
     pl.P = QP16; pl.A = 1; pl.G = (int)Gk; pl.CinP = 0x7fffffff;
     // k-groups (16 positions) per stage.  A stage ends in a barrier and the first fragment reads of the next one, ~1.4 k clocks
-    // against 0.8 k per step: the pre-split planes' kernel holds TMZ_KGS of them (LDS: 2 x (12 + 12) KB per k-group -- the packed
-    // operand is staged too; round 4 measured 3, 4 and 5 k-groups per stage at the same time per launch)
+    // against 0.8 k per step: the pre-split planes' kernel holds TMZ_KGS of them (LDS: 2 x 12 KB per k-group)
     const int kgs_req = (int)((w.x6 >> 12) & 7);           // (A/B runs: fewer k-groups per stage than the buffers hold)
     const int kgs_cap = pl.zp ? (kgs_req && kgs_req < TMZ_KGS ? kgs_req : TMZ_KGS) : 4;
     pl.KGS = Gk >= kgs_cap ? kgs_cap : (int)Gk;

@@ -209,7 +209,7 @@ def conv_kernel_name(kid):
 
 
 WGRAD_KERNEL_NAMES = {0: "wgrad_", 1: "conv_x6c_kernel<128, 4, true, false, false>", 2: "conv_x6c_kernel<128, 4, true, false, false>",
-                      3: "conv_x6c_kernel<128, 4, true, false, false>", 4: "conv_x6c_kernel<128, 3, true, true, false>",
+                      3: "conv_x6c_kernel<128, 4, true, false, false>", 4: "conv_x6c_kernel<128, 5, true, true, false>",
                       5: "sinc_x6_wgrad_kernel<"}
 
 GEMM_TIMER = None

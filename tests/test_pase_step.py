@@ -177,14 +177,18 @@ _PIPE_ERR = {}                 # (gold, pipe) -> {name: relL2 vs fp64}, to compa
                                         ("pase_step_cfg2_perturbed.npz", "frontend/PASE.cfg", "workers/workers.cfg"),
                                         ("pase_plus_step_smooth.npz", "frontend/PASE+.cfg", "workers/workers+.cfg"),
                                         ("pase_step_cfg2_smooth.npz", "frontend/PASE.cfg", "workers/workers.cfg"),
-                                        ("pase_plus_step_bs32_smooth.npz", "frontend/PASE+.cfg", "workers/workers+.cfg")],
-                         ids=["plus", "cfg2", "plus-perturbed", "cfg2-perturbed", "plus-smooth", "cfg2-smooth", "plus-bs32-smooth"])
+                                        ("pase_plus_step_bs32_smooth.npz", "frontend/PASE+.cfg", "workers/workers+.cfg"),
+                                        ("pase_plus_step_bs32_perturbed.npz", "frontend/PASE+.cfg", "workers/workers+.cfg"),
+                                        ("pase_step_cfg2_bs32_smooth.npz", "frontend/PASE.cfg", "workers/workers.cfg")],
+                         ids=["plus", "cfg2", "plus-perturbed", "cfg2-perturbed", "plus-smooth", "cfg2-smooth", "plus-bs32-smooth",
+                              "plus-bs32-perturbed", "cfg2-bs32-smooth"])
 def test_full_width_golden_step(dev, gold, fe, wk, x6):
     """Full-width one step vs the live reference's trainer step: PASE+.cfg + workers+.cfg (12 workers)
     and PASE.cfg + workers.cfg (decoder, r-less regressors, SPC / LIM / GIM); on the split-bf16 pipe (the default)
-    and on the exact-fp32 matrix pipe.  `plus-bs32-smooth` is the same judge on a live-reference step AT THE BENCHMARK'S
-    OWN SIZE (32 utterances x 32 000 samples, BASELINE.json configs[2]; fp32 and fp64 runs of /root/reference in the build
-    container, oracle/make_golden.py:gen_bs32): embedding and prediction combs, the 13 losses, gradient and post-Adam norms,
+    and on the exact-fp32 matrix pipe.  `plus-bs32-smooth` / `plus-bs32-perturbed` are the same judge on live-reference steps
+    AT THE BENCHMARK'S OWN SIZE (32 utterances x 32 000 samples, BASELINE.json configs[2]; fp32 and fp64 runs of /root/reference
+    in the build container, oracle/make_golden.py:gen_bs32), `cfg2-bs32-smooth` on BASELINE.json configs[1] at its full size
+    (PASE.cfg + workers.cfg, 32 x 16 000): embedding and prediction combs, the 13 losses, gradient and post-Adam norms,
     and every parameter's sampled gradients against the reference's fp64 step at 1.5 x the reference's own fp32 error + 2e-5."""
     if dev.type == "cpu":
         pytest.skip("full-width step is GPU-only")
@@ -229,9 +233,10 @@ def _full_width_golden_step(dev, gold, fe, wk, x6):
         # benchmark-size golden (oracle/make_golden.py:gen_bs32): the tensors are 6 ... 550 MB, the file holds strided combs
         # of them (comb_index) and their sums -- the embedding to the north-star tolerance at every sampled element
         from util import comb_index
-        for key, t, rtol in (("chunk_emb", chunk, 0.0), ("pred_mi", preds["mi"], 1e-4), ("pred_cmi", preds["cmi"], 1e-4),
-                             ("pred_mfcc", preds["mfcc"], 1e-4), ("pred_cchunk", preds["cchunk"], 1e-4),
-                             ("pred_lps", preds["lps"], 1e-4)):
+        have = sorted(k_[:-5] for k_ in g.files if k_.endswith("_comb"))
+        assert "chunk_emb" in have and len(have) >= 5, have
+        for key in have:
+            t, rtol = (chunk, 0.0) if key == "chunk_emb" else (preds[key[len("pred_"):]], 1e-4)
             flat = t.detach().reshape(-1)
             assert flat.numel() == int(g[key + "_numel"]), key
             idx = torch.as_tensor(comb_index(flat.numel(), g[key + "_comb"].size), device=dev)
