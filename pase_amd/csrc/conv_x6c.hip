@@ -2229,6 +2229,10 @@ bool pase_x6c_wgrad_plan(const PaseWgrad& w, PaseX6cWgrad& o) {
                 (long)w.S * w.g_ctot * w.Tg * 4 < (1L << 32)) ? 1 : 0;        // (32-bit byte offsets of the staging loads)
     // the split is paid once per staged element and shared by the row tiles of the workgroup: at most 64 rows would leave
     // half of every MFMA multiplying zeros
+    // (round 6 built the 64 x 256 tile for this kernel -- compute waves 2 x 2, 256 staged columns per k-group, for layers of
+    //  at most 64 output channels with taps: block 1 of the encoder, 64 x 1280 over 96 x 3200 positions -- correct, and
+    //  0.78 ms against 0.64 ms on the exact-fp32 pipe, same box: 16 conversions per staging lane and k-group feed only 24
+    //  MFMAs per compute wave.  Not kept.)
     if (o.a_rows <= 64) return false;
     // 1x1 layers: every staged element feeds only four row tiles and there are no taps to share the conversion between --
     // measured slower than the exact-fp32 matrix pipe on every PASE+ 1x1 weight gradient (profiles/gemm_launches_r03.json)
