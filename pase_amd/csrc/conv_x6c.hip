@@ -2039,6 +2039,11 @@ bool pase_x6c_plan(const PaseConvGemm& p, PaseX6cPlan& pl) {
     // k-groups per stage: three for 1x1 layers (no halo: 12 KB per k-group), two where a stage would otherwise be
     // shorter than four steps
     pl.KGS = pl.A == 1 ? (pl.G >= 3 ? 3 : pl.G) : ((pl.A < 4 && pl.G >= 2) ? 2 : 1);
+#ifndef PASE_X6C_KGS3      // (A/B builds: always three)
+    // 1x1 launches whose k-groups do not fill whole stages of three: the zero k-groups that pad the last stage are multiplied
+    // like any other (K = 256: 16 k-groups = 5 stages + 1 group, 18 steps for 16) -- two per stage then, when that divides
+    if (pl.A == 1 && pl.G > 3 && pl.G % 3 != 0 && pl.G % 2 == 0 && pl.G <= 64) pl.KGS = 2;
+#endif
     if (narrow && pl.KGS > 2) pl.KGS = 2;
     const int GS = (pl.G + pl.KGS - 1) / pl.KGS;
     pl.steps_total = GS * pl.KGS * pl.A;
