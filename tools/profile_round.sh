@@ -7,8 +7,8 @@ TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 mkdir -p gpurun_out
-B1="python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-h2d --no-capped-leg"
-B2="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-h2d --no-capped-leg"
+B1="python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-torch-gpu-baseline --no-h2d --no-capped-leg"
+B2="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-torch-gpu-baseline --no-h2d --no-capped-leg"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o r1 -- $B1 > gpurun_out/prof_$TAG.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch_$TAG -o r -- $B2 > gpurun_out/pmc_fetch_$TAG.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write_$TAG -o r -- $B2 > gpurun_out/pmc_write_$TAG.log 2>&1
