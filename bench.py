@@ -278,12 +278,23 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         if args.rccl_max_nchannels > 0:       # default: RCCL's own choice (recorded in config.rccl_max_nchannels)
             os.environ["NCCL_MAX_NCHANNELS"] = str(args.rccl_max_nchannels)
-        if shared:
-            backend = "gloo"
-            dist.init_process_group("gloo")
-        else:
-            backend = "nccl"
-            dist.init_process_group("nccl", device_id=dev)
+        # (the contract is ONE JSON line on stdout: gloo's C++ side prints "[Gloo] Rank 0 is connected to ..." to fd 1 while the
+        #  group forms -- fd 1 points at stderr for the duration of the rendezvous)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if shared:
+                backend = "gloo"
+                dist.init_process_group("gloo")
+            else:
+                backend = "nccl"
+                dist.init_process_group("nccl", device_id=dev)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     from pase_amd import _lib
     _lib.lib()   # fail loudly if the HIP library is missing
