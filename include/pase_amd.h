@@ -162,7 +162,8 @@ typedef struct PaseWgrad {
                               controls (the library reads no environment variables): bits 4-7 force an orientation
                               (pase_wgrad_plan_kind value, 0 = the library's routing); bit 8: 1x1 layers may take the split
                               kernel in either orientation; bit 9: no row-coalesced staging; bit 10: keep the
-                              one-channel (SincNet) layer off its window-image kernel; bits 12-14: k-groups per stage
+                              one-channel (SincNet) layer off its window-image kernel; bit 11: pre-split launches of >= 256 rows
+                              stay on the four-compute-wave kernel (no symmetric form); bits 12-14: k-groups per stage
                               of the pre-split-planes kernel (0 = its capacity)                                     */
     void* gx6;             /* scratch for the split-bf16 operands: pase_wgrad_x6_bytes(desc) bytes, 16-B
                               aligned, caller-owned, written and read by this launch only; NULL = fp32 matrix pipe */
@@ -176,7 +177,9 @@ long pase_wgrad_x6_bytes(const PaseWgrad* desc);
  * 3 rows = (channel, tap) read from row-major bf16 planes of z, columns = g staged;
  * 4 rows = g (packed), columns = (channel, tap) COPIED out of pre-split phase-decomposed bf16 planes of z~ (no conversion
  *   in the GEMM: the default for every layer with taps);
- * 5 one input channel (SincNet): sinc_x6.hip, both operands converted while staged, window image of z */
+ * 5 one input channel (SincNet): sinc_x6.hip, both operands converted while staged, window image of z;
+ * 7 as 4 for at least 256 rows of g: the symmetric form -- 256 x 128 workgroup tile, all eight waves multiply, the planes
+ *   copied by every wave's LDS DMA (x6c_wgrad_sym_kernel) */
 int pase_wgrad_plan_kind(const PaseWgrad* desc);
 
 /* ------------------------------------------------------------------------------------------

@@ -1731,6 +1731,208 @@ extern "C" int pase_x6c_trace_reset() {
 }
 #endif
 
+// ================================================================================================================
+// Weight gradients on pre-split planes, SYMMETRIC form (round 6): all eight waves multiply.
+//   dw[m, (ci, kk)] += sum_{s, q} g~[s, m, q] * z~[s, ci, q * stride + kk * tapstep - padL]        (tmode 1 with pl.zp)
+// conv_x6c_kernel<128, 5, true, true> keeps four waves for staging that have nothing to do but issue three DMA instructions per
+// k-group, while its four compute waves -- one per SIMD, nothing else to cover an L2 round trip or an LDS read -- run a 24-MFMA
+// step in ~1160 clocks (768 = the pipe) and every MFMA needs 256 bytes from L2 (12 KB of packed rows + 12 KB of staged columns
+// per step).  Here the workgroup tile is 256 x 128: wave w owns rows 32 w .. 32 w + 31 (same 32 x 128 wave tile, same two
+// accumulator sets, same step), TWO multiplying waves per SIMD cover each other's waits, the staged columns of a k-group feed
+// twice the MFMAs (192 bytes per MFMA), and the stage's 72 DMA instructions are shared out over all eight waves -- three at the
+// top of each of a stage's first three steps.  A stage = SIX k-groups (2 x 6 x 12 KB of LDS) = two turns of the three fragment
+// register sets: the loop body is one stage, unrolled, with the buffer chosen at run time.
+// The DMA is HIDDEN from the compiler (inline asm, M0 saved / restored): visible, it makes every later LDS read that may alias
+// its destination wait vmcnt(0) and every __syncthreads a full drain (the first build's ISA: one wait per step, accumulators
+// spilled around the two-buffer loop).  Hidden, the vector-memory counter still retires in order, so the compiler's own
+// s_waitcnt vmcnt(6) in front of a step's first MFMA (fragments of steps s + 1, s + 2 may stay in flight) now leaves "the six
+// newest operations" in flight, three of them this step's DMA: the fragment prefetch is effectively one step deep where DMA
+// is issued -- with two waves per SIMD a step is ~1.5 k clocks, more than an L2 round trip.  In front of the stage barrier
+// s_waitcnt vmcnt(6) by hand: the stage's DMA is nine fragment loads old.
+#ifdef PASE_HIPEMU
+__device__ __forceinline__ void x6c_dma16_hidden(const void* src, u32x4* lds_wave_base, int lane) {
+    __builtin_memcpy(&lds_wave_base[lane], src, 16);
+}
+#else
+__device__ __forceinline__ void x6c_dma16_hidden(const void* src, u32x4* lds_wave_base, int) {
+    const unsigned lds = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)(unsigned)(size_t)(__attribute__((address_space(3))) u32x4*)lds_wave_base);
+    unsigned m0_saved;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved)
+                 : "v"(src), "s"(lds)
+                 : "memory");
+}
+#endif
+constexpr int SYM_KGS = 6;
+__global__ void __launch_bounds__(NT, 2) x6c_wgrad_sym_kernel(PaseConvGemm p, PaseX6cPlan pl) {
+    constexpr int NPOS = 128, PLANE = 2 * NPOS, KGC = 3 * PLANE, BUF = SYM_KGS * KGC, NBT = 4;
+    __shared__ __attribute__((aligned(16))) u32x4 Xs[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = pase_uniform(tid >> 6);
+    const int fr = lane & 31, fk = lane >> 5;
+    // DMA role of this wave: octet fkL and column half whalf of the k-groups kgsel, kgsel + 2, kgsel + 4 of a stage
+    const int fkL = (wave >> 1) & 1, whalf = wave & 1, kgsel = wave >> 2;
+    const int ntiles = pl.n_row_tiles * pl.n_col_tiles;
+    const int nitems = ntiles * pl.splitk;
+    const int GS = (pl.G + SYM_KGS - 1) / SYM_KGS;
+    const int g_per = (GS + pl.splitk - 1) / pl.splitk;
+    const unsigned short* zpb = reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(p.wx6) + pl.zp_off);
+    const X6cRsrc a_rs = x6c_make_rsrc(p.wx6);
+    const unsigned a_loff = 16u * (unsigned)lane;
+    int bbase[NBT];
+#pragma unroll
+    for (int j = 0; j < NBT; ++j) bbase[j] = fk * NPOS + j * 32 + fr;
+    int bsel = 0;
+
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const int split = item / ntiles;
+        const int tile = xcd_swizzle(item - split * ntiles, ntiles);
+        const int mt = tile / pl.n_col_tiles, nt = tile - mt * pl.n_col_tiles;      // consecutive tiles: the column tiles of a row tile
+        const int m0 = mt * 256, n0 = nt * 128;
+        const int g_begin = split * g_per;
+        const int g_end = min(GS, g_begin + g_per);
+        if (g_begin >= g_end) continue;                                             // uniform
+        const int nst = g_end - g_begin;
+        // ---- this lane's column of the planes (see conv_x6c_kernel's setup_item, ZP): column j = (ci, kk) -> plane row ci * stride
+        // + b shifted by d; column K = the all-ones row (bias gradient); columns past the end alias the last real one
+        unsigned zp_col;
+        {
+            const int j = n0 + 64 * whalf + lane;
+            const bool ones = p.bias != nullptr && j == p.K;
+            const int jj = min(j, p.K - 1);
+            const int ci = (int)div_magic((unsigned)jj, pl.ncols_magic);
+            const int kk = zp_tap_of(jj - ci * p.taps, pl);
+            const int ob = kk * p.tapstep - p.padL - pl.t_dmin * p.stride;
+            const int db = (int)div_magic((unsigned)ob, pl.ps_magic);
+            const int b = ob - db * p.stride;
+            const int row = ones ? pl.zp_rows - 1 : ci * p.stride + b;
+            const int sh = ones ? 0 : db;
+            const int odd = sh & 1;
+            zp_col = (unsigned)odd * (unsigned)(pl.t_plane / 2) + (unsigned)(row * p.S) * (unsigned)pl.t_lseg + (unsigned)(sh - odd + fkL * 8);
+        }
+        // the three plane chunks of k-group kg of stage g -> stage buffer bs (this wave's octet / column half)
+        auto dma_kg = [&](int bs, int g, int kg) __attribute__((always_inline)) {
+            const int kgi = g * SYM_KGS + kg;
+            const int s_ = (int)div_magic((unsigned)kgi, pl.seg_magic);
+            const int q16 = kgi - s_ * pl.P;
+            const unsigned off = zp_col + (unsigned)(min(s_, p.S - 1) * pl.t_lseg + q16 * 16);
+            u32x4* dst = &Xs[bs * BUF + kg * KGC + fkL * NPOS + 64 * whalf];
+#pragma unroll
+            for (int pz = 0; pz < 3; ++pz) x6c_dma16_hidden(zpb + (size_t)pz * (size_t)pl.t_plane + off, dst + pz * PLANE, lane);
+        };
+        f32x16 accH[NBT], accS[NBT];
+#pragma unroll
+        for (int j = 0; j < NBT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                accH[j][r] = 0.f;
+                accS[j][r] = 0.f;
+            }
+        // packed rows of g: [32-row tile][step][plane][lane], one scalar byte offset that advances 3072 per step
+        unsigned ab = (unsigned)(16 * (((size_t)(mt * 8 + wave) * (unsigned)pl.steps_total + (size_t)g_begin * SYM_KGS) * 192u));
+        const int nsteps_run = nst * SYM_KGS;
+        int a_issued = 0;
+        auto load_a = [&](u32x4 (&a)[3]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int pz = 0; pz < 3; ++pz) a[pz] = x6c_buffer_load16(a_rs, a_loff + 1024u * pz, ab);
+            ++a_issued;
+            ab += (a_issued < nsteps_run) ? 3072u : 0u;         // (past the end: a harmless re-read of the last fragments)
+        };
+        u32x4 bq[2][2][3];
+        auto load_first = [&](const u32x4* xb) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pz = 0; pz < 3; ++pz) bq[0][i][pz] = xb[pz * PLANE + bbase[i]];
+        };
+        // one 24-MFMA step (conv_x6c_kernel's mfma_step): the six fragments of the next half read one per two MFMAs
+        auto mfma_step = [&](const u32x4 (&a)[3], const u32x4* xb, const u32x4* xn) __attribute__((always_inline)) {
+            constexpr int PZA[6] = {1, 0, 2, 0, 1, 0}, PZB[6] = {1, 2, 0, 1, 0, 0};
+            PASE_SGB(0x020, 3);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const u32x4* src = h == 0 ? xb : xn;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    bq[h ^ 1][i / 3][i % 3] = src[(i % 3) * PLANE + bbase[2 * (h ^ 1) + i / 3]];
+                    if (i < 5) {
+                        accS[2 * h] = pase_mfma_bf16_32x32x16(a[PZA[i]], bq[h][0][PZB[i]], accS[2 * h]);
+                        accS[2 * h + 1] = pase_mfma_bf16_32x32x16(a[PZA[i]], bq[h][1][PZB[i]], accS[2 * h + 1]);
+                    } else {
+                        accH[2 * h] = pase_mfma_bf16_32x32x16(a[0], bq[h][0][0], accH[2 * h]);
+                        accH[2 * h + 1] = pase_mfma_bf16_32x32x16(a[0], bq[h][1][0], accH[2 * h + 1]);
+                    }
+                    PASE_SGB(0x100, 1);
+                    PASE_SGB(0x008, 2);
+                }
+            }
+        };
+        u32x4 a0[3], a1[3], a2[3];
+        // ---- first stage of the item (every wave has passed the barrier that ended the previous item's last stage)
+        dma_kg(bsel, g_begin, kgsel);
+        dma_kg(bsel, g_begin, kgsel + 2);
+        dma_kg(bsel, g_begin, kgsel + 4);
+        load_a(a0);
+        load_a(a1);
+        x6c_vm_drain();
+        __syncthreads();
+        for (int gi = 0; gi < nst; ++gi) {
+            // the next stage arrives in the other buffer while this one is multiplied (past the item's last stage: that stage
+            // once more into the idle buffer -- a branch around the copies would split the steps into basic blocks)
+            const int g_next = min(g_begin + gi + 1, g_end - 1);
+            const u32x4* CUR = &Xs[bsel * BUF];
+            load_first(CUR);
+            auto st = [&](auto k_tag, const u32x4 (&acur)[3], u32x4 (&anxt)[3]) __attribute__((always_inline)) {
+                constexpr int k = decltype(k_tag)::value;
+                if constexpr (k < 3) dma_kg(bsel ^ 1, g_next, kgsel + 2 * k);
+                load_a(anxt);
+                mfma_step(acur, CUR + k * KGC, CUR + (k < SYM_KGS - 1 ? k + 1 : k) * KGC);
+            };
+            st(std::integral_constant<int, 0>{}, a0, a2);
+            st(std::integral_constant<int, 1>{}, a1, a0);
+            st(std::integral_constant<int, 2>{}, a2, a1);
+            st(std::integral_constant<int, 3>{}, a0, a2);
+            st(std::integral_constant<int, 4>{}, a1, a0);
+            st(std::integral_constant<int, 5>{}, a2, a1);
+#if !defined(PASE_HIPEMU)
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // this stage's DMA has landed (it is >= nine fragment loads old)
+#endif
+            __syncthreads();
+            bsel ^= 1;
+        }
+        // ---- += into the caller-zeroed dw (row-contiguous atomics; the bias column adds into dbias)
+#pragma unroll
+        for (int j = 0; j < NBT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accH[j][r] += accS[j][r];
+        const int rb = m0 + wave * 32 + 4 * fk;
+#pragma unroll
+        for (int j = 0; j < NBT; ++j) {
+            const int col = n0 + j * 32 + fr;
+            int dcol = col;
+            if (pl.t_stride > 1 && col < p.K) {
+                const int ci = (int)div_magic((unsigned)col, pl.ncols_magic);
+                dcol = ci * p.taps + zp_tap_of(col - ci * p.taps, pl);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = rb + (r & 3) + 8 * (r >> 2);
+                const float v = accH[j][r];
+                if (m < p.M) {
+                    if (col < p.K) atomicAdd(p.y + (size_t)m * p.Tout + dcol, v);
+                    else if (col == p.K && p.bias) atomicAdd(const_cast<float*>(p.bias) + m, v);
+                }
+            }
+        }
+#if !defined(PASE_HIPEMU)
+        // the fragment prefetches past the last step are never consumed and the last stage's surplus copy is in flight: drain
+        // both before the next item's prologue writes into the buffers
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
+        __syncthreads();
+    }
+}
+
 // weights (K-major fp32 pack wt[k * ldwt + m], k = ci * taps + kk) -> fragment-ordered bf16 planes:
 // out[((rt32 * steps + st) * 3 + plane) * 64 + lane], step st = g * A + a, lane = (fk, row): element e = channel'
 // 16 g + 8 fk + e at tap' a.  Zero for channels' past Cin * P, taps past the real count and rows past M.
@@ -2254,13 +2456,16 @@ bool pase_x6c_wgrad_plan(const PaseWgrad& w, PaseX6cWgrad& o) {
     // k-groups (16 positions) per stage.  A stage ends in a barrier and the first fragment reads of the next one, ~1.4 k clocks
     // against 0.8 k per step: the pre-split planes' kernel holds TMZ_KGS of them (LDS: 2 x 12 KB per k-group)
     const int kgs_req = (int)((w.x6 >> 12) & 7);           // (A/B runs: fewer k-groups per stage than the buffers hold)
-    const int kgs_cap = pl.zp ? (kgs_req && kgs_req < TMZ_KGS ? kgs_req : TMZ_KGS) : 4;
+    // round 6: pre-split launches with at least 256 rows of g run the SYMMETRIC form (x6c_wgrad_sym_kernel: 256 x 128 tile, all
+    // eight waves multiply, six k-groups per stage); x6 bit 11 keeps them on conv_x6c_kernel<128, 5, true, true> (A/B runs)
+    const bool sym = pl.zp && o.a_rows >= 256 && Gk >= 2 * SYM_KGS && !(w.x6 & 2048);
+    const int kgs_cap = sym ? SYM_KGS : (pl.zp ? (kgs_req && kgs_req < TMZ_KGS ? kgs_req : TMZ_KGS) : 4);
     pl.KGS = Gk >= kgs_cap ? kgs_cap : (int)Gk;
     const int GS = (pl.G + pl.KGS - 1) / pl.KGS;
     pl.steps_total = GS * pl.KGS;
-    pl.WM = 4; pl.NBT = 4; pl.BM = 128; pl.BN = 128;
+    pl.WM = sym ? 8 : 4; pl.NBT = 4; pl.BM = sym ? 256 : 128; pl.BN = 128;
     const int ncolw = c.K + ((pl.tmode == 1 && w.dbias) ? 1 : 0);
-    pl.n_row_tiles = (o.a_rows + 127) / 128;
+    pl.n_row_tiles = (o.a_rows + pl.BM - 1) / pl.BM;
     pl.n_col_tiles = (ncolw + 127) / 128;
     pl.seg_magic = magic_of(QP16);
     pl.ncols_magic = magic_of(c.taps);
@@ -2291,7 +2496,7 @@ bool pase_x6c_wgrad_plan(const PaseWgrad& w, PaseX6cWgrad& o) {
     }
     pl.splitk = (int)sk;
     pl.prio = x6c_prio();
-    pl.pack_chunks = (long)pl.n_row_tiles * 4 * pl.steps_total * 192;
+    pl.pack_chunks = (long)pl.n_row_tiles * pl.WM * pl.steps_total * 192;
     pl.prm_n = 0;
     pl.pack_bytes = pl.tmode == 3 ? 3 * pl.t_plane * 2 : pl.pack_chunks * 16;
     if (pl.pack_bytes >= (1L << 32)) return false;      // (32-bit scalar offsets of the fragment loads)
@@ -2332,7 +2537,8 @@ int pase_x6c_wgrad_launch(const PaseWgrad& w, const PaseX6cWgrad& o, hipStream_t
     long nwg = (long)pl.n_row_tiles * pl.n_col_tiles * pl.splitk;
     const long cap = w.max_wg > 0 ? w.max_wg : x6c_cu_count();
     if (nwg > cap) nwg = cap;
-    if (pl.zp) PASE_LAUNCH((conv_x6c_kernel<128, TMZ_KGS, true, true>), dim3((unsigned)nwg), dim3(NT), st, c, pl);
+    if (pl.zp && pl.WM == 8) PASE_LAUNCH(x6c_wgrad_sym_kernel, dim3((unsigned)nwg), dim3(NT), st, c, pl);
+    else if (pl.zp) PASE_LAUNCH((conv_x6c_kernel<128, TMZ_KGS, true, true>), dim3((unsigned)nwg), dim3(NT), st, c, pl);
     else PASE_LAUNCH((conv_x6c_kernel<128, 4, true>), dim3((unsigned)nwg), dim3(NT), st, c, pl);
     PASE_CHECK_LAUNCH();
     return 0;

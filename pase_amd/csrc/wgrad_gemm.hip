@@ -664,7 +664,7 @@ extern "C" int pase_wgrad_plan_kind(const PaseWgrad* d) {
     PaseSincPlan sp;
     if (!(d->x6 & 1024) && pase_sinc_x6_wgrad_plan(*d, sp)) return 5;
     PaseX6cWgrad o;
-    return pase_x6c_wgrad_plan(*d, o) ? (o.pl.zp ? 4 : o.pl.tmode) : 0;
+    return pase_x6c_wgrad_plan(*d, o) ? (o.pl.zp ? (o.pl.WM == 8 ? 7 : 4) : o.pl.tmode) : 0;
 }
 
 // 0 = accepted; the refusal code otherwise (shared by the launch and the query so that the two cannot disagree)

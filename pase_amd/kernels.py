@@ -210,7 +210,7 @@ def conv_kernel_name(kid):
 
 WGRAD_KERNEL_NAMES = {0: "wgrad_", 1: "conv_x6c_kernel<128, 4, true, false, false>", 2: "conv_x6c_kernel<128, 4, true, false, false>",
                       3: "conv_x6c_kernel<128, 4, true, false, false>", 4: "conv_x6c_kernel<128, 5, true, true, false>",
-                      5: "sinc_x6_wgrad_kernel<"}
+                      5: "sinc_x6_wgrad_kernel<", 7: "x6c_wgrad_sym_kernel"}
 
 GEMM_TIMER = None
 LAST_WGRAD_X6 = None       # did the most recent wgrad_gemm launch run on the split-bf16 kernel
@@ -457,6 +457,7 @@ def wgrad_gemm(g, z, dw, *, S, M, Tg, Ncols, Cin, Tz, taps, ldw=None, dbias=None
         d.x6 |= 256 if os.environ.get("PASE_X6C_WGRAD_FLAT") else 0
         d.x6 |= 512 if os.environ.get("PASE_X6C_NOVEC") else 0
         d.x6 |= 1024 if os.environ.get("PASE_SINC_X6", "1") == "0" else 0
+        d.x6 |= 2048 if os.environ.get("PASE_X6C_WGRAD_SYM", "1") == "0" else 0
         d.x6 |= (int(os.environ.get("PASE_X6C_TMKGS", "0")) & 7) << 12
     d.max_wg = _max_wg(max_wg)
     global LAST_WGRAD_X6, LAST_WGRAD_KIND

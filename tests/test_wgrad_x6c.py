@@ -70,6 +70,44 @@ def test_conv_weight_gradient(dev, wmode, Cin, Cout, k, st, T, S):
     assert _rel(db, b.grad) < 1e-6
 
 
+@pytest.mark.parametrize("Cin,Cout,k,st,T,S,maxwg", [
+    (24, 256, 11, 1, 200, 3, 0),     # one row tile of 256, 264 + 1 columns = three column tiles, 39 k-groups = 7 stages of six (odd)
+    (16, 300, 11, 2, 420, 2, 2),     # ragged second row tile (300 of 512), stride 2 (phase-ordered columns), two workgroups
+    (40, 520, 3, 1, 96, 4, 1),       # three row tiles, ONE workgroup walking every (slice, tile) item, 24 k-groups = 4 stages (even)
+    (12, 260, 30, 4, 400, 2, 3),     # ConvTranspose-like taps / stride (k 30, stride 4): eight tap-phase columns per plane row
+])
+def test_conv_weight_gradient_symmetric_form(dev, monkeypatch, Cin, Cout, k, st, T, S, maxwg):
+    """Round 6: pre-split weight gradients with at least 256 rows of g run x6c_wgrad_sym_kernel (plan kind 7): 256 x 128
+    workgroup tile, all eight waves multiply, six k-groups per stage in two separate LDS buffers; against fp64 and against the
+    four-compute-wave kernel (x6 bit 11, PASE_X6C_WGRAD_SYM=0)."""
+    if maxwg:
+        monkeypatch.setenv("PASE_X6C_MAXWG", str(maxwg))
+    torch.manual_seed(4)
+    x = torch.randn(S, Cin, T)
+    sc, sh, al = torch.rand(Cin) + 0.5, torch.randn(Cin) * 0.1, torch.rand(Cin) * 0.5
+    P = (k // 2 - 1, k // 2) if (st > 1 or k % 2 == 0) else (k // 2, k // 2)
+    w = torch.randn(Cout, Cin, k, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    y = F.conv1d(F.pad(_xf(x, sc, sh, al), P, mode="reflect"), w, b, stride=st)
+    g = torch.randn(y.shape)
+    (y * g.double()).sum().backward()
+    args = dict(S=S, M=Cout, Tg=y.shape[2], Ncols=y.shape[2], Cin=Cin, Tz=T, taps=k, in_scale=sc.to(dev), in_shift=sh.to(dev),
+                in_alpha=al.to(dev), stride=st, padL=P[0], pad_mode=K.PAD_REFLECT)
+    dw = torch.full((Cout, Cin * k), 0.25, device=dev)           # (the kernel ADDS into dw)
+    db = torch.zeros(Cout, device=dev)
+    K.wgrad_gemm(g.to(dev), x.to(dev), dw, dbias=db, **args)
+    assert K.LAST_WGRAD_X6 and K.LAST_WGRAD_KIND == 7
+    assert _rel((dw - 0.25).view(Cout, Cin, k), w.grad) < 1e-6
+    assert _rel(db, b.grad) < 1e-6
+    dw2 = torch.zeros(Cout, Cin * k, device=dev)                 # no bias gradient: no all-ones column
+    K.wgrad_gemm(g.to(dev), x.to(dev), dw2, **args)
+    assert K.LAST_WGRAD_KIND == 7 and _rel(dw2.view(Cout, Cin, k), w.grad) < 1e-6
+    monkeypatch.setenv("PASE_X6C_WGRAD_SYM", "0")
+    dw3 = torch.zeros(Cout, Cin * k, device=dev)
+    K.wgrad_gemm(g.to(dev), x.to(dev), dw3, **args)
+    assert K.LAST_WGRAD_KIND == 4 and _rel(dw3.view(Cout, Cin, k), w.grad) < 1e-6
+
+
 def test_conv_transpose_weight_gradient(dev, wmode):
     """nn.ConvTranspose1d weight gradient: G = PReLU(layer input) at the low rate (g_alpha), Z = dY, zero padding."""
     torch.manual_seed(2)
