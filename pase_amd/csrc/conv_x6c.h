@@ -36,6 +36,7 @@ struct PaseX6cPlan {
     int xp;             // convolution launches: the activation is pre-split (PaseConvGemm::xp6, pase_pack_xp): staging = copy
     int xp_tpad;        // ... padded positions per sequence: Ncols + A - 1
     long xp_plane;      // ... 16-byte chunks per plane: G * 2 * S * xp_tpad
+    int sym;            // convolution launches on a pre-split activation: the symmetric form (256 x 128 tile, no staging waves)
     int xPerm;          // pixel-shuffle launches: tile rows ordered (channel, phase) -> 16-byte output runs
     long pack_chunks;   // 16-byte chunks of the weight pack
     int prm_n;          // channels' of the expanded on-load parameter arrays behind the chunks (3 x prm_n floats)

@@ -242,6 +242,25 @@ __device__ __forceinline__ void x6c_load_lds4(const void* src, float* lds_wave_b
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
 #endif
+// The same copy HIDDEN from the compiler (symmetric forms: the waves that copy are the waves that read).  Visible, a pending LDS DMA
+// makes the compiler guard every later LDS read that may alias its destination with s_waitcnt vmcnt(0) and turns every
+// __syncthreads into a full drain; as inline asm it is invisible, and the wave waits for it by hand in front of the barrier that
+// publishes the stage.  M0 (the LDS base of the copy) is saved and restored: a reserved register the compiler may hold a value in.
+#ifdef PASE_HIPEMU
+__device__ __forceinline__ void x6c_dma16_hidden(const void* src, u32x4* lds_wave_base, int lane) {
+    __builtin_memcpy(&lds_wave_base[lane], src, 16);
+}
+#else
+__device__ __forceinline__ void x6c_dma16_hidden(const void* src, u32x4* lds_wave_base, int) {
+    const unsigned lds = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)(unsigned)(size_t)(__attribute__((address_space(3))) u32x4*)lds_wave_base);
+    unsigned m0_saved;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved)
+                 : "v"(src), "s"(lds)
+                 : "memory");
+}
+#endif
 struct alignas(16) X6cF4 { float x, y, z, w; };
 // Staging registers: eight fp32 values per slot as two 4-vectors (the row-coalesced weight-gradient path fills them with two
 // global_load_dwordx4, every other path with eight global_load_dword).
@@ -346,10 +365,17 @@ __device__ __forceinline__ void x6c_vmwait_slots(int nslots, bool two_per_slot) 
 // NARROW (convolutions of at most 64 rows: block 1 of the encoder): workgroup tile 64 x 256, compute waves 2 (rows) x 2 (column
 // halves) -- the 128-row tile would spend half of every MFMA on zero rows.  Same wave tile (32 x 128), same loop; the stage
 // holds 256 + 64 positions (<320, 2>).
-template <int NPOS, int KGS_T, bool TM = false, bool ZP = false, bool NARROW = false>
+// SYM (round 6; convolutions on a pre-split activation, pl.sym): the SYMMETRIC form -- no staging waves.  All eight waves
+// multiply (wave w owns rows 32 w .. of a 256 x 128 workgroup tile: two multiplying waves per SIMD cover each other's waits and
+// each other's epilogues' latencies, the staged columns of a k-group feed twice the MFMAs) and share out the stage's LDS DMA
+// among themselves: unit u = (k-group, octet, 64-position block) belongs to wave u mod 8, at most two units = six hidden DMA
+// instructions per wave and stage, issued at the top of the stage's first two steps (see x6c_wgrad_sym_kernel for why hidden
+// and why three at a time).
+template <int NPOS, int KGS_T, bool TM = false, bool ZP = false, bool NARROW = false, bool SYM = false>
 __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6cPlan pl) {
     static_assert(!(NARROW && TM), "the 64 x 256 tile is a convolution tile");
-    constexpr int WM = NARROW ? 2 : 4, WN = NARROW ? 2 : 1, NBT = 4;
+    static_assert(!SYM || (ZP && !TM && !NARROW), "the symmetric form copies a pre-split activation");
+    constexpr int WM = SYM ? 8 : (NARROW ? 2 : 4), WN = NARROW ? 2 : 1, NBT = 4;
     constexpr int BM = 32 * WM, BN = 32 * NBT * WN;
     constexpr int NPS = (NPOS + 127) / 128;        // position slots per thread and k-group
     constexpr int NSLOT = NPS * KGS_T;
@@ -379,8 +405,8 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     // kinds of work run on different pipes (matrix core / vector ALU) of the same SIMD concurrently, which an in-order
     // wave doing both cannot arrange; each role has its own vmcnt counter, so a staging wave waiting for activations from
     // HBM never holds back a weight fragment.  One barrier per stage joins them.
-    const bool stager = wave >= 4;                 // uniform
-    const int wm = NARROW ? (wave & 1) : (wave & 3), wn = NARROW ? ((wave >> 1) & 1) : 0;
+    const bool stager = !SYM && wave >= 4;         // uniform
+    const int wm = SYM ? wave : (NARROW ? (wave & 1) : (wave & 3)), wn = NARROW ? ((wave >> 1) & 1) : 0;
     const int fr = lane & 31, fk = lane >> 5;
     const int fkL = (wave >> 1) & 1;               // stager: octet of the k-group this wave stages (uniform)
     const int whalf = wave & 1;                    // stager: which 64 of a slot's 128 positions (uniform)
@@ -1233,8 +1259,59 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         asm volatile("" : "+v"(a0[pz]), "+v"(a1[pz]), "+v"(a2[pz]));
     }
 #endif
+    // ---- SYM: this wave's share of a stage's copy.  Unit u = (kg, octet, 64-position block), u = wave, wave + 8
+    constexpr int NP64 = NPOS / 64;
+    int sy_kg[2] = {0, 0}, sy_dst[2] = {0, 0};
+    unsigned sy_src[2] = {0u, 0u};
+    bool sy_on[2] = {false, false};
+    const u32x4* const sy_xpc = reinterpret_cast<const u32x4*>(p.xp6);
+    if constexpr (SYM) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int u = wave + 8 * j;                                        // uniform
+            sy_on[j] = u < KGS * 2 * NP64;
+            const int kg_ = u / (2 * NP64), rem = u - kg_ * (2 * NP64);
+            const int fk_ = rem / NP64, p64 = rem - fk_ * NP64;
+            // position i of the stage row -> (sequence, padded position): as the staging waves' setup_item
+            const int i = 64 * p64 + lane;
+            bool valid = i < span_len;
+            int k_, r_;
+            if (i < lenA + H) {
+                k_ = 0;
+                r_ = i;
+            } else {
+                const int d_ = i - (lenA + H);
+                const int k1 = (int)div_magic((unsigned)d_, pl.seg_magic);
+                k_ = 1 + k1;
+                r_ = d_ - k1 * segL;
+            }
+            const int q_ = (k_ == 0 ? qA : 0) + r_;
+            const int s_ = s0 + k_;
+            valid = valid && s_ < p.S;
+            sy_kg[j] = kg_;
+            sy_dst[j] = kg_ * KGC + fk_ * NPOS + 64 * p64;
+            // chunk offset inside a plane, without the k-group part ((gidx * 2 + fk) * S * xp_tpad)
+            sy_src[j] = (unsigned)(fk_ * p.S) * (unsigned)pl.xp_tpad + (unsigned)(valid ? s_ * pl.xp_tpad + q_ : 0);
+        }
+    }
+    auto sym_dma = [&](int j, int g, int bs) __attribute__((always_inline)) {
+        if constexpr (SYM) {
+            if (sy_on[j]) {                                                    // uniform
+                const int gidx = min(g * KGS + sy_kg[j], pl.G - 1);          // (stage padding: zero weights, any finite data)
+                const unsigned off = (unsigned)(gidx * 2 * p.S) * (unsigned)pl.xp_tpad + sy_src[j];
+                u32x4* dst = &Xs[bs * BUF + sy_dst[j]];
+#pragma unroll
+                for (int pz = 0; pz < 3; ++pz) x6c_dma16_hidden(sy_xpc + (size_t)pz * (size_t)pl.xp_plane + off, dst + pz * PLANE, lane);
+            }
+        }
+    };
+    if constexpr (SYM) {      // the item's first stage (every wave has passed the barrier that ended the previous item's last stage)
+        sym_dma(0, g_begin, bsel);
+        sym_dma(1, g_begin, bsel);
+    }
     load_a(a0);
     load_a(a1);
+    if constexpr (SYM) x6c_vm_drain();
     __syncthreads();
     if (wave == 0) X6C_STAMP(1);
     // step bookkeeping in increments (no multiplies, four scalar counters): chunk offset of the step's fragments inside Xs,
@@ -1243,6 +1320,15 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
     bool done = false;
     load_first(&Xs[xoff]);
     auto step = [&](const u32x4 (&acur)[3], u32x4 (&anxt)[3]) __attribute__((always_inline)) {
+        if constexpr (SYM) {
+            // the next stage's copy, three DMA instructions at the top of this stage's first two steps (uniform branches
+            // around hidden instructions: the compiler's vmcnt bookkeeping of the fragment loads is the same on both paths)
+            if (stages_left > 1) {
+                const int g_nxt = g_end - stages_left + 1;
+                if (steps_left == nsteps) sym_dma(0, g_nxt, bsel ^ 1);
+                else if (steps_left == nsteps - 1) sym_dma(1, g_nxt, bsel ^ 1);
+            }
+        }
         load_a(anxt);
         const u32x4* xb = &Xs[xoff];
         const bool kg_end = --taps_left == 0;                                 // uniform
@@ -1253,6 +1339,11 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         if (stage_end) {
             {
                 X6C_T0();
+#if !defined(PASE_HIPEMU)
+                // SYM: the next stage's copy has landed -- it is older than the fragment loads of this stage's steps from the
+                // second on, and the counter retires in order: at most the newest three loads may stay in flight
+                if constexpr (SYM) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+#endif
                 __syncthreads();
                 if (wave == 0) X6C_TACC(9);
             }
@@ -1701,7 +1792,8 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         if (lane == 0) red[0][wave][0] = lsum;
         __syncthreads();
         if (tid == 0) {
-            const double tsum = (double)red[0][0][0] + (double)red[0][1][0] + (double)red[0][2][0] + (double)red[0][3][0];
+            double tsum = (double)red[0][0][0] + (double)red[0][1][0] + (double)red[0][2][0] + (double)red[0][3][0];
+            if constexpr (SYM) tsum += (double)red[0][4][0] + (double)red[0][5][0] + (double)red[0][6][0] + (double)red[0][7][0];
             atomicAdd(p.loss_acc, tsum);
         }
     }
@@ -1749,21 +1841,6 @@ extern "C" int pase_x6c_trace_reset() {
 // newest operations" in flight, three of them this step's DMA: the fragment prefetch is effectively one step deep where DMA
 // is issued -- with two waves per SIMD a step is ~1.5 k clocks, more than an L2 round trip.  In front of the stage barrier
 // s_waitcnt vmcnt(6) by hand: the stage's DMA is nine fragment loads old.
-#ifdef PASE_HIPEMU
-__device__ __forceinline__ void x6c_dma16_hidden(const void* src, u32x4* lds_wave_base, int lane) {
-    __builtin_memcpy(&lds_wave_base[lane], src, 16);
-}
-#else
-__device__ __forceinline__ void x6c_dma16_hidden(const void* src, u32x4* lds_wave_base, int) {
-    const unsigned lds = (unsigned)__builtin_amdgcn_readfirstlane(
-        (int)(unsigned)(size_t)(__attribute__((address_space(3))) u32x4*)lds_wave_base);
-    unsigned m0_saved;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(m0_saved)
-                 : "v"(src), "s"(lds)
-                 : "memory");
-}
-#endif
 constexpr int SYM_KGS = 6;
 __global__ void __launch_bounds__(NT, 2) x6c_wgrad_sym_kernel(PaseConvGemm p, PaseX6cPlan pl) {
     constexpr int NPOS = 128, PLANE = 2 * NPOS, KGC = 3 * PLANE, BUF = SYM_KGS * KGC, NBT = 4;
@@ -2230,6 +2307,28 @@ bool pase_x6c_plan(const PaseConvGemm& p, PaseX6cPlan& pl) {
     pl.WM = 4;
     pl.BM = 128;
     pl.BN = 128;
+    // Round 6: launches on a pre-split activation with at least 256 rows and an epilogue without BatchNorm partial sums run the
+    // SYMMETRIC form (256 x 128 tile, all eight waves multiply and share out the stage's LDS DMA; conv_x6c_kernel<..., SYM>).
+    // Decided from the descriptor alone -- NOT from xp6 being there: the weight pack is sized and written before the caller
+    // has the activation planes, and its row-tile count is the plan's.  x6_ctl bit 7 forbids it (A/B runs).
+    const bool spectrum_op = p.post_op == PASE_POST_POW || p.post_op == PASE_POST_LOGPOW || p.post_op == PASE_POST_MAG;
+    pl.sym = (xp_want && !narrow && p.M >= 256 && !p.stat_part && !spectrum_op && !(p.x6_ctl & 128)) ? 1 : 0;
+    if (pl.sym && !force) {
+        // ... where the 256-row tiles do not cost whole rounds of the persistent grid: a round of 256-row tiles takes about two
+        // rounds of 128-row tiles (0.9 x measured), so the form is taken when 2 x its rounds <= the rounds of the 128-row tiling.
+        // Measured on the PASE+ bs32 step, same box: LPS heads (85 x 50 tiles against 169 x 50) 0.568 -> 0.516 ms, the 840-row
+        // heads -8 %, QRNN projection -2 %; M = 512 / 640 / 1920 (two, 2.5 and 7.5 tiles of 256 rows: 4 rounds against 3, 58 against
+        // 47, 10 against 9) +14 % / +10 % / +6 % -- those keep the staging-wave form.
+        const long cap = p.max_wg > 0 ? p.max_wg : x6c_cu_count();
+        const long ncolt = ((long)p.S * p.Ncols + 127) / 128;
+        const long r_sym = (((long)(p.M + 255) / 256) * ncolt + cap - 1) / cap;
+        const long r_std = (((long)(p.M + 127) / 128) * ncolt + cap - 1) / cap;
+        if (2 * r_sym > r_std) pl.sym = 0;
+    }
+    if (pl.sym) {
+        pl.WM = 8;
+        pl.BM = 256;
+    }
     if (narrow) {          // 64 x 256 (conv_x6c_kernel<320, 2, ..., NARROW>)
         pl.WM = 2;
         pl.BM = 64;
@@ -2247,6 +2346,11 @@ bool pase_x6c_plan(const PaseConvGemm& p, PaseX6cPlan& pl) {
     if (pl.A == 1 && pl.G > 3 && pl.G % 3 != 0 && pl.G % 2 == 0 && pl.G <= 64) pl.KGS = 2;
 #endif
     if (narrow && pl.KGS > 2) pl.KGS = 2;
+    if (pl.sym && pl.KGS * pl.A < 2) {      // (a stage of one step has no second step to issue the second DMA unit in)
+        pl.sym = 0;
+        pl.WM = 4;
+        pl.BM = 128;
+    }
     const int GS = (pl.G + pl.KGS - 1) / pl.KGS;
     pl.steps_total = GS * pl.KGS * pl.A;
     const long ntot = (long)p.S * p.Ncols;
@@ -2323,6 +2427,10 @@ int pase_x6c_launch(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st
     const dim3 grid((unsigned)nwg), block(NT);
     if (pl.WM == 2) {
         PASE_LAUNCH((conv_x6c_kernel<320, 2, false, false, true>), grid, block, st, p, pl);
+    } else if (pl.sym) {
+        if (!pl.xp) return -12;      // the plan (and the weight pack's row tiles) counted on the pre-split activation
+        if (pl.A == 1) PASE_LAUNCH((conv_x6c_kernel<128, 3, false, true, false, true>), grid, block, st, p, pl);
+        else PASE_LAUNCH((conv_x6c_kernel<192, 2, false, true, false, true>), grid, block, st, p, pl);
     } else if (pl.xp) {
         if (pl.A == 1) PASE_LAUNCH((conv_x6c_kernel<128, 3, false, true>), grid, block, st, p, pl);
         else PASE_LAUNCH((conv_x6c_kernel<192, 2, false, true>), grid, block, st, p, pl);
