@@ -56,7 +56,7 @@ def union_us(iv):
 
 # (template arguments <NPOS, KGS, TM, ZP, NARROW>: TM = true marks a weight gradient; first match wins)
 FAMILY = (("split-bf16 weight gradients", ("conv_x6c_kernel<128, 3, true", "conv_x6c_kernel<128, 4, true", "conv_x6c_kernel<128, 5, true",
-                                           "sinc_x6_wgrad")),
+                                           "x6c_wgrad_sym_kernel", "sinc_x6_wgrad")),
           ("split-bf16 convolutions / data gradients", ("conv_x6c_kernel<192", "conv_x6c_kernel<128, 3, false", "conv_x6c_kernel<320",
                                                          "sinc_x6_fwd")),
           ("exact-fp32 GEMMs", ("conv_gemm_kernel", "wgrad_gemm_kernel", "wgrad_flat_kernel")),
