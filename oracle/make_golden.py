@@ -128,7 +128,7 @@ def perturb_affine(module, seed=123, smooth=False):
                     p.fill_(1.0)
 
 
-def _ref_step(seed, B, T, fe_name, wk_name, double=False, perturb=False):
+def _ref_step(seed, B, T, fe_name, wk_name, double=False, perturb=False, fe_over=None):
     """One reference training step (trainer.py:229-232 -> worker_scheduler._base_scheduler) of a
     frontend cfg + workers cfg on a seeded synthetic batch.  Returns (model, param checksums, losses,
     chunk, preds); _base_scheduler has stepped the optimizers, so `.grad` holds the step's gradients
@@ -138,7 +138,7 @@ def _ref_step(seed, B, T, fe_name, wk_name, double=False, perturb=False):
     from pase.models.WorkerScheduler.worker_scheduler import backprop_scheduler
     import torch.optim as optim
     with open(os.path.join(REF, "cfg", "frontend", fe_name)) as f:
-        fe_cfg = json.load(f)
+        fe_cfg = dict(json.load(f), **(fe_over or {}))      # (fe_over: WaveFe keyword arguments on top of the cfg file)
     minions_cfg = quiet(worker_parser, os.path.join(REF, "cfg", "workers", wk_name))
     for _t, lst in minions_cfg.items():
         for c in lst:
@@ -257,7 +257,7 @@ def comb_index(numel, n):
     return (np.arange(n) * st) % numel
 
 
-def gen_bs32(mode="smooth", seed=2, B=32, T=32000, stem=None, only=None, fe_name="PASE+.cfg", wk_name="workers+.cfg"):
+def gen_bs32(mode="smooth", seed=2, B=32, T=32000, stem=None, only=None, fe_name="PASE+.cfg", wk_name="workers+.cfg", fe_over=None):
     """ONE live-reference step at the BENCHMARK's own size (BASELINE.json configs[2]: PASE+.cfg + workers+.cfg, 32 utterances x
     32 000 samples), fp32 and fp64 -- round-5 review: the bs32 gates compared the HIP path with the oracle port only; this is
     the reference-generated anchor at that size.  Stored compactly (a few MB): parameter checksums, the 13 losses, per-tensor
@@ -268,7 +268,7 @@ def gen_bs32(mode="smooth", seed=2, B=32, T=32000, stem=None, only=None, fe_name
     stem = stem or ("pase_plus_step_bs32_%s" % mode)
     perturb = "smooth" if mode == "smooth" else True
     if only in (None, "f32"):
-        model, (names, sums, sq), losses, chunk, preds = _ref_step(seed, B, T, fe_name, wk_name, perturb=perturb)
+        model, (names, sums, sq), losses, chunk, preds = _ref_step(seed, B, T, fe_name, wk_name, perturb=perturb, fe_over=fe_over)
         gnames = [n for n, p in model.named_parameters()]
         gsq = np.array([float((p.grad.double() ** 2).sum()) for n, p in model.named_parameters()])
         gsum = np.array([float(p.grad.double().sum()) for n, p in model.named_parameters()])
@@ -283,13 +283,14 @@ def gen_bs32(mode="smooth", seed=2, B=32, T=32000, stem=None, only=None, fe_name
             combs[key + "_sum"] = float(flat.double().sum())
             combs[key + "_sq"] = float((flat.double() ** 2).sum())
             combs[key + "_numel"] = flat.numel()
-        np.savez(os.path.join(GOLD, stem + ".npz"), seed=seed, B=B, T=T, compact=1, param_names=np.array(names), param_sum=sums,
+        np.savez(os.path.join(GOLD, stem + ".npz"), seed=seed, B=B, T=T, compact=1, fe_over=json.dumps(fe_over or {}),
+                 param_names=np.array(names), param_sum=sums,
                  param_sq=sq, loss_names=np.array(list(losses.keys())), loss_values=np.array([float(v) for v in losses.values()]),
                  grad_names=np.array(gnames), grad_sq=gsq, grad_sum=gsum, post_sq=post_sq, post_sum=post_sum, **combs)
         _save_grad_comb(model, losses, os.path.join(GOLD, stem + "_grads.npz"), seed, B, T, False)
         del model, chunk, preds, losses
     if only in (None, "f64"):
-        model, _cs, losses, chunk, preds = _ref_step(seed, B, T, fe_name, wk_name, double=True, perturb=perturb)
+        model, _cs, losses, chunk, preds = _ref_step(seed, B, T, fe_name, wk_name, double=True, perturb=perturb, fe_over=fe_over)
         _save_grad_comb(model, losses, os.path.join(GOLD, stem + "_grads_f64.npz"), seed, B, T, True)
 
 
@@ -312,6 +313,11 @@ if __name__ == "__main__":
     torch.set_num_threads(os.cpu_count())
     if sys.argv[1:2] == ["bs32"]:          # the benchmark-size golden (minutes, tens of GB): bs32 [smooth|perturbed] [f32|f64]
         gen_bs32(sys.argv[2] if len(sys.argv) > 2 else "smooth", only=sys.argv[3] if len(sys.argv) > 3 else None)
+        sys.exit(0)
+    if sys.argv[1:2] == ["emb256"]:        # BASELINE.json configs[4]'s model (2 x QRNN, lnorm; built through WaveFe's kwargs) at 32 x 32 000
+        gen_bs32(sys.argv[2] if len(sys.argv) > 2 else "smooth", fe_over=dict(rnn_layers=2, norm_type="lnorm"),
+                 stem="pase_plus_step_emb256_bs32_%s" % (sys.argv[2] if len(sys.argv) > 2 else "smooth"),
+                 only=sys.argv[3] if len(sys.argv) > 3 else None)
         sys.exit(0)
     if sys.argv[1:2] == ["cfg2bs32"]:      # BASELINE.json configs[1] at its full size: PASE.cfg + workers.cfg, 32 x 16 000
         gen_bs32(sys.argv[2] if len(sys.argv) > 2 else "smooth", seed=4, B=32, T=16000, fe_name="PASE.cfg", wk_name="workers.cfg",
