@@ -98,7 +98,8 @@ typedef struct PaseConvGemm {
                               (SincNet) layer off its window-image kernel; bit 4: no 64 x 256 tile for launches of at
                               most 64 rows; bit 5: the general epilogue on every tile (no lean store / MSE path); bit 6: the bias
                               added in the epilogue instead of being the accumulators' initial value; bit 7: launches on a
-                              pre-split activation stay on the staging-wave form (no symmetric 256 x 128 tile); bits 8-15: start
+                              pre-split activation stay on the staging-wave form (no symmetric form); bits 17 / 18: the
+                              eight-wave / the four-wave symmetric form wherever eligible (A/B runs); bits 8-15: start
                               the persistent workgroups n x 512 clocks out of phase (A/B runs and tests; the library
                               itself reads NO environment variables)                                             */
     int max_wg;            /* cap on the persistent grid of the split-bf16 kernel (0 = one workgroup per CU, 256):
@@ -121,9 +122,10 @@ int pase_conv_gemm_splitk(const PaseConvGemm* desc);
  * kernel (sinc_x6.hip: the SincNet layer).  For tests and bench reports. */
 int pase_conv_gemm_plan_kind(const PaseConvGemm* desc);
 /* which kernel INSTANTIATION the launch runs (reports: bench.py matches it against the kernel names of a rocprofv3 trace):
- * 0 = conv_gemm_kernel (exact-fp32 pipe), 1 = sinc_x6_fwd_kernel, otherwise conv_x6c_kernel<NPOS, KGS, false, ZP, NARROW, SYM> as
- * NPOS * 100 + KGS * 10 + 4 * SYM + 2 * ZP + NARROW (ZP: the pre-split activation of xp6 is staged by LDS DMA; SYM: the
- * symmetric 256 x 128 form of such launches) */
+ * 0 = conv_gemm_kernel (exact-fp32 pipe), 1 = sinc_x6_fwd_kernel, otherwise conv_x6c_kernel<NPOS, KGS, false, ZP, NARROW, SYM, DUO> as
+ * NPOS * 1000 + KGS * 100 + 8 * DUO + 4 * SYM + 2 * ZP + NARROW (ZP: the pre-split activation of xp6 is staged by LDS DMA; SYM:
+ * the symmetric form of such launches -- all waves multiply -- on a 256 x 128 tile, or with DUO on 128 x 128 tiles, two
+ * four-wave workgroups per CU) */
 int pase_conv_gemm_kernel_id(const PaseConvGemm* desc);
 /* bytes of the split-bf16 pack the launch described by desc (wx6 ignored) would read; 0 = this shape only runs on
  * the fp32 matrix pipe */

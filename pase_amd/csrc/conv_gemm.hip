@@ -1179,7 +1179,7 @@ extern "C" int pase_conv_gemm_plan_kind(const PaseConvGemm* d) {
 
 // Which kernel instantiation the launch runs, for reports (bench.py's roofline.dominant matches it against the kernel names
 // of a rocprofv3 trace) and tests: 0 = exact-fp32 matrix pipe (conv_gemm_kernel), 1 = sinc_x6_fwd_kernel, otherwise
-// conv_x6c_kernel<NPOS, KGS, false, ZP, NARROW, SYM> encoded as NPOS * 100 + KGS * 10 + 4 * SYM + 2 * ZP + NARROW
+// conv_x6c_kernel<NPOS, KGS, false, ZP, NARROW, SYM, DUO> encoded as NPOS * 1000 + KGS * 100 + 8 * DUO + 4 * SYM + 2 * ZP + NARROW
 extern "C" int pase_conv_gemm_kernel_id(const PaseConvGemm* d) {
     if (d->M <= 0 || d->K <= 0 || d->S <= 0 || d->Ncols <= 0 || d->K != d->Cin * d->taps) return 0;
     const HostPlan h = make_plan(*d, d->wx6 != nullptr);
@@ -1187,7 +1187,7 @@ extern "C" int pase_conv_gemm_kernel_id(const PaseConvGemm* d) {
     if (!h.x6c) return 0;
     const bool narrow = h.c.WM == 2;
     const int npos = narrow ? 320 : (h.c.A == 1 ? 128 : 192), kgs = narrow ? 2 : (h.c.A == 1 ? 3 : 2);
-    return npos * 100 + kgs * 10 + (h.c.xp ? 2 : 0) + (narrow ? 1 : 0) + ((h.c.sym && h.c.xp) ? 4 : 0);
+    return npos * 1000 + kgs * 100 + (h.c.xp ? 2 : 0) + (narrow ? 1 : 0) + ((h.c.sym && h.c.xp) ? 4 : 0) + ((h.c.sym == 2 && h.c.xp) ? 8 : 0);
 }
 
 extern "C" long pase_conv_gemm_x6_bytes(const PaseConvGemm* d) {

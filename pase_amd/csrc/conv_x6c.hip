@@ -371,11 +371,20 @@ __device__ __forceinline__ void x6c_vmwait_slots(int nslots, bool two_per_slot) 
 // among themselves: unit u = (k-group, octet, 64-position block) belongs to wave u mod 8, at most two units = six hidden DMA
 // instructions per wave and stage, issued at the top of the stage's first two steps (see x6c_wgrad_sym_kernel for why hidden
 // and why three at a time).
-template <int NPOS, int KGS_T, bool TM = false, bool ZP = false, bool NARROW = false, bool SYM = false>
+// DUO (SYM only): the same with FOUR waves per workgroup -- 128 x 128 tile, 256 threads, TWO workgroups per CU (73 KB of LDS each).
+// The two workgroups of a CU run out of step, so one's epilogue (the matrix pipe idles: 13 k of an LPS head's 38 k clocks) lies
+// under the other's MFMA loop; the price is that they do not share a staged k-group (256 bytes from L2 per MFMA, as in the
+// staging-wave form) and that each wave issues up to nine DMA instructions per stage.  Same row tiling as the staging-wave form:
+// no weight-pack or round-count consequences.
+template <int NPOS, int KGS_T, bool TM = false, bool ZP = false, bool NARROW = false, bool SYM = false, bool DUO = false>
 __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6cPlan pl) {
     static_assert(!(NARROW && TM), "the 64 x 256 tile is a convolution tile");
     static_assert(!SYM || (ZP && !TM && !NARROW), "the symmetric form copies a pre-split activation");
-    constexpr int WM = SYM ? 8 : (NARROW ? 2 : 4), WN = NARROW ? 2 : 1, NBT = 4;
+    static_assert(!DUO || SYM, "DUO is a symmetric form");
+    constexpr int NTH = DUO ? 256 : NT;            // threads of the workgroup
+    constexpr int SYW = DUO ? 4 : 8;               // SYM: waves that share out the stage's copy
+    constexpr int SYU = DUO ? 3 : 2;               // ... units (k-group, octet, 64-position block) per wave at most
+    constexpr int WM = SYM ? SYW : (NARROW ? 2 : 4), WN = NARROW ? 2 : 1, NBT = 4;
     constexpr int BM = 32 * WM, BN = 32 * NBT * WN;
     constexpr int NPS = (NPOS + 127) / 128;        // position slots per thread and k-group
     constexpr int NSLOT = NPS * KGS_T;
@@ -1261,14 +1270,21 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
 #endif
     // ---- SYM: this wave's share of a stage's copy.  Unit u = (kg, octet, 64-position block), u = wave, wave + 8
     constexpr int NP64 = NPOS / 64;
-    int sy_kg[2] = {0, 0}, sy_dst[2] = {0, 0};
-    unsigned sy_src[2] = {0u, 0u};
-    bool sy_on[2] = {false, false};
+    int sy_kg[SYU], sy_dst[SYU];
+    unsigned sy_src[SYU];
+    bool sy_on[SYU];
+#pragma unroll
+    for (int j = 0; j < SYU; ++j) {
+        sy_kg[j] = 0;
+        sy_dst[j] = 0;
+        sy_src[j] = 0u;
+        sy_on[j] = false;
+    }
     const u32x4* const sy_xpc = reinterpret_cast<const u32x4*>(p.xp6);
     if constexpr (SYM) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int u = wave + 8 * j;                                        // uniform
+        for (int j = 0; j < SYU; ++j) {
+            const int u = wave + SYW * j;                                      // uniform
             sy_on[j] = u < KGS * 2 * NP64;
             const int kg_ = u / (2 * NP64), rem = u - kg_ * (2 * NP64);
             const int fk_ = rem / NP64, p64 = rem - fk_ * NP64;
@@ -1306,8 +1322,8 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         }
     };
     if constexpr (SYM) {      // the item's first stage (every wave has passed the barrier that ended the previous item's last stage)
-        sym_dma(0, g_begin, bsel);
-        sym_dma(1, g_begin, bsel);
+#pragma unroll
+        for (int j = 0; j < SYU; ++j) sym_dma(j, g_begin, bsel);
     }
     load_a(a0);
     load_a(a1);
@@ -1327,6 +1343,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 const int g_nxt = g_end - stages_left + 1;
                 if (steps_left == nsteps) sym_dma(0, g_nxt, bsel ^ 1);
                 else if (steps_left == nsteps - 1) sym_dma(1, g_nxt, bsel ^ 1);
+                else if (SYU > 2 && steps_left == nsteps - 2) sym_dma(SYU - 1, g_nxt, bsel ^ 1);
             }
         }
         load_a(anxt);
@@ -1640,7 +1657,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         if (p.stat_part) {
             __syncthreads();
             // one partial (sum, sumsq) per (column tile, output row); rows are channels here
-            for (int ml = tid; ml < BM; ml += NT) {
+            for (int ml = tid; ml < BM; ml += NTH) {
                 const int m = m0 + ml;
                 if (m < pe.M) {
                     float s1 = 0.f, s2 = 0.f;
@@ -1793,7 +1810,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
         __syncthreads();
         if (tid == 0) {
             double tsum = (double)red[0][0][0] + (double)red[0][1][0] + (double)red[0][2][0] + (double)red[0][3][0];
-            if constexpr (SYM) tsum += (double)red[0][4][0] + (double)red[0][5][0] + (double)red[0][6][0] + (double)red[0][7][0];
+            if constexpr (SYM && !DUO) tsum += (double)red[0][4][0] + (double)red[0][5][0] + (double)red[0][6][0] + (double)red[0][7][0];
             atomicAdd(p.loss_acc, tsum);
         }
     }
@@ -2313,7 +2330,17 @@ bool pase_x6c_plan(const PaseConvGemm& p, PaseX6cPlan& pl) {
     // has the activation planes, and its row-tile count is the plan's.  x6_ctl bit 7 forbids it (A/B runs).
     const bool spectrum_op = p.post_op == PASE_POST_POW || p.post_op == PASE_POST_LOGPOW || p.post_op == PASE_POST_MAG;
     pl.sym = (xp_want && !narrow && p.M >= 256 && !p.stat_part && !spectrum_op && !(p.x6_ctl & 128)) ? 1 : 0;
-    if (pl.sym && !force) {
+    // ... or its four-wave variant, two workgroups per CU (DUO, pl.sym == 2): same 128-row tiling as the staging-wave form, so it
+    // has no round-count condition and takes launches from 128 rows on.  x6_ctl bits 17 / 18 (A/B runs): bit 17 = the eight-wave
+    // form wherever it is eligible, never DUO; bit 18 = DUO wherever it is eligible.
+    const bool duo_ok = xp_want && !narrow && p.M >= 128 && !p.stat_part && !spectrum_op && !(p.x6_ctl & 128);
+    if ((p.x6_ctl & 0x40000) && duo_ok) pl.sym = 2;
+    // Routing between the two (measured per launch on the PASE+ bs32 step, same box, profiles/experiments/ab_r06.json): 1x1
+    // launches take DUO (LPS heads 0.590 staging-wave -> 0.520 eight-wave -> 0.500 DUO; M = 1920: 0.145 -> 0.132); launches with
+    // taps take the eight-wave form where its 256-row tiles fill whole rounds (QRNN projection 0.351 -> 0.331, DUO 0.357) and DUO
+    // otherwise (M = 512 x 2 taps 0.411 -> 0.395, block 1's data gradient 0.520 -> 0.463)
+    if (pl.sym == 1 && pl.A == 1 && duo_ok && !(p.x6_ctl & 0x20000)) pl.sym = 2;
+    if (pl.sym == 1 && !force && !(p.x6_ctl & 0x20000)) {
         // ... where the 256-row tiles do not cost whole rounds of the persistent grid: a round of 256-row tiles takes about two
         // rounds of 128-row tiles (0.9 x measured), so the form is taken when 2 x its rounds <= the rounds of the 128-row tiling.
         // Measured on the PASE+ bs32 step, same box: LPS heads (85 x 50 tiles against 169 x 50) 0.568 -> 0.516 ms, the 840-row
@@ -2323,9 +2350,10 @@ bool pase_x6c_plan(const PaseConvGemm& p, PaseX6cPlan& pl) {
         const long ncolt = ((long)p.S * p.Ncols + 127) / 128;
         const long r_sym = (((long)(p.M + 255) / 256) * ncolt + cap - 1) / cap;
         const long r_std = (((long)(p.M + 127) / 128) * ncolt + cap - 1) / cap;
-        if (2 * r_sym > r_std) pl.sym = 0;
+        if (2 * r_sym > r_std) pl.sym = duo_ok ? 2 : 0;
     }
-    if (pl.sym) {
+    if (pl.sym == 0 && duo_ok && !(p.x6_ctl & 0x20000)) pl.sym = 2;      // (pre-split launches of 128 ... 255 rows)
+    if (pl.sym == 1) {
         pl.WM = 8;
         pl.BM = 256;
     }
@@ -2427,6 +2455,13 @@ int pase_x6c_launch(const PaseConvGemm& p, const PaseX6cPlan& pl, hipStream_t st
     const dim3 grid((unsigned)nwg), block(NT);
     if (pl.WM == 2) {
         PASE_LAUNCH((conv_x6c_kernel<320, 2, false, false, true>), grid, block, st, p, pl);
+    } else if (pl.sym == 2) {
+        if (!pl.xp) return -12;
+        long nwg2 = (long)pl.n_row_tiles * pl.n_col_tiles * pl.splitk;
+        if (nwg2 > 2 * cap) nwg2 = 2 * cap;                                  // two workgroups per CU
+        const dim3 grid2((unsigned)nwg2), block2(256);
+        if (pl.A == 1) PASE_LAUNCH((conv_x6c_kernel<128, 3, false, true, false, true, true>), grid2, block2, st, p, pl);
+        else PASE_LAUNCH((conv_x6c_kernel<192, 2, false, true, false, true, true>), grid2, block2, st, p, pl);
     } else if (pl.sym) {
         if (!pl.xp) return -12;      // the plan (and the weight pack's row tiles) counted on the pre-split activation
         if (pl.A == 1) PASE_LAUNCH((conv_x6c_kernel<128, 3, false, true, false, true>), grid, block, st, p, pl);

@@ -135,6 +135,7 @@ def _conv_desc(x, w, y, *, S, Cin, Tin, M, K, taps, Ncols, Tout, ldw=None, bias=
                 | (32 if os.environ.get("PASE_X6C_LEANEPI", "1") == "0" else 0)
                 | (64 if os.environ.get("PASE_X6C_BIASINIT", "1") == "0" else 0)
                 | (128 if os.environ.get("PASE_X6C_SYM", "1") == "0" else 0)
+                | {"8": 0x20000, "duo": 0x40000}.get(os.environ.get("PASE_X6C_SYM", ""), 0)
                 | ((int(os.environ.get("PASE_X6C_STAGGER", "0")) & 255) << 8))
     d.max_wg = _max_wg(max_wg)
     return d
@@ -206,12 +207,12 @@ def conv_kernel_name(kid):
     if kid == 1:
         return "sinc_x6_fwd_kernel"
     b = lambda v: "true" if v else "false"
-    return "conv_x6c_kernel<%d, %d, false, %s, %s, %s>" % (kid // 100, (kid // 10) % 10, b((kid % 10) & 2), b((kid % 10) & 1),
-                                                           b((kid % 10) & 4))
+    fl = kid % 100
+    return "conv_x6c_kernel<%d, %d, false, %s, %s, %s, %s>" % (kid // 1000, (kid // 100) % 10, b(fl & 2), b(fl & 1), b(fl & 4), b(fl & 8))
 
 
-WGRAD_KERNEL_NAMES = {0: "wgrad_", 1: "conv_x6c_kernel<128, 4, true, false, false, false>", 2: "conv_x6c_kernel<128, 4, true, false, false, false>",
-                      3: "conv_x6c_kernel<128, 4, true, false, false, false>", 4: "conv_x6c_kernel<128, 5, true, true, false, false>",
+WGRAD_KERNEL_NAMES = {0: "wgrad_", 1: "conv_x6c_kernel<128, 4, true, false, false, false, false>", 2: "conv_x6c_kernel<128, 4, true, false, false, false, false>",
+                      3: "conv_x6c_kernel<128, 4, true, false, false, false, false>", 4: "conv_x6c_kernel<128, 5, true, true, false, false, false>",
                       5: "sinc_x6_wgrad_kernel<", 7: "x6c_wgrad_sym_kernel"}
 
 GEMM_TIMER = None

@@ -217,8 +217,9 @@ def test_presplit_activation_is_the_default_of_wide_1x1_and_2tap_launches(dev, m
 @pytest.mark.parametrize("maxwg", [0, 2])
 def test_symmetric_form_of_presplit_launches(dev, monkeypatch, maxwg):
     """Round 6: launches on a pre-split activation with >= 256 rows and no BatchNorm partial sums run the symmetric form of the
-    kernel (conv_x6c_kernel<..., SYM>: 256 x 128 tile, all eight waves multiply and share out the LDS DMA; PaseConvGemm::x6_ctl
-    bit 7 / PASE_X6C_SYM=0 keeps the staging-wave form).  A 1x1 layer with bias and a ragged second 256-row tile whose k-groups
+    kernel (conv_x6c_kernel<..., SYM>: 256 x 128 tile, all eight waves multiply and share out the LDS DMA -- PASE_X6C_SYM=8 -- or its
+    four-wave variant DUO, two 128 x 128 workgroups per CU -- PASE_X6C_SYM=duo; PaseConvGemm::x6_ctl bit 7 / PASE_X6C_SYM=0 keeps
+    the staging-wave form).  A 1x1 layer with bias and a ragged second 256-row tile whose k-groups
     do not fill the last stage, and a ConvTranspose1d (k 30, stride 10: three taps', pixel-shuffle store with (channel, phase)
     rows) -- each against fp64 and against the staging-wave form."""
     from pase_amd import engine as E
@@ -237,16 +238,17 @@ def test_symmetric_form_of_presplit_launches(dev, monkeypatch, maxwg):
     xin = torch.where(x > 0, x, x * al[None, :, None]).double()
     ref = torch.einsum("mk,skt->smt", w.double(), xin) + b.double()[None, :, None]
     got = {}
-    for sym in ("1", "0"):
+    for sym in ("8", "duo", "0"):
         monkeypatch.setenv("PASE_X6C_SYM", sym)
         y = torch.zeros(S, Cout, T, device=dev)
         K.conv_gemm(x.to(dev), w.to(dev), y, S=S, Cin=Cin, Tin=T, M=Cout, K=Cin, taps=1, Ncols=T, Tout=T, bias=b.to(dev),
                     in_alpha=al.to(dev))
         assert K.LAST_PLAN_KIND == 2 and K.LAST_XP
-        assert K.LAST_KERNEL == "conv_x6c_kernel<128, 3, false, true, false, %s>" % ("true" if sym == "1" else "false")
+        assert K.LAST_KERNEL == "conv_x6c_kernel<128, 3, false, true, false, %s>" % (
+            {"8": "true, false", "0": "false, false", "duo": "true, true"}[sym])
         got[sym] = y.cpu()
         assert _rel(y, ref) < 1e-6, sym
-    assert _rel(got["1"], got["0"].double()) < 5e-7
+    assert _rel(got["8"], got["0"].double()) < 5e-7 and _rel(got["duo"], got["0"].double()) < 5e-7
     # ---- ConvTranspose1d(48 -> 40, k 30, stride 10): rows = (channel, phase) = 400, three taps'
     S, Cin, Cout, k, st, T = 3, 48, 40, 30, 10, 70
     x = torch.randn(S, Cin, T)
@@ -255,15 +257,16 @@ def test_symmetric_form_of_presplit_launches(dev, monkeypatch, maxwg):
     b = torch.randn(Cout)
     xin = torch.where(x > 0, x, x * al[None, :, None]).double()
     ref = F.conv_transpose1d(xin, w.double(), b.double(), stride=st, padding=(k - st) // 2)
-    for sym in ("1", "0"):
+    for sym in ("8", "duo", "0"):
         monkeypatch.setenv("PASE_X6C_SYM", sym)
         y = E.deconv_fwd(Act(x.to(dev), C=Cin, alpha=al.to(dev)), w.to(dev), b.to(dev), Cout=Cout, k=k, stride=st)
         assert K.LAST_PLAN_KIND == 2 and K.LAST_XP
-        assert K.LAST_KERNEL == "conv_x6c_kernel<192, 2, false, true, false, %s>" % ("true" if sym == "1" else "false")
+        assert K.LAST_KERNEL == "conv_x6c_kernel<192, 2, false, true, false, %s>" % (
+            {"8": "true, false", "0": "false, false", "duo": "true, true"}[sym])
         assert tuple(y.shape) == tuple(ref.shape)
         got[sym] = y.cpu()
         assert _rel(y, ref) < 1e-6, sym
-    assert _rel(got["1"], got["0"].double()) < 5e-7
+    assert _rel(got["8"], got["0"].double()) < 5e-7 and _rel(got["duo"], got["0"].double()) < 5e-7
 
 
 def test_infinite_activation_stays_non_finite_where_the_reference_is(dev):
@@ -550,10 +553,11 @@ def test_persistent_grid_with_few_workgroups_matches_fp64(dev, monkeypatch, case
     assert K.LAST_PLAN_KIND == 2 and K.LAST_KERNEL.startswith("conv_x6c_kernel<"), K.LAST_KERNEL
     # (the instantiation the report names is the one the shape implies: 1x1 -> <128, 3, ...>, taps -> <192, 2, ...>; ZP = pre-split)
     # ... and SYM = the symmetric 256 x 128 form: pre-split launches of >= 256 rows without BatchNorm partial sums (the MSE case)
-    sym = K.LAST_XP and case == "mse-ragged"
+    # (1x1 launches take its four-wave variant, DUO: two workgroups per CU; 128 rows are enough)
+    sym = K.LAST_XP and case == "mse-ragged"          # (the store cases write BatchNorm partial sums or have 70 rows)
     assert K.LAST_KERNEL == "conv_x6c_kernel<%s, false, %s, false, %s>" % (
         "128, 3" if case in ("one-by-one-ragged-cols", "mse-ragged") else "192, 2", "true" if K.LAST_XP else "false",
-        "true" if sym else "false")
+        "true, true" if sym else "false, false"), (case, K.LAST_KERNEL)
     if case == "mse-ragged":
         pred, tgt = ref
         g, acc = extra
