@@ -91,7 +91,9 @@ typedef struct PaseConvGemm {
                               > 0): channel-minor bf16 planes with the on-load transform and the padding applied, in the
                               chunk order of the kernel's LDS image -- staging becomes a copy.  The library asks for it on
                               stride-1 launches with one or two taps and >= 1024 rows, where a column tile is re-staged by
-                              every row tile (the 256 -> 21 525 heads: 169 times)                                 */
+                              every row tile (the 256 -> 21 525 heads: 169 times).  Where it is asked for and the launch
+                              has >= 128 rows, the weight pack is laid out for the symmetric kernel forms (x6_ctl bit 7),
+                              which have no other way to stage: pase_conv_gemm then returns -12 when xp6 is NULL  */
     int x6_ctl;            /* split-bf16 plan control (0 = the library's routing).  bit 0: take the split-bf16 kernel
                               wherever it has a plan, skipping the measured per-shape routing rules; bit 1: ask for the
                               pre-split activation on every stride-1 launch; bit 2: never; bit 3: keep the one-channel

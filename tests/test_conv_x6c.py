@@ -417,6 +417,20 @@ def test_plan_kind_and_pack_contract(dev):
     assert lib.pase_conv_gemm_plan_kind(C.byref(d1)) == 3
     d1.x6_ctl = 8
     assert lib.pase_conv_gemm_x6_bytes(C.byref(d1)) == 0
+    # a launch the library wants the pre-split activation for (1x1, >= 1024 rows) has its weight pack laid out for the symmetric
+    # kernel forms, which stage by copy only: without xp6 the launch is refused (-12), nothing is written
+    x2 = torch.randn(2, 256, 200, device=dev)
+    w2 = torch.randn(1024, 256, device=dev)
+    y2 = torch.full((2, 1024, 200), 7.0, device=dev)
+    d2 = K._conv_desc(x2, w2, y2, S=2, Cin=256, Tin=200, M=1024, K=256, taps=1, Ncols=200, Tout=200)
+    assert lib.pase_conv_gemm_xp_bytes(C.byref(d2)) > 0
+    buf2 = torch.zeros(lib.pase_conv_gemm_x6_bytes(C.byref(d2)), dtype=torch.uint8, device=dev)
+    d2.wx6 = buf2.data_ptr()
+    assert lib.pase_pack_x6(C.byref(d2), None) == 0
+    assert lib.pase_conv_gemm_kernel_id(C.byref(d2)) % 100 & 4, "symmetric form expected"
+    assert lib.pase_conv_gemm(C.byref(d2), None) == -12
+    torch.cuda.synchronize()
+    assert bool((y2 == 7.0).all())
 
 
 def test_persistent_workgroups_take_several_items(dev, monkeypatch):
