@@ -423,13 +423,14 @@ def test_plan_kind_and_pack_contract(dev):
     w2 = torch.randn(1024, 256, device=dev)
     y2 = torch.full((2, 1024, 200), 7.0, device=dev)
     d2 = K._conv_desc(x2, w2, y2, S=2, Cin=256, Tin=200, M=1024, K=256, taps=1, Ncols=200, Tout=200)
-    assert lib.pase_conv_gemm_xp_bytes(C.byref(d2)) > 0
+    d2.x6_ctl = 0          # the library's own routing, whatever this parametrisation forces on the other cases
     buf2 = torch.zeros(lib.pase_conv_gemm_x6_bytes(C.byref(d2)), dtype=torch.uint8, device=dev)
     d2.wx6 = buf2.data_ptr()
+    assert lib.pase_conv_gemm_xp_bytes(C.byref(d2)) > 0
     assert lib.pase_pack_x6(C.byref(d2), None) == 0
-    assert lib.pase_conv_gemm_kernel_id(C.byref(d2)) % 100 & 4, "symmetric form expected"
     assert lib.pase_conv_gemm(C.byref(d2), None) == -12
-    torch.cuda.synchronize()
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
     assert bool((y2 == 7.0).all())
 
 
