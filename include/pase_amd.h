@@ -100,7 +100,8 @@ typedef struct PaseConvGemm {
                               (SincNet) layer off its window-image kernel; bit 4: no 64 x 256 tile for launches of at
                               most 64 rows; bit 5: the general epilogue on every tile (no lean store / MSE path); bit 6: the bias
                               added in the epilogue instead of being the accumulators' initial value; bit 7: launches on a
-                              pre-split activation stay on the staging-wave form (no symmetric form); bits 17 / 18: the
+                              pre-split activation stay on the staging-wave form (no symmetric form); bit 16: strided launches
+                              with an even stride load single samples while staging (default: pairs of phases); bits 17 / 18: the
                               eight-wave / the four-wave symmetric form wherever eligible (A/B runs); bits 8-15: start
                               the persistent workgroups n x 512 clocks out of phase (A/B runs and tests; the library
                               itself reads NO environment variables)                                             */

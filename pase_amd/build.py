@@ -136,7 +136,7 @@ def check_x6c_staging_isa(asm_text):
             continue
         if cur is None:
             continue
-        m = re.match(r"\s*global_load_dword(?:x4)?\s+(v\[\d+:\d+\]|v\d+),.*; staging set (\d+)", line)
+        m = re.match(r"\s*global_load_dword(?:x2|x4)?\s+(v\[\d+:\d+\]|v\d+),.*; staging set (\d+)", line)
         if m:
             for r in regs_of(m.group(1)):
                 cur["load"].setdefault(r, set()).add(int(m.group(2)))

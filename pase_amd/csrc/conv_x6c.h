@@ -37,6 +37,7 @@ struct PaseX6cPlan {
     int xp_tpad;        // ... padded positions per sequence: Ncols + A - 1
     long xp_plane;      // ... 16-byte chunks per plane: G * 2 * S * xp_tpad
     int sym;            // convolution launches on a pre-split activation: the symmetric form (256 x 128 tile, no staging waves)
+    int pairs;          // strided convolution launches with an even stride: interior slots load (phase, phase + 1) pairs
     int xPerm;          // pixel-shuffle launches: tile rows ordered (channel, phase) -> 16-byte output runs
     long pack_chunks;   // 16-byte chunks of the weight pack
     int prm_n;          // channels' of the expanded on-load parameter arrays behind the chunks (3 x prm_n floats)

@@ -275,6 +275,15 @@ template <int E, int RS>
 __device__ __forceinline__ void x6c_gload(x6c_f4 (&q)[2], const float* base, unsigned voff_bytes) {
     q[E >> 2][E & 3] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + voff_bytes);
 }
+template <int E, int RS>
+__device__ __forceinline__ void x6c_gload2(x6c_f4 (&q)[2], const float* base, unsigned voff_bytes) {
+    const char* a = reinterpret_cast<const char*>(base) + voff_bytes;
+    float lo, hi;
+    __builtin_memcpy(&lo, a, 4);
+    __builtin_memcpy(&hi, a + 4, 4);
+    q[E >> 2][E & 3] = lo;
+    q[E >> 2][(E & 3) + 1] = hi;
+}
 template <int RS>
 __device__ __forceinline__ void x6c_gload_x8(x6c_f4 (&q)[2], const float* base, unsigned voff_bytes) {
     const X6cF4* s4 = reinterpret_cast<const X6cF4*>(reinterpret_cast<const char*>(base) + voff_bytes);
@@ -305,6 +314,16 @@ __device__ __forceinline__ void x6c_gload(x6c_f4 (&q)[2], const float* base, uns
                  : "v"(voff_bytes), "s"(base), "n"(RS)
                  : "memory");
 }
+// elements E, E + 1 (E even) = two consecutive samples: one 8-byte load at 4-byte alignment (strided launches with an even
+// stride: the phases of a channel are consecutive samples and a pair never straddles two channels)
+template <int E, int RS>
+__device__ __forceinline__ void x6c_gload2(x6c_f4 (&q)[2], const float* base, unsigned voff_bytes) {
+    static_assert((E & 1) == 0, "pairs start at even elements");
+    if constexpr ((E & 3) == 0)
+        asm volatile("global_load_dwordx2 %0, %1, %2 ; staging set %3" : "=v"(q[E >> 2].lo) : "v"(voff_bytes), "s"(base), "n"(RS) : "memory");
+    else
+        asm volatile("global_load_dwordx2 %0, %1, %2 ; staging set %3" : "=v"(q[E >> 2].hi) : "v"(voff_bytes), "s"(base), "n"(RS) : "memory");
+}
 template <int RS>
 __device__ __forceinline__ void x6c_gload_x8(x6c_f4 (&q)[2], const float* base, unsigned voff_bytes) {
     asm volatile("global_load_dwordx4 %0, %2, %3 ; staging set %4\n\tglobal_load_dwordx4 %1, %2, %3 offset:16"
@@ -323,22 +342,23 @@ __device__ __forceinline__ void x6c_claim(x6c_f4 (&q)[2]) {
     asm volatile("; claim staging set %2 regs %0 %1" : "+v"(q[0]), "+v"(q[1]) : "n"(RS));
 }
 #endif
-// wait until at most `per_slot` * nslots of this wave's loads are outstanding (nslots: uniform, 0 .. 5; per_slot 8, or 2 on the
-// row-coalesced weight-gradient path)
-__device__ __forceinline__ void x6c_vmwait_slots(int nslots, bool two_per_slot) {
-    const int n = nslots <= 0 ? 0 : (two_per_slot ? 2 : 8) * (nslots > 5 ? 5 : nslots);
-    switch (n) {
-        case 0: x6c_vmwait<0>(); break;
-        case 2: x6c_vmwait<2>(); break;
-        case 4: x6c_vmwait<4>(); break;
-        case 6: x6c_vmwait<6>(); break;
-        case 8: x6c_vmwait<8>(); break;
-        case 10: x6c_vmwait<10>(); break;
-        case 16: x6c_vmwait<16>(); break;
-        case 24: x6c_vmwait<24>(); break;
-        case 32: x6c_vmwait<32>(); break;
-        default: x6c_vmwait<40>(); break;
-    }
+// wait until at most `per_slot` * nslots of this wave's loads are outstanding (nslots: uniform; per_slot = the FEWEST loads a
+// live slot issues: 8, 2 on the row-coalesced weight-gradient path, 4 where interior slots load pairs -- slots that issue more
+// only make the wait stricter than needed).  Rounded down to an instantiated count: stricter, never looser.
+__device__ __forceinline__ void x6c_vmwait_slots(int nslots, int per_slot) {
+    const int n = nslots <= 0 ? 0 : per_slot * nslots;
+    if (n >= 40) x6c_vmwait<40>();
+    else if (n >= 32) x6c_vmwait<32>();
+    else if (n >= 24) x6c_vmwait<24>();
+    else if (n >= 20) x6c_vmwait<20>();
+    else if (n >= 16) x6c_vmwait<16>();
+    else if (n >= 12) x6c_vmwait<12>();
+    else if (n >= 10) x6c_vmwait<10>();
+    else if (n >= 8) x6c_vmwait<8>();
+    else if (n >= 6) x6c_vmwait<6>();
+    else if (n >= 4) x6c_vmwait<4>();
+    else if (n >= 2) x6c_vmwait<2>();
+    else x6c_vmwait<0>();
 }
 
 // NPOS: positions (16-byte chunks) per (plane, fk) row of a k-group; KGS_T: k-groups a stage buffer holds.
@@ -763,6 +783,19 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             int bph = c0l - cq0 * pl.P;
             const float* bp = xbase + (size_t)cq0 * p.Tin + bph;
             const int to_next = p.Tin - (pl.P - 1);
+            if (pl.pairs) {
+                // even stride: the octet starts at an even phase and elements (e, e + 1) are two consecutive samples of one
+                // channel -- four 8-byte loads per slot instead of eight 4-byte ones (lanes are P samples apart: every load
+                // instruction of a strided launch touches the same ~P / 32 x 64 cache lines whatever its width)
+                pase_static_for<4>([&](auto et) __attribute__((always_inline)) {
+                    constexpr int e = 2 * decltype(et)::value;
+                    x6c_gload2<e, rs>(xreg[rs][sl], bp, pos_voff[par][ps] * 4u);
+                    bph += 2;
+                    const bool wrap = bph == pl.P;                                // uniform
+                    bp += wrap ? to_next + 1 : 2;
+                    bph = wrap ? 0 : bph;
+                });
+            } else {
             pase_static_for<8>([&](auto et) __attribute__((always_inline)) {
                 constexpr int e = decltype(et)::value;
                 x6c_gload<e, rs>(xreg[rs][sl], bp, pos_voff[par][ps] * 4u);
@@ -770,6 +803,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                 bp += wrap ? to_next : 1;
                 bph = wrap ? 0 : bph;
             });
+            }
             xmask[rs][sl] = (0u - vbit) & 0xffu;
         } else
         if (all_inter) {
@@ -923,6 +957,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             });
         };
         int nlive = 0;                 // live slots of this wave for the current item: 8 * nlive loads per stage
+        const int per_slot = (TM && pl.t_vec) ? 2 : ((!TM && pl.pairs) ? 4 : 8);      // fewest loads of a live slot (uniform)
         auto prologue = [&](int item) __attribute__((always_inline)) {
             if (wave == 4) X6C_STAMP(4);
             setup_item(item);
@@ -938,7 +973,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
             });
             load_stage(std::integral_constant<int, 0>{}, g_begin);
             if (1 < nst) load_stage(std::integral_constant<int, 1>{}, g_begin + 1);
-            x6c_vmwait_slots(1 < nst ? nlive : 0, TM && pl.t_vec);         // stage 0 has landed
+            x6c_vmwait_slots(1 < nst ? nlive : 0, per_slot);         // stage 0 has landed
             store_stage(std::integral_constant<int, 0>{}, g_begin, bsel);
             if (2 < nst) load_stage(std::integral_constant<int, 2>{}, g_begin + 2);
             if (wave == 4) X6C_STAMP(5);
@@ -1037,7 +1072,7 @@ __global__ void __launch_bounds__(NT, 2) conv_x6c_kernel(PaseConvGemm p, PaseX6c
                             // in flight: stage gi + 1 (set rn, the older one) and stage gi + 2
                             {
                                 X6C_T0();
-                                x6c_vmwait_slots(gi + 2 < nst ? nlive : 0, TM && pl.t_vec);
+                                x6c_vmwait_slots(gi + 2 < nst ? nlive : 0, per_slot);
                                 if (wave == 4) X6C_TACC(10);
                             }
                             {
@@ -2392,6 +2427,7 @@ bool pase_x6c_plan(const PaseConvGemm& p, PaseX6cPlan& pl) {
         pl.epi32 = (out_elems < (1u << 29) && lab_elems < (1u << 29) && !(p.x6_ctl & 32)) ? 1 : 0;
     }
     pl.tmode = 0;
+    pl.pairs = (pl.P > 1 && (pl.P & 1) == 0 && !(p.x6_ctl & 0x10000)) ? 1 : 0;      // (x6_ctl bit 16: single loads, A/B runs)
     pl.xp_tpad = p.Ncols + pl.A - 1;
     pl.xp_plane = xp_want ? (long)pl.G * 2 * p.S * pl.xp_tpad : 0;
     pl.xp = (xp_want && p.xp6 != nullptr) ? 1 : 0;

@@ -136,6 +136,7 @@ def _conv_desc(x, w, y, *, S, Cin, Tin, M, K, taps, Ncols, Tout, ldw=None, bias=
                 | (64 if os.environ.get("PASE_X6C_BIASINIT", "1") == "0" else 0)
                 | (128 if os.environ.get("PASE_X6C_SYM", "1") == "0" else 0)
                 | {"8": 0x20000, "duo": 0x40000}.get(os.environ.get("PASE_X6C_SYM", ""), 0)
+                | (0x10000 if os.environ.get("PASE_X6C_PAIRS", "1") == "0" else 0)
                 | ((int(os.environ.get("PASE_X6C_STAGGER", "0")) & 255) << 8))
     d.max_wg = _max_wg(max_wg)
     return d
