@@ -38,8 +38,8 @@ def build_trace_lib():
 
 def run_shape(name, dev):
     S = 96
-    if name in ("blk5", "blk7", "blk3", "blk6"):
-        Cin, Cout, k, st, Tin = {"blk3": (128, 128, 11, 1, 1600), "blk5": (256, 256, 11, 1, 800),
+    if name in ("blk1", "blk5", "blk7", "blk3", "blk6"):
+        Cin, Cout, k, st, Tin = {"blk1": (64, 64, 20, 10, 32000), "blk3": (128, 128, 11, 1, 1600), "blk5": (256, 256, 11, 1, 800),
                                  "blk6": (256, 512, 11, 2, 800), "blk7": (512, 512, 11, 2, 400)}[name]
         pL, pR = E.reflect_pads(k, st)
         x = torch.randn(S, Cin, Tin, device=dev)
