@@ -446,6 +446,12 @@ def main():
     # bracketed by HIP events on the launch stream (outside the timed region above)
     from pase_amd import kernels as K
     K.GEMM_TIMER = K.GemmTimer()
+    # one untimed step in the timer's own layout first (with the timer on, every stream of the step is serialised onto the main
+    # one: the caching allocator meets block sizes it has not seen, and a hipMalloc between a launch's start event and the launch
+    # is GPU idle time inside the bracket -- round 6: a run's weight-gradient figure read 130 instead of 157 TFLOP/s for it)
+    tr._eager_step(batch)
+    sync()
+    K.GEMM_TIMER = K.GemmTimer()
     extra = 2
     for _ in range(extra):
         tr._eager_step(batch)          # (eager even when the timed steps were graph replays: per-launch events)
