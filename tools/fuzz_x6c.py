@@ -61,6 +61,49 @@ def one_conv(rng):
     return e, tag
 
 
+def one_mse(rng):
+    """1x1 projection with the fused r-context MSE epilogue (the LPS-style heads): loss sum, prediction, d(loss)/d(prediction)"""
+    Cin = rng.choice([64, 128, 256, 272, 768])
+    D = rng.choice([3, 21, 40, 123, 300])
+    r = rng.choice([3, 5, 7])
+    Fr = rng.randint(20, 260)
+    B = rng.randint(1, 6)
+    outs = rng.choice(["both", "grad", "pred"])
+    os.environ["PASE_X6C_FORCE"] = "1"
+    os.environ["PASE_X6C_XP"] = rng.choice(["", "1", "0"])
+    os.environ["PASE_X6C_SYM"] = rng.choice(["1", "1", "8", "duo", "0"])
+    maxwg = rng.choice([0, 0, 1, 3])
+    if maxwg:
+        os.environ["PASE_X6C_MAXWG"] = str(maxwg)
+    else:
+        os.environ.pop("PASE_X6C_MAXWG", None)
+    M = D * r
+    h = torch.randn(B, Cin, Fr)
+    w = torch.randn(M, Cin) * 0.2
+    b = torch.randn(M)
+    al = torch.rand(Cin) * 0.5
+    lab = torch.randn(B, D, Fr)
+    hin = torch.where(h > 0, h, h * al[None, :, None]).double()
+    pred = torch.einsum("mk,bkt->bmt", w.double(), hin) + b.double()[None, :, None]
+    padded = F.pad(lab.double(), (r // 2, r // 2))
+    tgt = torch.stack([padded[:, :, t:t + r].reshape(B, -1) for t in range(Fr)], 2)
+    ref_loss = ((pred - tgt) ** 2).sum()
+    y = torch.full((B, M, Fr), float("nan"), device=dev) if outs != "grad" else None
+    g = torch.full((B, M, Fr), float("nan"), device=dev) if outs != "pred" else None
+    acc = torch.zeros(1, dtype=torch.float64, device=dev)
+    K.conv_gemm(h.to(dev), w.to(dev), y, S=B, Cin=Cin, Tin=Fr, M=M, K=Cin, taps=1, Ncols=Fr, Tout=Fr, bias=b.to(dev),
+                in_alpha=al.to(dev), epilogue=K.EPI_MSE_CTX, label=lab.to(dev), grad_out=g, loss_acc=acc, grad_scale=0.5, r_ctx=r,
+                label_D=D)
+    e = abs(float(acc) - float(ref_loss)) / float(ref_loss)
+    if y is not None:
+        e = max(e, rel(y, pred))
+    if g is not None:
+        e = max(e, 0.5 * rel(g, 0.5 * (pred - tgt)))      # (the gradient is a difference of two O(1) numbers: 2e-6 bound)
+    tag = "mse Cin%d D%d r%d F%d B%d outs=%s xp=%r sym=%s maxwg=%d kind %s %s" % (
+        Cin, D, r, Fr, B, outs, os.environ["PASE_X6C_XP"], os.environ["PASE_X6C_SYM"], maxwg, K.LAST_PLAN_KIND, K.LAST_KERNEL)
+    return e, tag
+
+
 def one_wgrad(rng):
     Cin = rng.choice([12, 16, 24, 40, 64, 100, 128])
     Cout = rng.choice([96, 130, 256, 260, 300, 512, 520])
@@ -109,7 +152,7 @@ def main():
     torch.manual_seed(seed)
     bad, kinds, worst = 0, {}, 0.0
     for i in range(n):
-        fn = one_conv if i % 2 == 0 else one_wgrad
+        fn = (one_conv, one_wgrad, one_mse)[i % 3]
         try:
             e, tag = fn(rng)
         except Exception as ex:      # a refusal (-11 / -12 ...) of a forced combination is reported, not fatal
